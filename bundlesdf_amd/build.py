@@ -1,0 +1,63 @@
+"""Builds libnof_hip.so (the C-ABI library of include/nof_hip.h) for gfx950 with hipcc, in-tree.
+
+    python -m bundlesdf_amd.build [--force]
+
+hipcc cross-compiles without a GPU.  Object files are cached under bundlesdf_amd/csrc/build/ and are
+rebuilt when their source (or a header) is newer.
+"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, 'csrc')
+OBJ = os.path.join(CSRC, 'build')
+LIB = os.path.join(HERE, 'libnof_hip.so')
+SOURCES = ['nof_capi.hip', 'nof_hash.hip', 'nof_trace.hip', 'nof_loss.hip', 'nof_pose.hip', 'nof_mlp.hip', 'nof_mesh.hip']
+HEADERS = [os.path.join(CSRC, 'nof_common.h'), os.path.join(HERE, '..', 'include', 'nof_hip.h')]
+FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=off', '-munsafe-fp-atomics',
+         '-Wno-unused-result', '-Wno-pass-failed']
+
+
+def hipcc():
+    for c in (os.environ.get('HIPCC'), '/opt/rocm/bin/hipcc', 'hipcc'):
+        if c and (os.path.isabs(c) and os.path.exists(c) or not os.path.isabs(c)):
+            return c
+    raise RuntimeError('hipcc not found')
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
+
+
+def build(force=False, verbose=True):
+    os.makedirs(OBJ, exist_ok=True)
+    cc = hipcc()
+    objs, procs = [], []
+    for src in SOURCES:
+        s = os.path.join(CSRC, src)
+        if not os.path.exists(s):
+            continue
+        o = os.path.join(OBJ, src.replace('.hip', '.o'))
+        objs.append(o)
+        if force or _stale(o, [s] + HEADERS):
+            cmd = [cc] + FLAGS + ['-x', 'hip', '-c', s, '-o', o]
+            if verbose:
+                print(' '.join(cmd), flush=True)
+            procs.append((src, subprocess.Popen(cmd)))
+    failed = [src for src, p in procs if p.wait() != 0]
+    if failed:
+        raise RuntimeError(f'hipcc failed for {failed}')
+    if force or procs or _stale(LIB, objs):
+        cmd = [cc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs
+        if verbose:
+            print(' '.join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == '__main__':
+    print(build(force='--force' in sys.argv))

@@ -1,0 +1,15 @@
+// Error plumbing of the C ABI (include/nof_hip.h).
+#include "nof_common.h"
+
+static thread_local char g_nof_err[512] = "";
+
+int nof_set_error(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_nof_err, sizeof(g_nof_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+extern "C" const char* nof_last_error(void) { return g_nof_err; }
+extern "C" int nof_version(void) { return 100; }

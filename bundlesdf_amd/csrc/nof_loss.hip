@@ -1,0 +1,209 @@
+// Depth-guided compositing, loss terms and dL/draw in one pass; fused Adam; small reductions.
+//
+//   raw2outputs                 nerf_runner.py:1132-1169   (weights come from (depth - z)/trunc only)
+//   train_loop loss assembly    nerf_runner.py:680-732
+//   get_masks / get_sdf_loss    nerf_helpers.py:367-399
+//   torch.optim.Adam step       nerf_runner.py:502,756-761
+// One wave64 per ray: lanes stride over the S samples, three short passes, wave reductions by DPP shuffles;
+// raw[R,S,4] is read as one float4 per sample and dL/draw written the same way.
+#include "nof_common.h"
+#pragma clang fp contract(off)
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+__device__ __forceinline__ float depth_weight(const NofLossCfg& c, float depth, float z, bool invalid) {
+  const float sfd = (depth - z) / c.trunc;
+  float w = sigmoidf_(sfd * c.sdf_lambda) * sigmoidf_(-sfd * c.sdf_lambda);
+  const bool mask = (z - depth <= c.trunc * c.neg_trunc_ratio) && (z - depth >= -c.trunc);
+  return invalid ? 0.0f : (mask ? w : 0.0f);
+}
+
+__global__ __launch_bounds__(64) void k_composite_loss(NofLossCfg c, const float4* __restrict__ raw,
+                                                        const float* __restrict__ z_vals, const uint8_t* __restrict__ valid,
+                                                        const float* __restrict__ batch, int64_t R, int S,
+                                                        float* __restrict__ rgb_map, float* __restrict__ weights,
+                                                        float4* __restrict__ draw, float* __restrict__ loss_out) {
+  const int64_t r = blockIdx.x;
+  const int lane = threadIdx.x;
+  const float* row = batch + r * NOF_RAY_COLS;
+  const float gt[3] = {row[3], row[4], row[5]};
+  const float depth = row[6];
+  const bool first = row[8] == 0.0f;
+  const bool type1 = row[9] == 1.0f;
+  const bool type0 = row[9] == 0.0f;
+  const bool invalid = depth > c.far_sc;
+  const int64_t base = r * S;
+
+  float wsum = 0.0f, nvalid = 0.0f;
+  for (int s = lane; s < S; s += 64) {
+    wsum += depth_weight(c, depth, z_vals[base + s], invalid);
+    nvalid += valid[base + s] ? 1.0f : 0.0f;
+  }
+  wsum = wave_sum(wsum);
+  nvalid = wave_sum(nvalid);
+  const float denom = wsum + 1e-10f;
+
+  float m0 = 0.f, m1 = 0.f, m2 = 0.f;
+  for (int s = lane; s < S; s += 64) {
+    float w = depth_weight(c, depth, z_vals[base + s], invalid) / denom;
+    if (!valid[base + s]) w = 0.0f;                                   // nerf_runner.py:1166
+    if (weights) weights[base + s] = w;
+    const float4 q = raw[base + s];
+    m0 += w * sigmoidf_(q.x);
+    m1 += w * sigmoidf_(q.y);
+    m2 += w * sigmoidf_(q.z);
+  }
+  m0 = wave_sum(m0); m1 = wave_sum(m1); m2 = wave_sum(m2);
+  const bool valid_ray = (nvalid > 0.0f) && type0;                     // nerf_runner.py:693
+  const float ray_w = valid_ray ? (first ? c.first_frame_weight : 1.0f) : 0.0f;
+  if (lane == 0) { rgb_map[r * 3] = m0; rgb_map[r * 3 + 1] = m1; rgb_map[r * 3 + 2] = m2; }
+  const float e0 = m0 - gt[0], e1 = m1 - gt[1], e2 = m2 - gt[2];
+  const float inv3R = 1.0f / (3.0f * (float)R);
+  const float invRS = 1.0f / ((float)R * (float)S);
+  const float k_rgb = 2.0f * ray_w * c.rgb_weight * inv3R;
+  const float dm0 = k_rgb * e0, dm1 = k_rgb * e1, dm2 = k_rgb * e2;
+
+  float l_fs = 0.f, l_empty = 0.f, l_sdf = 0.f, l_fsrgb = 0.f;
+  const bool valid_depth = (depth >= c.near_sc) && (depth <= c.far_sc);
+  for (int s = lane; s < S; s += 64) {
+    const float z = z_vals[base + s];
+    const bool v = valid[base + s] != 0;
+    float w = depth_weight(c, depth, z, invalid) / denom;
+    if (!v) w = 0.0f;
+    const float4 q = raw[base + s];
+    const float sdf = q.w;
+    const float sw = (v && !type1) ? ray_w : 0.0f;                      // nerf_runner.py:699,723
+    const float c0 = sigmoidf_(q.x), c1 = sigmoidf_(q.y), c2 = sigmoidf_(q.z);
+    float4 g;
+    g.x = dm0 * w * c0 * (1.0f - c0);
+    g.y = dm1 * w * c1 * (1.0f - c1);
+    g.z = dm2 * w * c2 * (1.0f - c2);
+    float gs = 0.0f;
+    const bool front = z < depth - c.trunc;
+    const bool back = z > depth + c.trunc * c.neg_trunc_ratio;
+    if (invalid && sdf < c.fs_sdf) {                                     // nerf_helpers.py:387-389
+      const float d = sdf - c.fs_sdf;
+      l_fs += d * d * sw;
+      gs += 2.0f * d * sw * 0.5f * c.fs_weight * invRS;
+    }
+    if (front && !invalid && sdf < 1.0f) {                               // nerf_helpers.py:391-392
+      l_empty += fabsf(sdf - 1.0f) * sw;
+      gs += -sw * c.empty_weight * c.fs_weight * invRS;
+    }
+    if (!front && !back && valid_depth) {                                // nerf_helpers.py:372,395
+      const float d = (z + sdf * c.trunc) - depth;
+      l_sdf += d * d * sw;
+      gs += 2.0f * d * c.trunc * sw * 0.5f * c.trunc_weight * invRS;
+    }
+    if (c.fs_rgb_weight > 0.0f && front) {                               // nerf_runner.py:730-732
+      const float k = 2.0f * sw * c.fs_rgb_weight * invRS / 3.0f;
+      l_fsrgb += ((c0 - 1.0f) * (c0 - 1.0f) + (c1 - 1.0f) * (c1 - 1.0f) + (c2 - 1.0f) * (c2 - 1.0f)) * sw;
+      g.x += k * (c0 - 1.0f) * c0 * (1.0f - c0);
+      g.y += k * (c1 - 1.0f) * c1 * (1.0f - c1);
+      g.z += k * (c2 - 1.0f) * c2 * (1.0f - c2);
+    }
+    g.w = gs;
+    g.x *= c.grad_scale; g.y *= c.grad_scale; g.z *= c.grad_scale; g.w *= c.grad_scale;
+    draw[base + s] = g;
+  }
+  l_fs = wave_sum(l_fs); l_empty = wave_sum(l_empty); l_sdf = wave_sum(l_sdf); l_fsrgb = wave_sum(l_fsrgb);
+  if (lane == 0 && loss_out) {
+    const float rgb_loss = c.rgb_weight * (e0 * e0 + e1 * e1 + e2 * e2) * ray_w * inv3R;
+    const float fs_loss = c.fs_weight * (0.5f * l_fs + c.empty_weight * l_empty) * invRS;
+    const float sdf_loss = c.trunc_weight * 0.5f * l_sdf * invRS;
+    const float fsrgb = c.fs_rgb_weight * l_fsrgb * invRS / 3.0f;
+    atomicAdd(&loss_out[0], rgb_loss + fs_loss + sdf_loss + fsrgb);
+    atomicAdd(&loss_out[1], rgb_loss);
+    atomicAdd(&loss_out[2], fs_loss);
+    atomicAdd(&loss_out[3], sdf_loss);
+    atomicAdd(&loss_out[4], fsrgb);
+    atomicAdd(&loss_out[5], nvalid);
+    atomicAdd(&loss_out[6], valid_ray ? 1.0f : 0.0f);
+  }
+}
+
+extern "C" int nof_composite_loss(const NofLossCfg* cfg, const float* raw, const float* z_vals, const uint8_t* valid,
+                                   const float* batch, int64_t R, int32_t S, float* rgb_map, float* weights, float* draw,
+                                   float* loss_out, void* stream) {
+  NOF_ARG(cfg && raw && z_vals && valid && batch && rgb_map && draw && R >= 0 && S >= 1);
+  if (R == 0) return 0;
+  hipLaunchKernelGGL(k_composite_loss, dim3((unsigned)R), dim3(64), 0, (hipStream_t)stream, *cfg, (const float4*)raw,
+                     z_vals, valid, batch, R, S, rgb_map, weights, (float4*)draw, loss_out);
+  NOF_LAUNCH_OK();
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// torch.optim.Adam, single tensor form: m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2;
+// p -= (lr/bc1) * m / (sqrt(v)/sqrt(bc2) + eps).  HBM streaming: 16 B read + 16 B written per parameter.
+__global__ __launch_bounds__(256) void k_adam(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
+                                               float* __restrict__ v, int64_t n, int64_t n_basic, float step_basic,
+                                               float step_pose, float b1, float b2, float eps, float inv_sqrt_bc2) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const float gi = g[i];
+    const float mi = b1 * m[i] + (1.0f - b1) * gi;
+    const float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
+    const float denom = sqrtf(vi) * inv_sqrt_bc2 + eps;
+    const float ss = (i < n_basic) ? step_basic : step_pose;
+    p[i] = p[i] - ss * (mi / denom);
+    m[i] = mi;
+    v[i] = vi;
+    g[i] = 0.0f;                                                       // optimizer.zero_grad() for the next step
+  }
+}
+
+extern "C" int nof_adam_step(float* params, float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, int64_t n_basic,
+                              float lr, float lr_pose, float beta1, float beta2, float eps, int32_t step, void* stream) {
+  NOF_ARG(params && grads && exp_avg && exp_avg_sq && n >= 0 && n_basic >= 0 && n_basic <= n && step >= 1);
+  if (n == 0) return 0;
+  const double bc1 = 1.0 - pow((double)beta1, (double)step);
+  const double bc2 = 1.0 - pow((double)beta2, (double)step);
+  const float inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
+  const int64_t blocks = nof_div_up(n, 256) < 4096 ? nof_div_up(n, 256) : 4096;
+  hipLaunchKernelGGL(k_adam, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, params, grads, exp_avg,
+                     exp_avg_sq, n, n_basic, (float)(lr / bc1), (float)(lr_pose / bc1), beta1, beta2, eps, inv_sqrt_bc2);
+  NOF_LAUNCH_OK();
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_reduce_partials(const float* __restrict__ partials, int n_rows, int n_cols,
+                                                          float* __restrict__ out) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n_cols) return;
+  float s = 0.0f;
+  for (int i = 0; i < n_rows; ++i) s += partials[(size_t)i * n_cols + j];
+  out[j] += s;
+}
+
+extern "C" int nof_reduce_partials(const float* partials, int32_t n_rows, int32_t n_cols, float* out, void* stream) {
+  NOF_ARG(partials && out && n_rows >= 0 && n_cols >= 0);
+  if (n_cols == 0 || n_rows == 0) return 0;
+  hipLaunchKernelGGL(k_reduce_partials, dim3((unsigned)nof_div_up(n_cols, 256)), dim3(256), 0, (hipStream_t)stream,
+                     partials, n_rows, n_cols, out);
+  NOF_LAUNCH_OK();
+  return 0;
+}
+
+__global__ void k_feature_reg(const float* __restrict__ data, float* __restrict__ grad, int n, float k) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) grad[i] += k * data[i];
+}
+
+extern "C" int nof_small_regs(const float* feat_data, float* grad_feat, int32_t n_feat, float feature_reg_weight,
+                               float grad_scale, void* stream) {
+  if (n_feat <= 0 || feature_reg_weight == 0.0f) return 0;
+  NOF_ARG(feat_data && grad_feat);
+  const float k = 2.0f * feature_reg_weight / (float)n_feat * grad_scale;   // d/dx w*mean(x^2)  (nerf_runner.py:746)
+  hipLaunchKernelGGL(k_feature_reg, dim3((unsigned)nof_div_up(n_feat, 256)), dim3(256), 0, (hipStream_t)stream, feat_data,
+                     grad_feat, n_feat, k);
+  NOF_LAUNCH_OK();
+  return 0;
+}

@@ -1,0 +1,834 @@
+// SDF + colour tiny-MLPs (NeRFSmall, nerf_helpers.py:243-321) forward / backward on gfx950 matrix cores.
+//
+// MI355X-first design (nothing here mirrors the reference's cuBLAS-per-layer structure):
+//   * one wave64 owns a tile of 32 samples; every layer is a chain of v_mfma_f32_32x32x{16 bf16|16 f16|2 f32};
+//   * "swapped" orientation  D[neuron][sample] = W[neuron][k] X[k][sample]  puts one SAMPLE per lane with its 16
+//     neurons of a 32-block in registers, and that accumulator layout IS the B-operand layout of the next layer
+//     once the weight matrix' K columns are permuted to match -> layers chain in registers, no LDS round trip,
+//     no cross-lane traffic.  The permuted weight fragments are packed once per workgroup into LDS;
+//   * the backward needs sample-contracted GEMMs (dW = dY X^T).  Instead of transposing through LDS, every layer is
+//     ALSO evaluated in the other orientation D[sample][neuron] (operands swapped, same fragments): that leaves one
+//     NEURON per lane with 16 samples in registers = exactly the A/B operand layout of the dW MFMA.  The matrix cores
+//     are ~idle in this network (53 kFLOP/sample), so spending 2x MFMAs to delete all transposes is the cheap side;
+//   * dW / db accumulate in registers (AGPRs) across a persistent loop, are reduced per workgroup in LDS and written
+//     as per-workgroup partial sums (deterministic, no global atomics on 9k hot addresses);
+//   * forward activations are recomputed in the backward (features are re-read, 128 B/sample) - nothing [B,64]
+//     ever goes to HBM.
+// Accumulator layout of v_mfma_f32_32x32x*: lane l = (hi = l>>5, j = l&31) holds column j, rows (r&3)+8(r>>2)+4hi.
+#include "nof_common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+struct PrecF32 {
+  static constexpr int KR = 1;
+  typedef float elem;
+  typedef float frag;
+  static __device__ __forceinline__ frag pack(const float* v) { return v[0]; }
+  static __device__ __forceinline__ f32x16 mma(frag a, frag b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+  }
+};
+struct PrecBF16 {
+  static constexpr int KR = 8;
+  typedef __bf16 elem;
+  typedef bf16x8 frag;
+  static __device__ __forceinline__ frag pack(const float* v) {
+    frag f;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) f[t] = (__bf16)v[t];
+    return f;
+  }
+  static __device__ __forceinline__ f32x16 mma(frag a, frag b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+  }
+};
+struct PrecF16 {
+  static constexpr int KR = 8;
+  typedef _Float16 elem;
+  typedef f16x8 frag;
+  static __device__ __forceinline__ frag pack(const float* v) {
+    frag f;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) f[t] = (_Float16)v[t];
+    return f;
+  }
+  static __device__ __forceinline__ f32x16 mma(frag a, frag b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+  }
+};
+
+__host__ __device__ __forceinline__ constexpr int nloc(int hi, int r) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
+
+// ---- layer bookkeeping (runtime, from the descriptor) -------------------------------------------
+__host__ __device__ __forceinline__ int lay_qn(int l) { return l == 0 ? 1 : 2; }
+__host__ __device__ __forceinline__ int lay_pn(const NofMlpDesc& d, int l) { return d.out_dim[l] > 32 ? 2 : 1; }
+__host__ __device__ inline int pair_base(const NofMlpDesc& d, int l) {
+  int s = 0;
+  for (int k = 0; k < l; ++k) s += lay_pn(d, k) * lay_qn(k);
+  return s;
+}
+__host__ __device__ inline int oblk_base(const NofMlpDesc& d, int l) {
+  int s = 0;
+  for (int k = 0; k < l; ++k) s += lay_pn(d, k);
+  return s;
+}
+
+// weight-matrix column that input slot (q, hi, r) of layer l reads; -1 = structural zero
+__device__ __forceinline__ int inmap(const NofMlpDesc& d, int l, int q, int hi, int r) {
+  if (l == 0) {
+    const int c = 16 * hi + r;                                       // hash features, natural order 2*level + ch
+    return c < d.in_feat ? c : -1;
+  }
+  if (l == d.n_sigma) {                                               // colour layer 0: [views | geo_feat] (nerf_helpers.py:316)
+    if (q == 0) {
+      const int o = nloc(hi, r);                                      // sigma output o: 0 = sdf, 1..geo = geo_feat
+      return (o >= 1 && o <= d.geo) ? d.n_view + o - 1 : -1;
+    }
+    const int u = 16 * hi + r;
+    return u < d.n_view ? u : -1;
+  }
+  const int c = 32 * q + nloc(hi, r);
+  return c < d.in_dim[l] ? c : -1;
+}
+// weight-matrix column of orientation-2 lane j of input block q (used when flushing dW)
+__device__ __forceinline__ int colmap(const NofMlpDesc& d, int l, int q, int j) {
+  if (l == 0) return j < d.in_feat ? j : -1;
+  if (l == d.n_sigma) {
+    if (q == 0) return (j >= 1 && j <= d.geo) ? d.n_view + j - 1 : -1;
+    return j < d.n_view ? j : -1;
+  }
+  const int c = 32 * q + j;
+  return c < d.in_dim[l] ? c : -1;
+}
+
+// Packs the fp32 PyTorch-layout weights into MFMA fragments in LDS.
+//   fw[(pair_base(l) + p*QN + q)][step][lane][t] = W_l[32p + i][inmap(l,q,hi,KR*step+t)]                (lane = hi*32+i)
+//   bw[(pair_base(l) + q*PN + p)][step][lane][t] = W_l[32p + nloc(hi,KR*step+t)][inmap(l,q,hi(i),r(i))]
+template <class P>
+__device__ void pack_weights(const NofMlpDesc& d, const float* __restrict__ params, typename P::elem* fw,
+                             typename P::elem* bw, float* bias, int n_layers, bool want_bw) {
+  constexpr int KR = P::KR;
+  const int npair = pair_base(d, n_layers);
+  const int total = npair * 16 * 64;
+  for (int e = threadIdx.x; e < total; e += blockDim.x) {
+    const int lane = e & 63, r = (e >> 6) & 15;
+    int pair = e >> 10, l = 0;
+    for (;; ++l) {
+      const int cnt = lay_pn(d, l) * lay_qn(l);
+      if (pair < cnt) break;
+      pair -= cnt;
+    }
+    const int qn = lay_qn(l), pn = lay_pn(d, l), base = pair_base(d, l);
+    const int hi = lane >> 5, i = lane & 31;
+    const float* W = params + d.w_off[l];
+    const int in_dim = d.in_dim[l], out_dim = d.out_dim[l];
+    {
+      const int p = pair / qn, q = pair % qn;
+      const int row = 32 * p + i, col = inmap(d, l, q, hi, r);
+      const float v = (row < out_dim && col >= 0) ? W[row * in_dim + col] : 0.0f;
+      fw[(((size_t)(base + p * qn + q) * (16 / KR) + r / KR) * 64 + lane) * KR + r % KR] = (typename P::elem)v;
+    }
+    if (want_bw) {
+      const int q = pair / pn, p = pair % pn;
+      const int hi_i = (i >> 2) & 1, r_i = (i & 3) + 4 * (i >> 3);
+      const int row = 32 * p + nloc(hi, r), col = inmap(d, l, q, hi_i, r_i);
+      const float v = (row < out_dim && col >= 0) ? W[row * in_dim + col] : 0.0f;
+      bw[(((size_t)(base + q * pn + p) * (16 / KR) + r / KR) * 64 + lane) * KR + r % KR] = (typename P::elem)v;
+    }
+  }
+  const int nob = oblk_base(d, n_layers);
+  for (int e = threadIdx.x; e < nob * 32; e += blockDim.x) {
+    int ob = e >> 5, l = 0;
+    for (;; ++l) {
+      const int pn = lay_pn(d, l);
+      if (ob < pn) break;
+      ob -= pn;
+    }
+    const int row = 32 * ob + (e & 31);
+    bias[e] = row < d.out_dim[l] ? params[d.b_off[l] + row] : 0.0f;
+  }
+}
+
+// ---- one dense layer, both orientations -------------------------------------------------------------
+// orientation 1: out[p][r] = neuron 32p + nloc(hi,r) of sample j          (lane = sample)
+template <class P, int QN, int PN>
+__device__ __forceinline__ void dense_o1(const typename P::elem* fwl, const float* bl, const float (&in)[QN][16],
+                                         float (&out)[PN][16], int lane) {
+  constexpr int KR = P::KR, NSTEP = 16 / KR;
+  const int hi = lane >> 5;
+#pragma unroll
+  for (int p = 0; p < PN; ++p) {
+    f32x16 acc;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const float4 bv = *(const float4*)&bl[32 * p + 8 * g + 4 * hi];
+      acc[4 * g] = bv.x; acc[4 * g + 1] = bv.y; acc[4 * g + 2] = bv.z; acc[4 * g + 3] = bv.w;
+    }
+#pragma unroll
+    for (int q = 0; q < QN; ++q)
+#pragma unroll
+      for (int s = 0; s < NSTEP; ++s) {
+        const typename P::frag a = *(const typename P::frag*)&fwl[(((size_t)(p * QN + q) * NSTEP + s) * 64 + lane) * KR];
+        const typename P::frag b = P::pack(&in[q][KR * s]);
+        acc = P::mma(a, b, acc);
+      }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) out[p][r] = acc[r];
+  }
+}
+// orientation 2: out[p][r] = neuron 32p + j at sample nloc(hi,r)          (lane = neuron)
+template <class P, int QN, int PN>
+__device__ __forceinline__ void dense_o2(const typename P::elem* fwl, const float* bl, const float (&in)[QN][16],
+                                         float (&out)[PN][16], int lane) {
+  constexpr int KR = P::KR, NSTEP = 16 / KR;
+  const int j = lane & 31;
+#pragma unroll
+  for (int p = 0; p < PN; ++p) {
+    const float bv = bl[32 * p + j];
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = bv;
+#pragma unroll
+    for (int q = 0; q < QN; ++q)
+#pragma unroll
+      for (int s = 0; s < NSTEP; ++s) {
+        const typename P::frag a = P::pack(&in[q][KR * s]);
+        const typename P::frag b = *(const typename P::frag*)&fwl[(((size_t)(p * QN + q) * NSTEP + s) * 64 + lane) * KR];
+        acc = P::mma(a, b, acc);
+      }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) out[p][r] = acc[r];
+  }
+}
+
+template <int PN>
+__device__ __forceinline__ uint32_t relu_mask(float (&h)[PN][16]) {
+  uint32_t m = 0;
+#pragma unroll
+  for (int p = 0; p < PN; ++p)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      if (h[p][r] > 0.0f) m |= 1u << (p * 16 + r);
+      else h[p][r] = 0.0f;
+    }
+  return m;
+}
+template <int PN>
+__device__ __forceinline__ void apply_mask(float (&g)[PN][16], uint32_t m) {
+#pragma unroll
+  for (int p = 0; p < PN; ++p)
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+      if (!((m >> (p * 16 + r)) & 1u)) g[p][r] = 0.0f;
+}
+
+// ---- tile I/O ------------------------------------------------------------------------------------
+// orientation 1 features: lane (sample j, hi) slot r = feature 16hi + r = (level 8hi + r/2, ch r&1)
+__device__ __forceinline__ void load_feat_o1(const float2* __restrict__ feat, int L, int64_t B, int64_t b, int hi,
+                                             float (&x)[1][16]) {
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int level = 8 * hi + k;
+    float2 v = make_float2(0.f, 0.f);
+    if (level < L && b < B) v = feat[(int64_t)level * B + b];
+    x[0][2 * k] = v.x;
+    x[0][2 * k + 1] = v.y;
+  }
+}
+__device__ __forceinline__ void load_view_o1(const float* __restrict__ view, int S, int64_t B, int64_t b, int hi,
+                                             float (&x)[16]) {
+  if (hi == 0 && b < B) {
+    const float4* v = (const float4*)(view + (b / S) * NOF_VIEW_COLS);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const float4 t = v[g];
+      x[4 * g] = t.x; x[4 * g + 1] = t.y; x[4 * g + 2] = t.z; x[4 * g + 3] = t.w;
+    }
+  } else {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) x[r] = 0.0f;
+  }
+}
+
+#define LAYER_FW(l) (fw + (size_t)pair_base(d, (l)) * 16 * 64)
+#define LAYER_BW(l) (bw + (size_t)pair_base(d, (l)) * 16 * 64)
+#define LAYER_BIAS(l) (bias + oblk_base(d, (l)) * 32)
+
+// =====================================================================================================
+// forward: raw[b] = (rgb_raw[3], sdf)
+// =====================================================================================================
+template <class P, int NS, int NC, bool SDF_ONLY>
+__global__ __launch_bounds__(256) void k_mlp_fwd(NofMlpDesc d, const float* __restrict__ params,
+                                                  const float2* __restrict__ feat, int L, const float* __restrict__ view,
+                                                  int S, float* __restrict__ out, int64_t B) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int NL = SDF_ONLY ? NS : NS + NC;
+  typedef typename P::elem elem;
+  const int npair = pair_base(d, NL);
+  elem* fw = (elem*)smem;
+  float* bias = (float*)(smem + (size_t)npair * 16 * 64 * sizeof(elem));
+  pack_weights<P>(d, params, fw, nullptr, bias, NL, false);
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int hi = lane >> 5, j = lane & 31;
+  const int64_t ntiles = (B + 31) / 32;
+  for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < ntiles; tile += (int64_t)gridDim.x * 4) {
+    asm volatile("" ::: "memory");                    // keep the weight fragments in LDS (no hoisting into VGPRs)
+    const int64_t b = tile * 32 + j;
+    float x[1][16];
+    load_feat_o1(feat, L, B, b, hi, x);
+    float h[2][16], so[1][16];
+    dense_o1<P, 1, 2>(LAYER_FW(0), LAYER_BIAS(0), x, h, lane);
+    relu_mask<2>(h);
+#pragma unroll
+    for (int l = 1; l < NS - 1; ++l) {
+      float h2[2][16];
+      dense_o1<P, 2, 2>(LAYER_FW(l), LAYER_BIAS(l), h, h2, lane);
+      relu_mask<2>(h2);
+#pragma unroll
+      for (int p = 0; p < 2; ++p)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) h[p][r] = h2[p][r];
+    }
+    dense_o1<P, 2, 1>(LAYER_FW(NS - 1), LAYER_BIAS(NS - 1), h, so, lane);
+    if constexpr (SDF_ONLY) {
+      if (hi == 0 && b < B) out[b] = so[0][0];
+    } else {
+      float cin[2][16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) cin[0][r] = so[0][r];
+      load_view_o1(view, S, B, b, hi, cin[1]);
+      dense_o1<P, 2, 2>(LAYER_FW(NS), LAYER_BIAS(NS), cin, h, lane);
+      relu_mask<2>(h);
+#pragma unroll
+      for (int l = NS + 1; l < NS + NC - 1; ++l) {
+        float h2[2][16];
+        dense_o1<P, 2, 2>(LAYER_FW(l), LAYER_BIAS(l), h, h2, lane);
+        relu_mask<2>(h2);
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) h[p][r] = h2[p][r];
+      }
+      float co[1][16];
+      dense_o1<P, 2, 1>(LAYER_FW(NS + NC - 1), LAYER_BIAS(NS + NC - 1), h, co, lane);
+      if (hi == 0 && b < B) ((float4*)out)[b] = make_float4(co[0][0], co[0][1], co[0][2], so[0][0]);
+    }
+  }
+}
+
+// =====================================================================================================
+// backward (forward recomputed): dfeat, dview, per-workgroup dW/db partials
+// =====================================================================================================
+template <class P, int PN>
+__device__ __forceinline__ void to_frags(const float (&h)[PN][16], typename P::frag (&f)[PN][16 / P::KR]) {
+#pragma unroll
+  for (int p = 0; p < PN; ++p)
+#pragma unroll
+    for (int s = 0; s < 16 / P::KR; ++s) f[p][s] = P::pack(&h[p][P::KR * s]);
+}
+
+// dIn for input block q, orientation 1 (lane = sample) and 2 (lane = input neuron)
+template <class P, int PN, bool O1, bool O2>
+__device__ __forceinline__ void bwd_data(const typename P::elem* bwl, int q, const float (&dout1)[PN][16],
+                                         float (&din1)[16], float (&din2)[16], int lane) {
+  constexpr int KR = P::KR, NSTEP = 16 / KR;
+  f32x16 a1, a2;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { a1[r] = 0.0f; a2[r] = 0.0f; }
+#pragma unroll
+  for (int p = 0; p < PN; ++p)
+#pragma unroll
+    for (int s = 0; s < NSTEP; ++s) {
+      const typename P::frag w = *(const typename P::frag*)&bwl[(((size_t)(q * PN + p) * NSTEP + s) * 64 + lane) * KR];
+      const typename P::frag g = P::pack(&dout1[p][KR * s]);
+      if constexpr (O1) a1 = P::mma(w, g, a1);
+      if constexpr (O2) a2 = P::mma(g, w, a2);
+    }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { din1[r] = a1[r]; din2[r] = a2[r]; }
+}
+
+template <int NS, int NC>
+struct Shp {                                       // compile-time layer shapes (32-neuron blocks)
+  static constexpr int NL = NS + NC;
+  static constexpr __host__ __device__ int pn(int l) { return (l == NS - 1 || l == NL - 1) ? 1 : 2; }
+  static constexpr __host__ __device__ int qn(int l) { return l == 0 ? 1 : 2; }
+  // rows of a dW accumulator that can be non-zero: sigma head has 16 outputs (regs 0..7), colour head 3 (regs 0..3)
+  static constexpr __host__ __device__ int nacc(int l) { return l == NS - 1 ? 8 : (l == NL - 1 ? 4 : 16); }
+};
+
+// db += sum_samples dOut ; dW += dOut (x) in   for one layer (orientation-2 operands, contraction over the 32 samples)
+template <class P, int PN, int QN, int NACC>
+__device__ __forceinline__ void dw_step(float (&dw)[2][2][16], float (&db)[2], const float (&g2)[2][16],
+                                        const typename P::frag (&in2l)[2][16 / P::KR]) {
+  constexpr int KR = P::KR, NSTEP = 16 / KR;
+#pragma unroll
+  for (int p = 0; p < PN; ++p) {
+    float sdb = 0.0f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sdb += g2[p][r];
+    db[p] += sdb;
+#pragma unroll
+    for (int q = 0; q < QN; ++q) {
+      f32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = r < NACC ? dw[p][q][r] : 0.0f;
+#pragma unroll
+      for (int s = 0; s < NSTEP; ++s) acc = P::mma(P::pack(&g2[p][KR * s]), in2l[q][s], acc);
+#pragma unroll
+      for (int r = 0; r < NACC; ++r) dw[p][q][r] = acc[r];
+    }
+  }
+}
+
+template <class P, int NS, int NC>
+__global__ __launch_bounds__(256) void k_mlp_bwd(NofMlpDesc d, const float* __restrict__ params,
+                                                  const float2* __restrict__ feat, int L, const float* __restrict__ view,
+                                                  int S, const float4* __restrict__ draw, float2* __restrict__ dfeat,
+                                                  float* __restrict__ dview, float* __restrict__ partials, int64_t B) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int NL = NS + NC;
+  constexpr int KR = P::KR, NSTEP = 16 / KR;
+  typedef typename P::elem elem;
+  typedef typename P::frag frag;
+  const int npair = pair_base(d, NL);
+  elem* fw = (elem*)smem;
+  elem* bw = fw + (size_t)npair * 16 * 64;
+  float* bias = (float*)(bw + (size_t)npair * 16 * 64);
+  pack_weights<P>(d, params, fw, bw, bias, NL, true);
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int hi = lane >> 5, j = lane & 31;
+
+  typedef Shp<NS, NC> SH;
+  float dw[NL][2][2][16];                             // persistent per-wave dW accumulators (only the live entries are touched)
+  float db[NL][2];
+#pragma unroll
+  for (int l = 0; l < NL; ++l)
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      if (p < SH::pn(l)) db[l][p] = 0.0f;
+#pragma unroll
+      for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (p < SH::pn(l) && q < SH::qn(l) && r < SH::nacc(l)) dw[l][p][q][r] = 0.0f;
+    }
+
+  const int64_t ntiles = (B + 31) / 32;
+  for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < ntiles; tile += (int64_t)gridDim.x * 4) {
+    asm volatile("" ::: "memory");                    // keep the weight fragments in LDS (no hoisting into VGPRs)
+    const int64_t t0 = tile * 32;
+    const int64_t b = t0 + j;
+    // ---------------- forward recompute, both orientations ----------------
+    float x[1][16];
+    load_feat_o1(feat, L, B, b, hi, x);
+    uint32_t m1[NL], m2[NL];                          // ReLU masks per layer output (hidden layers only)
+    frag in2[NL][2][NSTEP];                           // orientation-2 INPUT of layer l (l >= 1), as MFMA operands
+    float h[2][16];
+    {
+      float h2[2][16];
+      dense_o1<P, 1, 2>(LAYER_FW(0), LAYER_BIAS(0), x, h, lane);
+      dense_o2<P, 1, 2>(LAYER_FW(0), LAYER_BIAS(0), x, h2, lane);
+      m1[0] = relu_mask<2>(h);
+      m2[0] = relu_mask<2>(h2);
+      to_frags<P, 2>(h2, in2[1]);
+    }
+#pragma unroll
+    for (int l = 1; l < NS - 1; ++l) {
+      float hn[2][16], h2[2][16];
+      dense_o1<P, 2, 2>(LAYER_FW(l), LAYER_BIAS(l), h, hn, lane);
+      dense_o2<P, 2, 2>(LAYER_FW(l), LAYER_BIAS(l), h, h2, lane);
+      m1[l] = relu_mask<2>(hn);
+      m2[l] = relu_mask<2>(h2);
+      to_frags<P, 2>(h2, in2[l + 1]);
+#pragma unroll
+      for (int p = 0; p < 2; ++p)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) h[p][r] = hn[p][r];
+    }
+    float cin[2][16];
+    {
+      float so[1][16], so2[1][16];
+      dense_o1<P, 2, 1>(LAYER_FW(NS - 1), LAYER_BIAS(NS - 1), h, so, lane);
+      dense_o2<P, 2, 1>(LAYER_FW(NS - 1), LAYER_BIAS(NS - 1), h, so2, lane);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) cin[0][r] = so[0][r];
+      frag t[1][NSTEP];
+      to_frags<P, 1>(so2, t);
+#pragma unroll
+      for (int s = 0; s < NSTEP; ++s) in2[NS][0][s] = t[0][s];
+    }
+    load_view_o1(view, S, B, b, hi, cin[1]);
+    {                                                 // orientation-2 view block: lane u = j (< 16), reg r <-> sample nloc(hi,r)
+      float v2[1][16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int64_t bs = t0 + nloc(hi, r);
+        v2[0][r] = (j < NOF_VIEW_COLS && bs < B) ? view[(bs / S) * NOF_VIEW_COLS + j] : 0.0f;
+      }
+      frag t[1][NSTEP];
+      to_frags<P, 1>(v2, t);
+#pragma unroll
+      for (int s = 0; s < NSTEP; ++s) in2[NS][1][s] = t[0][s];
+    }
+    {
+      float h2[2][16];
+      dense_o1<P, 2, 2>(LAYER_FW(NS), LAYER_BIAS(NS), cin, h, lane);
+      dense_o2<P, 2, 2>(LAYER_FW(NS), LAYER_BIAS(NS), cin, h2, lane);
+      m1[NS] = relu_mask<2>(h);
+      m2[NS] = relu_mask<2>(h2);
+      to_frags<P, 2>(h2, in2[NS + 1]);
+    }
+#pragma unroll
+    for (int l = NS + 1; l < NL - 1; ++l) {
+      float hn[2][16], h2[2][16];
+      dense_o1<P, 2, 2>(LAYER_FW(l), LAYER_BIAS(l), h, hn, lane);
+      dense_o2<P, 2, 2>(LAYER_FW(l), LAYER_BIAS(l), h, h2, lane);
+      m1[l] = relu_mask<2>(hn);
+      m2[l] = relu_mask<2>(h2);
+      to_frags<P, 2>(h2, in2[l + 1]);
+#pragma unroll
+      for (int p = 0; p < 2; ++p)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) h[p][r] = hn[p][r];
+    }
+    // (the last colour layer's output is not needed: its gradient comes from draw)
+
+    // ---------------- backward ----------------
+    // top gradients: draw[b] = (d rgb_raw[3], d sdf)
+    float g1[2][16], g2[2][16];                       // dOut of the current layer (orientation 1 / 2); block 1 unused for PN = 1
+    float dsdf1 = 0.0f;
+    float dsdf2[16];
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { g1[p][r] = 0.0f; g2[p][r] = 0.0f; }
+    if (hi == 0 && b < B) {
+      const float4 t = draw[b];
+      g1[0][0] = t.x; g1[0][1] = t.y; g1[0][2] = t.z;
+      dsdf1 = t.w;
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int64_t bs = t0 + nloc(hi, r);
+      float v = 0.0f, w = 0.0f;
+      if (j < 4 && bs < B) {
+        const float* dr = (const float*)&draw[bs];
+        v = (j < 3) ? dr[j] : 0.0f;
+        w = (j == 0) ? dr[3] : 0.0f;
+      }
+      g2[0][r] = v;
+      dsdf2[r] = w;
+    }
+
+    // per layer: db, dW (needs in2[l]); dIn (both orientations) -> masked -> g1/g2 of layer l-1
+#define BWD_LAYER_COMMON(l, PN_, QN_, NACC_) dw_step<P, PN_, QN_, NACC_>(dw[l], db[l], g2, in2[l]);
+
+    // ---- colour net, last layer down to colour layer 1 ----
+#pragma unroll
+    for (int l = NL - 1; l > NS; --l) {
+      float d1[2][16], d2[2][16];
+      if (l == NL - 1) {
+        BWD_LAYER_COMMON(l, 1, 2, 4)
+        float ga[1][16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ga[0][r] = g1[0][r];
+        bwd_data<P, 1, true, true>(LAYER_BW(l), 0, ga, d1[0], d2[0], lane);
+        bwd_data<P, 1, true, true>(LAYER_BW(l), 1, ga, d1[1], d2[1], lane);
+      } else {
+        BWD_LAYER_COMMON(l, 2, 2, 16)
+        bwd_data<P, 2, true, true>(LAYER_BW(l), 0, g1, d1[0], d2[0], lane);
+        bwd_data<P, 2, true, true>(LAYER_BW(l), 1, g1, d1[1], d2[1], lane);
+      }
+      apply_mask<2>(d1, m1[l - 1]);
+      apply_mask<2>(d2, m2[l - 1]);
+#pragma unroll
+      for (int p = 0; p < 2; ++p)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { g1[p][r] = d1[p][r]; g2[p][r] = d2[p][r]; }
+    }
+    // ---- colour layer 0: inputs = [sigma-out block | view block] ----
+    {
+      float ds1[16], ds2[16], dv1[16], dv2[16];
+      BWD_LAYER_COMMON(NS, 2, 2, 16)
+      bwd_data<P, 2, true, true>(LAYER_BW(NS), 0, g1, ds1, ds2, lane);
+      bwd_data<P, 2, false, true>(LAYER_BW(NS), 1, g1, dv1, dv2, lane);
+      // dview[ray][u] += sum over the tile's samples (lane u = j, regs <-> samples; a tile may straddle two rays)
+      {
+        const int64_t ray0 = t0 / S;
+        float sa = 0.0f, sb = 0.0f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int64_t bs = t0 + nloc(hi, r);
+          if (bs < B) {
+            if (bs / S == ray0) sa += dv2[r];
+            else sb += dv2[r];
+          }
+        }
+        sa += __shfl_xor(sa, 32, 64);
+        sb += __shfl_xor(sb, 32, 64);
+        // orientation-2 lane j of a bwd_data result is input SLOT (hi_j, r_j); for the view block slot -> u = 16 hi_j + r_j
+        const int hi_j = (j >> 2) & 1, u = (j & 3) + 4 * (j >> 3);
+        if (hi == 0 && hi_j == 0 && u < d.n_view) {
+          if (sa != 0.0f) atomicAdd(&dview[ray0 * NOF_VIEW_COLS + u], sa);
+          if (sb != 0.0f) atomicAdd(&dview[(ray0 + 1) * NOF_VIEW_COLS + u], sb);
+        }
+      }
+      // gradient of the sigma net output block: geo_feat grads + the loss' own d sdf
+#pragma unroll
+      for (int p = 0; p < 2; ++p)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { g1[p][r] = 0.0f; g2[p][r] = 0.0f; }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { g1[0][r] = ds1[r]; g2[0][r] = ds2[r]; }
+      if (hi == 0) g1[0][0] += dsdf1;
+      if (j == 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) g2[0][r] += dsdf2[r];
+      }
+    }
+    // ---- sigma net: last layer down to layer 1 ----
+#pragma unroll
+    for (int l = NS - 1; l >= 1; --l) {
+      float d1[2][16], d2[2][16];
+      if (l == NS - 1) {
+        BWD_LAYER_COMMON(l, 1, 2, 8)
+        float ga[1][16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ga[0][r] = g1[0][r];
+        bwd_data<P, 1, true, true>(LAYER_BW(l), 0, ga, d1[0], d2[0], lane);
+        bwd_data<P, 1, true, true>(LAYER_BW(l), 1, ga, d1[1], d2[1], lane);
+      } else {
+        BWD_LAYER_COMMON(l, 2, 2, 16)
+        bwd_data<P, 2, true, true>(LAYER_BW(l), 0, g1, d1[0], d2[0], lane);
+        bwd_data<P, 2, true, true>(LAYER_BW(l), 1, g1, d1[1], d2[1], lane);
+      }
+      apply_mask<2>(d1, m1[l - 1]);
+      apply_mask<2>(d2, m2[l - 1]);
+#pragma unroll
+      for (int p = 0; p < 2; ++p)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { g1[p][r] = d1[p][r]; g2[p][r] = d2[p][r]; }
+    }
+    // ---- sigma layer 0: dW needs the features in orientation 2 (lane = feature j, regs <-> samples) ----
+    {
+      float f2[1][16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int64_t bs = t0 + nloc(hi, r);
+        const int level = j >> 1;
+        f2[0][r] = (level < L && bs < B) ? ((const float*)&feat[(int64_t)level * B + bs])[j & 1] : 0.0f;
+      }
+      frag t[1][NSTEP];
+      to_frags<P, 1>(f2, t);
+#pragma unroll
+      for (int s = 0; s < NSTEP; ++s) in2[0][0][s] = t[0][s];
+      BWD_LAYER_COMMON(0, 2, 1, 16)
+      float df1[16], dummy[16];
+      bwd_data<P, 2, true, false>(LAYER_BW(0), 0, g1, df1, dummy, lane);
+      if (b < B) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const int level = 8 * hi + k;
+          if (level < L) dfeat[(int64_t)level * B + b] = make_float2(df1[2 * k], df1[2 * k + 1]);
+        }
+      }
+    }
+#undef BWD_LAYER_COMMON
+  }
+
+  // ---------------- reduce the workgroup's dW/db and write its row of `partials` ----------------
+  __syncthreads();
+  float* red = (float*)smem;
+  for (int e = threadIdx.x; e < d.n_params; e += blockDim.x) red[e] = 0.0f;
+  __syncthreads();
+#pragma unroll
+  for (int l = 0; l < NL; ++l) {
+    const int in_dim = d.in_dim[l], out_dim = d.out_dim[l];
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      if (p < SH::pn(l)) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          if (q < SH::qn(l)) {
+            const int col = colmap(d, l, q, j);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              if (r < SH::nacc(l)) {
+                const int row = 32 * p + nloc(hi, r);
+                if (col >= 0 && row < out_dim) atomicAdd(&red[d.w_off[l] + row * in_dim + col], dw[l][p][q][r]);
+              }
+            }
+          }
+        }
+        const int row = 32 * p + j;
+        if (row < out_dim) atomicAdd(&red[d.b_off[l] + row], db[l][p]);
+      }
+    }
+  }
+  __syncthreads();
+  float* dst = partials + (size_t)blockIdx.x * d.n_params;
+  for (int e = threadIdx.x; e < d.n_params; e += blockDim.x) dst[e] = red[e];
+}
+
+// =====================================================================================================
+// host side
+// =====================================================================================================
+static int check_desc(const NofMlpDesc* d) {
+  if (!d) return nof_set_error(-1, "mlp descriptor is NULL");
+  if (d->hidden != 64) return nof_set_error(-1, "mlp: hidden width must be 64 (got %d)", d->hidden);
+  if (d->n_sigma < 2 || d->n_sigma > 3 || d->n_color < 2 || d->n_color > 3)
+    return nof_set_error(-1, "mlp: supported depths are num_layers in {2,3}, num_layers_color in {2,3} (got %d,%d)",
+                         d->n_sigma, d->n_color);
+  if (d->in_feat < 1 || d->in_feat > 32) return nof_set_error(-1, "mlp: L*C must be <= 32 (got %d)", d->in_feat);
+  if (d->n_view < 0 || d->n_view > NOF_VIEW_COLS) return nof_set_error(-1, "mlp: n_view must be <= 16 (got %d)", d->n_view);
+  if (d->geo != 15) return nof_set_error(-1, "mlp: geo_feat_dim must be 15 (got %d)", d->geo);
+  if (d->precision < 0 || d->precision > 2) return nof_set_error(-1, "mlp: precision must be 0 (fp32), 1 (bf16) or 2 (fp16)");
+  const int nl = d->n_sigma + d->n_color;
+  for (int l = 0; l < nl; ++l) {
+    const int exp_in = l == 0 ? d->in_feat : (l == d->n_sigma ? d->n_view + d->geo : 64);
+    const int exp_out = l == d->n_sigma - 1 ? 1 + d->geo : (l == nl - 1 ? 3 : 64);
+    if (d->in_dim[l] != exp_in || d->out_dim[l] != exp_out)
+      return nof_set_error(-1, "mlp: layer %d is %dx%d, expected %dx%d", l, d->out_dim[l], d->in_dim[l], exp_out, exp_in);
+  }
+  return 0;
+}
+
+static size_t elem_size(int precision) { return precision == 0 ? 4 : 2; }
+static int n_pairs(const NofMlpDesc& d, int nl) { return pair_base(d, nl); }
+static int n_oblk(const NofMlpDesc& d, int nl) { return oblk_base(d, nl); }
+
+template <class K>
+static int set_smem(K kernel, size_t bytes) {
+  if (bytes > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e != hipSuccess) return nof_set_error((int)e, "hipFuncSetAttribute(%zu B LDS): %s", bytes, hipGetErrorString(e));
+  }
+  return 0;
+}
+
+#define DISPATCH_SHAPE(P, FN, ...)                                                                        \
+  if (d->n_sigma == 2 && d->n_color == 3) { FN(P, 2, 3, __VA_ARGS__) }                                    \
+  else if (d->n_sigma == 3 && d->n_color == 2) { FN(P, 3, 2, __VA_ARGS__) }                               \
+  else if (d->n_sigma == 2 && d->n_color == 2) { FN(P, 2, 2, __VA_ARGS__) }                               \
+  else { FN(P, 3, 3, __VA_ARGS__) }
+#define DISPATCH_PREC(FN, ...)                                                                            \
+  if (d->precision == 0) { DISPATCH_SHAPE(PrecF32, FN, __VA_ARGS__) }                                     \
+  else if (d->precision == 1) { DISPATCH_SHAPE(PrecBF16, FN, __VA_ARGS__) }                               \
+  else { DISPATCH_SHAPE(PrecF16, FN, __VA_ARGS__) }
+
+static int g_bwd_blocks = 0;
+extern "C" int nof_mlp_bwd_blocks(void) {
+  if (g_bwd_blocks == 0) {
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) {
+      hipDeviceProp_t prop;
+      if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
+    }
+    (void)hipGetLastError();
+    g_bwd_blocks = cus;
+  }
+  return g_bwd_blocks;
+}
+
+extern "C" int nof_mlp_fwd(const NofMlpDesc* d, const float* mlp_params, const float* feat, int32_t L, const float* view,
+                            int32_t S, float* raw, int64_t B, void* stream) {
+  if (int e = check_desc(d)) return e;
+  NOF_ARG(mlp_params && feat && view && raw && B >= 0 && S >= 1 && L >= 1 && L * 2 == d->in_feat);
+  if (B == 0) return 0;
+  const int nl = d->n_sigma + d->n_color;
+  const size_t shm = (size_t)n_pairs(*d, nl) * 16 * 64 * elem_size(d->precision) + (size_t)n_oblk(*d, nl) * 32 * 4;
+  const int64_t ntiles = (B + 31) / 32;
+  const unsigned blocks = (unsigned)(nof_div_up(ntiles, 4) < 1024 ? nof_div_up(ntiles, 4) : 1024);
+#define LAUNCH_FWD(P, NS_, NC_, dummy)                                                                    \
+  {                                                                                                       \
+    auto kern = k_mlp_fwd<P, NS_, NC_, false>;                                                            \
+    if (int e = set_smem(kern, shm)) return e;                                                            \
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), shm, (hipStream_t)stream, *d, mlp_params,           \
+                       (const float2*)feat, (int)L, view, (int)S, raw, B);                                \
+  }
+  DISPATCH_PREC(LAUNCH_FWD, 0)
+#undef LAUNCH_FWD
+  NOF_LAUNCH_OK();
+  return 0;
+}
+
+extern "C" int nof_mlp_sdf(const NofMlpDesc* d, const float* mlp_params, const float* feat, int32_t L, float* sdf,
+                            int64_t B, void* stream) {
+  if (int e = check_desc(d)) return e;
+  NOF_ARG(mlp_params && feat && sdf && B >= 0 && L >= 1 && L * 2 == d->in_feat);
+  if (B == 0) return 0;
+  const int nl = d->n_sigma;
+  const size_t shm = (size_t)n_pairs(*d, nl) * 16 * 64 * elem_size(d->precision) + (size_t)n_oblk(*d, nl) * 32 * 4;
+  const int64_t ntiles = (B + 31) / 32;
+  const unsigned blocks = (unsigned)(nof_div_up(ntiles, 4) < 1024 ? nof_div_up(ntiles, 4) : 1024);
+#define LAUNCH_SDF(P, NS_, NC_, dummy)                                                                    \
+  {                                                                                                       \
+    auto kern = k_mlp_fwd<P, NS_, NC_, true>;                                                             \
+    if (int e = set_smem(kern, shm)) return e;                                                            \
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), shm, (hipStream_t)stream, *d, mlp_params,           \
+                       (const float2*)feat, (int)L, (const float*)nullptr, 1, sdf, B);                    \
+  }
+  DISPATCH_PREC(LAUNCH_SDF, 0)
+#undef LAUNCH_SDF
+  NOF_LAUNCH_OK();
+  return 0;
+}
+
+extern "C" int nof_mlp_bwd(const NofMlpDesc* d, const float* mlp_params, const float* feat, int32_t L, const float* view,
+                            int32_t S, const float* draw, float* dfeat, float* dview, float* partials, int64_t B,
+                            void* stream) {
+  if (int e = check_desc(d)) return e;
+  NOF_ARG(mlp_params && feat && view && draw && dfeat && dview && partials && B >= 0 && S >= 32 && L * 2 == d->in_feat);
+  const int nl = d->n_sigma + d->n_color;
+  size_t shm = 2 * (size_t)n_pairs(*d, nl) * 16 * 64 * elem_size(d->precision) + (size_t)n_oblk(*d, nl) * 32 * 4;
+  if (shm < (size_t)d->n_params * 4) shm = (size_t)d->n_params * 4;
+  const unsigned blocks = (unsigned)nof_mlp_bwd_blocks();
+#define LAUNCH_BWD(P, NS_, NC_, dummy)                                                                    \
+  {                                                                                                       \
+    auto kern = k_mlp_bwd<P, NS_, NC_>;                                                                   \
+    if (int e = set_smem(kern, shm)) return e;                                                            \
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), shm, (hipStream_t)stream, *d, mlp_params,           \
+                       (const float2*)feat, (int)L, view, (int)S, (const float4*)draw, (float2*)dfeat,    \
+                       dview, partials, B);                                                               \
+  }
+  DISPATCH_PREC(LAUNCH_BWD, 0)
+#undef LAUNCH_BWD
+  NOF_LAUNCH_OK();
+  return 0;
+}
+
+// ---- test hook: one 32x32 output tile with the operand layouts used above -----------------------------
+template <class P>
+__global__ void k_mfma_probe(const float* __restrict__ Am, const float* __restrict__ Bm, float* __restrict__ D, int K) {
+  constexpr int KR = P::KR;
+  const int lane = threadIdx.x, hi = lane >> 5, i = lane & 31;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+  for (int k0 = 0; k0 < K; k0 += 2 * KR) {
+    float a[KR], b[KR];
+#pragma unroll
+    for (int t = 0; t < KR; ++t) {
+      const int k = k0 + KR * hi + t;                                  // A[i][k] (32xK row-major), B[k][j] (Kx32 row-major)
+      a[t] = Am[i * K + k];
+      b[t] = Bm[k * 32 + i];
+    }
+    acc = P::mma(P::pack(a), P::pack(b), acc);
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) D[nloc(hi, r) * 32 + i] = acc[r];
+}
+
+extern "C" int nof_mfma_probe(int32_t precision, const float* A, const float* Bm, float* D, int32_t K, void* stream) {
+  NOF_ARG(A && Bm && D && K > 0 && K % 16 == 0 && precision >= 0 && precision <= 2);
+  if (precision == 0) hipLaunchKernelGGL(k_mfma_probe<PrecF32>, dim3(1), dim3(64), 0, (hipStream_t)stream, A, Bm, D, K);
+  else if (precision == 1) hipLaunchKernelGGL(k_mfma_probe<PrecBF16>, dim3(1), dim3(64), 0, (hipStream_t)stream, A, Bm, D, K);
+  else hipLaunchKernelGGL(k_mfma_probe<PrecF16>, dim3(1), dim3(64), 0, (hipStream_t)stream, A, Bm, D, K);
+  NOF_LAUNCH_OK();
+  return 0;
+}

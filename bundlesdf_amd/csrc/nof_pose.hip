@@ -1,0 +1,241 @@
+// Per-frame SE(3) pose corrections: forward (tanh -> se3 exp -> Delta @ c2w), analytic backward, and the
+// per-ray accumulation of dL/dDelta from point and view-direction gradients.
+//
+//   PoseArray.get_matrices            nerf_helpers.py:143-154
+//   pytorch3d se3_exp_map             (third-party; algorithm restated in oracle/nof_oracle.py:se3_exp)
+//   tf = get_matrices(frame_ids) @ c2w_array[frame_ids]      nerf_runner.py:1051-1053
+//   input_dirs = tf[:3,:3] @ viewdirs -> SHEncoder           nerf_runner.py:1282-1283, nerf_helpers.py:67-105
+// The reference leaves these gradients to autograd over ~20 eager kernels; here they are three tiny launches.
+#include "nof_common.h"
+#pragma clang fp contract(off)
+
+struct Se3 {
+  float R[9], V[9], K[9], K2[9];
+  float th, A, Bc, Cc;
+  float u[3], w[3], tanhv[6];
+  bool clamped;
+};
+
+__device__ __forceinline__ void mat3mul(const float* a, const float* b, float* c) {
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) c[i * 3 + j] = (a[i * 3] * b[j] + a[i * 3 + 1] * b[3 + j]) + a[i * 3 + 2] * b[6 + j];
+}
+
+__device__ void se3_forward(const float* xi, float max_trans, float max_rot, Se3& s) {
+#pragma unroll
+  for (int k = 0; k < 6; ++k) s.tanhv[k] = tanhf(xi[k]);
+#pragma unroll
+  for (int k = 0; k < 3; ++k) { s.u[k] = s.tanhv[k] * max_trans; s.w[k] = s.tanhv[3 + k] * max_rot; }
+  const float nrm = (s.w[0] * s.w[0] + s.w[1] * s.w[1]) + s.w[2] * s.w[2];
+  const float eps = 1e-4f;
+  s.clamped = nrm < eps;
+  s.th = sqrtf(fmaxf(nrm, eps));
+  const float K[9] = {0.f, -s.w[2], s.w[1], s.w[2], 0.f, -s.w[0], -s.w[1], s.w[0], 0.f};
+#pragma unroll
+  for (int k = 0; k < 9; ++k) s.K[k] = K[k];
+  mat3mul(s.K, s.K, s.K2);
+  const float th = s.th, sn = sinf(th), cs = cosf(th);
+  s.A = sn / th;
+  s.Bc = (1.0f - cs) / (th * th);
+  s.Cc = (th - sn) / (th * th * th);
+#pragma unroll
+  for (int k = 0; k < 9; ++k) {
+    const float e = (k == 0 || k == 4 || k == 8) ? 1.0f : 0.0f;
+    s.R[k] = (s.A * s.K[k] + s.Bc * s.K2[k]) + e;
+    s.V[k] = (e + s.Bc * s.K[k]) + s.Cc * s.K2[k];
+  }
+}
+
+__global__ void k_pose_fwd(const float* __restrict__ pose, const float* __restrict__ c2w, float max_trans, float max_rot,
+                           float* __restrict__ tf, int F) {
+  const int f = blockIdx.x * blockDim.x + threadIdx.x;
+  if (f >= F) return;
+  const float* M = c2w + (size_t)f * 16;
+  float D[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+  if (pose != nullptr && f != 0) {                                     // frame 0 is the anchor (nerf_helpers.py:151-153)
+    Se3 s;
+    se3_forward(pose + (size_t)f * 6, max_trans, max_rot, s);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+#pragma unroll
+      for (int j = 0; j < 3; ++j) D[i * 4 + j] = s.R[i * 3 + j];
+      D[i * 4 + 3] = (s.V[i * 3] * s.u[0] + s.V[i * 3 + 1] * s.u[1]) + s.V[i * 3 + 2] * s.u[2];
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      tf[(size_t)f * 12 + i * 4 + j] =
+          ((D[i * 4] * M[j] + D[i * 4 + 1] * M[4 + j]) + D[i * 4 + 2] * M[8 + j]) + D[i * 4 + 3] * M[12 + j];
+}
+
+__global__ void k_pose_bwd(const float* __restrict__ pose, const float* __restrict__ g_delta, float max_trans,
+                           float max_rot, float* __restrict__ grad_pose, int F) {
+  const int f = blockIdx.x * blockDim.x + threadIdx.x;
+  if (f >= F || f == 0) return;
+  Se3 s;
+  se3_forward(pose + (size_t)f * 6, max_trans, max_rot, s);
+  const float* G = g_delta + (size_t)f * 12;
+  float GR[9], Gt[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+#pragma unroll
+    for (int j = 0; j < 3; ++j) GR[i * 3 + j] = G[i * 4 + j];
+    Gt[i] = G[i * 4 + 3];
+  }
+  float gu[3], GV[9];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) gu[j] = (s.V[j] * Gt[0] + s.V[3 + j] * Gt[1]) + s.V[6 + j] * Gt[2];   // V^T Gt
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) GV[i * 3 + j] = Gt[i] * s.u[j];
+  float gA = 0.f, gB = 0.f, gC = 0.f;
+#pragma unroll
+  for (int k = 0; k < 9; ++k) {
+    gA += GR[k] * s.K[k];
+    gB += GR[k] * s.K2[k] + GV[k] * s.K[k];
+    gC += GV[k] * s.K2[k];
+  }
+  float GK2[9], GK[9], Kt[9], t1[9], t2[9];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) GK2[k] = s.Bc * GR[k] + s.Cc * GV[k];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) Kt[i * 3 + j] = s.K[j * 3 + i];
+  mat3mul(GK2, Kt, t1);                                               // d(K K)/dK : G Kt + Kt G
+  mat3mul(Kt, GK2, t2);
+#pragma unroll
+  for (int k = 0; k < 9; ++k) GK[k] = (s.A * GR[k] + s.Bc * GV[k]) + (t1[k] + t2[k]);
+  float gw[3] = {GK[7] - GK[5], GK[2] - GK[6], GK[3] - GK[1]};
+  if (!s.clamped) {
+    const float th = s.th, sn = sinf(th), cs = cosf(th);
+    const float dA = (th * cs - sn) / (th * th);
+    const float dB = (th * sn - 2.0f * (1.0f - cs)) / (th * th * th);
+    const float dC = ((1.0f - cs) * th - 3.0f * (th - sn)) / (th * th * th * th);
+    const float gth = (gA * dA + gB * dB) + gC * dC;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) gw[k] += gth * s.w[k] / th;
+  }
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    grad_pose[(size_t)f * 6 + k] += gu[k] * max_trans * (1.0f - s.tanhv[k] * s.tanhv[k]);
+    grad_pose[(size_t)f * 6 + 3 + k] += gw[k] * max_rot * (1.0f - s.tanhv[3 + k] * s.tanhv[3 + k]);
+  }
+}
+
+__device__ __forceinline__ float wave_sum_p(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// one wave per ray: G += g (x) [q,1] over the ray's samples, q = c2w (rays_d z) (the point BEFORE the correction),
+// plus the view-direction path through the SH Jacobian.
+__global__ __launch_bounds__(64) void k_pose_grad_accum(const float* __restrict__ dpts, const float* __restrict__ dview,
+                                                         const float* __restrict__ batch, const float* __restrict__ z_vals,
+                                                         const float* __restrict__ c2w, const float* __restrict__ tf, int ff,
+                                                         int sh_degree, int64_t R, int S, float* __restrict__ g_delta,
+                                                         float* __restrict__ grad_feat) {
+  const int64_t r = blockIdx.x;
+  const int lane = threadIdx.x;
+  const float* row = batch + r * NOF_RAY_COLS;
+  const int f = (int)row[8];
+  if (grad_feat != nullptr && lane < ff) atomicAdd(&grad_feat[(size_t)f * ff + lane], dview[r * NOF_VIEW_COLS + lane]);
+  if (f == 0 || g_delta == nullptr) return;
+  const float* M = c2w + (size_t)f * 16;
+  const float dx = row[0], dy = row[1], dz = row[2];
+  float G[12];
+#pragma unroll
+  for (int k = 0; k < 12; ++k) G[k] = 0.0f;
+  if (dpts != nullptr) {
+    for (int s = lane; s < S; s += 64) {
+      const int64_t b = r * S + s;
+      const float z = z_vals[b];
+      const float px = dx * z, py = dy * z, pz = dz * z;
+      float q[3];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) q[k] = ((M[k * 4] * px + M[k * 4 + 1] * py) + M[k * 4 + 2] * pz) + M[k * 4 + 3];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        const float g = dpts[b * 3 + i];
+        G[i * 4 + 0] += g * q[0];
+        G[i * 4 + 1] += g * q[1];
+        G[i * 4 + 2] += g * q[2];
+        G[i * 4 + 3] += g;
+      }
+    }
+  }
+  if (lane == 0 && dview != nullptr && sh_degree > 1) {
+    // world view dir d = tf_R v ; dL/dd through SH (nerf_helpers.py:72-85), then dL/dDelta_R += g (x) (c2w_R v)
+    const float nrm = sqrtf(dx * dx + dy * dy + dz * dz);
+    const float v[3] = {dx / nrm, dy / nrm, dz / nrm};
+    const float* T = tf + (size_t)f * 12;
+    float d[3], cv[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      d[k] = (T[k * 4] * v[0] + T[k * 4 + 1] * v[1]) + T[k * 4 + 2] * v[2];
+      cv[k] = (M[k * 4] * v[0] + M[k * 4 + 1] * v[1]) + M[k * 4 + 2] * v[2];
+    }
+    const float* gs = dview + r * NOF_VIEW_COLS + ff;
+    const float x = d[0], y = d[1], z = d[2];
+    const float C1 = 0.4886025119029199f;
+    float gx = -C1 * gs[3], gy = -C1 * gs[1], gz = C1 * gs[2];
+    if (sh_degree > 2) {
+      const float a0 = 1.0925484305920792f, a1 = -1.0925484305920792f, a2 = 0.31539156525252005f,
+                  a3 = -1.0925484305920792f, a4 = 0.5462742152960396f;
+      gx += gs[4] * a0 * y + gs[6] * a2 * (-2.0f * x) + gs[7] * a3 * z + gs[8] * a4 * (2.0f * x);
+      gy += gs[4] * a0 * x + gs[5] * a1 * z + gs[6] * a2 * (-2.0f * y) + gs[8] * a4 * (-2.0f * y);
+      gz += gs[5] * a1 * y + gs[6] * a2 * (4.0f * z) + gs[7] * a3 * x;
+    }
+    const float gd[3] = {gx, gy, gz};
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      G[i * 4 + 0] += gd[i] * cv[0];
+      G[i * 4 + 1] += gd[i] * cv[1];
+      G[i * 4 + 2] += gd[i] * cv[2];
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 12; ++k) {
+    const float t = wave_sum_p(G[k]);
+    if (lane == 0) atomicAdd(&g_delta[(size_t)f * 12 + k], t);
+  }
+}
+
+extern "C" int nof_pose_fwd(const float* pose_data, const float* c2w, float max_trans, float max_rot_rad, float* tf,
+                             int32_t F, void* stream) {
+  NOF_ARG(c2w && tf && F >= 0);
+  if (F == 0) return 0;
+  hipLaunchKernelGGL(k_pose_fwd, dim3((unsigned)nof_div_up(F, 64)), dim3(64), 0, (hipStream_t)stream, pose_data, c2w,
+                     max_trans, max_rot_rad, tf, F);
+  NOF_LAUNCH_OK();
+  return 0;
+}
+
+extern "C" int nof_pose_bwd(const float* pose_data, const float* g_delta, float max_trans, float max_rot_rad,
+                             float* grad_pose, int32_t F, void* stream) {
+  NOF_ARG(pose_data && g_delta && grad_pose && F >= 0);
+  if (F == 0) return 0;
+  hipLaunchKernelGGL(k_pose_bwd, dim3((unsigned)nof_div_up(F, 64)), dim3(64), 0, (hipStream_t)stream, pose_data, g_delta,
+                     max_trans, max_rot_rad, grad_pose, F);
+  NOF_LAUNCH_OK();
+  return 0;
+}
+
+extern "C" int nof_pose_grad_accum(const float* dpts, const float* dview, const float* batch, const float* z_vals,
+                                    const float* c2w, const float* tf, int32_t ff, int32_t sh_degree, int64_t R, int32_t S,
+                                    float* g_delta, float* grad_feat, void* stream) {
+  NOF_ARG(batch && z_vals && c2w && tf && R >= 0 && S >= 1 && ff >= 0 && ff <= NOF_VIEW_COLS);
+  NOF_ARG(sh_degree >= 1 && sh_degree <= 3);
+  NOF_ARG(ff == 0 || grad_feat == nullptr || dview != nullptr);
+  if (R == 0) return 0;
+  hipLaunchKernelGGL(k_pose_grad_accum, dim3((unsigned)R), dim3(64), 0, (hipStream_t)stream, dpts, dview, batch, z_vals,
+                     c2w, tf, ff, sh_degree, R, S, g_delta, grad_feat);
+  NOF_LAUNCH_OK();
+  return 0;
+}

@@ -1,0 +1,443 @@
+// Occupancy grid, ray / occupied-voxel intersection, z sampling and point generation for gfx950.
+//
+// Replaces, on a dense 2^level bitfield (<= 64^3 bits = 32 KiB, L2/L1 resident):
+//   kaolin SPC octree build + unbatched_query + unbatched_raytrace      Utils.py:362-371,393,457
+//   common.postprocessOctreeRayTracing                                  common.cu:129-167
+//   common.sampleRaysUniformOccupiedVoxels                              common.cu:41-125
+//   sample_rays_uniform / sample_rays_uniform_occupied_voxels / render_rays point generation
+//                                                                       nerf_runner.py:67-87,979-1011,1044-1083,1242-1245
+// Intersection definition (shared with oracle/nof_oracle.py:trace_rays): float32 slab test per cell with
+// plane coordinates i*cs-1 (exact), t = (plane - o) * (1/d); 3-D DDA visits cells in plane-crossing order and
+// evaluates every interval from the integer cell index (never incrementally), so that a cell's [t_in,t_out]
+// is bit-identical to the brute-force slab test of the oracle.
+#include "nof_common.h"
+#pragma clang fp contract(off)
+
+#define ZERO_DIR 1e-20f
+#define MIN_LEN 1e-4f
+
+// ------------------------------------------------------------------------------------------------
+__global__ void k_occ_build(const int32_t* __restrict__ coords, int64_t P, int shift, int n, uint32_t* __restrict__ bits) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= P) return;
+  const int nmax = n << shift;
+  int x = coords[i * 3 + 0], y = coords[i * 3 + 1], z = coords[i * 3 + 2];
+  x = min(max(x, 0), nmax - 1) >> shift;
+  y = min(max(y, 0), nmax - 1) >> shift;
+  z = min(max(z, 0), nmax - 1) >> shift;
+  const uint32_t id = ((uint32_t)x * n + y) * n + z;
+  atomicOr(&bits[id >> 5], 1u << (id & 31));
+}
+
+__device__ __forceinline__ bool occ_test(const uint32_t* __restrict__ bits, int n, int x, int y, int z) {
+  const uint32_t id = ((uint32_t)x * n + y) * n + z;
+  return (bits[id >> 5] >> (id & 31)) & 1u;
+}
+
+__global__ void k_occ_query(const uint32_t* __restrict__ bits, int n, const float* __restrict__ pts,
+                            uint8_t* __restrict__ inside, int64_t N) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  int c[3];
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {                                     // kaolin quantize_points: floor(clamp(n*(x+1)/2, 0, n-1))
+    float q = (float)n * (pts[i * 3 + d] + 1.0f) / 2.0f;
+    q = fminf(fmaxf(q, 0.0f), (float)n - 1.0f);
+    c[d] = (int)floorf(q);
+  }
+  inside[i] = occ_test(bits, n, c[0], c[1], c[2]) ? 1 : 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+struct Axis {
+  float o, inv;
+  bool zero;
+  int step;
+};
+
+__device__ __forceinline__ void cell_slab(const Axis& a, int i, float cs, float& tmin, float& tmax) {
+  const float lo = (float)i * cs - 1.0f;
+  const float hi = (float)(i + 1) * cs - 1.0f;
+  if (a.zero) {
+    const bool in = (lo <= a.o) && (a.o < hi);
+    tmin = in ? -NOF_INF : NOF_INF;
+    tmax = in ? NOF_INF : -NOF_INF;
+  } else {
+    const float t0 = (lo - a.o) * a.inv;
+    const float t1 = (hi - a.o) * a.inv;
+    tmin = fminf(t0, t1);
+    tmax = fmaxf(t0, t1);
+  }
+}
+
+// Walks the occupied cells of one ray; writes at most max_hits intervals. Returns the number written.
+__device__ int trace_one(const uint32_t* __restrict__ bits, int n, const float o[3], const float d[3], int max_hits,
+                         float* __restrict__ tio, int32_t* __restrict__ cid, int* overflow) {
+  const float cs = 2.0f / (float)n;
+  Axis ax[3];
+  float tenter = 0.0f, texit = NOF_INF;
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    ax[a].o = o[a];
+    ax[a].zero = fabsf(d[a]) < ZERO_DIR;
+    ax[a].inv = ax[a].zero ? 0.0f : 1.0f / d[a];
+    ax[a].step = d[a] > 0.0f ? 1 : -1;
+    if (ax[a].zero) {
+      if (!(-1.0f <= o[a] && o[a] < 1.0f)) texit = -NOF_INF;
+    } else {
+      const float t0 = (-1.0f - o[a]) * ax[a].inv, t1 = (1.0f - o[a]) * ax[a].inv;
+      tenter = fmaxf(tenter, fminf(t0, t1));
+      texit = fminf(texit, fmaxf(t0, t1));
+    }
+  }
+  if (!(tenter <= texit)) return 0;
+  int c[3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    const float p = ax[a].zero ? o[a] : (o[a] + tenter * d[a]);
+    int i = (int)floorf((p + 1.0f) / cs);
+    i = min(max(i, 0), n - 1);
+    if (!ax[a].zero) {
+      // make the start cell consistent with the exact plane times: tmin <= tenter <= tmax
+      for (int it = 0; it < 4; ++it) {
+        float tmin, tmax;
+        cell_slab(ax[a], i, cs, tmin, tmax);
+        if (tmax < tenter && i + ax[a].step >= 0 && i + ax[a].step < n) i += ax[a].step;
+        else if (tmin > tenter && i - ax[a].step >= 0 && i - ax[a].step < n) i -= ax[a].step;
+        else break;
+      }
+    }
+    c[a] = i;
+  }
+  int nh = 0;
+  const int max_iter = 3 * n + 8;
+  for (int it = 0; it < max_iter; ++it) {
+    float tmin[3], tmax[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) cell_slab(ax[a], c[a], cs, tmin[a], tmax[a]);
+    const float tin = fmaxf(fmaxf(fmaxf(tmin[0], tmin[1]), tmin[2]), 0.0f);
+    const float tout = fminf(fminf(tmax[0], tmax[1]), tmax[2]);
+    if (tin <= tout && occ_test(bits, n, c[0], c[1], c[2])) {
+      if (tin == 0.0f || tout == 0.0f) break;                       // common.cu:140 (terminator)
+      if (!(fabsf(tout - tin) < MIN_LEN)) {                          // common.cu:142
+        if (nh < max_hits) {
+          tio[2 * nh] = tin;
+          tio[2 * nh + 1] = tout;
+          if (cid) cid[nh] = (int32_t)(((uint32_t)c[0] * n + c[1]) * n + c[2]);
+          ++nh;
+        } else {
+          *overflow = 1;
+        }
+      }
+    }
+    int a = 0;                                                        // leave through the nearest exit plane (ties: x, y, z)
+    if (tmax[1] < tmax[a]) a = 1;
+    if (tmax[2] < tmax[a]) a = 2;
+    if (ax[a].zero) break;
+    c[a] += ax[a].step;
+    if (c[a] < 0 || c[a] >= n) break;
+  }
+  return nh;
+}
+
+__global__ __launch_bounds__(64) void k_trace_rays(const uint32_t* __restrict__ bits, int n, const float* __restrict__ rays_o,
+                                                    const float* __restrict__ rays_d, int64_t R, int max_hits,
+                                                    float* __restrict__ t_in_out, int32_t* __restrict__ cell_ids,
+                                                    int32_t* __restrict__ n_hits, int32_t* __restrict__ flags) {
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= R) return;
+  const float o[3] = {rays_o[r * 3], rays_o[r * 3 + 1], rays_o[r * 3 + 2]};
+  const float d[3] = {rays_d[r * 3], rays_d[r * 3 + 1], rays_d[r * 3 + 2]};
+  float* tio = t_in_out + r * max_hits * 2;
+  int32_t* cid = cell_ids ? cell_ids + r * max_hits : nullptr;
+  int overflow = 0;
+  const int nh = trace_one(bits, n, o, d, max_hits, tio, cid, &overflow);
+  for (int k = nh; k < max_hits; ++k) {                              // zero padding = at::zeros in common.cu:158
+    tio[2 * k] = 0.0f;
+    tio[2 * k + 1] = 0.0f;
+    if (cid) cid[k] = -1;
+  }
+  n_hits[r] = nh;
+  if (overflow && flags) atomicOr(&flags[0], 1);
+}
+
+// ------------------------------------------------------------------------------------------------
+// SH of the world view direction (nerf_helpers.py:67-105), degree <= 4
+__device__ __forceinline__ void sh_eval(int degree, float x, float y, float z, float* out) {
+  out[0] = 0.28209479177387814f;
+  if (degree > 1) {
+    out[1] = -0.4886025119029199f * y;
+    out[2] = 0.4886025119029199f * z;
+    out[3] = -0.4886025119029199f * x;
+  }
+  if (degree > 2) {
+    const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+    out[4] = 1.0925484305920792f * xy;
+    out[5] = -1.0925484305920792f * yz;
+    out[6] = 0.31539156525252005f * (2.0f * zz - xx - yy);
+    out[7] = -1.0925484305920792f * xz;
+    out[8] = 0.5462742152960396f * (xx - yy);
+    if (degree > 3) {
+      out[9] = -0.5900435899266435f * y * (3.0f * xx - yy);
+      out[10] = 2.890611442640554f * xy * z;
+      out[11] = -0.4570457994644658f * y * (4.0f * zz - xx - yy);
+      out[12] = 0.3731763325901154f * z * (2.0f * zz - 3.0f * xx - 3.0f * yy);
+      out[13] = -0.4570457994644658f * x * (4.0f * zz - xx - yy);
+      out[14] = 1.445305721320277f * z * (xx - yy);
+      out[15] = -0.5900435899266435f * x * (xx - 3.0f * yy);
+    }
+  }
+}
+
+__global__ __launch_bounds__(64) void k_batch_trace(const float* __restrict__ pool, const int64_t* __restrict__ ids,
+                                                     const float* __restrict__ tf, const float* __restrict__ frame_feat, int ff,
+                                                     int sh_degree, const uint32_t* __restrict__ bits, int n, int64_t R,
+                                                     int max_hits, float* __restrict__ batch, float* __restrict__ rays_o_w,
+                                                     float* __restrict__ viewdirs_w, float* __restrict__ view,
+                                                     float* __restrict__ t_in_out, int32_t* __restrict__ cell_ids,
+                                                     int32_t* __restrict__ n_hits, int32_t* __restrict__ flags) {
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= R) return;
+  const int64_t src = ids ? ids[r] : r;
+  float row[NOF_RAY_COLS];
+#pragma unroll
+  for (int k = 0; k < NOF_RAY_COLS; ++k) {
+    row[k] = pool[src * NOF_RAY_COLS + k];
+    batch[r * NOF_RAY_COLS + k] = row[k];
+  }
+  const int f = (int)row[8];
+  const float* T = tf + (int64_t)f * 12;
+  // viewdirs = rays_d / |rays_d| (nerf_runner.py:1047); rays_o = 0 so rays_o_w = translation (:1056)
+  const float nrm = sqrtf(row[0] * row[0] + row[1] * row[1] + row[2] * row[2]);
+  const float v[3] = {row[0] / nrm, row[1] / nrm, row[2] / nrm};
+  float o[3], d[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    o[i] = T[i * 4 + 3];
+    d[i] = (T[i * 4 + 0] * v[0] + T[i * 4 + 1] * v[1]) + T[i * 4 + 2] * v[2];
+    rays_o_w[r * 3 + i] = o[i];
+    viewdirs_w[r * 3 + i] = d[i];
+  }
+  float vw[NOF_VIEW_COLS];
+#pragma unroll
+  for (int k = 0; k < NOF_VIEW_COLS; ++k) vw[k] = 0.0f;
+  float sh[16];
+  sh_eval(sh_degree, d[0], d[1], d[2], sh);
+  const int nsh = sh_degree * sh_degree;
+  for (int k = 0; k < ff; ++k) vw[k] = frame_feat[(int64_t)f * ff + k];      // [frame_features | SH] (nerf_runner.py:1270-1286)
+  for (int k = 0; k < nsh && ff + k < NOF_VIEW_COLS; ++k) vw[ff + k] = sh[k];
+#pragma unroll
+  for (int k = 0; k < NOF_VIEW_COLS; ++k) view[r * NOF_VIEW_COLS + k] = vw[k];
+
+  float* tio = t_in_out + r * max_hits * 2;
+  int32_t* cid = cell_ids ? cell_ids + r * max_hits : nullptr;
+  int overflow = 0;
+  const int nh = trace_one(bits, n, o, d, max_hits, tio, cid, &overflow);
+  for (int k = nh; k < max_hits; ++k) {
+    tio[2 * k] = 0.0f;
+    tio[2 * k + 1] = 0.0f;
+    if (cid) cid[k] = -1;
+  }
+  n_hits[r] = nh;
+  if (overflow && flags) atomicOr(&flags[0], 1);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Philox4x32-10 (Salmon et al. 2011) -> one uniform in [0,1)
+__device__ __forceinline__ float philox_uniform(uint64_t seed, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3) {
+  uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+  uint32_t x0 = c0, x1 = c1, x2 = c2, x3 = c3;
+#pragma unroll
+  for (int i = 0; i < 10; ++i) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * x0;
+    const uint64_t p1 = (uint64_t)0xCD9E8D57u * x2;
+    const uint32_t y0 = (uint32_t)(p1 >> 32) ^ x1 ^ k0;
+    const uint32_t y1 = (uint32_t)p1;
+    const uint32_t y2 = (uint32_t)(p0 >> 32) ^ x3 ^ k1;
+    const uint32_t y3 = (uint32_t)p0;
+    x0 = y0; x1 = y1; x2 = y2; x3 = y3;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  return (float)(x0 >> 8) * (1.0f / 16777216.0f);
+}
+
+__device__ __forceinline__ float lin01(int i, int N) {               // torch.linspace(0,1,N)[i] in float32
+  const float step = 1.0f / (float)(N - 1);                          // upper half: one rounding (fused), as ATen computes it
+  return (i < N / 2) ? (float)i * step : __builtin_fmaf(-step, (float)(N - 1 - i), 1.0f);
+}
+
+// sample_rays_uniform (nerf_runner.py:67-87) for one sample index
+__device__ __forceinline__ float stratified(int i, int N, float near, float far, float u) {
+  const float t = lin01(i, N);
+  const float zi = near * (1.0f - t) + far * t;
+  float lower = zi, upper = zi;
+  if (i > 0) {
+    const float tp = lin01(i - 1, N);
+    const float zp = near * (1.0f - tp) + far * tp;
+    lower = 0.5f * (zi + zp);
+  }
+  if (i < N - 1) {
+    const float tn = lin01(i + 1, N);
+    const float zn = near * (1.0f - tn) + far * tn;
+    upper = 0.5f * (zn + zi);
+  }
+  float z = lower + (upper - lower) * u;
+  return fminf(fmaxf(z, near), far);
+}
+
+// One workgroup per ray: lanes stage the (clipped) z intervals in LDS, lane 0 sums their lengths in
+// order, then every lane places its sample by the reference's sequential subtraction walk.
+__global__ void k_sample_points(NofSampleCfg cfg, const float* __restrict__ batch, const float* __restrict__ tf,
+                                const float* __restrict__ t_in_out, const int32_t* __restrict__ n_hits, int max_hits,
+                                const float* __restrict__ u_occ, const float* __restrict__ u_dep,
+                                float* __restrict__ z_vals, float* __restrict__ pts_w, uint8_t* __restrict__ valid,
+                                int32_t* __restrict__ flags) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* zin = smem;
+  float* zout = smem + max_hits;
+  __shared__ float s_total;
+  const int64_t r = blockIdx.x;
+  const int S = cfg.n_samples + cfg.n_around;
+  const float* row = batch + r * NOF_RAY_COLS;
+  const float dx = row[0], dy = row[1], dz = row[2];
+  const float depth = row[6];
+  const int f = (int)row[8];
+  const float nrm = sqrtf(dx * dx + dy * dy + dz * dz);
+  const float vz = fabsf(dz / nrm);                                   // |viewdirs_z| (nerf_runner.py:987-990)
+  const bool valid_depth = (depth >= cfg.near_sc) && (depth <= cfg.far_sc);
+  const int nh = n_hits[r];
+  for (int h = threadIdx.x; h < nh; h += blockDim.x) {
+    float zi = t_in_out[(r * max_hits + h) * 2] * vz;
+    float zo = t_in_out[(r * max_hits + h) * 2 + 1] * vz;
+    if (valid_depth && zi > 0.0f && zo > 0.0f) {                       // nerf_runner.py:995-999
+      const float cap = depth + cfg.trunc;
+      zi = fminf(fmaxf(zi, 0.0f), cap);
+      zo = fminf(fmaxf(zo, 0.0f), cap);
+    }
+    zin[h] = zi;
+    zout[h] = zo;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float tot = 0.0f;
+    for (int h = 0; h < nh; ++h) tot += zout[h] - zin[h];              // depths_lens.sum (:1002-1003), in order
+    s_total = tot;
+  }
+  __syncthreads();
+  const int s = threadIdx.x;
+  if (s >= S) return;
+  const float total = s_total;
+  float z;
+  bool occupied_mode;
+  int N, i;
+  float u;
+  if (s < cfg.n_samples) {
+    occupied_mode = true; N = cfg.n_samples; i = s;
+    u = u_occ ? u_occ[r * cfg.n_samples + i] : philox_uniform(cfg.seed, (uint32_t)r, (uint32_t)s, cfg.step, 0u);
+  } else {
+    N = cfg.n_around; i = s - cfg.n_samples;
+    occupied_mode = !valid_depth;                                       // nerf_runner.py:1072-1076
+    u = u_dep ? u_dep[r * cfg.n_around + i] : philox_uniform(cfg.seed, (uint32_t)r, (uint32_t)s, cfg.step, 0u);
+  }
+  if (!occupied_mode) {
+    const float nd = depth - cfg.trunc;                                  // nerf_runner.py:1067-1071
+    const float fd = depth + cfg.trunc * cfg.neg_trunc_ratio;
+    z = stratified(i, N, nd, fd, u);
+  } else if (nh == 0) {
+    z = 0.0f;                                                            // common.cu:54 (no box -> z_vals stays 0)
+  } else {
+    float zr = stratified(i, N, 0.0f, total, u);
+    int ib = 0;
+    for (;;) {                                                           // common.cu:56-104
+      if (ib >= nh) {
+        z = zout[nh - 1];
+        if (zr > 1e-4f && flags) atomicOr(&flags[0], 2);                // the reference would print + spin here
+        break;
+      }
+      const float bl = zout[ib] - zin[ib];
+      if (zr <= bl) { z = zin[ib] + zr; break; }
+      zr -= bl;
+      ++ib;
+    }
+  }
+  const int64_t b = r * S + s;
+  z_vals[b] = z;
+  const float px = dx * z, py = dy * z, pz = dz * z;                     // pts = rays_d * z (nerf_runner.py:1083)
+  const float* T = tf + (int64_t)f * 12;
+  bool ok = true;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {                                           // transform_pts (Utils.py:253-257)
+    const float x = ((T[k * 4 + 0] * px + T[k * 4 + 1] * py) + T[k * 4 + 2] * pz) + T[k * 4 + 3];
+    pts_w[b * 3 + k] = x;
+    ok = ok && (fabsf(x) <= 1.0f);                                         // nerf_runner.py:1245
+  }
+  valid[b] = ok ? 1 : 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+extern "C" int nof_occgrid_build(const int32_t* coords, int64_t P, int32_t max_level, int32_t level,
+                                  uint32_t* occ_bits, void* stream) {
+  NOF_ARG(occ_bits && level >= 0 && level <= 8 && max_level >= level && max_level <= 10 && P >= 0);
+  const int n = 1 << level;
+  const size_t words = ((size_t)n * n * n + 31) / 32;
+  NOF_HIP(hipMemsetAsync(occ_bits, 0, words * 4, (hipStream_t)stream));
+  if (P == 0) return 0;
+  NOF_ARG(coords);
+  hipLaunchKernelGGL(k_occ_build, dim3((unsigned)nof_div_up(P, 256)), dim3(256), 0, (hipStream_t)stream, coords, P,
+                     max_level - level, n, occ_bits);
+  NOF_LAUNCH_OK();
+  return 0;
+}
+
+extern "C" int nof_occgrid_query(const uint32_t* occ_bits, int32_t level, const float* pts, uint8_t* inside,
+                                  int64_t N, void* stream) {
+  NOF_ARG(occ_bits && pts && inside && level >= 0 && level <= 8 && N >= 0);
+  if (N == 0) return 0;
+  hipLaunchKernelGGL(k_occ_query, dim3((unsigned)nof_div_up(N, 256)), dim3(256), 0, (hipStream_t)stream, occ_bits,
+                     1 << level, pts, inside, N);
+  NOF_LAUNCH_OK();
+  return 0;
+}
+
+extern "C" int nof_trace_rays(const uint32_t* occ_bits, int32_t level, const float* rays_o, const float* rays_d, int64_t R,
+                               int32_t max_hits, float* t_in_out, int32_t* cell_ids, int32_t* n_hits, int32_t* flags,
+                               void* stream) {
+  NOF_ARG(occ_bits && rays_o && rays_d && t_in_out && n_hits && level >= 0 && level <= 8 && max_hits >= 1 && R >= 0);
+  if (R == 0) return 0;
+  hipLaunchKernelGGL(k_trace_rays, dim3((unsigned)nof_div_up(R, 64)), dim3(64), 0, (hipStream_t)stream, occ_bits,
+                     1 << level, rays_o, rays_d, R, max_hits, t_in_out, cell_ids, n_hits, flags);
+  NOF_LAUNCH_OK();
+  return 0;
+}
+
+extern "C" int nof_batch_trace(const float* pool, const int64_t* ids, const float* tf, const float* frame_feat, int32_t ff,
+                                int32_t sh_degree, const uint32_t* occ_bits, int32_t level, int64_t R, int32_t max_hits,
+                                float* batch, float* rays_o_w, float* viewdirs_w, float* view, float* t_in_out,
+                                int32_t* cell_ids, int32_t* n_hits, int32_t* flags, void* stream) {
+  NOF_ARG(pool && tf && occ_bits && batch && rays_o_w && viewdirs_w && view && t_in_out && n_hits);
+  NOF_ARG(level >= 0 && level <= 8 && max_hits >= 1 && R >= 0 && sh_degree >= 1 && sh_degree <= 4);
+  NOF_ARG(ff >= 0 && ff + sh_degree * sh_degree <= NOF_VIEW_COLS && (ff == 0 || frame_feat));
+  if (R == 0) return 0;
+  hipLaunchKernelGGL(k_batch_trace, dim3((unsigned)nof_div_up(R, 64)), dim3(64), 0, (hipStream_t)stream, pool, ids, tf,
+                     frame_feat, ff, sh_degree, occ_bits, 1 << level, R, max_hits, batch, rays_o_w, viewdirs_w, view,
+                     t_in_out, cell_ids, n_hits, flags);
+  NOF_LAUNCH_OK();
+  return 0;
+}
+
+extern "C" int nof_sample_points(const NofSampleCfg* cfg, const float* batch, const float* tf, const float* t_in_out,
+                                  const int32_t* n_hits, int64_t R, int32_t max_hits, const float* u_occ, const float* u_dep,
+                                  float* z_vals, float* pts_w, uint8_t* valid, int32_t* flags, void* stream) {
+  NOF_ARG(cfg && batch && tf && t_in_out && n_hits && z_vals && pts_w && valid && R >= 0 && max_hits >= 1);
+  NOF_ARG(cfg->n_samples >= 2 && cfg->n_around >= 0 && cfg->n_around != 1);
+  const int S = cfg->n_samples + cfg->n_around;
+  NOF_ARG(S <= 1024);
+  if (R == 0) return 0;
+  const int threads = (int)nof_div_up(S, 64) * 64;
+  const size_t shm = sizeof(float) * 2 * (size_t)max_hits;
+  hipLaunchKernelGGL(k_sample_points, dim3((unsigned)R), dim3(threads), shm, (hipStream_t)stream, *cfg, batch, tf, t_in_out,
+                     n_hits, max_hits, u_occ, u_dep, z_vals, pts_w, valid, flags);
+  NOF_LAUNCH_OK();
+  return 0;
+}

@@ -1,0 +1,195 @@
+"""ctypes binding of libnof_hip.so (include/nof_hip.h).
+
+The product path has NO fallback: if the shared library is missing or a call fails, an exception is
+raised.  Tensors are torch CUDA tensors used purely as device memory; every call is enqueued on
+torch's current stream.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libnof_hip.so')
+
+NOF_MAX_LEVELS = 16
+NOF_MAX_LAYERS = 8
+RAY_COLS = 12
+VIEW_COLS = 16
+
+
+class NofError(RuntimeError):
+    pass
+
+
+class NofHashGrid(C.Structure):
+    _fields_ = [('L', C.c_int32), ('C', C.c_int32),
+                ('scale', C.c_float * NOF_MAX_LEVELS),
+                ('resolution', C.c_uint32 * NOF_MAX_LEVELS),
+                ('offset', C.c_uint32 * NOF_MAX_LEVELS),
+                ('size', C.c_uint32 * NOF_MAX_LEVELS),
+                ('hashed', C.c_uint32 * NOF_MAX_LEVELS)]
+
+
+class NofSampleCfg(C.Structure):
+    _fields_ = [('n_samples', C.c_int32), ('n_around', C.c_int32),
+                ('near_sc', C.c_float), ('far_sc', C.c_float), ('trunc', C.c_float), ('neg_trunc_ratio', C.c_float),
+                ('seed', C.c_uint64), ('step', C.c_uint32)]
+
+
+class NofMlpDesc(C.Structure):
+    _fields_ = [('n_sigma', C.c_int32), ('n_color', C.c_int32), ('hidden', C.c_int32), ('in_feat', C.c_int32),
+                ('n_view', C.c_int32), ('geo', C.c_int32),
+                ('w_off', C.c_int32 * NOF_MAX_LAYERS), ('b_off', C.c_int32 * NOF_MAX_LAYERS),
+                ('out_dim', C.c_int32 * NOF_MAX_LAYERS), ('in_dim', C.c_int32 * NOF_MAX_LAYERS),
+                ('n_params', C.c_int32), ('precision', C.c_int32)]
+
+
+class NofLossCfg(C.Structure):
+    _fields_ = [(k, C.c_float) for k in ('trunc', 'neg_trunc_ratio', 'sdf_lambda', 'near_sc', 'far_sc', 'rgb_weight',
+                                         'fs_weight', 'trunc_weight', 'empty_weight', 'fs_sdf', 'fs_rgb_weight',
+                                         'first_frame_weight', 'grad_scale')]
+
+
+_P = C.c_void_p
+_I64, _I32, _F = C.c_int64, C.c_int32, C.c_float
+_SIGNATURES = {
+    'nof_version': ([], C.c_int),
+    'nof_hash_encode_fwd': ([C.POINTER(NofHashGrid), _P, _P, _P, _I64, _P], C.c_int),
+    'nof_hash_encode_bwd': ([C.POINTER(NofHashGrid), _P, _P, _P, _P, _P, _I64, _P], C.c_int),
+    'nof_hash_corner_indices': ([C.POINTER(NofHashGrid), _P, _P, _I64, _P], C.c_int),
+    'nof_pose_fwd': ([_P, _P, _F, _F, _P, _I32, _P], C.c_int),
+    'nof_pose_bwd': ([_P, _P, _F, _F, _P, _I32, _P], C.c_int),
+    'nof_occgrid_build': ([_P, _I64, _I32, _I32, _P, _P], C.c_int),
+    'nof_occgrid_query': ([_P, _I32, _P, _P, _I64, _P], C.c_int),
+    'nof_trace_rays': ([_P, _I32, _P, _P, _I64, _I32, _P, _P, _P, _P, _P], C.c_int),
+    'nof_batch_trace': ([_P, _P, _P, _P, _I32, _I32, _P, _I32, _I64, _I32, _P, _P, _P, _P, _P, _P, _P, _P, _P], C.c_int),
+    'nof_sample_points': ([C.POINTER(NofSampleCfg), _P, _P, _P, _P, _I64, _I32, _P, _P, _P, _P, _P, _P, _P], C.c_int),
+    'nof_mlp_fwd': ([C.POINTER(NofMlpDesc), _P, _P, _I32, _P, _I32, _P, _I64, _P], C.c_int),
+    'nof_mlp_bwd_blocks': ([], C.c_int),
+    'nof_mlp_bwd': ([C.POINTER(NofMlpDesc), _P, _P, _I32, _P, _I32, _P, _P, _P, _P, _I64, _P], C.c_int),
+    'nof_reduce_partials': ([_P, _I32, _I32, _P, _P], C.c_int),
+    'nof_mlp_sdf': ([C.POINTER(NofMlpDesc), _P, _P, _I32, _P, _I64, _P], C.c_int),
+    'nof_composite_loss': ([C.POINTER(NofLossCfg), _P, _P, _P, _P, _I64, _I32, _P, _P, _P, _P, _P], C.c_int),
+    'nof_pose_grad_accum': ([_P, _P, _P, _P, _P, _P, _I32, _I32, _I64, _I32, _P, _P, _P], C.c_int),
+    'nof_small_regs': ([_P, _P, _I32, _F, _F, _P], C.c_int),
+    'nof_adam_step': ([_P, _P, _P, _P, _I64, _I64, _F, _F, _F, _F, _F, _I32, _P], C.c_int),
+    'nof_mfma_probe': ([_I32, _P, _P, _P, _I32, _P], C.c_int),
+    'nof_sdf_grid_query': ([C.POINTER(NofHashGrid), C.POINTER(NofMlpDesc), _P, _P, _P, _I32, C.c_float * 3, C.c_float * 3,
+                            C.c_int32 * 3, _P, _P], C.c_int),
+    'nof_marching_tets_count': ([_P, C.c_int32 * 3, _F, _P, _P], C.c_int),
+    'nof_marching_tets_emit': ([_P, C.c_int32 * 3, _F, C.c_float * 3, C.c_float * 3, _P, _P, _I64, _P], C.c_int),
+}
+OPTIONAL = {'nof_sdf_grid_query', 'nof_marching_tets_count', 'nof_marching_tets_emit'}
+
+_lib = None
+
+
+def exported_symbols():
+    return sorted(_SIGNATURES) + ['nof_last_error']
+
+
+def load():
+    """dlopen libnof_hip.so; raises NofError (never falls back) when it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise NofError(f'{LIB_PATH} is missing: run `python -m bundlesdf_amd.build` (hipcc --offload-arch=gfx950). '
+                       'There is no CPU fallback for the Neural Object Field hot path.')
+    lib = C.CDLL(LIB_PATH)
+    lib.nof_last_error.restype = C.c_char_p
+    lib.nof_last_error.argtypes = []
+    for name, (args, res) in _SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError:
+            if name in OPTIONAL:
+                continue
+            raise NofError(f'{LIB_PATH} does not export {name}; rebuild it')
+        fn.argtypes = args
+        fn.restype = res
+    _lib = lib
+    return lib
+
+
+def _ptr(t):
+    if t is None:
+        return None
+    if isinstance(t, torch.Tensor):
+        assert t.is_cuda and t.is_contiguous(), 'device pointer arguments must be contiguous CUDA tensors'
+        return C.c_void_p(t.data_ptr())
+    raise TypeError(type(t))
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def call(name, *args):
+    lib = load()
+    conv = []
+    for a in args:
+        conv.append(_ptr(a) if (a is None or isinstance(a, torch.Tensor)) else a)
+    rc = getattr(lib, name)(*conv, _stream())
+    if rc != 0:
+        raise NofError(f'{name} failed with code {rc}: {lib.nof_last_error().decode()}')
+
+
+# ---------------------------------------------------------------------------------------------------
+def make_hash_grid(n_levels, level_dim, base_resolution, log2_hashmap_size, desired_resolution):
+    """Host-side level table: allocation per grid.py:110,127-134 (float64), indexing constants per
+    gridencoder.cu:154-156 evaluated in float32.  Returns (NofHashGrid, offsets int64 [L+1], n_entries)."""
+    if level_dim != 2:
+        raise NofError('feature_grid_dim must be 2')
+    if n_levels > NOF_MAX_LEVELS or n_levels < 2:
+        raise NofError(f'num_levels must be in [2,{NOF_MAX_LEVELS}]')
+    per_level_scale = np.exp2(np.log2(desired_resolution / base_resolution) / (n_levels - 1))
+    offsets, offset = [], 0
+    max_params = 2 ** log2_hashmap_size
+    for i in range(n_levels):
+        resolution = int(np.ceil(base_resolution * per_level_scale ** i))
+        params_in_level = min(max_params, (resolution + 1) ** 3)
+        params_in_level = int(np.ceil(params_in_level / 8) * 8)
+        offsets.append(offset)
+        offset += params_in_level
+    offsets.append(offset)
+    g = NofHashGrid()
+    g.L, g.C = n_levels, level_dim
+    S = np.float32(np.log2(per_level_scale))
+    for l in range(n_levels):
+        scale = np.float32(np.exp2(np.float32(np.float32(l) * S)).astype(np.float32) * np.float32(base_resolution) - np.float32(1.0))
+        res = int(np.ceil(scale)) + 1
+        size = offsets[l + 1] - offsets[l]
+        stride, d = 1, 0
+        while d < 3 and stride <= size:
+            stride *= res + 1
+            d += 1
+        g.scale[l] = float(scale)
+        g.resolution[l] = res
+        g.offset[l] = offsets[l]
+        g.size[l] = size
+        g.hashed[l] = 1 if stride > size else 0
+    return g, np.array(offsets, dtype=np.int64), int(offset), float(per_level_scale)
+
+
+def make_mlp_desc(n_sigma, n_color, in_feat, n_view, precision=1, hidden=64, geo=15):
+    """Layer table in PyTorch parameter order (NeRFSmall.parameters(): sigma_net W,b ... color_net W,b)."""
+    d = NofMlpDesc()
+    d.n_sigma, d.n_color, d.hidden, d.in_feat, d.n_view, d.geo = n_sigma, n_color, hidden, in_feat, n_view, geo
+    d.precision = precision
+    dims = []
+    for l in range(n_sigma):
+        dims.append((1 + geo if l == n_sigma - 1 else hidden, in_feat if l == 0 else hidden))
+    for l in range(n_color):
+        dims.append((3 if l == n_color - 1 else hidden, n_view + geo if l == 0 else hidden))
+    off = 0
+    for l, (o, i) in enumerate(dims):
+        d.w_off[l] = off
+        off += o * i
+        d.b_off[l] = off
+        off += o
+        d.out_dim[l], d.in_dim[l] = o, i
+    d.n_params = off
+    return d, dims

@@ -1,0 +1,175 @@
+/* libnof_hip.so -- C ABI of the MI355X (gfx950) Neural Object Field hot path.
+ *
+ * Drop-in boundary for the native operators the reference (NVlabs/BundleSDF) binds through
+ * pybind11/ATen (file:line into /root/reference):
+ *   gridencoder.grid_encode_forward / grid_encode_backward   mycuda/torch_ngp_grid_encoder/bindings.cpp:16-19,
+ *                                                            gridencoder.h:23-24, gridencoder.cu:447-502
+ *   common.sampleRaysUniformOccupiedVoxels                   mycuda/bindings.cpp:15, common.cu:107-125
+ *   common.postprocessOctreeRayTracing                       mycuda/bindings.cpp:17, common.cu:151-167
+ *   kaolin.render.spc.unbatched_raytrace (+ octree build/query)   Utils.py:362-371,393,457
+ *   pytorch3d.transforms.se3_exp_map                         nerf_helpers.py:15,150
+ *   NeRFSmall Linear/ReLU GEMMs (cuBLAS under autocast)      nerf_helpers.py:243-321, nerf_runner.py:1289-1294
+ *   raw2outputs + loss assembly (eager PyTorch)              nerf_runner.py:1132-1169,679-752, nerf_helpers.py:367-399
+ *   torch.optim.Adam + schedule                              nerf_runner.py:492-504,756-763
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless its name starts with h_ ; the caller (PyTorch) owns and
+ *     allocates every buffer, including scratch; nothing here allocates or synchronises the host;
+ *   - `stream` is a hipStream_t passed as void* (torch.cuda.current_stream().cuda_stream);
+ *   - all entry points are hipGraph-capturable (kernel launches + hipMemsetAsync only);
+ *   - return 0 on success, <0 for an argument error, >0 = hipError_t; text via nof_last_error();
+ *   - float == IEEE binary32; row-major; sample index b = ray*S + s.
+ */
+#ifndef NOF_HIP_H
+#define NOF_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NOF_MAX_LEVELS 16
+#define NOF_MAX_LAYERS 8
+#define NOF_RAY_COLS 12          /* dir 0-2, rgb 3-5, depth 6, mask 7, frame 8, type 9, near 10, far 11 (nerf_runner.py:259-300) */
+#define NOF_VIEW_COLS 16         /* per-ray view vector: [frame_features(ff) | SH(9) | 0 pad] */
+
+const char* nof_last_error(void);
+int nof_version(void);
+
+/* ---- multires hash grid (replaces gridencoder.*) --------------------------------------------- */
+typedef struct {
+  int32_t  L, C;                          /* levels, features per level (C must be 2) */
+  float    scale[NOF_MAX_LEVELS];         /* exp2f(l*S)*H-1 evaluated on the host in float32 (gridencoder.cu:155) */
+  uint32_t resolution[NOF_MAX_LEVELS];    /* ceil(scale)+1                      (gridencoder.cu:156) */
+  uint32_t offset[NOF_MAX_LEVELS];        /* first table row of the level       (grid.py:127-134) */
+  uint32_t size[NOF_MAX_LEVELS];          /* rows in the level (hashmap_size)   (gridencoder.cu:154) */
+  uint32_t hashed[NOF_MAX_LEVELS];        /* 1: fast_hash, 0: dense stride index (gridencoder.cu:66-83) */
+} NofHashGrid;
+
+/* pts_w [B,3] in [-1,1] (the module maps (x+1)/2, grid.py:160); table [rows,2]; feat [L,B,2] (level-major,
+ * the reference's own kernel layout gridencoder.cu:384).  Out-of-range points give zeros. */
+int nof_hash_encode_fwd(const NofHashGrid* h_grid, const float* pts_w, const float* table,
+                        float* feat, int64_t B, void* stream);
+/* dfeat [L,B,2]; grad_table [rows,2] is ACCUMULATED into (caller zeroes it once per step);
+ * dpts [B,3] (may be NULL) is overwritten with dL/dpts_w (kernel_input_backward, gridencoder.cu:340-365). */
+int nof_hash_encode_bwd(const NofHashGrid* h_grid, const float* pts_w, const float* table, const float* dfeat,
+                        float* grad_table, float* dpts, int64_t B, void* stream);
+/* debug/parity: the 8 absolute table rows each (point, level) touches -> idx [B,L,8] int32 (-1 if out of range) */
+int nof_hash_corner_indices(const NofHashGrid* h_grid, const float* pts_w, int32_t* idx, int64_t B, void* stream);
+
+/* ---- pose corrections (replaces PoseArray.get_matrices + pytorch3d se3_exp_map) ---------------- */
+/* pose_data [F,6] (may be NULL: identity), c2w [F,16] row-major 4x4 -> tf [F,12] = (Delta_i @ c2w_i)[:3,:4];
+ * Delta_0 = I (nerf_helpers.py:151-153).  max_rot in radians. */
+int nof_pose_fwd(const float* pose_data, const float* c2w, float max_trans, float max_rot_rad,
+                 float* tf, int32_t F, void* stream);
+/* g_delta [F,12] = dL/dDelta_i[:3,:4] -> grad_pose [F,6] ACCUMULATED (frame 0 gets 0). */
+int nof_pose_bwd(const float* pose_data, const float* g_delta, float max_trans, float max_rot_rad,
+                 float* grad_pose, int32_t F, void* stream);
+
+/* ---- occupancy grid + ray tracing (replaces the kaolin SPC octree + postprocessOctreeRayTracing) -- */
+/* coords [P,3] int32 occupied cells at max_level (already dilated/clamped, nerf_runner.py:453-465);
+ * occ_bits: ceil(n^3/32) uint32 words of the level-`level` grid, bit id = (x*n+y)*n+z, n = 2^level.
+ * The function clears and fills occ_bits. */
+int nof_occgrid_build(const int32_t* coords, int64_t P, int32_t max_level, int32_t level,
+                      uint32_t* occ_bits, void* stream);
+/* pts [N,3] -> inside [N] uint8: 1 if the level cell containing the point is occupied
+ * (OctreeManager.get_center_ids >= 0, Utils.py:392-394). */
+int nof_occgrid_query(const uint32_t* occ_bits, int32_t level, const float* pts, uint8_t* inside,
+                      int64_t N, void* stream);
+/* rays_o [R,3], rays_d [R,3] (unit, world) -> t_in_out [R,max_hits,2] zero padded, cell_ids [R,max_hits]
+ * (may be NULL), n_hits [R]; flags[0] |= 1 if any ray overflowed max_hits.
+ * Semantics = OctreeManager.ray_trace (Utils.py:443-475) + common.cu:129-149. */
+int nof_trace_rays(const uint32_t* occ_bits, int32_t level, const float* rays_o, const float* rays_d,
+                   int64_t R, int32_t max_hits, float* t_in_out, int32_t* cell_ids, int32_t* n_hits,
+                   int32_t* flags, void* stream);
+
+/* ---- one training batch: gather + ray setup + trace (render_rays nerf_runner.py:1044-1060) ------ */
+/* pool [N,12]; ids [R] int64 rows of the pool (NULL: rows 0..R-1); tf [F,12].
+ * Outputs: batch [R,12] gathered rows; rays_o_w [R,3]; viewdirs_w [R,3]; view [R,16] = [ff|SH9|0];
+ * frame_feat [F,ff] may be NULL when ff == 0. */
+int nof_batch_trace(const float* pool, const int64_t* ids, const float* tf, const float* frame_feat, int32_t ff,
+                    int32_t sh_degree, const uint32_t* occ_bits, int32_t level, int64_t R, int32_t max_hits,
+                    float* batch, float* rays_o_w, float* viewdirs_w, float* view,
+                    float* t_in_out, int32_t* cell_ids, int32_t* n_hits, int32_t* flags, void* stream);
+
+typedef struct {
+  int32_t  n_samples, n_around;           /* N_samples, N_samples_around_depth (config.yml:18-19) */
+  float    near_sc, far_sc;               /* near*sc_factor, far*sc_factor */
+  float    trunc;                         /* get_truncation() (nerf_runner.py:663-676) */
+  float    neg_trunc_ratio;
+  uint64_t seed;                          /* Philox key when u_occ/u_dep are NULL */
+  uint32_t step;                          /* Philox counter word 2 */
+} NofSampleCfg;
+/* z sampling + point generation (nerf_runner.py:979-1011,1063-1083,1242-1245; common.cu:41-105).
+ * u_occ [R,n_samples], u_dep [R,n_around] injected uniforms or NULL (Philox4x32-10).
+ * Outputs z_vals [R,S], pts_w [R*S,3], valid [R*S] uint8. */
+int nof_sample_points(const NofSampleCfg* h_cfg, const float* batch, const float* tf, const float* t_in_out,
+                      const int32_t* n_hits, int64_t R, int32_t max_hits, const float* u_occ, const float* u_dep,
+                      float* z_vals, float* pts_w, uint8_t* valid, int32_t* flags, void* stream);
+
+/* ---- SDF + colour tiny-MLPs on MFMA (replaces NeRFSmall's cuBLAS GEMMs) ------------------------ */
+typedef struct {
+  int32_t n_sigma, n_color;               /* NeRFSmall(num_layers, num_layers_color) nerf_helpers.py:244 */
+  int32_t hidden;                         /* 64 */
+  int32_t in_feat;                        /* L*C <= 32 */
+  int32_t n_view;                         /* ff + SH coeffs <= 16 */
+  int32_t geo;                            /* geo_feat_dim = 15 */
+  int32_t w_off[NOF_MAX_LAYERS];          /* float offsets of W_l [out,in] inside `mlp_params` (PyTorch parameter order) */
+  int32_t b_off[NOF_MAX_LAYERS];
+  int32_t out_dim[NOF_MAX_LAYERS], in_dim[NOF_MAX_LAYERS];
+  int32_t n_params;
+  int32_t precision;                      /* 0: fp32 MFMA (exact), 1: bf16 MFMA, 2: fp16 MFMA */
+} NofMlpDesc;
+/* feat [L,B,2]; view [R,16]; raw [B,4] = (rgb_raw[3], sdf)  (nerf_helpers.py:319). */
+int nof_mlp_fwd(const NofMlpDesc* h_desc, const float* mlp_params, const float* feat, int32_t L,
+                const float* view, int32_t S, float* raw, int64_t B, void* stream);
+/* draw [B,4] -> dfeat [L,B,2] (overwritten), dview [R,16] ACCUMULATED, partials [n_blocks, n_params]
+ * overwritten with per-workgroup weight-gradient partial sums (reduce with nof_reduce_partials).
+ * n_blocks must equal nof_mlp_bwd_blocks(). */
+int nof_mlp_bwd_blocks(void);
+int nof_mlp_bwd(const NofMlpDesc* h_desc, const float* mlp_params, const float* feat, int32_t L,
+                const float* view, int32_t S, const float* draw, float* dfeat, float* dview,
+                float* partials, int64_t B, void* stream);
+/* out[j] += sum_i partials[i,j] */
+int nof_reduce_partials(const float* partials, int32_t n_rows, int32_t n_cols, float* out, void* stream);
+/* sigma_net only: feat [L,B,2] -> sdf [B]  (NeRFSmall.forward_sdf, nerf_helpers.py:296-302) */
+int nof_mlp_sdf(const NofMlpDesc* h_desc, const float* mlp_params, const float* feat, int32_t L,
+                float* sdf, int64_t B, void* stream);
+
+/* ---- compositing + losses + dL/draw (raw2outputs, train_loop, get_sdf_loss) ---------------------- */
+typedef struct {
+  float trunc, neg_trunc_ratio, sdf_lambda;
+  float near_sc, far_sc;
+  float rgb_weight, fs_weight, trunc_weight, empty_weight, fs_sdf, fs_rgb_weight;
+  float first_frame_weight;
+  float grad_scale;                       /* multiplies every gradient (1/world_size for DP averaging) */
+} NofLossCfg;
+/* raw [R,S,4], z_vals [R,S], valid [R,S] u8, batch [R,12] ->
+ * rgb_map [R,3], weights [R,S] (may be NULL), draw [R,S,4], loss_out [8] ACCUMULATED:
+ * 0 total, 1 rgb, 2 fs(+empty), 3 sdf, 4 fs_rgb, 5 n_valid_samples, 6 n_valid_rays. */
+int nof_composite_loss(const NofLossCfg* h_cfg, const float* raw, const float* z_vals, const uint8_t* valid,
+                       const float* batch, int64_t R, int32_t S, float* rgb_map, float* weights, float* draw,
+                       float* loss_out, void* stream);
+
+/* ---- pose / feature gradients of a batch ---------------------------------------------------------- */
+/* dpts [R*S,3] (from nof_hash_encode_bwd), dview [R,16] (from nof_mlp_bwd), batch, z_vals, c2w [F,16],
+ * tf [F,12] -> g_delta [F,12] ACCUMULATED (dL/dDelta), grad_feat [F,ff] ACCUMULATED (may be NULL). */
+int nof_pose_grad_accum(const float* dpts, const float* dview, const float* batch, const float* z_vals,
+                        const float* c2w, const float* tf, int32_t ff, int32_t sh_degree, int64_t R, int32_t S,
+                        float* g_delta, float* grad_feat, void* stream);
+/* grad += 2*w*data/numel  (feature_reg, nerf_runner.py:745-747) and pose_reg (:749-752) */
+int nof_small_regs(const float* feat_data, float* grad_feat, int32_t n_feat, float feature_reg_weight,
+                   float grad_scale, void* stream);
+
+/* ---- optimiser ---------------------------------------------------------------------------------- */
+/* torch.optim.Adam(betas, eps=1e-15, weight_decay=0) over the flat buffer; entries [0,n_basic) use lr,
+ * [n_basic,n) use lr_pose (param groups nerf_runner.py:498-500).  step is 1-based.  Grads are zeroed. */
+int nof_adam_step(float* params, float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, int64_t n_basic,
+                  float lr, float lr_pose, float beta1, float beta2, float eps, int32_t step, void* stream);
+
+/* ---- test hook: raw MFMA tile  D[32,32] = A[32,K] * B[K,32] with the operand layouts nof_mlp uses ---- */
+int nof_mfma_probe(int32_t precision, const float* A, const float* Bm, float* D, int32_t K, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

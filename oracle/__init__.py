@@ -1,0 +1,23 @@
+"""CPU oracle for the Neural Object Field hot path -- TEST INFRASTRUCTURE ONLY.
+
+This package is a CPU restatement (PyTorch fp32 + NumPy + a small C library) of the
+reference algorithm on the path named by BASELINE.json:north_star.  Every function
+cites the reference file:line it follows.
+
+Rules (enforced by tests/test_no_oracle_in_product.py):
+  * only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg
+    may import anything from here -- and there only as the checker, never as the thing
+    being measured or shipped;
+  * nothing under ``bundlesdf_amd/`` imports it; the product fails loudly when the HIP
+    extension is missing.
+
+Pinning status (see DESIGN.md "Oracle"):
+  * NeRFSmall, SHEncoder, raw2outputs, get_sdf_loss/get_masks, sample_rays_uniform,
+    ray_box_intersection_batch, get_camera_rays_np, get_truncation and the train_loop
+    loss assembly are PINNED against outputs of the reference's own pure-PyTorch code
+    executed on CPU (tests/golden/make_golden.py -> tests/golden/*.npz).
+  * the multires hash encoder (CUDA only in the reference), the kaolin octree ray
+    tracer and pytorch3d's se3_exp_map are third-party/CUDA code that cannot run here:
+    for those the oracle is a restatement of the published algorithm and parity is
+    UNPINNED ("parity unpinned": the reference holds no golden vectors for them).
+"""

@@ -1,0 +1,399 @@
+"""Operator-level parity: every C-ABI entry point of libnof_hip.so against the CPU oracle (oracle/nof_oracle.py)
+on seeded inputs.  Bit-exact for index / interval / z work, stated tolerances for floating point."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import nof_oracle as O
+from tests import util as U
+
+pytestmark = pytest.mark.gpu
+
+
+def cpu(t):
+    return t.detach().cpu().numpy()
+
+
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("precision,K,tol", [(0, 32, 1e-5), (1, 64, 2e-2), (2, 64, 2e-3)])
+def test_mfma_operand_layout(nof, precision, K, tol):
+    """A[32,K] @ B[K,32] through the exact operand / accumulator layouts nof_mlp uses (asymmetric inputs)."""
+    rng = np.random.default_rng(precision)
+    A = rng.normal(size=(32, K)).astype(np.float32)
+    Bm = rng.normal(size=(K, 32)).astype(np.float32)
+    D = torch.zeros(32, 32, device='cuda')
+    nof.call('nof_mfma_probe', precision, U.dev(A), U.dev(Bm), D, K)
+    torch.cuda.synchronize()
+    ref = A.astype(np.float64) @ Bm.astype(np.float64)
+    err = np.abs(cpu(D) - ref).max() / np.abs(ref).max()
+    assert err < tol, err
+
+
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("L,T,finest", [(16, 14, 256), (4, 22, 128), (16, 19, 512)])
+def test_hash_forward_backward(nof, L, T, finest):
+    g, geo = U.make_grids(nof, L=L, T=T, finest=finest)
+    B = 3000
+    pts = U.test_points(B, seed=L)
+    torch.manual_seed(0)
+    table = (torch.rand(geo.n_entries, 2) * 2 - 1) * 0.1
+    d_pts, d_table = U.dev(pts), table.cuda()
+    feat = torch.empty(L, B, 2, device='cuda')
+    nof.call('nof_hash_encode_fwd', C.byref(g), d_pts, d_table, feat, B)
+    idx = torch.empty(B, L, 8, dtype=torch.int32, device='cuda')
+    nof.call('nof_hash_corner_indices', C.byref(g), d_pts, idx, B)
+    torch.cuda.synchronize()
+
+    # integer part: bit-exact table rows
+    x01 = ((pts + np.float32(1.0)) * np.float32(0.5)).astype(np.float32)
+    oob = ((x01 < 0) | (x01 > 1)).any(-1)
+    ref_idx = O.hash_corner_indices(x01, geo)
+    got_idx = cpu(idx).astype(np.int64)
+    assert (got_idx[oob] == -1).all()
+    assert np.array_equal(got_idx[~oob], ref_idx[~oob])
+
+    # floating point part
+    tp = torch.from_numpy(pts).requires_grad_(True)
+    tt = table.clone().requires_grad_(True)
+    ref = O.hash_encode((tp + 1) / 2, tt, geo)
+    got = cpu(feat).transpose(1, 0, 2).reshape(B, L * 2)
+    assert np.abs(got - ref.detach().numpy()).max() < 2e-6
+    assert (got[oob] == 0).all()
+
+    # backward: table grads (atomic scatter) and input grads
+    torch.manual_seed(1)
+    dy = torch.randn(B, L * 2)
+    ref.backward(dy)
+    dfeat = dy.reshape(B, L, 2).permute(1, 0, 2).contiguous().cuda()
+    gtab = torch.zeros(geo.n_entries, 2, device='cuda')
+    dpts = torch.full((B, 3), 7.0, device='cuda')
+    nof.call('nof_hash_encode_bwd', C.byref(g), d_pts, d_table, dfeat, gtab, dpts, B)
+    torch.cuda.synchronize()
+    gt_ref = tt.grad.numpy()
+    assert np.abs(cpu(gtab) - gt_ref).max() < 1e-4 * max(1.0, np.abs(gt_ref).max())
+    dp_ref = tp.grad.numpy()
+    assert np.abs(cpu(dpts) - dp_ref).max() < 2e-4 * max(1.0, np.abs(dp_ref).max())
+
+
+# ------------------------------------------------------------------------------------------------
+def test_pose_forward_backward(nof):
+    F = 9
+    rng = np.random.default_rng(3)
+    pose = rng.normal(size=(F, 6)).astype(np.float32) * 0.8
+    pose[1] = 0.0                       # |w|^2 below the 1e-4 clamp
+    pose[2, 3:] = 1e-3
+    c2w = np.tile(np.eye(4, dtype=np.float32), (F, 1, 1))
+    for f in range(F):
+        q, _ = np.linalg.qr(rng.normal(size=(3, 3)))
+        c2w[f, :3, :3] = q
+        c2w[f, :3, 3] = rng.normal(size=3)
+    mt, mr = 0.105, 20.0
+    tf = torch.empty(F, 12, device='cuda')
+    nof.call('nof_pose_fwd', U.dev(pose), U.dev(c2w.reshape(F, 16)), C.c_float(mt), C.c_float(mr / 180 * np.pi), tf, F)
+    tp = torch.from_numpy(pose).requires_grad_(True)
+    Ts = O.pose_matrices(tp, mt, mr)
+    ref = (Ts @ torch.from_numpy(c2w))[:, :3, :4]
+    torch.cuda.synchronize()
+    assert np.abs(cpu(tf).reshape(F, 3, 4) - ref.detach().numpy()).max() < 2e-6
+    G = torch.from_numpy(rng.normal(size=(F, 3, 4)).astype(np.float32))
+    (Ts[:, :3, :4] * G).sum().backward()
+    gp = torch.zeros(F, 6, device='cuda')
+    nof.call('nof_pose_bwd', U.dev(pose), G.reshape(F, 12).cuda().contiguous(), C.c_float(mt), C.c_float(mr / 180 * np.pi), gp, F)
+    torch.cuda.synchronize()
+    ref_g = tp.grad.numpy()
+    assert np.abs(cpu(gp) - ref_g).max() < 2e-4 * max(1.0, np.abs(ref_g).max())
+    assert (cpu(gp)[0] == 0).all()
+
+
+# ------------------------------------------------------------------------------------------------
+def _build_occ(nof, occ, level):
+    n = occ.shape[0]
+    bits = torch.zeros((n ** 3 + 31) // 32, dtype=torch.int32, device='cuda')
+    coords = U.dev(U.occ_to_coords(occ))
+    nof.call('nof_occgrid_build', coords, coords.shape[0], level, level, bits)
+    return bits
+
+
+@pytest.mark.parametrize("level,fill", [(4, 0.15), (5, 0.05), (3, 0.5), (6, 0.02)])
+def test_trace_bit_identical(nof, level, fill):
+    n = 1 << level
+    occ = U.random_occ(n, fill, seed=level)
+    bits = _build_occ(nof, occ, level)
+    R = 600
+    o, d = U.random_rays(R, seed=level)
+    # axis aligned / diagonal / grazing / inside-origin rays (SURVEY 8c golden list)
+    o[0], d[0] = [-3, 0.01, 0.02], [1, 0, 0]
+    o[1], d[1] = [0.3, 3, -0.2], [0, -1, 0]
+    o[2], d[2] = [-2, -2, -2], np.array([1, 1, 1]) / np.sqrt(3)
+    o[3], d[3] = [-3, 1.0, 0.0], [1, 0, 0]                      # grazing the +y face
+    o[4], d[4] = [0.01, 0.02, 0.03], [0, 0, 1]                  # origin inside the cube
+    o[5], d[5] = [-3, 0.5, 0.5], [1, 0, 0]                      # along a cell boundary plane
+    o[6], d[6] = [3, 3, 3], [1, 0, 0]                           # misses everything
+    o, d = o.astype(np.float32), d.astype(np.float32)
+    H = 3 * n + 2
+    tio = torch.empty(R, H, 2, device='cuda')
+    cid = torch.empty(R, H, dtype=torch.int32, device='cuda')
+    nh = torch.empty(R, dtype=torch.int32, device='cuda')
+    flags = torch.zeros(4, dtype=torch.int32, device='cuda')
+    nof.call('nof_trace_rays', bits, level, U.dev(o), U.dev(d), R, H, tio, cid, nh, flags)
+    torch.cuda.synchronize()
+    r_tio, r_cid, r_nh = O.trace_rays(occ, o, d, max_hits=H)
+    assert cpu(flags)[0] == 0
+    assert np.array_equal(cpu(nh), r_nh)
+    assert np.array_equal(cpu(cid), r_cid)                       # bit-identical ray-hit indices
+    assert np.array_equal(cpu(tio).view(np.uint32), r_tio.view(np.uint32))   # bit-identical intervals
+    # occupancy query
+    q = np.random.default_rng(0).uniform(-1.1, 1.1, size=(5000, 3)).astype(np.float32)
+    inside = torch.empty(5000, dtype=torch.uint8, device='cuda')
+    nof.call('nof_occgrid_query', bits, level, U.dev(q), inside, 5000)
+    torch.cuda.synchronize()
+    qi = np.floor(np.clip(n * (q + 1.0) / 2.0, 0, n - 1.0)).astype(np.int64)
+    assert np.array_equal(cpu(inside).astype(bool), occ[qi[:, 0], qi[:, 1], qi[:, 2]])
+
+
+def _scene(nof, R=300, level=4, seed=0, n_frames=5):
+    """Random occupancy + camera-like rays with depths; returns everything the sampler needs."""
+    rng = np.random.default_rng(seed)
+    n = 1 << level
+    occ = np.zeros((n, n, n), bool)
+    c = (np.indices((n, n, n)).transpose(1, 2, 3, 0) + 0.5) / n * 2 - 1
+    occ[np.linalg.norm(c, axis=-1) < 0.55] = True
+    cfg = O.default_cfg(sc_factor=5.0, N_samples=64, N_samples_around_depth=32, far=1.0, num_levels=16,
+                        log2_hashmap_size=14, finest_res=256)
+    F = n_frames
+    c2w = np.tile(np.eye(4, dtype=np.float32), (F, 1, 1))
+    for f in range(F):
+        pos = rng.normal(size=3)
+        pos = pos / np.linalg.norm(pos) * 3.0
+        zax = pos / np.linalg.norm(pos)                              # GL camera looks along -z
+        xax = np.cross([0, 0, 1.0], zax)
+        xax /= np.linalg.norm(xax)
+        yax = np.cross(zax, xax)
+        c2w[f, :3, 0], c2w[f, :3, 1], c2w[f, :3, 2], c2w[f, :3, 3] = xax, yax, zax, pos
+    batch = np.zeros((R, 12), np.float32)
+    batch[:, 0] = rng.uniform(-0.2, 0.2, R)
+    batch[:, 1] = rng.uniform(-0.2, 0.2, R)
+    batch[:, 2] = -1.0
+    batch[:, 3:6] = rng.uniform(0, 1, (R, 3))
+    batch[:, 6] = rng.uniform(2.4, 3.2, R)                          # depth (normalised units)
+    batch[:, 7] = 1
+    batch[:, 8] = rng.integers(0, F, R)
+    batch[::7, 6] = 99 * cfg['sc_factor']                           # BAD_DEPTH rays (type stays 0: uncertain free space)
+    batch[5::11, 9] = 1
+    batch[:, 10], batch[:, 11] = 1.0, 5.0
+    return cfg, occ, c2w, batch
+
+
+def test_sample_points_bit_identical(nof):
+    level = 4
+    cfg, occ, c2w, batch = _scene(nof, level=level)
+    R, F = batch.shape[0], c2w.shape[0]
+    bits = _build_occ(nof, occ, level)
+    rng = np.random.default_rng(1)
+    pose = (rng.normal(size=(F, 6)) * 0.3).astype(np.float32)
+    mt, mr = cfg['max_trans'] * cfg['sc_factor'], cfg['max_rot']
+    tf = torch.empty(F, 12, device='cuda')
+    nof.call('nof_pose_fwd', U.dev(pose), U.dev(c2w.reshape(F, 16)), C.c_float(mt), C.c_float(mr / 180 * np.pi), tf, F)
+    H = 3 * (1 << level) + 2
+    d_batch = torch.empty(R, 12, device='cuda')
+    o_w = torch.empty(R, 3, device='cuda')
+    d_w = torch.empty(R, 3, device='cuda')
+    view = torch.empty(R, 16, device='cuda')
+    tio = torch.empty(R, H, 2, device='cuda')
+    cid = torch.empty(R, H, dtype=torch.int32, device='cuda')
+    nh = torch.empty(R, dtype=torch.int32, device='cuda')
+    flags = torch.zeros(4, dtype=torch.int32, device='cuda')
+    ids = torch.arange(R, device='cuda').flip(0).contiguous()
+    nof.call('nof_batch_trace', U.dev(batch), ids, tf, None, 0, 3, bits, level, R, H, d_batch, o_w, d_w, view, tio, cid,
+             nh, flags)
+    torch.cuda.synchronize()
+    bb = batch[::-1].copy()
+    assert np.array_equal(cpu(d_batch), bb)
+    # ray setup vs oracle (fp tolerance), trace vs oracle on the SAME o,d (bit-exact)
+    field = O.OracleField(cfg, O.HashGeometry(16, 2, 16, 14, 256), O.FieldShape(), F, c2w, occ, pose=pose)
+    Ns, Na = cfg['N_samples'], cfg['N_samples_around_depth']
+    u_occ = rng.random((R, Ns)).astype(np.float32)
+    u_dep = rng.random((R, Na)).astype(np.float32)
+    z_ref, tr = field.trace_and_sample(torch.from_numpy(bb), u_occ, u_dep)
+    assert np.abs(cpu(o_w) - tr['rays_o_w'].numpy()).max() < 1e-5
+    assert np.abs(cpu(d_w) - tr['viewdirs_w'].numpy()).max() < 1e-6
+    sh_ref = O.sh_encode(tr['viewdirs_w'], 3).numpy()
+    assert np.abs(cpu(view)[:, :9] - sh_ref).max() < 1e-5 and (cpu(view)[:, 9:] == 0).all()
+    r_tio, r_cid, r_nh = O.trace_rays(occ, cpu(o_w), cpu(d_w), max_hits=H)
+    assert np.array_equal(cpu(nh), r_nh) and np.array_equal(cpu(cid), r_cid)
+    assert np.array_equal(cpu(tio).view(np.uint32), r_tio.view(np.uint32))
+
+    trunc = O.get_truncation(cfg, 0)
+    sc = nof.NofSampleCfg(Ns, Na, cfg['near'] * cfg['sc_factor'], cfg['far'] * cfg['sc_factor'], trunc,
+                          cfg['neg_trunc_ratio'], 1234, 0)
+    S = Ns + Na
+    z = torch.empty(R, S, device='cuda')
+    pts = torch.empty(R * S, 3, device='cuda')
+    valid = torch.empty(R * S, dtype=torch.uint8, device='cuda')
+    nof.call('nof_sample_points', C.byref(sc), d_batch, tf, tio, nh, R, H, U.dev(u_occ), U.dev(u_dep), z, pts, valid, flags)
+    torch.cuda.synchronize()
+    assert cpu(flags)[0] == 0
+    # z from the oracle sampler fed with the GPU's own (bit-identical) intervals
+    z_same = O.sample_z(r_tio, (bb[:, 2] / np.sqrt((bb[:, :3] ** 2).sum(-1, dtype=np.float32))).astype(np.float32),
+                        bb[:, 6], cfg, trunc, u_occ, u_dep)
+    assert np.array_equal(cpu(z).view(np.uint32), z_same.view(np.uint32))          # bit-identical z samples
+    assert np.abs(cpu(z) - z_ref.numpy()).max() < 1e-4
+    # points + validity
+    with torch.no_grad():
+        fw = field.forward(torch.from_numpy(bb), torch.from_numpy(cpu(z)))
+    assert np.abs(cpu(pts).reshape(R, S, 3) - fw['pts_w'].numpy()).max() < 1e-5
+    v_ref = fw['valid_samples'].numpy().reshape(-1)
+    assert (cpu(valid).astype(bool) != v_ref).mean() < 1e-3
+    # Philox path: in range, deterministic, different per step
+    z1 = torch.empty_like(z); z2 = torch.empty_like(z); z3 = torch.empty_like(z)
+    nof.call('nof_sample_points', C.byref(sc), d_batch, tf, tio, nh, R, H, None, None, z1, pts, valid, flags)
+    nof.call('nof_sample_points', C.byref(sc), d_batch, tf, tio, nh, R, H, None, None, z2, pts, valid, flags)
+    sc.step = 1
+    nof.call('nof_sample_points', C.byref(sc), d_batch, tf, tio, nh, R, H, None, None, z3, pts, valid, flags)
+    torch.cuda.synchronize()
+    assert torch.equal(z1, z2) and not torch.equal(z1, z3)
+    has = cpu(nh) > 0
+    assert np.isfinite(cpu(z1)).all() and (cpu(z1)[has] > 0).all()
+
+
+# ------------------------------------------------------------------------------------------------
+def _mlp_setup(nof, ns, nc, ff, L, precision, seed=0):
+    torch.manual_seed(seed)
+    n_view = 9 + ff
+    shape = O.FieldShape(input_ch=2 * L, input_ch_views=n_view, num_layers=ns, num_layers_color=nc)
+    params = O.init_mlp_params(shape)
+    for W, b in params:                                  # make biases / weights less tame than the default init
+        b.add_(torch.randn_like(b) * 0.1)
+    desc, dims = nof.make_mlp_desc(ns, nc, 2 * L, n_view, precision)
+    flat = torch.cat([torch.cat([W.reshape(-1), b.reshape(-1)]) for W, b in params])
+    assert flat.numel() == desc.n_params == shape.n_params()
+    return shape, params, desc, flat
+
+
+TOL = {0: 2e-5, 1: 3e-2, 2: 4e-3}
+
+
+@pytest.mark.parametrize("ns,nc,ff,L", [(2, 3, 0, 16), (3, 2, 2, 16), (2, 3, 2, 4), (2, 2, 0, 16), (3, 3, 0, 16)])
+@pytest.mark.parametrize("precision", [0, 1, 2])
+def test_mlp_forward(nof, ns, nc, ff, L, precision):
+    shape, params, desc, flat = _mlp_setup(nof, ns, nc, ff, L, precision)
+    R, S = 37, 40
+    B = R * S                                            # not a multiple of 32: exercises the tail tile
+    torch.manual_seed(5)
+    feat = torch.randn(B, 2 * L) * 0.5
+    view = torch.zeros(R, 16)
+    view[:, :9 + ff] = torch.randn(R, 9 + ff)
+    x = torch.cat([feat, view[:, :9 + ff].repeat_interleave(S, 0)], -1)
+    ref = O.mlp_forward(shape, params, x).detach().numpy()
+    d_feat = feat.reshape(B, L, 2).permute(1, 0, 2).contiguous().cuda()
+    raw = torch.zeros(B, 4, device='cuda')
+    nof.call('nof_mlp_fwd', C.byref(desc), flat.cuda(), d_feat, L, view.cuda(), S, raw, B)
+    sdf = torch.zeros(B, device='cuda')
+    nof.call('nof_mlp_sdf', C.byref(desc), flat.cuda(), d_feat, L, sdf, B)
+    torch.cuda.synchronize()
+    scale = np.abs(ref).max()
+    assert np.abs(cpu(raw) - ref).max() / scale < TOL[precision]
+    assert np.abs(cpu(sdf) - ref[:, 3]).max() / scale < TOL[precision]
+
+
+@pytest.mark.parametrize("ns,nc,ff,L", [(2, 3, 0, 16), (3, 2, 2, 16), (2, 3, 2, 4)])
+@pytest.mark.parametrize("precision", [0, 1, 2])
+def test_mlp_backward(nof, ns, nc, ff, L, precision):
+    shape, params, desc, flat = _mlp_setup(nof, ns, nc, ff, L, precision, seed=2)
+    R, S = 21, 48                                        # S not a multiple of 32: tiles straddle rays
+    B = R * S
+    torch.manual_seed(6)
+    feat = (torch.randn(B, 2 * L) * 0.5).requires_grad_(True)
+    view_t = torch.randn(R, 9 + ff).requires_grad_(True)
+    ps = [[W.clone().requires_grad_(True), b.clone().requires_grad_(True)] for W, b in params]
+    x = torch.cat([feat, view_t.repeat_interleave(S, 0)], -1)
+    out = O.mlp_forward(shape, ps, x)
+    draw = torch.randn(B, 4)
+    (out * draw).sum().backward()
+    view = torch.zeros(R, 16)
+    view[:, :9 + ff] = view_t.detach()
+    d_feat = feat.detach().reshape(B, L, 2).permute(1, 0, 2).contiguous().cuda()
+    nblk = nof.load().nof_mlp_bwd_blocks()
+    dfeat = torch.full((L, B, 2), 3.0, device='cuda')
+    dview = torch.zeros(R, 16, device='cuda')
+    partials = torch.full((nblk, desc.n_params), 5.0, device='cuda')
+    nof.call('nof_mlp_bwd', C.byref(desc), flat.cuda(), d_feat, L, view.cuda(), S, draw.cuda(), dfeat, dview, partials, B)
+    gflat = torch.zeros(desc.n_params, device='cuda')
+    nof.call('nof_reduce_partials', partials, nblk, desc.n_params, gflat)
+    torch.cuda.synchronize()
+    tol = TOL[precision] * 2
+    ref_df = feat.grad.numpy()
+    got_df = cpu(dfeat).transpose(1, 0, 2).reshape(B, 2 * L)
+    assert np.abs(got_df - ref_df).max() / np.abs(ref_df).max() < tol
+    ref_dv = view_t.grad.numpy()
+    assert np.abs(cpu(dview)[:, :9 + ff] - ref_dv).max() / np.abs(ref_dv).max() < tol
+    assert (cpu(dview)[:, 9 + ff:] == 0).all()
+    ref_g = torch.cat([torch.cat([W.grad.reshape(-1), b.grad.reshape(-1)]) for W, b in ps]).numpy()
+    got_g = cpu(gflat)
+    for l in range(ns + nc):                             # per layer so that a small layer cannot hide behind a big one
+        lo, hi = desc.w_off[l], desc.b_off[l] + desc.out_dim[l]
+        assert np.abs(got_g[lo:hi] - ref_g[lo:hi]).max() / np.abs(ref_g[lo:hi]).max() < tol, f'layer {l}'
+
+
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("fs_rgb", [0.0, 0.5])
+def test_composite_loss(nof, fs_rgb):
+    cfg, occ, c2w, batch = _scene(nof, R=200)
+    cfg['fs_rgb_weight'] = fs_rgb
+    R = batch.shape[0]
+    S = 96
+    rng = np.random.default_rng(4)
+    trunc = O.get_truncation(cfg, 0)
+    depth = batch[:, 6:7]
+    z = (np.where(depth > 50, 2.8, depth) + rng.uniform(-3 * trunc, 3 * trunc, (R, S))).astype(np.float32)
+    raw = torch.from_numpy(rng.normal(size=(R, S, 4)).astype(np.float32) * 1.5).requires_grad_(True)
+    valid = torch.from_numpy(rng.random((R, S)) > 0.1)
+    valid[3] = False
+    tb = torch.from_numpy(batch)
+    rgb_map, w = O.raw2outputs(raw, torch.from_numpy(z), tb[:, 6], valid, cfg, trunc)
+    out = O.losses(rgb_map, raw, torch.from_numpy(z), valid, tb, cfg, trunc)
+    out['loss'].backward()
+    lc = nof.NofLossCfg(trunc, cfg['neg_trunc_ratio'], cfg['sdf_lambda'], cfg['near'] * cfg['sc_factor'],
+                        cfg['far'] * cfg['sc_factor'], cfg['rgb_weight'], cfg['fs_weight'], cfg['trunc_weight'],
+                        cfg['empty_weight'], cfg['fs_sdf'], cfg['fs_rgb_weight'], cfg['first_frame_weight'], 1.0)
+    g_rgb = torch.empty(R, 3, device='cuda')
+    g_w = torch.empty(R, S, device='cuda')
+    g_draw = torch.empty(R, S, 4, device='cuda')
+    g_loss = torch.zeros(8, device='cuda')
+    nof.call('nof_composite_loss', C.byref(lc), raw.detach().cuda(), U.dev(z), valid.to(torch.uint8).cuda(), tb.cuda(),
+             R, S, g_rgb, g_w, g_draw, g_loss)
+    torch.cuda.synchronize()
+    assert np.abs(cpu(g_rgb) - rgb_map.detach().numpy()).max() < 2e-6
+    assert np.abs(cpu(g_w) - w.detach().numpy()).max() < 2e-6
+    ref_d = raw.grad.numpy()
+    assert np.abs(cpu(g_draw) - ref_d).max() < 1e-5 * np.abs(ref_d).max() + 1e-9
+    L = cpu(g_loss)
+    assert abs(L[0] - out['loss'].item()) < 1e-4 * abs(out['loss'].item())
+    assert abs(L[1] - out['rgb_loss'].item()) < 1e-4 * abs(out['rgb_loss'].item()) + 1e-9
+    assert abs(L[2] - out['fs_loss'].item()) < 1e-4 * abs(out['fs_loss'].item()) + 1e-9
+    assert abs(L[3] - out['sdf_loss'].item()) < 1e-4 * abs(out['sdf_loss'].item()) + 1e-9
+
+
+# ------------------------------------------------------------------------------------------------
+def test_adam_matches_torch(nof):
+    n, nb = 10000, 9000
+    torch.manual_seed(0)
+    p0 = torch.randn(n)
+    pa = p0[:nb].clone().requires_grad_(True)
+    pb = p0[nb:].clone().requires_grad_(True)
+    opt = torch.optim.Adam([{'params': [pa], 'lr': 0.01}, {'params': [pb], 'lr': 0.003}], betas=(0.9, 0.999), eps=1e-15)
+    p, m, v = p0.clone().cuda(), torch.zeros(n, device='cuda'), torch.zeros(n, device='cuda')
+    for step in range(1, 6):
+        g = torch.randn(n) * (10.0 ** -step)
+        g[::5] = 0
+        pa.grad, pb.grad = g[:nb].clone(), g[nb:].clone()
+        opt.step()
+        gd = g.clone().cuda()
+        nof.call('nof_adam_step', p, gd, m, v, n, nb, C.c_float(0.01), C.c_float(0.003), C.c_float(0.9), C.c_float(0.999),
+                 C.c_float(1e-15), step)
+        torch.cuda.synchronize()
+        assert (gd == 0).all()
+        ref = torch.cat([pa.detach(), pb.detach()]).numpy()
+        assert np.abs(cpu(p) - ref).max() < 2e-6
