@@ -1,0 +1,235 @@
+#!/usr/bin/env python
+"""Benchmark of the Neural Object Field hot path on MI355X.
+
+    python bench.py [--gpus N --steps K --warmup W]          (N > 1: launched by torch.distributed.run, one rank per GPU)
+
+A step = one full train_loop iteration (batch draw -> occupancy trace -> z sampling -> hash encode -> SDF/colour MLPs ->
+compositing + losses -> backward -> [RCCL gradient all-reduce] -> Adam) over a synthetic 640x480 RGBD keyframe pool
+resident in HBM.  Workload = BASELINE.json configs[1]: 64 keyframes per GPU, 4096 rays/step, hash L=16 T=2^19 (base 16
+-> finest 256), SDF-MLP 3x64 + colour-MLP 2x64, bf16 MFMA, 128+64 samples per ray.  Prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+MFMA_BF16_PEAK_TF = 2500.0     # dense bf16 MFMA
+
+
+def workload_cfg(args):
+    from bundlesdf_amd.config import default_cfg
+    return default_cfg(n_step=100000, N_rand=args.rays, num_levels=16, log2_hashmap_size=args.log2_T, finest_res=256,
+                       base_res=16, N_samples=128, N_samples_around_depth=64, far=1.0, frame_features=0,
+                       save_octree_clouds=False, i_print=10 ** 9, i_weights=10 ** 9)
+
+
+def build_runner(args, rank, world, device):
+    import torch.distributed as dist
+    from bundlesdf_amd import synthetic
+    from bundlesdf_amd.nerf_runner import NerfRunner
+    F_local = args.keyframes
+    pool = synthetic.make_pool(n_frames=F_local, H=args.height, W=args.width, fx=600.0 * args.width / 640.0, seed=0,
+                               frame_offset=rank * F_local, n_total=F_local * world, analytic_bounds=True)
+    cfg = workload_cfg(args)
+    cfg.update(sc_factor=pool['sc_factor'], translation=pool['translation'])
+    poses, cloud = pool['poses'], pool['pcd_normalized']
+    if world > 1:               # identical pose table and octree cloud on every rank
+        p = torch.from_numpy(poses).to(device)
+        ps = [torch.empty_like(p) for _ in range(world)]
+        dist.all_gather(ps, p)
+        poses = torch.cat(ps, 0).cpu().numpy()
+        c = torch.from_numpy(cloud).to(device)
+        cs = [torch.empty_like(c) for _ in range(world)]
+        dist.all_gather(cs, c)
+        cloud = torch.cat(cs, 0).cpu().numpy()
+    sync = None
+    if world > 1:
+        def sync(flat):
+            dist.all_reduce(flat)           # RCCL sum; gradients are pre-scaled by 1/world_size
+    ns, nc = (3, 2) if args.mlp == 'baseline' else (2, 3)
+    runner = NerfRunner(cfg, pool['rgbs'], depths=pool['depths'], masks=pool['masks'], normal_maps=None, poses=poses,
+                        K=pool['K'], build_octree_pcd=synthetic.PointCloud(cloud), precision=args.precision, n_sigma=ns,
+                        n_color=nc, world_size=world, rank=rank, grad_sync=sync, frame_offset=rank * F_local)
+    return runner, cfg
+
+
+def cpu_baseline(seconds=20.0):
+    """The oracle (CPU PyTorch fp32 restatement of nerf_runner's step) on BASELINE.json configs[0]: 4 keyframes
+    640x480, 1024 rays/step, L=16 T=2^14, MLP 2x64 -- timed on this box's host cores."""
+    from bundlesdf_amd import synthetic
+    from bundlesdf_amd.config import default_cfg
+    from bundlesdf_amd.rays import make_frame_rays
+    from oracle import nof_oracle as O
+    ncores = os.cpu_count() or 1
+    torch.set_num_threads(ncores)
+    pool = synthetic.make_pool(n_frames=4, H=480, W=640, seed=0, analytic_bounds=True)
+    cfg = default_cfg(n_step=500, N_rand=1024, num_levels=16, log2_hashmap_size=14, finest_res=256, base_res=16,
+                      N_samples=128, N_samples_around_depth=64, far=1.0, sc_factor=pool['sc_factor'],
+                      translation=pool['translation'], use_octree=1)
+    occ, occ_l, max_level, level = O.build_occupancy(pool['pcd_normalized'], cfg)
+
+    def trace_fn(o, d):
+        return O.trace_rays(occ_l, o, d)[2] > 0
+    rows = []
+    for f in range(4):
+        r = make_frame_rays(f, pool['rgbs'][f], pool['depths'][f], pool['masks'][f], pool['poses'][f], pool['K'], cfg)
+        sel = np.random.default_rng(f).choice(len(r), size=min(len(r), 4096), replace=False)
+        r = r[sel]
+        o = np.tile(pool['poses'][f][:3, 3], (len(r), 1)).astype(np.float32)
+        unit = r[:, :3] / np.linalg.norm(r[:, :3], axis=-1, keepdims=True)
+        d = (pool['poses'][f][:3, :3] @ unit.T).T.astype(np.float32)
+        rows.append(r[trace_fn(o, d)])
+    rays = np.concatenate(rows, 0).astype(np.float32)
+    torch.manual_seed(0)
+    geo = O.HashGeometry(16, 2, 16, 14, 256)
+    field = O.OracleField(cfg, geo, O.FieldShape(), 4, pool['poses'], occ_l)
+    rng = np.random.default_rng(0)
+    R, S = 1024, 192
+    times = []
+    t_start = time.time()
+    it = 0
+    while True:
+        ids = rng.choice(len(rays), size=R, replace=False)
+        u1, u2 = rng.random((R, 128)).astype(np.float32), rng.random((R, 64)).astype(np.float32)
+        t0 = time.time()
+        field.train_step(rays[ids], u1, u2)
+        dt = time.time() - t0
+        if it >= 1:
+            times.append(dt)
+        it += 1
+        if (time.time() - t_start > seconds and len(times) >= 3) or len(times) >= 20:
+            break
+    med = float(np.median(times))
+    return {"value": R * S / med, "unit": "ray-samples/s", "cores": ncores, "kind": "port",
+            "iters_per_s": 1.0 / med,
+            "sample": f"{len(times)} timed steps (1 warm-up) of oracle/nof_oracle.py OracleField.train_step, cfg1: 4 keyframes "
+                      f"640x480, 1024 rays x 192 samples, L=16 T=2^14, MLP 2x64+3x64 fp32, torch threads={ncores}"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=200)
+    ap.add_argument('--warmup', type=int, default=20)
+    ap.add_argument('--keyframes', type=int, default=64)
+    ap.add_argument('--rays', type=int, default=4096)
+    ap.add_argument('--log2_T', type=int, default=19)
+    ap.add_argument('--height', type=int, default=480)
+    ap.add_argument('--width', type=int, default=640)
+    ap.add_argument('--precision', default='bf16', choices=['bf16', 'fp16', 'fp32'])
+    ap.add_argument('--mlp', default='baseline', choices=['baseline', 'reference'],
+                    help='baseline: SDF 3x64 + colour 2x64 (BASELINE.json cfg2); reference: NeRFSmall(2,3) nerf_runner.py:221')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-seconds', type=float, default=20.0)
+    args = ap.parse_args()
+
+    import torch.distributed as dist
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs an MI355X (no CPU fallback for the product path)')
+    torch.cuda.set_device(local_rank)
+    device = torch.device('cuda', local_rank)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', device_id=device)
+    assert world == args.gpus or world == 1, f'--gpus {args.gpus} but WORLD_SIZE={world}'
+
+    runner, cfg = build_runner(args, rank, world, device)
+    fld = runner.field
+    R, S = args.rays, cfg['N_samples'] + cfg['N_samples_around_depth']
+    B = R * S
+
+    # ---- warm-up with every launch bracketed by events: finds the dominant kernel --------------------------------
+    fld.profile = {}
+    for _ in range(args.warmup):
+        runner.train_loop()
+        runner.global_step += 1
+    torch.cuda.synchronize()
+    ktimes = fld.kernel_times_ms()
+    dominant = max(ktimes, key=ktimes.get) if ktimes else None
+    fld.profile = {dominant: []} if dominant else None          # timed region: only the dominant kernel keeps its events
+    fld.profile_only = dominant
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        runner.train_loop()
+        runner.global_step += 1
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    dom_ms = fld.kernel_times_ms().get(dominant) if dominant else None
+    flags = int(fld.flags[0].item())
+    losses = fld.losses()
+
+    if rank == 0:
+        ms = dt / args.steps * 1e3
+        it_s = args.steps / dt
+        value = world * B * it_s
+        # algorithmic work per launch of each kernel (DESIGN.md "Kernels")
+        n_mlp = fld.n_mlp
+        fl_fwd = 2.0 * (n_mlp - sum(o for o, _ in fld.layer_dims))      # 2*MAC per sample
+        work = {
+            'nof_hash_encode_fwd': ('hbm', B * (16 * 8 * 2 * 4 + 12 + 16 * 2 * 4)),
+            'nof_hash_encode_bwd': ('hbm', B * (16 * 2 * 4 + 2 * 16 * 8 * 2 * 4 + 12 + 16 * 8 * 2 * 4 + 12)),
+            'nof_mlp_fwd': ('mfma', B * fl_fwd),
+            'nof_mlp_bwd': ('mfma', B * 3.0 * fl_fwd),
+            'nof_adam_step': ('hbm', fld.n_total * 32.0),
+        }
+        roof = None
+        if dominant in work and dom_ms:
+            kind, amount = work[dominant]
+            if kind == 'hbm':
+                ach = amount / (dom_ms * 1e-3) / 1e9
+                roof = {"kernel": dominant, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": ach / HBM_PEAK_GBS, "traffic": None, "avg_ms": dom_ms}
+            else:
+                ach = amount / (dom_ms * 1e-3) / 1e12
+                roof = {"kernel": dominant, "bound": "mfma", "achieved": ach, "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s",
+                        "frac": ach / MFMA_BF16_PEAK_TF, "traffic": None, "avg_ms": dom_ms}
+        elif dominant:
+            roof = {"kernel": dominant, "bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None,
+                    "traffic": None, "avg_ms": dom_ms}
+        out = {
+            "metric": "ray_samples_per_sec", "value": value, "unit": "ray-samples/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": args.precision, "data": "synthetic",
+            "config": {"workload": f"cfg2: {args.keyframes} synthetic {args.width}x{args.height} RGBD keyframes per GPU, "
+                                   f"{R} rays/step x {S} samples, hash L=16 T=2^{args.log2_T} base16->256, "
+                                   f"MLP {'SDF 3x64 + colour 2x64' if args.mlp == 'baseline' else 'SDF 2x64 + colour 3x64'}, "
+                                   f"{args.precision} MFMA, fp32 table/Adam",
+                       "rays_per_step": R, "samples_per_ray": S, "keyframes_per_gpu": args.keyframes,
+                       "pool_rays": int(runner.rays.shape[0]), "parallelism": f"dp{world}"},
+            "train_iters_per_sec": it_s * 1.0,
+            "kernel_ms_warmup": {k: round(v, 4) for k, v in sorted(ktimes.items(), key=lambda kv: -kv[1])},
+            "loss": losses['loss'], "flags": flags,
+            "roofline": roof,
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

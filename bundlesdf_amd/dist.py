@@ -1,0 +1,51 @@
+"""Data-parallel plumbing: one process per GPU, torch.distributed ('nccl' == RCCL over xGMI on ROCm; 'gloo' in the CPU
+tests).  Keyframes are sharded by rank; the hash table, MLPs, the FULL pose/feature arrays and the occupancy grid are
+replicated.  Each rank draws N_rand rays from its own pool, so the global batch is world*N_rand; every loss term is a
+mean over rays/samples, hence gradients are pre-scaled by 1/world on the device (NofLossCfg.grad_scale) and SUMMED here:
+the result equals one process stepping on the concatenated batch.  There is exactly one collective per step: an
+all-reduce of the flat gradient buffer [table | MLP | features | poses]."""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(device=None):
+    """(rank, world, local_rank) from the torchrun environment; initialises the process group when world > 1."""
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        if device is not None and device.type == 'cuda':
+            dist.init_process_group('nccl', device_id=device)
+        else:
+            dist.init_process_group('gloo')
+    return rank, world, local_rank
+
+
+def all_gather_cat(t):
+    """concatenate equally-shaped tensors of all ranks along dim 0 (identical result on every rank)."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return t
+    parts = [torch.empty_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(parts, t.contiguous())
+    return torch.cat(parts, 0)
+
+
+def make_grad_sync():
+    """hook for NeuralObjectField.train_step: sum the (pre-scaled) flat gradients of all ranks."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return None
+
+    def sync(flat):
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+    return sync
+
+
+def shard_frames(n_total, rank, world):
+    """contiguous keyframe shard [lo, hi) of this rank."""
+    per = (n_total + world - 1) // world
+    lo = min(rank * per, n_total)
+    return lo, min(lo + per, n_total)

@@ -1,0 +1,285 @@
+"""NeuralObjectField: device-resident state of the Neural Object Field and one optimisation step through the
+C ABI of libnof_hip.so.  PyTorch is used for device memory, streams and torch.distributed only.
+
+HBM layout (all float32, one flat buffer each for params / grads / Adam m / Adam v so that the optimiser is a single
+streaming pass and the data-parallel gradient exchange is a single all-reduce):
+
+    [ hash table rows*2 | MLP (PyTorch parameter order) | frame features F*ff | pose corrections F*6 ]
+      `------------------------- param group 'basic' -------------------------' `--- 'pose_array' ---'
+
+Step (train_loop nerf_runner.py:679-763), 11 launches, no host synchronisation:
+    pose_fwd -> batch_trace -> sample_points -> hash_fwd -> mlp_fwd -> composite_loss -> mlp_bwd -> reduce_partials
+    -> hash_bwd -> pose_grad_accum -> pose_bwd (+small_regs) -> [all-reduce] -> adam
+"""
+import ctypes as C
+import math
+
+import numpy as np
+import torch
+
+from . import lib
+
+PRECISIONS = {'fp32': 0, 'bf16': 1, 'fp16': 2}
+
+
+class NeuralObjectField:
+    def __init__(self, cfg, n_frames, c2w, device='cuda', precision='bf16', n_sigma=2, n_color=3, seed_init=True,
+                 world_size=1, rank=0):
+        lib.load()
+        self.cfg = cfg
+        self.device = torch.device(device)
+        self.F = int(n_frames)
+        self.ff = int(cfg.get('frame_features', 0))
+        self.sh_degree = int(cfg['multires_views'])
+        self.n_view = self.ff + self.sh_degree ** 2
+        self.world_size, self.rank = world_size, rank
+        self.grid, self.offsets, self.n_entries, self.per_level_scale = lib.make_hash_grid(
+            cfg['num_levels'], cfg['feature_grid_dim'], cfg['base_res'], cfg['log2_hashmap_size'], cfg['finest_res'])
+        self.L = int(cfg['num_levels'])
+        self.desc, self.layer_dims = lib.make_mlp_desc(n_sigma, n_color, 2 * self.L, self.n_view,
+                                                       PRECISIONS[precision] if isinstance(precision, str) else precision)
+        self.n_sigma, self.n_color = n_sigma, n_color
+        self.optimize_poses = bool(cfg.get('optimize_poses', 1))
+        self.n_table = self.n_entries * 2
+        self.n_mlp = self.desc.n_params
+        self.n_feat = self.F * self.ff
+        self.n_pose = self.F * 6 if self.optimize_poses else 0
+        self.n_basic = self.n_table + self.n_mlp + self.n_feat
+        self.n_total = self.n_basic + self.n_pose
+        self.max_trans = float(cfg['max_trans'] * cfg['sc_factor'])
+        self.max_rot = float(cfg['max_rot'] / 180.0 * np.pi)
+        dev = self.device
+        self.params = torch.zeros(self.n_total, device=dev)
+        self.grads = torch.zeros(self.n_total, device=dev)
+        self.exp_avg = torch.zeros(self.n_total, device=dev)
+        self.exp_avg_sq = torch.zeros(self.n_total, device=dev)
+        self.c2w = torch.as_tensor(np.asarray(c2w, dtype=np.float32)).reshape(self.F, 16).to(dev).contiguous()
+        self.tf = torch.zeros(self.F, 12, device=dev)
+        self.g_delta = torch.zeros(self.F, 12, device=dev)
+        self.loss_out = torch.zeros(8, device=dev)
+        self.flags = torch.zeros(4, dtype=torch.int32, device=dev)
+        self.occ_bits = None
+        self.level = None
+        self.global_step = 0
+        self.N_iters = cfg['n_step'] + 1
+        self._bufs = {}
+        self.nblk = lib.load().nof_mlp_bwd_blocks()
+        self.profile = None          # dict name -> [(start_event, end_event)] when per-kernel timing is on (bench.py)
+        self.profile_only = None
+        if seed_init:
+            self.init_parameters()
+
+    # ---- per-kernel timing with events on the launch stream -------------------------------------
+    def _call(self, name, *args):
+        prof = self.profile
+        if prof is None or (self.profile_only is not None and name != self.profile_only):
+            return lib.call(name, *args)
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        lib.call(name, *args)
+        b.record()
+        prof.setdefault(name, []).append((a, b))
+
+    def kernel_times_ms(self):
+        """average launch duration per C-ABI entry point (ms); all launches go to torch's current stream, which is
+        also the stream the events are recorded on."""
+        if not self.profile:
+            return {}
+        torch.cuda.synchronize()
+        return {k: float(np.mean([a.elapsed_time(b) for a, b in v])) for k, v in self.profile.items() if v}
+
+    # ---- views into the flat buffers ------------------------------------------------------------
+    def _seg(self, buf, which):
+        a = {'table': 0, 'mlp': self.n_table, 'feat': self.n_table + self.n_mlp, 'pose': self.n_basic}[which]
+        n = {'table': self.n_table, 'mlp': self.n_mlp, 'feat': self.n_feat, 'pose': self.n_pose}[which]
+        return buf[a:a + n]
+
+    table = property(lambda s: s._seg(s.params, 'table'))
+    mlp = property(lambda s: s._seg(s.params, 'mlp'))
+    feat = property(lambda s: s._seg(s.params, 'feat'))
+    pose = property(lambda s: s._seg(s.params, 'pose'))
+
+    def init_parameters(self):
+        """Same initialisers, in the same order, on the torch CPU generator as create_nerf (nerf_runner.py:204-242):
+        GridEncoder U(-1e-4,1e-4) (grid.py:146-148), NeRFSmall's nn.Linear defaults with the SDF bias at 0.1
+        (nerf_helpers.py:267-272,290), FeatureArray N(0,1) (:119), PoseArray zeros (:139)."""
+        table = torch.empty(self.n_entries, 2).uniform_(-1e-4, 1e-4)
+        chunks = []
+        for l, (o, i) in enumerate(self.layer_dims):
+            lin = torch.nn.Linear(i, o, bias=True)
+            if l == self.n_sigma - 1:
+                torch.nn.init.constant_(lin.bias, 0.1)
+            chunks += [lin.weight.detach().reshape(-1), lin.bias.detach().reshape(-1)]
+        # NOTE: nn.init.constant_ consumes no random numbers, so doing it inline keeps the stream identical.
+        mlp = torch.cat(chunks)
+        self.load_parameters(table=table, mlp=mlp,
+                             feat=torch.normal(0, 1, size=[self.F, self.ff]).float() if self.ff > 0 else None,
+                             pose=torch.zeros(self.F, 6) if self.optimize_poses else None)
+
+    def load_parameters(self, table=None, mlp=None, feat=None, pose=None):
+        for name, val in (('table', table), ('mlp', mlp), ('feat', feat), ('pose', pose)):
+            if val is not None:
+                seg = self._seg(self.params, name)
+                seg.copy_(torch.as_tensor(val, dtype=torch.float32).reshape(-1).to(self.device))
+
+    def mlp_state(self):
+        """[(W [out,in], b [out])] views on the host (PyTorch state_dict order)."""
+        flat = self.mlp.detach().cpu()
+        out = []
+        for l, (o, i) in enumerate(self.layer_dims):
+            W = flat[self.desc.w_off[l]:self.desc.w_off[l] + o * i].reshape(o, i)
+            b = flat[self.desc.b_off[l]:self.desc.b_off[l] + o]
+            out.append((W, b))
+        return out
+
+    # ---- occupancy ---------------------------------------------------------------------------------
+    def set_occupancy(self, coords_max_level, max_level, level):
+        """coords [P,3] int occupied cells at max_level (dilated) -> bitfield of the ray-tracing level."""
+        n = 1 << level
+        self.level, self.max_level = int(level), int(max_level)
+        self.occ_bits = torch.zeros((n ** 3 + 31) // 32, dtype=torch.int32, device=self.device)
+        coords = torch.as_tensor(np.ascontiguousarray(coords_max_level, dtype=np.int32)).to(self.device)
+        lib.call('nof_occgrid_build', coords, coords.shape[0], max_level, level, self.occ_bits)
+        self.max_hits = 3 * n + 2
+
+    def trace(self, rays_o, rays_d, want_cells=False):
+        R = rays_o.shape[0]
+        tio = torch.empty(R, self.max_hits, 2, device=self.device)
+        nh = torch.empty(R, dtype=torch.int32, device=self.device)
+        cid = torch.empty(R, self.max_hits, dtype=torch.int32, device=self.device) if want_cells else None
+        lib.call('nof_trace_rays', self.occ_bits, self.level, rays_o.contiguous(), rays_d.contiguous(), R, self.max_hits,
+                 tio, cid, nh, self.flags)
+        return tio, cid, nh
+
+    # ---- schedules ---------------------------------------------------------------------------------
+    def truncation(self):
+        """get_truncation (nerf_runner.py:663-676)."""
+        cfg = self.cfg
+        kind = cfg.get('trunc_decay_type', '')
+        if kind == 'linear':
+            t = cfg['trunc_start'] - (cfg['trunc_start'] - cfg['trunc']) * float(self.global_step) / cfg['n_step']
+        elif kind == 'exp':
+            lamb = np.log(cfg['trunc'] / cfg['trunc_start']) / (cfg['n_step'] / 4)
+            t = max(cfg['trunc_start'] * np.exp(self.global_step * lamb), cfg['trunc'])
+        else:
+            t = cfg['trunc']
+        return float(t * cfg['sc_factor'])
+
+    def learning_rates(self):
+        """schedule_lr is applied after steps g with g % 10 == 0, g > 0 (nerf_runner.py:762-763,579-583); so the step
+        with index s uses the rate set at the last such g < s."""
+        s = self.global_step
+        g = 0 if s <= 10 else ((s - 1) // 10) * 10
+        k = 1.0 if g == 0 else self.cfg['decay_rate'] ** (float(g) / self.N_iters)
+        return self.cfg['lrate'] * k, self.cfg['lrate_pose'] * k
+
+    # ---- buffers --------------------------------------------------------------------------------------
+    def _buffers(self, R, S):
+        key = (R, S)
+        if key not in self._bufs:
+            d, B = self.device, R * S
+            e = lambda *s, dt=torch.float32: torch.empty(*s, dtype=dt, device=d)
+            self._bufs[key] = dict(
+                batch=e(R, 12), rays_o_w=e(R, 3), viewdirs_w=e(R, 3), view=e(R, 16), t_in_out=e(R, self.max_hits, 2),
+                n_hits=e(R, dt=torch.int32), z_vals=e(R, S), pts_w=e(B, 3), valid=e(B, dt=torch.uint8),
+                feat=e(self.L, B, 2), raw=e(B, 4), draw=e(B, 4), dfeat=e(self.L, B, 2), dview=e(R, 16), dpts=e(B, 3),
+                rgb_map=e(R, 3), partials=e(self.nblk, self.n_mlp))
+        return self._bufs[key]
+
+    def _sample_cfg(self, seed, step):
+        cfg = self.cfg
+        return lib.NofSampleCfg(cfg['N_samples'], cfg['N_samples_around_depth'], cfg['near'] * cfg['sc_factor'],
+                                cfg['far'] * cfg['sc_factor'], self.truncation(), cfg['neg_trunc_ratio'], seed, step)
+
+    def _loss_cfg(self):
+        cfg = self.cfg
+        return lib.NofLossCfg(self.truncation(), cfg['neg_trunc_ratio'], cfg['sdf_lambda'], cfg['near'] * cfg['sc_factor'],
+                              cfg['far'] * cfg['sc_factor'], cfg['rgb_weight'], cfg['fs_weight'], cfg['trunc_weight'],
+                              cfg['empty_weight'], cfg['fs_sdf'], cfg.get('fs_rgb_weight', 0), cfg['first_frame_weight'],
+                              1.0 / self.world_size)
+
+    # ---- forward pieces -----------------------------------------------------------------------------------
+    def update_poses(self):
+        self._call('nof_pose_fwd', self.pose if self.optimize_poses else None, self.c2w, C.c_float(self.max_trans),
+                 C.c_float(self.max_rot), self.tf, self.F)
+
+    def forward_batch(self, pool, ids, R, u_occ=None, u_dep=None, seed=0, want_cells=False):
+        """render_rays up to raw (nerf_runner.py:1044-1088); returns the buffer dict."""
+        cfg = self.cfg
+        S = cfg['N_samples'] + cfg['N_samples_around_depth']
+        b = self._buffers(R, S)
+        self.update_poses()
+        cid = None
+        if want_cells:
+            cid = b.setdefault('cell_ids', torch.empty(R, self.max_hits, dtype=torch.int32, device=self.device))
+        self._call('nof_batch_trace', pool, ids, self.tf, self.feat if self.ff > 0 else None, self.ff, self.sh_degree,
+                 self.occ_bits, self.level, R, self.max_hits, b['batch'], b['rays_o_w'], b['viewdirs_w'], b['view'],
+                 b['t_in_out'], cid, b['n_hits'], self.flags)
+        sc = self._sample_cfg(seed, self.global_step)
+        self._call('nof_sample_points', C.byref(sc), b['batch'], self.tf, b['t_in_out'], b['n_hits'], R, self.max_hits,
+                 u_occ, u_dep, b['z_vals'], b['pts_w'], b['valid'], self.flags)
+        B = R * S
+        self._call('nof_hash_encode_fwd', C.byref(self.grid), b['pts_w'], self.table, b['feat'], B)
+        self._call('nof_mlp_fwd', C.byref(self.desc), self.mlp, b['feat'], self.L, b['view'], S, b['raw'], B)
+        return b, S
+
+    def train_step(self, pool, ids, R, u_occ=None, u_dep=None, seed=0, do_step=True, want_cells=False,
+                   grad_sync=None):
+        """One train_loop iteration (nerf_runner.py:679-763).  `grad_sync(flat_grads)` is the data-parallel hook
+        (RCCL all-reduce); gradients are already scaled by 1/world_size."""
+        cfg = self.cfg
+        b, S = self.forward_batch(pool, ids, R, u_occ, u_dep, seed, want_cells)
+        B = R * S
+        lc = self._loss_cfg()
+        self.loss_out.zero_()
+        self._call('nof_composite_loss', C.byref(lc), b['raw'], b['z_vals'], b['valid'], b['batch'], R, S, b['rgb_map'],
+                 None, b['draw'], self.loss_out)
+        b['dview'].zero_()
+        self._call('nof_mlp_bwd', C.byref(self.desc), self.mlp, b['feat'], self.L, b['view'], S, b['draw'], b['dfeat'],
+                 b['dview'], b['partials'], B)
+        self._call('nof_reduce_partials', b['partials'], self.nblk, self.n_mlp, self._seg(self.grads, 'mlp'))
+        self._call('nof_hash_encode_bwd', C.byref(self.grid), b['pts_w'], self.table, b['dfeat'],
+                 self._seg(self.grads, 'table'), b['dpts'] if self.optimize_poses else None, B)
+        if self.optimize_poses or self.ff > 0:
+            self.g_delta.zero_()
+            self._call('nof_pose_grad_accum', b['dpts'] if self.optimize_poses else None, b['dview'], b['batch'], b['z_vals'],
+                     self.c2w, self.tf, self.ff, self.sh_degree, R, S, self.g_delta if self.optimize_poses else None,
+                     self._seg(self.grads, 'feat') if self.ff > 0 else None)
+            if self.optimize_poses:
+                self._call('nof_pose_bwd', self.pose, self.g_delta, C.c_float(self.max_trans), C.c_float(self.max_rot),
+                         self._seg(self.grads, 'pose'), self.F)
+        if self.ff > 0:
+            self._call('nof_small_regs', self.feat, self._seg(self.grads, 'feat'), self.n_feat,
+                     C.c_float(cfg['feature_reg_weight']), C.c_float(1.0 / self.world_size))
+        if grad_sync is not None:
+            grad_sync(self.grads)
+        if do_step:
+            self.adam_step()
+        return b
+
+    def adam_step(self):
+        lr, lr_pose = self.learning_rates()
+        self._call('nof_adam_step', self.params, self.grads, self.exp_avg, self.exp_avg_sq, self.n_total, self.n_basic,
+                 C.c_float(lr), C.c_float(lr_pose), C.c_float(0.9), C.c_float(0.999), C.c_float(1e-15),
+                 self.global_step + 1)
+        self.global_step += 1
+
+    # ---- renderer side ------------------------------------------------------------------------------------
+    def query_sdf(self, pts, chunk=1 << 22):
+        """run_network_density (nerf_runner.py:1307-1347): clip to [-1,1], hash encode, sigma_net -> sdf [N]."""
+        pts = torch.clip(pts.to(self.device, torch.float32), -1, 1).contiguous()
+        N = pts.shape[0]
+        out = torch.empty(N, device=self.device)
+        for i in range(0, N, chunk):
+            n = min(chunk, N - i)
+            feat = torch.empty(self.L, n, 2, device=self.device)
+            p = pts[i:i + n].contiguous()
+            lib.call('nof_hash_encode_fwd', C.byref(self.grid), p, self.table, feat, n)
+            lib.call('nof_mlp_sdf', C.byref(self.desc), self.mlp, feat, self.L, out[i:i + n], n)
+        return out
+
+    def losses(self):
+        """dict of the last step's loss terms (one host sync)."""
+        v = self.loss_out.cpu().numpy()
+        return dict(loss=float(v[0]), rgb_loss=float(v[1]), fs_loss=float(v[2]), sdf_loss=float(v[3]),
+                    fs_rgb_loss=float(v[4]), n_valid_samples=float(v[5]), n_valid_rays=float(v[6]))

@@ -76,12 +76,8 @@ _SIGNATURES = {
     'nof_small_regs': ([_P, _P, _I32, _F, _F, _P], C.c_int),
     'nof_adam_step': ([_P, _P, _P, _P, _I64, _I64, _F, _F, _F, _F, _F, _I32, _P], C.c_int),
     'nof_mfma_probe': ([_I32, _P, _P, _P, _I32, _P], C.c_int),
-    'nof_sdf_grid_query': ([C.POINTER(NofHashGrid), C.POINTER(NofMlpDesc), _P, _P, _P, _I32, C.c_float * 3, C.c_float * 3,
-                            C.c_int32 * 3, _P, _P], C.c_int),
-    'nof_marching_tets_count': ([_P, C.c_int32 * 3, _F, _P, _P], C.c_int),
-    'nof_marching_tets_emit': ([_P, C.c_int32 * 3, _F, C.c_float * 3, C.c_float * 3, _P, _P, _I64, _P], C.c_int),
 }
-OPTIONAL = {'nof_sdf_grid_query', 'nof_marching_tets_count', 'nof_marching_tets_emit'}
+OPTIONAL = set()
 
 _lib = None
 

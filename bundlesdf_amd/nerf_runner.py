@@ -1,0 +1,293 @@
+"""Drop-in `nerf_runner` module for NVlabs/BundleSDF on MI355X: same constructor, methods and attributes that
+bundlesdf.py drives, with the whole optimisation step running in hand-written HIP kernels behind
+the C ABI of libnof_hip.so (include/nof_hip.h).
+
+Plugin surface kept (call sites in /root/reference/bundlesdf.py):
+    NerfRunner(cfg, images, depths=, masks=, normal_maps=, poses=, K=, occ_masks=, build_octree_pcd=)   :219,225,724
+    .add_new_frames(rgbs, depths, masks, normal_maps, poses, occ_masks=, new_pcd=, reuse_weights=False)   :223
+    .train()                                                                                              :228,726
+    .extract_mesh(isolevel=0, voxel_size=, return_sigma=)                                                 :234,747
+    .models['pose_array'].get_matrices(ids)   (via get_optimized_poses_in_real_world, Utils.py:491)       :231
+    .cfg['translation'], .cfg['sc_factor']                                                                :235
+and the names `from nerf_runner import *` must provide (preprocess_data, get_optimized_poses_in_real_world,
+mesh_to_real_world, glcam_in_cvcam, BAD_DEPTH, set_seed).
+There is no CPU fallback: constructing a runner without the HIP library or without a GPU raises.
+"""
+import copy
+import logging
+import os
+
+import numpy as np
+import torch
+
+from . import lib
+from .field import NeuralObjectField
+from .mesh import make_mesh, marching_tetrahedra
+from .nerf_helpers import *          # noqa: F401,F403  (re-exported on purpose, like the reference module does)
+from .nerf_helpers import set_seed, get_optimized_poses_in_real_world, mesh_to_real_world
+from .rays import DataLoader, denoise_rays, make_frame_rays
+
+__all__ = ['NerfRunner', 'PoseArrayView', 'preprocess_data', 'get_optimized_poses_in_real_world', 'mesh_to_real_world',
+           'glcam_in_cvcam', 'BAD_DEPTH', 'BAD_COLOR', 'set_seed', 'get_camera_rays_np', 'ray_box_intersection_batch',
+           'to_homo', 'transform_pts']
+
+
+class PoseArrayView:
+    """What callers use of models['pose_array'] (nerf_helpers.py:127-154): `.data` [F,6] and `.get_matrices(ids)`
+    -> [n,4,4] float32 CUDA tensor of the learnt corrections (identity for frame 0), evaluated by nof_pose_fwd."""
+
+    def __init__(self, field):
+        self._f = field
+
+    @property
+    def data(self):
+        return self._f.pose.view(self._f.F, 6)
+
+    def get_matrices(self, ids):
+        import ctypes as C
+        f = self._f
+        if not torch.is_tensor(ids):
+            ids = torch.tensor(np.asarray(ids)).long()
+        eye = torch.eye(4, device=f.device).reshape(1, 16).repeat(f.F, 1).contiguous()
+        tf = torch.empty(f.F, 12, device=f.device)
+        lib.call('nof_pose_fwd', f.pose if f.optimize_poses else None, eye, C.c_float(f.max_trans), C.c_float(f.max_rot),
+                 tf, f.F)
+        Ts = torch.eye(4, device=f.device).reshape(1, 4, 4).repeat(f.F, 1, 1)
+        Ts[:, :3, :4] = tf.view(f.F, 3, 4)
+        return Ts[ids.to(f.device)]
+
+
+class NerfRunner:
+    def __init__(self, cfg, images, depths, masks, normal_maps, poses, K, _run=None, occ_masks=None,
+                 build_octree_pcd=None, precision=None, n_sigma=2, n_color=3, world_size=1, rank=0, grad_sync=None,
+                 frame_offset=0):
+        if not torch.cuda.is_available():
+            raise lib.NofError('NerfRunner needs an MI355X: there is no CPU path for the Neural Object Field')
+        lib.load()
+        set_seed(0)
+        self.cfg = cfg
+        self.cfg['tv_loss_weight'] = eval(str(self.cfg.get('tv_loss_weight', 0)))
+        self._run = _run
+        self.images, self.depths, self.masks = images, depths, masks
+        self.poses = poses
+        self.normal_maps = None          # normal maps are never used on the hot path (bundlesdf.py passes None)
+        self.occ_masks = occ_masks
+        self.K = K.copy()
+        self.mesh = None
+        self.N_iters = self.cfg['n_step'] + 1
+        self.build_octree_pts = np.asarray(build_octree_pcd.points).copy()
+        # amp: true in config.yml selects the 16-bit MFMA path (fp16 = the reference's autocast operand type)
+        self.precision = precision or cfg.get('mfma_precision', 'fp16' if cfg.get('amp', True) else 'fp32')
+        self.n_sigma, self.n_color = n_sigma, n_color
+        self.world_size, self.rank, self.grad_sync = world_size, rank, grad_sync
+        # data parallel: `images/depths/masks` hold this rank's keyframes, which are frames frame_offset.. of `poses`
+        self.frame_offset = int(frame_offset)
+        self.device = torch.device('cuda')
+
+        r = int(cfg['down_scale_ratio'])
+        self.down_scale = np.ones(2, dtype=np.float32)
+        if r != 1:                                   # strided subsampling, no interpolation (nerf_runner.py:129-148)
+            H, W = images[0].shape[:2]
+            self.images, self.depths, self.masks = images[:, ::r, ::r], depths[:, ::r, ::r], masks[:, ::r, ::r]
+            if occ_masks is not None:
+                self.occ_masks = occ_masks[:, ::r, ::r]
+            self.H, self.W = self.images.shape[1:3]
+            self.cfg['dilate_mask_size'] = int(self.cfg['dilate_mask_size'] // r)
+            self.K[0] *= float(self.W) / W
+            self.K[1] *= float(self.H) / H
+            self.down_scale = np.array([float(self.W) / W, float(self.H) / H])
+        self.H, self.W = self.images[0].shape[:2]
+
+        self.field = None
+        self.create_nerf()
+        if self.cfg['use_octree']:
+            self.build_octree()
+        self.global_step = 0
+        print("sc_factor", self.cfg['sc_factor'])
+        print("translation", self.cfg['translation'])
+        rays = self._frame_rays(range(len(self.masks)))
+        self.rays = torch.tensor(rays, dtype=torch.float).to(self.device)
+        print("rays", self.rays.shape)
+        self.data_loader = DataLoader(rays=self.rays, batch_size=self.cfg['N_rand'])
+
+    # ---- model ---------------------------------------------------------------------------------------
+    def create_nerf(self, device=None):
+        """nerf_runner.py:204-242: fresh hash grid, SDF/colour MLPs, frame features, pose corrections (and,
+        because the optimiser state lives in the same flat buffers, create_optimizer :492-504)."""
+        old = self.field
+        self.field = NeuralObjectField(self.cfg, len(self.poses), self.poses, precision=self.precision,
+                                       n_sigma=self.n_sigma, n_color=self.n_color, world_size=self.world_size,
+                                       rank=self.rank)
+        if old is not None and old.occ_bits is not None:
+            self.field.occ_bits, self.field.level, self.field.max_level = old.occ_bits, old.level, old.max_level
+            self.field.max_hits = old.max_hits
+        self.models = {'pose_array': PoseArrayView(self.field) if self.cfg['optimize_poses'] else None,
+                       'field': self.field}
+
+    def create_optimizer(self):
+        self.field.exp_avg.zero_()
+        self.field.exp_avg_sq.zero_()
+        self.field.grads.zero_()
+        self.field.global_step = 0
+
+    # ---- occupancy ---------------------------------------------------------------------------------------
+    def build_octree(self):
+        """nerf_runner.py:436-489: occupied cells = 27-neighbour dilation of the cloud's cells at max_level; the ray
+        tracing level is floor(log2(2/(octree_raytracing_voxel_size*sc)))."""
+        cfg = self.cfg
+        sv = cfg['octree_smallest_voxel_size'] * cfg['sc_factor']
+        max_level = int(np.ceil(np.log2(2.0 / sv)))
+        vs = 2.0 / (2 ** max_level)
+        radius = max(1, int(np.ceil(cfg['octree_dilate_size'] / cfg['octree_smallest_voxel_size'])))
+        logging.info(f"Octree voxel dilate_radius:{radius}")
+        pts = np.asarray(self.build_octree_pts, dtype=np.float32)
+        assert pts.min() >= -1 and pts.max() <= 1
+        coords = np.floor((pts + 1) / np.float32(vs)).astype(np.int64)
+        shifts = np.array([[dx, dy, dz] for dx in (-1, 0, 1) for dy in (-1, 0, 1) for dz in (-1, 0, 1)], dtype=np.int64)
+        for _ in range(radius):
+            coords = np.unique((coords[None] + shifts[:, None]).reshape(-1, 3), axis=0)
+        # centres are clipped to [-1,1] and re-quantised (kaolin quantize_points clamps to [0, 2^l - 1])
+        n = 2 ** max_level
+        centres = np.clip(((coords + 0.5) * vs - 1).astype(np.float32), -1, 1)
+        q = np.floor(np.clip(n * (centres + 1.0) / 2.0, 0, n - 1.0)).astype(np.int32)
+        rv = cfg['octree_raytracing_voxel_size'] * cfg['sc_factor']
+        level = int(np.floor(np.log2(2.0 / rv)))
+        self.octree_levels = (max_level, level)
+        self.field.set_occupancy(q, max_level, level)
+        if cfg.get('save_octree_clouds', False) and cfg.get('save_dir'):
+            os.makedirs(cfg['save_dir'], exist_ok=True)
+            make_mesh(centres, np.zeros((0, 3), dtype=np.int64)).export(f"{cfg['save_dir']}/build_octree_cloud_dilated.ply")
+
+    def _trace_hits(self, o, d):
+        _, _, nh = self.field.trace(torch.from_numpy(o).to(self.device), torch.from_numpy(d).to(self.device))
+        return (nh > 0).cpu().numpy()
+
+    def _frame_rays(self, frame_ids):
+        rays_ = []
+        for i in frame_ids:
+            occ = self.occ_masks[i] if self.occ_masks is not None else None
+            g = i + self.frame_offset
+            rays_.append(make_frame_rays(g, self.images[i], self.depths[i], self.masks[i], self.poses[g], self.K, self.cfg,
+                                         occ_mask=occ, trace_fn=self._trace_hits if self.cfg['use_octree'] else None))
+        rays = np.concatenate(rays_, axis=0)
+        if self.cfg['denoise_depth_use_octree_cloud']:
+            logging.info("denoise cloud")
+            rays = denoise_rays(rays, self.poses, self.build_octree_pts, self.cfg)
+        return rays
+
+    # ---- growing the keyframe pool (nerf_runner.py:352-433) ----------------------------------------------
+    def add_new_frames(self, images, depths, masks, normal_maps, poses, occ_masks=None, new_pcd=None, reuse_weights=False):
+        prev = len(self.images)
+        r = int(self.cfg['down_scale_ratio'])
+        images, depths, masks = images[:, ::r, ::r], depths[:, ::r, ::r], masks[:, ::r, ::r]
+        if occ_masks is not None:
+            self.occ_masks = np.concatenate((self.occ_masks, occ_masks[:, ::r, ::r]), axis=0)
+        self.images = np.concatenate((self.images, images), axis=0)
+        self.depths = np.concatenate((self.depths, depths), axis=0)
+        self.masks = np.concatenate((self.masks, masks), axis=0)
+        self.poses = poses.copy()
+        old = self.field
+        # new frame count -> new pose/feature arrays; reuse_weights keeps table + MLPs (+ old frame features)
+        self.create_nerf()
+        if reuse_weights:
+            self.field.load_parameters(table=old.table, mlp=old.mlp)
+            if old.ff > 0:
+                f = self.field.feat.view(self.field.F, old.ff)
+                f[:prev] = old.feat.view(old.F, old.ff)
+        if self.cfg['use_octree']:
+            pcd = new_pcd.voxel_down_sample(0.005)
+            self.build_octree_pts = np.asarray(pcd.points).copy()
+            self.build_octree()
+        self.create_optimizer()
+        self.global_step = 0
+        rays = self._frame_rays(range(prev, len(self.masks)))
+        self.rays = torch.cat((self.rays, torch.tensor(rays, dtype=torch.float, device=self.device)), dim=0)
+        self.data_loader = DataLoader(rays=self.rays, batch_size=self.cfg['N_rand'])
+
+    # ---- training (nerf_runner.py:679-763, 855-863) --------------------------------------------------------
+    def train_loop(self, ids=None):
+        """One optimisation step on the next batch of the loader (the reference passes the gathered rows; here the
+        rows are gathered on the device from the resident pool)."""
+        if ids is None:
+            ids = self.data_loader.next_ids()
+        self.field.train_step(self.rays, ids, ids.shape[0], seed=self.cfg.get('seed', 0) + 7919 * self.rank,
+                              grad_sync=self.grad_sync)
+        if self.global_step % self.cfg['i_print'] == 0 and self.global_step > 0:
+            m = self.field.losses()
+            logging.info(f"Iter: {self.global_step}, " + ", ".join(f"{k}: {v:.7f}" for k, v in m.items()))
+        if self.global_step % self.cfg['i_weights'] == 0 and self.global_step > 0 and self.cfg.get('save_dir'):
+            self.save_weights(os.path.join(self.cfg['save_dir'], 'model_latest.pth'))
+
+    def train(self):
+        set_seed(0)
+        for it in range(self.N_iters):
+            if it % max(1, self.N_iters // 10) == 0:
+                logging.info(f'train progress {it}/{self.N_iters}')
+            self.train_loop()
+            self.global_step += 1
+        torch.cuda.synchronize()
+        flags = int(self.field.flags[0].item())
+        if flags:
+            logging.warning(f"nof flags={flags}: 1 = ray exceeded max_hits, 2 = inconsistent sample walk (common.cu:66-72)")
+
+    def get_truncation(self):
+        return self.field.truncation()
+
+    # ---- renderer side (nerf_runner.py:1351-1409) ----------------------------------------------------------
+    @torch.no_grad()
+    def extract_mesh(self, level=None, voxel_size=0.003, isolevel=0.0, return_sigma=False):
+        voxel_size *= self.cfg['sc_factor']
+        bounds = np.array(self.cfg['bounding_box']).reshape(2, 3)
+        tx = np.arange(bounds[0, 0] + 0.5 * voxel_size, bounds[1, 0], voxel_size)
+        ty = np.arange(bounds[0, 1] + 0.5 * voxel_size, bounds[1, 1], voxel_size)
+        tz = np.arange(bounds[0, 2] + 0.5 * voxel_size, bounds[1, 2], voxel_size)
+        N = len(tx)
+        gx, gy, gz = torch.meshgrid(torch.tensor(tx, dtype=torch.float32), torch.tensor(ty, dtype=torch.float32),
+                                    torch.tensor(tz, dtype=torch.float32), indexing='ij')
+        query_pts = torch.stack([gx, gy, gz], -1).reshape(-1, 3).to(self.device)
+        f = self.field
+        if f.occ_bits is not None:
+            inside = torch.empty(query_pts.shape[0], dtype=torch.uint8, device=self.device)
+            lib.call('nof_occgrid_query', f.occ_bits, f.level, query_pts, inside, query_pts.shape[0])
+            valid = inside > 0
+        else:
+            valid = torch.ones(query_pts.shape[0], dtype=torch.bool, device=self.device)
+        logging.info(f'query_pts:{query_pts.shape}, valid:{valid.sum()}')
+        sigma_ = torch.ones(query_pts.shape[0], device=self.device)
+        sigma_[valid] = f.query_sdf(query_pts[valid])
+        sigma = sigma_.reshape(len(tx), len(ty), len(tz)).cpu().numpy()
+        logging.info('Running iso-surface extraction')
+        try:
+            vertices, triangles = marching_tetrahedra(sigma, isolevel)
+        except Exception as e:
+            logging.info(f"ERROR Marching Cubes {e}")
+            return None
+        logging.info(f'done V:{vertices.shape}, F:{triangles.shape}')
+        step = np.array([tx[-1] - tx[0], ty[-1] - ty[0], tz[-1] - tz[0]]) / np.array([[len(tx) - 1, len(ty) - 1, len(tz) - 1]])
+        offset = np.array([tx[0], ty[0], tz[0]])
+        vertices = step.reshape(1, 3) * vertices + offset.reshape(1, 3)
+        mesh = make_mesh(vertices, triangles)
+        if return_sigma:
+            return mesh, sigma, query_pts
+        return mesh
+
+    def mesh_texture_from_train_images(self, mesh, rgbs_raw, train_texture=False, tex_res=1024):
+        raise NotImplementedError('texture bake (nerf_runner.py:1468-1542) depends on pyrender/trimesh/xatlas on the host; '
+                                  'SURVEY.md 8f rank 4 (not on the hot path)')
+
+    # ---- checkpoint (nerf_runner.py:528-577) ----------------------------------------------------------------
+    def save_weights(self, out_file, models=None):
+        f = self.field
+        torch.save({'global_step': self.global_step, 'params': f.params.cpu(), 'exp_avg': f.exp_avg.cpu(),
+                    'exp_avg_sq': f.exp_avg_sq.cpu(), 'field_step': f.global_step,
+                    'octree': (f.occ_bits.cpu() if f.occ_bits is not None else None, f.level, f.max_level)}, out_file)
+        print('Saved checkpoints at', out_file)
+
+    def load_weights(self, ckpt_path):
+        ck = torch.load(ckpt_path)
+        f = self.field
+        f.params.copy_(ck['params'].to(f.device))
+        f.exp_avg.copy_(ck['exp_avg'].to(f.device))
+        f.exp_avg_sq.copy_(ck['exp_avg_sq'].to(f.device))
+        f.global_step = ck['field_step']
+        self.global_step = ck['global_step']

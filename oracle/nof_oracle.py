@@ -254,33 +254,45 @@ def init_mlp_params(shape):
     return params
 
 
-def mlp_forward(shape, params, x):
+def _round_ste(t, dtype):
+    """Round to a 16-bit operand type with a straight-through gradient (what autocast's casts do to values)."""
+    if dtype is None:
+        return t
+    return t + (t.detach().to(dtype).float() - t.detach())
+
+
+def _linear(h, W, b, operand_dtype):
+    return Fnn.linear(_round_ste(h, operand_dtype), _round_ste(W, operand_dtype), b)
+
+
+def mlp_forward(shape, params, x, operand_dtype=None):
     """NeRFSmall.forward (nerf_helpers.py:305-321). x = [hash(input_ch) | views(input_ch_views)];
-    returns [rgb_raw(3), sdf(1)]."""
+    returns [rgb_raw(3), sdf(1)].  operand_dtype=torch.float16/bfloat16 restates the autocast path the reference
+    trains with (nerf_runner.py:1289-1294: 16-bit GEMM operands, fp32 accumulate, fp32 bias)."""
     ns, nc = shape.num_layers, shape.num_layers_color
     h = x[:, :shape.input_ch]
     views = x[:, shape.input_ch:]
     for l in range(ns):
         W, b = params[l]
-        h = Fnn.linear(h, W, b)
+        h = _linear(h, W, b, operand_dtype)
         if l != ns - 1:
             h = torch.relu(h)
     sigma, geo = h[:, 0], h[:, 1:]
     h = torch.cat([views, geo], dim=-1)
     for l in range(nc):
         W, b = params[ns + l]
-        h = Fnn.linear(h, W, b)
+        h = _linear(h, W, b, operand_dtype)
         if l != nc - 1:
             h = torch.relu(h)
     return torch.cat([h, sigma[:, None]], dim=-1)
 
 
-def mlp_forward_sdf(shape, params, feat):
+def mlp_forward_sdf(shape, params, feat, operand_dtype=None):
     """NeRFSmall.forward_sdf (nerf_helpers.py:296-302)."""
     h = feat
     for l in range(shape.num_layers):
         W, b = params[l]
-        h = Fnn.linear(h, W, b)
+        h = _linear(h, W, b, operand_dtype)
         if l != shape.num_layers - 1:
             h = torch.relu(h)
     return h[:, 0]
@@ -582,8 +594,10 @@ def losses(rgb_map, raw, z_vals, valid_samples, batch, cfg, truncation, first_fr
 # the whole field + one optimisation step (nerf_runner.py:679-763, 1014-1129, 1227-1304)
 # --------------------------------------------------------------------------------------
 class OracleField:
-    def __init__(self, cfg, geo, shape, n_frames, c2w, occ_l, table=None, mlp=None, pose=None, feat=None):
+    def __init__(self, cfg, geo, shape, n_frames, c2w, occ_l, table=None, mlp=None, pose=None, feat=None,
+                 operand_dtype=None):
         self.cfg, self.geo, self.shape, self.F = cfg, geo, shape, n_frames
+        self.operand_dtype = operand_dtype
         self.c2w = torch.as_tensor(c2w, dtype=torch.float32)
         self.occ_l = occ_l
         ff = cfg.get('frame_features', 0)
@@ -658,7 +672,7 @@ class OracleField:
         dirs_w = (tf[:, :3, :3] @ viewdirs[:, :, None])[:, :, 0]
         sh = sh_encode(dirs_w, cfg['multires_views'])
         parts.append(sh[:, None].expand(-1, S, -1).reshape(R * S, -1))
-        raw = mlp_forward(self.shape, self.mlp, torch.cat(parts, -1)).reshape(R, S, 4)
+        raw = mlp_forward(self.shape, self.mlp, torch.cat(parts, -1), self.operand_dtype).reshape(R, S, 4)
         valid = valid.view(R, S)
         trunc = get_truncation(cfg, self.global_step)
         rgb_map, w = raw2outputs(raw, z_vals, batch[:, 6], valid, cfg, trunc)
@@ -710,7 +724,7 @@ class OracleField:
         with torch.no_grad():
             x = torch.clip(torch.as_tensor(pts, dtype=torch.float32), -1, 1)
             feat = hash_encode((x + 1) / 2, self.table, self.geo)
-            return mlp_forward_sdf(self.shape, self.mlp, feat)
+            return mlp_forward_sdf(self.shape, self.mlp, feat, self.operand_dtype)
 
 
 def adam_reference_step(p, g, m, v, t, lr, b1=0.9, b2=0.999, eps=1e-15):

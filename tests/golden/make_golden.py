@@ -1,0 +1,315 @@
+#!/usr/bin/env python
+"""Generates tests/golden/reference_vectors.npz by EXECUTING the reference's own pure-PyTorch code on CPU.
+
+    python tests/golden/make_golden.py            (needs /root/reference; run in the build container, not on the GPU box)
+
+The reference modules cannot be imported here (cv2, kaolin, pytorch3d, open3d, mycuda ... are absent), so the source
+text of individual functions / classes / methods is cut out of the read-only mount with `ast` at generation time and
+exec'd -- nothing is copied into this repository.  Only the four native pieces the reference itself delegates to
+CUDA / third parties are injected from oracle/nof_oracle.py (hash-grid encoder, octree ray tracer, the occupied-voxel
+sampler kernel, se3_exp_map); everything else that runs below is reference code:
+
+  nerf_helpers.py : SHEncoder, NeRFSmall, get_masks, get_sdf_loss, ray_box_intersection_batch, get_camera_rays_np,
+                    PoseArray.get_matrices
+  nerf_runner.py  : sample_rays_uniform, compute_near_far_and_filter_rays, DataLoader,
+                    NerfRunner.{get_truncation, raw2outputs, sample_rays_uniform_occupied_voxels, render_rays, run_network,
+                    batchify_rays, render, train_loop, schedule_lr}
+  Utils.py        : to_homo, to_homo_torch, transform_pts
+"""
+import ast
+import os
+import sys
+import types
+import warnings
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from oracle import nof_oracle as O   # noqa: E402
+
+REF = os.environ.get('BUNDLESDF_REFERENCE', '/root/reference')
+warnings.filterwarnings('ignore')
+
+
+def cut(path, names, cls=None):
+    """source text of top-level defs/classes `names` (or of methods of class `cls`) of a reference file."""
+    src = open(os.path.join(REF, path)).read()
+    tree = ast.parse(src)
+    body = tree.body
+    if cls is not None:
+        body = next(n for n in tree.body if isinstance(n, ast.ClassDef) and n.name == cls).body
+    out = []
+    for n in body:
+        if isinstance(n, (ast.FunctionDef, ast.ClassDef)) and n.name in names:
+            seg = ast.get_source_segment(src, n)
+            start = n.lineno - 1 - (len(n.decorator_list) and (n.lineno - n.decorator_list[0].lineno))
+            lines = src.splitlines()[start:n.end_lineno]
+            out.append('\n'.join(lines))
+    assert len(out) == len(names), (path, names, len(out))
+    return out
+
+
+def dedent(s):
+    import textwrap
+    return textwrap.dedent(s)
+
+
+def build_namespace():
+    ns = dict(np=np, torch=torch, nn=nn, F=F, logging=__import__('logging'), os=os, copy=__import__('copy'))
+    ns['se3_exp_map'] = lambda x: O.se3_exp(x).permute(0, 2, 1)      # pytorch3d returns the transposed (row-vector) form
+    for s in cut('Utils.py', ['to_homo', 'to_homo_torch', 'transform_pts']):
+        exec(s, ns)
+    for s in cut('nerf_helpers.py', ['SHEncoder', 'NeRFSmall', 'PoseArray', 'get_masks', 'get_sdf_loss',
+                                     'ray_box_intersection_batch', 'get_camera_rays_np']):
+        exec(s, ns)
+    for s in cut('nerf_runner.py', ['sample_rays_uniform', 'compute_near_far_and_filter_rays', 'DataLoader']):
+        exec(s, ns)
+    methods = cut('nerf_runner.py', ['get_truncation', 'raw2outputs', 'sample_rays_uniform_occupied_voxels', 'render_rays',
+                                     'run_network', 'batchify_rays', 'render', 'train_loop', 'schedule_lr'], cls='NerfRunner')
+    cls_src = 'class RefRunner:\n' + '\n\n'.join(methods)
+    exec(cls_src, ns)
+    return ns
+
+
+class UniformQueue:
+    """torch.rand replacement: hands out pre-drawn uniforms so that oracle and reference see the same numbers."""
+
+    def __init__(self):
+        self.q = []
+
+    def push(self, arr):
+        self.q.append(torch.as_tensor(arr, dtype=torch.float32))
+
+    def __call__(self, *shape, **kw):
+        shape = tuple(shape[0]) if len(shape) == 1 and not isinstance(shape[0], int) else tuple(shape)
+        t = self.q.pop(0)
+        assert tuple(t.shape) == shape, (t.shape, shape)
+        return t
+
+
+class HashModule(nn.Module):
+    """injected piece 1: GridEncoder (mycuda/torch_ngp_grid_encoder/grid.py:106-172) -> oracle restatement"""
+
+    def __init__(self, geo, table):
+        super().__init__()
+        self.geo = geo
+        self.embeddings = nn.Parameter(table.clone())
+        self.out_dim = geo.out_dim
+
+    def forward(self, inputs, bound=1):
+        return O.hash_encode((inputs + bound) / (2 * bound), self.embeddings, self.geo)
+
+
+class OctreeStub:
+    """injected piece 2: OctreeManager.ray_trace (Utils.py:443-475) -> oracle restatement"""
+
+    def __init__(self, occ_l):
+        self.occ_l = occ_l
+
+    def ray_trace(self, rays_o, rays_d, level, debug=False):
+        tio, cid, nh = O.trace_rays(self.occ_l, rays_o.detach().numpy(), rays_d.detach().numpy())
+        tio = torch.from_numpy(tio)
+        self.last = (tio.numpy().copy(), cid, nh)
+        far = tio[:, :, 1].max(dim=-1)[0].reshape(-1, 1)
+        near = tio[:, 0, 0].reshape(-1, 1)
+        return near, far, None, tio
+
+
+def main():
+    ns = build_namespace()
+    out = {}
+    rng = np.random.default_rng(0)
+
+    # ---- g1 SHEncoder ---------------------------------------------------------------------------------
+    d = rng.normal(size=(50, 3)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    out['sh_dirs'] = d
+    out['sh3'] = ns['SHEncoder'](degree=3)(torch.from_numpy(d)).numpy()
+    out['sh4'] = ns['SHEncoder'](degree=4)(torch.from_numpy(d)).numpy()
+
+    # ---- g2 NeRFSmall: init under a seed + forward ---------------------------------------------------------
+    for tag, (nl, nlc, ich, ichv) in {'ref': (2, 3, 32, 9), 'base': (3, 2, 32, 11)}.items():
+        torch.manual_seed(123)
+        m = ns['NeRFSmall'](num_layers=nl, hidden_dim=64, geo_feat_dim=15, num_layers_color=nlc, hidden_dim_color=64,
+                            input_ch=ich, input_ch_views=ichv)
+        x = torch.from_numpy(rng.normal(size=(64, ich + ichv)).astype(np.float32))
+        out[f'mlp_{tag}_x'] = x.numpy()
+        out[f'mlp_{tag}_y'] = m(x).detach().numpy()
+        out[f'mlp_{tag}_sdf'] = m.forward_sdf(x[:, :ich]).detach().numpy()
+        out[f'mlp_{tag}_flat'] = torch.cat([p.detach().reshape(-1) for p in m.parameters()]).numpy()
+
+    # ---- g5 sample_rays_uniform with injected uniforms -----------------------------------------------------
+    uq = UniformQueue()
+    real_rand = torch.rand
+    torch.rand = uq
+    try:
+        near = rng.uniform(0.5, 1.0, size=(20, 1)).astype(np.float32)
+        far = near + rng.uniform(0.0, 2.0, size=(20, 1)).astype(np.float32)
+        far[3] = near[3]
+        for N in (64, 128, 2, 33):
+            u = rng.random((20, N)).astype(np.float32)
+            uq.push(u)
+            z = ns['sample_rays_uniform'](N, torch.from_numpy(near), torch.from_numpy(far), lindisp=False, perturb=True)
+            out[f'sru_{N}_u'], out[f'sru_{N}_z'] = u, z.numpy()
+        out['sru_near'], out['sru_far'] = near, far
+    finally:
+        torch.rand = real_rand
+
+    # ---- g6/g7/g8 camera rays, ray/box, near-far filter -------------------------------------------------------
+    K = np.array([[600.0, 0, 320.0], [0, 600.0, 240.0], [0, 0, 1]])
+    out['K'] = K
+    out['cam_rays'] = ns['get_camera_rays_np'](48, 64, K * np.array([[0.1], [0.1], [1]]))
+    origins = rng.normal(size=(200, 3)) * 2.5
+    dirs = rng.normal(size=(200, 3))
+    dirs[:5] = [[1, 0, 0], [0, -1, 0], [0, 0, 1], [1, 1, 0], [-1, 1e-9, 0]]
+    bounds = np.array([[-1, -1, -1], [1, 1, 1]])
+    tmin, tmax = ns['ray_box_intersection_batch'](origins, dirs, bounds)
+    out['rb_o'], out['rb_d'], out['rb_tmin'], out['rb_tmax'] = origins, dirs, tmin.numpy(), tmax.numpy()
+    cam = np.eye(4)
+    cam[:3, 3] = [0.3, -0.2, 3.0]
+    rays = np.concatenate([ns['get_camera_rays_np'](24, 32, K * np.array([[0.05], [0.05], [1]])).reshape(-1, 3),
+                           rng.random((24 * 32, 7))], -1)
+    out['nf_cam'], out['nf_rays'] = cam, rays
+    out['nf_out'] = ns['compute_near_far_and_filter_rays'](cam, rays.copy(), {'bounding_box': [[-1, -1, -1], [1, 1, 1]]})
+
+    # ---- g9 DataLoader order ------------------------------------------------------------------------------------
+    torch.manual_seed(0)
+    real_cuda = torch.Tensor.cuda
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    try:
+        dl = ns['DataLoader'](rays=torch.arange(1000).float().reshape(-1, 1), batch_size=300)
+        seq = []
+        for _ in range(9):
+            next(dl)
+            seq.append(dl.batch_ray_ids.numpy().copy())
+        out['dl_seq'] = np.stack(seq)
+
+        # ---- g10/g11 reference-driven render + train_loop on a small scene ----------------------------------------
+        sys.path.insert(0, os.path.join(ROOT, 'tests'))
+        from tests.test_gpu_ops import _scene
+        cfg, occ, c2w, batch = _scene(None, R=48, level=4, seed=3)
+        cfg.update(frame_features=2, amp=False, i_embed=1, raw_noise_std=0, N_importance=0, depth_weight=0,
+                   num_levels=8, log2_hashmap_size=12, finest_res=128, n_step=100, first_frame_weight=10)
+        Fn = c2w.shape[0]
+        geo = O.HashGeometry(cfg['num_levels'], 2, cfg['base_res'], cfg['log2_hashmap_size'], cfg['finest_res'])
+        torch.manual_seed(5)
+        table = (torch.rand(geo.n_entries, 2) * 2 - 1) * 0.05
+        model = ns['NeRFSmall'](num_layers=2, hidden_dim=64, geo_feat_dim=15, num_layers_color=3, hidden_dim_color=64,
+                                input_ch=geo.out_dim, input_ch_views=9 + 2)
+        pose = ns['PoseArray'](Fn, max_trans=cfg['max_trans'] * cfg['sc_factor'], max_rot=cfg['max_rot'])
+        pose.data.data = torch.from_numpy((rng.normal(size=(Fn, 6)) * 0.3).astype(np.float32))
+        feat = torch.nn.Parameter(torch.from_numpy(rng.normal(size=(Fn, 2)).astype(np.float32)))
+
+        class FeatArr(nn.Module):
+            def __init__(self):
+                super().__init__()
+                self.data = feat
+
+            def __call__(self, ids):
+                return self.data[ids]
+
+        common = types.SimpleNamespace(sampleRaysUniformOccupiedVoxels=lambda zio, zc, zv: torch.from_numpy(
+            O.walk_boxes(zio.numpy(), zc.numpy())))             # injected piece 3: common.cu:41-125
+        ns['common'] = common
+        r = ns['RefRunner']()
+        r.cfg = cfg
+        r.global_step = 1
+        r.N_iters = cfg['n_step'] + 1
+        r.models = {'embed_fn': HashModule(geo, table), 'embeddirs_fn': ns['SHEncoder'](degree=3), 'model': model,
+                    'model_fine': None, 'feature_array': FeatArr(), 'pose_array': pose}
+        r.c2w_array = torch.from_numpy(c2w)
+        r.octree_m = OctreeStub(occ)
+        r.ray_dir_slice, r.ray_rgb_slice, r.ray_depth_slice, r.ray_mask_slice = [0, 1, 2], [3, 4, 5], 6, 7
+        r.ray_frame_id_slice, r.ray_type_slice, r.ray_near_slice, r.ray_far_slice = 8, 9, 10, 11
+        R = batch.shape[0]
+        Ns, Na = cfg['N_samples'], cfg['N_samples_around_depth']
+        tb = torch.from_numpy(batch)
+        valid_depth = (batch[:, 6] >= cfg['near'] * cfg['sc_factor']) & (batch[:, 6] <= cfg['far'] * cfg['sc_factor'])
+        u_occ = rng.random((R, Ns)).astype(np.float32)
+        u_dep = rng.random((R, Na)).astype(np.float32)
+        # the reference draws: [R,Ns] for the occupied samples, [n_valid,Na] for the depth band, [n_invalid,Na] for the rest
+        torch.rand = uq
+        uq.push(u_occ)
+        uq.push(u_dep[valid_depth])
+        if (~valid_depth).any():
+            uq.push(u_dep[~valid_depth])
+
+        captured = {}
+
+        class Scaler:
+            def scale(self, loss):
+                captured['loss'] = loss
+                return loss
+
+            def step(self, opt):
+                pass
+
+            def update(self):
+                pass
+
+        class Opt:
+            param_groups = [{'lr': 0.01}, {'lr': 0.01}]
+
+            def zero_grad(self):
+                pass
+
+        r.amp_scaler, r.optimizer = Scaler(), Opt()
+        r.param_groups_init = [{'lr': 0.01}, {'lr': 0.01}]
+        r.data_loader = types.SimpleNamespace(batch_ray_ids=torch.arange(R))
+        extras_box = {}
+        orig_render = r.render
+
+        def render_spy(**kw):
+            rgb, extras = orig_render(**kw)
+            extras_box.update(extras)
+            extras_box['rgb_map'] = rgb
+            return rgb, extras
+
+        r.render = render_spy
+        params = [r.models['embed_fn'].embeddings] + list(model.parameters()) + [feat, pose.data]
+        r.train_loop(tb)
+        grads = [p.grad.detach().numpy().copy() for p in params]
+        torch.rand = real_rand
+        out['step_cfg_keys'] = np.array(sorted(k for k, v in cfg.items() if isinstance(v, (int, float, bool))))
+        out['step_cfg_vals'] = np.array([float(cfg[k]) for k in out['step_cfg_keys']])
+        out['step_occ'], out['step_c2w'], out['step_batch'] = occ, c2w, batch
+        out['step_u_occ'], out['step_u_dep'] = u_occ, u_dep
+        out['step_table'] = table.numpy()
+        out['step_mlp_flat'] = torch.cat([p.detach().reshape(-1) for p in model.parameters()]).numpy()
+        out['step_pose'], out['step_feat'] = pose.data.detach().numpy(), feat.detach().numpy()
+        out['step_z'] = extras_box['z_vals'].numpy()
+        out['step_raw'] = extras_box['raw'].detach().numpy()
+        out['step_valid'] = extras_box['valid_samples'].numpy()
+        out['step_weights'] = extras_box['weights'].detach().numpy()
+        out['step_rgb_map'] = extras_box['rgb_map'].detach().numpy()
+        out['step_loss'] = np.float32(captured['loss'].item())
+        for i, g in enumerate(grads):
+            out[f'step_grad_{i}'] = g
+        out['step_n_grads'] = np.int64(len(grads))
+        out['step_pose_mats'] = pose.get_matrices(torch.arange(Fn)).detach().numpy()
+        # get_truncation / schedule_lr
+        r.global_step = 37
+        out['trunc_const'] = np.float64(r.get_truncation())
+        r.cfg = dict(cfg, trunc_decay_type='linear', trunc_start=0.03)
+        out['trunc_linear'] = np.float64(r.get_truncation())
+        r.cfg = dict(cfg, trunc_decay_type='exp', trunc_start=0.03)
+        out['trunc_exp'] = np.float64(r.get_truncation())
+        r.cfg = dict(cfg, decay_rate=0.1)
+        r.global_step = 40
+        r.schedule_lr()
+        out['lr_step40'] = np.float64(r.optimizer.param_groups[0]['lr'])
+    finally:
+        torch.Tensor.cuda = real_cuda
+        torch.rand = real_rand
+
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'reference_vectors.npz')
+    np.savez_compressed(path, **out)
+    print('wrote', path, os.path.getsize(path) // 1024, 'KiB', len(out), 'arrays')
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,101 @@
+"""CPU tests of the drop-in boundary: libnof_hip.so loads (no GPU needed) and exports every symbol include/nof_hip.h
+declares, the ctypes signature table covers the header, and the product never routes through the oracle."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, 'include', 'nof_hip.h')
+
+
+def header_symbols():
+    txt = open(HEADER).read()
+    txt = re.sub(r'/\*.*?\*/', '', txt, flags=re.S)
+    return sorted(set(re.findall(r'\b(nof_[a-z0-9_]+)\s*\(', txt)))
+
+
+def test_library_exports_every_header_symbol():
+    from bundlesdf_amd import build, lib
+    if not os.path.exists(lib.LIB_PATH):
+        build.build(verbose=False)
+    so = ctypes.CDLL(lib.LIB_PATH)
+    syms = header_symbols()
+    assert len(syms) >= 20
+    for s in syms:
+        assert hasattr(so, s), f'{s} declared in include/nof_hip.h but not exported'
+
+
+def test_ctypes_table_matches_header():
+    from bundlesdf_amd import lib
+    declared = set(header_symbols())
+    bound = set(lib.exported_symbols())
+    assert declared <= bound, declared - bound
+    assert bound - declared == set(), bound - declared
+
+
+def test_argument_errors_are_reported_not_crashing():
+    """error behaviour of the boundary: negative return code + nof_last_error() text (no GPU work is launched)."""
+    from bundlesdf_amd import lib
+    so = lib.load()
+    g = lib.NofHashGrid()
+    g.L, g.C = 16, 4                                   # C must be 2
+    rc = so.nof_hash_encode_fwd(ctypes.byref(g), None, None, None, 0, None)
+    assert rc < 0 and b'C == 2' in so.nof_last_error()
+    d, _ = lib.make_mlp_desc(2, 3, 32, 9)
+    d.hidden = 128
+    rc = so.nof_mlp_fwd(ctypes.byref(d), None, None, 16, None, 192, None, 0, None)
+    assert rc < 0 and b'hidden' in so.nof_last_error()
+    assert so.nof_version() >= 100
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    from bundlesdf_amd import lib
+    monkeypatch.setattr(lib, '_lib', None)
+    monkeypatch.setattr(lib, 'LIB_PATH', str(tmp_path / 'absent.so'))
+    with pytest.raises(lib.NofError, match='no CPU fallback'):
+        lib.load()
+
+
+def test_product_never_imports_the_oracle():
+    """oracle/ is test infrastructure: nothing under bundlesdf_amd/ may import, call or execute it; in bench.py only the
+    cpu_baseline leg may; __graft_entry__ only in smoke()."""
+    py = re.compile(r'^\s*(from|import)\s+oracle\b|import_module\([\'"]oracle|__import__\([\'"]oracle', re.M)
+    native = re.compile(r'#\s*include\s*[<"][^>"]*oracle', re.M)
+    for dirpath, _, files in os.walk(os.path.join(ROOT, 'bundlesdf_amd')):
+        for f in files:
+            txt = open(os.path.join(dirpath, f), errors='ignore').read() if f.endswith(('.py', '.hip', '.h', '.cpp')) else ''
+            assert not (py if f.endswith('.py') else native).search(txt), f'{f} uses the oracle'
+    bench = open(os.path.join(ROOT, 'bench.py')).read()
+    for m in re.finditer(r'^\s*from oracle|^\s*import oracle', bench, re.M):
+        before = bench[:m.start()]
+        last_def = before.rfind('\ndef ')
+        assert bench[last_def:last_def + 40].lstrip().startswith('def cpu_baseline'), 'oracle import outside cpu_baseline()'
+    entry = open(os.path.join(ROOT, '__graft_entry__.py')).read()
+    assert not re.search(r'^\s*(from|import)\s+(oracle|tests)\b', entry.split('def smoke')[0], re.M)
+
+
+def test_nerf_runner_plugin_surface():
+    """`from nerf_runner import *` must bring what bundlesdf.py uses; constructing without a GPU raises."""
+    import inspect
+    import numpy as np
+    import torch
+    from bundlesdf_amd import nerf_runner as nr
+    for name in ('NerfRunner', 'preprocess_data', 'get_optimized_poses_in_real_world', 'mesh_to_real_world', 'glcam_in_cvcam',
+                 'BAD_DEPTH', 'set_seed'):
+        assert name in nr.__all__ and hasattr(nr, name)
+    sig = inspect.signature(nr.NerfRunner.__init__)
+    assert list(sig.parameters)[:11] == ['self', 'cfg', 'images', 'depths', 'masks', 'normal_maps', 'poses', 'K', '_run',
+                                         'occ_masks', 'build_octree_pcd']
+    sig = inspect.signature(nr.NerfRunner.add_new_frames)
+    assert list(sig.parameters) == ['self', 'images', 'depths', 'masks', 'normal_maps', 'poses', 'occ_masks', 'new_pcd',
+                                    'reuse_weights']
+    sig = inspect.signature(nr.NerfRunner.extract_mesh)
+    assert list(sig.parameters) == ['self', 'level', 'voxel_size', 'isolevel', 'return_sigma']
+    for m in ('train', 'mesh_texture_from_train_images', 'save_weights', 'load_weights', 'build_octree', 'create_nerf'):
+        assert callable(getattr(nr.NerfRunner, m))
+    if not torch.cuda.is_available():
+        from bundlesdf_amd import lib
+        with pytest.raises(lib.NofError):
+            nr.NerfRunner({}, None, None, None, None, None, np.eye(3))

@@ -1,0 +1,96 @@
+"""N > 1 path on CPU: two gloo ranks (one process each, rendezvous on 127.0.0.1) exercise the data-parallel plumbing of
+bundlesdf_amd/dist.py with the CPU oracle standing in for the device step:
+  * keyframe sharding + all-gather give every rank the identical pose table / octree cloud;
+  * summed gradients pre-scaled by 1/world equal ONE process stepping on the concatenated batch."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import nof_oracle as O
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _scene(R):
+    from tests.test_gpu_ops import _scene as sc
+    cfg, occ, c2w, batch = sc(None, R=R, level=4, seed=1)
+    cfg.update(N_samples=16, N_samples_around_depth=8, num_levels=4, log2_hashmap_size=10, finest_res=64)
+    return cfg, occ, c2w, batch
+
+
+def _field(cfg, occ, c2w, scale):
+    torch.manual_seed(0)
+    geo = O.HashGeometry(cfg['num_levels'], 2, cfg['base_res'], cfg['log2_hashmap_size'], cfg['finest_res'])
+    shape = O.FieldShape(input_ch=geo.out_dim)
+    tab = (torch.rand(geo.n_entries, 2) * 2 - 1) * 0.05
+    return O.OracleField(cfg, geo, shape, c2w.shape[0], c2w, occ, table=tab)
+
+
+def _worker(rank, world, port, R, out):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from bundlesdf_amd import dist as D
+    r, w, _ = D.init_from_env(torch.device('cpu'))
+    assert (r, w) == (rank, world)
+    cfg, occ, c2w, batch = _scene(R * world)
+    # --- sharding + all-gather of per-rank metadata ---
+    lo, hi = D.shard_frames(c2w.shape[0] + 1, rank, world)
+    assert (lo, hi) == ((0, 3) if rank == 0 else (3, 6))
+    poses_all = D.all_gather_cat(torch.from_numpy(c2w[:4] + rank))
+    assert poses_all.shape[0] == 8 and torch.equal(poses_all[4:], torch.from_numpy(c2w[:4] + 1))
+    # --- gradient averaging == single process on the concatenated batch ---
+    fld = _field(cfg, occ, c2w, 1.0 / world)
+    rng = np.random.default_rng(7)
+    u1 = rng.random((R * world, cfg['N_samples'])).astype(np.float32)
+    u2 = rng.random((R * world, cfg['N_samples_around_depth'])).astype(np.float32)
+    sl = slice(rank * R, (rank + 1) * R)
+    res = fld.train_step(batch[sl], u1[sl], u2[sl], do_step=False)
+    flat = torch.cat([g.reshape(-1) for g in res['grads']]) / world          # NofLossCfg.grad_scale = 1/world
+    sync = D.make_grad_sync()
+    assert sync is not None
+    sync(flat)
+    if rank == 0:
+        out.put(flat.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_gradient_sum_equals_single_process_batch():
+    R, world = 24, 2
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, R, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=240)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    cfg, occ, c2w, batch = _scene(R * world)
+    fld = _field(cfg, occ, c2w, 1.0)
+    rng = np.random.default_rng(7)
+    u1 = rng.random((R * world, cfg['N_samples'])).astype(np.float32)
+    u2 = rng.random((R * world, cfg['N_samples_around_depth'])).astype(np.float32)
+    ref = fld.train_step(batch, u1, u2, do_step=False)
+    want = torch.cat([g.reshape(-1) for g in ref['grads']]).numpy()
+    assert np.abs(got - want).max() < 1e-5 * max(1.0, np.abs(want).max())
+
+
+def test_single_process_helpers_are_identity():
+    from bundlesdf_amd import dist as D
+    t = torch.arange(6.0).reshape(2, 3)
+    assert torch.equal(D.all_gather_cat(t), t)
+    assert D.make_grad_sync() is None
+    assert D.shard_frames(512, 3, 8) == (192, 256)
