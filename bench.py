@@ -20,6 +20,10 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+def log(msg):
+    print(f'[bench {time.strftime("%H:%M:%S")}] {msg}', file=sys.stderr, flush=True)
+
+
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 MFMA_BF16_PEAK_TF = 2500.0     # dense bf16 MFMA
 
@@ -68,8 +72,11 @@ def cpu_baseline(seconds=20.0):
     from bundlesdf_amd.config import default_cfg
     from bundlesdf_amd.rays import make_frame_rays
     from oracle import nof_oracle as O
-    ncores = os.cpu_count() or 1
+    # threads actually used: all host cores up to 32 (the oracle's small tensor ops stop scaling, and oversubscribing a
+    # 100+-core host makes every op slower)
+    ncores = min(os.cpu_count() or 1, 32)
     torch.set_num_threads(ncores)
+    log(f'cpu_baseline: {ncores} threads of {os.cpu_count()} cores')
     pool = synthetic.make_pool(n_frames=4, H=480, W=640, seed=0, analytic_bounds=True)
     cfg = default_cfg(n_step=500, N_rand=1024, num_levels=16, log2_hashmap_size=14, finest_res=256, base_res=16,
                       N_samples=128, N_samples_around_depth=64, far=1.0, sc_factor=pool['sc_factor'],
@@ -104,8 +111,9 @@ def cpu_baseline(seconds=20.0):
         dt = time.time() - t0
         if it >= 1:
             times.append(dt)
+        log(f'cpu_baseline: step {it} took {dt:.2f}s')
         it += 1
-        if (time.time() - t_start > seconds and len(times) >= 3) or len(times) >= 20:
+        if (time.time() - t_start > seconds and len(times) >= 1) or len(times) >= 20:
             break
     med = float(np.median(times))
     return {"value": R * S / med, "unit": "ray-samples/s", "cores": ncores, "kind": "port",
@@ -144,8 +152,10 @@ def main():
         dist.init_process_group('nccl', device_id=device)
     assert world == args.gpus or world == 1, f'--gpus {args.gpus} but WORLD_SIZE={world}'
 
+    log(f'rank {rank}/{world}: building the keyframe pool and ray table')
     runner, cfg = build_runner(args, rank, world, device)
     fld = runner.field
+    log(f'pool ready: {runner.rays.shape[0]} rays, level {fld.level}, table {fld.n_entries} rows')
     R, S = args.rays, cfg['N_samples'] + cfg['N_samples_around_depth']
     B = R * S
 
@@ -155,6 +165,7 @@ def main():
         runner.train_loop()
         runner.global_step += 1
     torch.cuda.synchronize()
+    log('warm-up done')
     ktimes = fld.kernel_times_ms()
     dominant = max(ktimes, key=ktimes.get) if ktimes else None
     fld.profile = {dominant: []} if dominant else None          # timed region: only the dominant kernel keeps its events
@@ -176,6 +187,7 @@ def main():
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    log(f'timed region done: {dt / args.steps * 1e3:.3f} ms/step')
     dom_ms = fld.kernel_times_ms().get(dominant) if dominant else None
     flags = int(fld.flags[0].item())
     losses = fld.losses()
@@ -225,7 +237,7 @@ def main():
         }
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

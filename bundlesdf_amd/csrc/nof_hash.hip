@@ -7,7 +7,15 @@
 //     keeps those levels' table rows in ITS 4 MiB L2 (placement is a speed assumption only);
 //   * features are stored level-major [L,B,2] so each XCD streams its own contiguous slab (8 B/lane);
 //   * table rows are one aligned 8-byte gather (C == 2); 8 gathers are issued back to back per lane;
-//   * backward recomputes indices/weights (no dy_dx tensor) and uses hardware fp32 atomics.
+//   * backward recomputes indices/weights (no dy_dx tensor).  gfx950 executes fp32 atomics memory-side (~12 ns per op
+//     on one line), and with one (sample, level) per lane the coarse levels funnel ~10^5 atomics into each of a few
+//     dozen lines (measured: 13.6 ms per step at cfg2).  The scatter is therefore three launches:
+//       k_hash_dx      input gradients per sample from gathers only (no atomics);
+//       k_hash_bwd_lds levels whose whole slice fits in LDS accumulate there (ds_add_f32) and are flushed once per
+//                      workgroup, skipping untouched entries;
+//       k_hash_bwd_agg all other levels: lanes of a wave are consecutive samples of ONE ray, so lanes falling into the
+//                      same cell form contiguous runs; a segmented shuffle-sum merges each run and only its first lane
+//                      issues the 16 atomics (16x fewer at the coarsest hashed level, 1x at the finest).
 #include "nof_common.h"
 #pragma clang fp contract(off)
 
@@ -88,18 +96,24 @@ __global__ __launch_bounds__(256) void k_hash_fwd(NofHashGrid g, const float* __
   feat[(int64_t)level * B + b] = acc;
 }
 
-__global__ __launch_bounds__(256) void k_hash_bwd(NofHashGrid g, const float* __restrict__ pts_w,
-                                                   const float2* __restrict__ table, const float2* __restrict__ dfeat,
-                                                   float* __restrict__ grad_table, float* __restrict__ dpts, int64_t B) {
-  const int level = blockIdx.x % g.L;
-  const int64_t b = (int64_t)(blockIdx.x / g.L) * 256 + threadIdx.x;
-  if (b >= B) return;
-  const HashLevel lv = load_level(g, level);
-  const CellPos c = locate(pts_w, b, lv.scale);
-  if (c.oob) return;                                                // gridencoder.cu:276-281
-  const float2 gr = dfeat[(int64_t)level * B + b];
+// ---- backward -----------------------------------------------------------------------------------------
+struct Scatter {
   uint32_t idx[8];
-  float w[8];
+  float vx[8], vy[8];
+  uint32_t key;                                                    // cell id (10 bits per axis) or ~0 when out of range
+};
+
+__device__ __forceinline__ Scatter make_scatter(const HashLevel& lv, const float* __restrict__ pts_w,
+                                                const float2* __restrict__ dfeat, int level, int64_t b, int64_t B) {
+  Scatter sc;
+  sc.key = 0xFFFFFFFFu;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) { sc.idx[k] = 0; sc.vx[k] = 0.f; sc.vy[k] = 0.f; }
+  if (b >= B) return sc;
+  const CellPos c = locate(pts_w, b, lv.scale);
+  if (c.oob) return sc;                                              // gridencoder.cu:276-281
+  const float2 gr = dfeat[(int64_t)level * B + b];
+  sc.key = c.g[0] | (c.g[1] << 10) | (c.g[2] << 20);
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
     float wk = 1.0f;
@@ -109,14 +123,109 @@ __global__ __launch_bounds__(256) void k_hash_bwd(NofHashGrid g, const float* __
       if (k & (1 << d)) { wk *= c.f[d]; p[d] = c.g[d] + 1u; }
       else              { wk *= 1.0f - c.f[d]; p[d] = c.g[d]; }
     }
-    w[k] = wk;
-    idx[k] = grid_index(lv, p[0], p[1], p[2]);
+    sc.idx[k] = grid_index(lv, p[0], p[1], p[2]);
+    sc.vx[k] = wk * gr.x;
+    sc.vy[k] = wk * gr.y;
   }
-  if (dpts != nullptr) {
+  return sc;
+}
+
+// Segmented sum over runs of equal keys (runs are contiguous: lanes = consecutive samples of a ray).  After the call the
+// FIRST lane of every run holds the run's total; returns whether this lane is such a leader.
+__device__ __forceinline__ bool wave_merge_runs(Scatter& sc) {
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const uint32_t ok_key = __shfl_down(sc.key, off, 64);
+    const bool ok = (lane + off < 64) && (ok_key == sc.key);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const float tx = __shfl_down(sc.vx[k], off, 64);
+      const float ty = __shfl_down(sc.vy[k], off, 64);
+      if (ok) { sc.vx[k] += tx; sc.vy[k] += ty; }
+    }
+  }
+  const uint32_t prev = __shfl_up(sc.key, 1, 64);
+  return (lane == 0 || prev != sc.key) && sc.key != 0xFFFFFFFFu;
+}
+
+struct LevelList {
+  int32_t n;
+  int32_t level[NOF_MAX_LEVELS];
+};
+
+// levels that do not fit LDS: wave-merged global atomics
+__global__ __launch_bounds__(256) void k_hash_bwd_agg(NofHashGrid g, LevelList ll, const float* __restrict__ pts_w,
+                                                       const float2* __restrict__ dfeat, float* __restrict__ grad_table,
+                                                       int64_t B, uint32_t merge_max_res) {
+  const int level = ll.level[blockIdx.x % ll.n];
+  const int64_t b = (int64_t)(blockIdx.x / ll.n) * 256 + threadIdx.x;
+  const HashLevel lv = load_level(g, level);
+  Scatter sc = make_scatter(lv, pts_w, dfeat, level, b, B);
+  bool lead = sc.key != 0xFFFFFFFFu;
+  if (lv.res <= merge_max_res) lead = wave_merge_runs(sc);          // block-uniform branch
+  if (lead) {
+    float* __restrict__ gt = grad_table + 2 * (size_t)lv.offset;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {                                     // gridencoder.cu:317-333 (fp32 atomics)
+      atomicAdd(&gt[2 * (size_t)sc.idx[k]], sc.vx[k]);
+      atomicAdd(&gt[2 * (size_t)sc.idx[k] + 1], sc.vy[k]);
+    }
+  }
+}
+
+// levels whose slice fits LDS: accumulate privately, flush once
+__global__ __launch_bounds__(1024) void k_hash_bwd_lds(NofHashGrid g, LevelList ll, int chunks, const float* __restrict__ pts_w,
+                                                        const float2* __restrict__ dfeat, float* __restrict__ grad_table,
+                                                        int64_t B) {
+  extern __shared__ __attribute__((aligned(16))) float acc[];
+  const int level = ll.level[blockIdx.x % ll.n];
+  const int chunk = blockIdx.x / ll.n;
+  const HashLevel lv = load_level(g, level);
+  const int n2 = 2 * (int)lv.size;
+  for (int e = threadIdx.x; e < n2; e += blockDim.x) acc[e] = 0.0f;
+  __syncthreads();
+  const int64_t per = ((B + chunks - 1) / chunks + 63) / 64 * 64;     // whole waves per chunk
+  const int64_t lo = (int64_t)chunk * per;
+  const int64_t hi = lo + per < B ? lo + per : B;
+  for (int64_t base = lo; base < hi; base += blockDim.x) {
+    const int64_t b = base + threadIdx.x;
+    Scatter sc = make_scatter(lv, pts_w, dfeat, level, b < hi ? b : B, B);
+    if (wave_merge_runs(sc)) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        atomicAdd(&acc[2 * sc.idx[k]], sc.vx[k]);
+        atomicAdd(&acc[2 * sc.idx[k] + 1], sc.vy[k]);
+      }
+    }
+  }
+  __syncthreads();
+  float* __restrict__ gt = grad_table + 2 * (size_t)lv.offset;
+  for (int e = threadIdx.x; e < n2; e += blockDim.x) {
+    const float v = acc[e];
+    if (v != 0.0f) atomicAdd(&gt[e], v);
+  }
+}
+
+// dL/dpts_w per sample: gathers only (kernel_input_backward + the dy_dx part of kernel_grid, gridencoder.cu:202-245,340-365)
+__global__ __launch_bounds__(256) void k_hash_dx(NofHashGrid g, const float* __restrict__ pts_w,
+                                                  const float2* __restrict__ table, const float2* __restrict__ dfeat,
+                                                  float* __restrict__ dpts, int64_t B) {
+  const int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (b >= B) return;
+  float dx[3] = {0.f, 0.f, 0.f};
+  for (int level = 0; level < g.L; ++level) {
+    const HashLevel lv = load_level(g, level);
+    const CellPos c = locate(pts_w, b, lv.scale);
+    if (c.oob) break;                                                  // the point is out of range for every level
+    const float2 gr = dfeat[(int64_t)level * B + b];
     const float2* __restrict__ tl = table + lv.offset;
     float2 v[8];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) v[k] = tl[idx[k]];
+    for (int k = 0; k < 8; ++k) {
+      const uint32_t p0 = c.g[0] + (k & 1), p1 = c.g[1] + ((k >> 1) & 1), p2 = c.g[2] + ((k >> 2) & 1);
+      v[k] = tl[grid_index(lv, p0, p1, p2)];
+    }
     // dy/dx01[gd] = scale * sum_{other two dims} w' * (f_right - f_left)   (gridencoder.cu:202-245)
 #pragma unroll
     for (int gd = 0; gd < 3; ++gd) {
@@ -133,15 +242,11 @@ __global__ __launch_bounds__(256) void k_hash_bwd(NofHashGrid g, const float* __
         const float2 l = v[k], r = v[k | (1 << gd)];
         s += wk * ((r.x - l.x) * gr.x + (r.y - l.y) * gr.y);
       }
-      atomicAdd(&dpts[b * 3 + gd], s * 0.5f);                       // d x01 / d x = 1/2 (grid.py:160)
+      dx[gd] += s;
     }
   }
-  float* __restrict__ gt = grad_table + 2 * (size_t)lv.offset;
 #pragma unroll
-  for (int k = 0; k < 8; ++k) {                                     // gridencoder.cu:317-333 (fp32 atomics)
-    atomicAdd(&gt[2 * (size_t)idx[k]], w[k] * gr.x);
-    atomicAdd(&gt[2 * (size_t)idx[k] + 1], w[k] * gr.y);
-  }
+  for (int gd = 0; gd < 3; ++gd) dpts[b * 3 + gd] = dx[gd] * 0.5f;    // d x01 / d x = 1/2 (grid.py:160)
 }
 
 __global__ __launch_bounds__(256) void k_hash_indices(NofHashGrid g, const float* __restrict__ pts_w,
@@ -185,12 +290,37 @@ extern "C" int nof_hash_encode_bwd(const NofHashGrid* g, const float* pts_w, con
   if (int e = check_grid(g)) return e;
   NOF_ARG(pts_w && table && dfeat && grad_table && B >= 0);
   if (B == 0) return 0;
-  if (dpts) NOF_HIP(hipMemsetAsync(dpts, 0, sizeof(float) * 3 * (size_t)B, (hipStream_t)stream));
-  const int64_t blocks = nof_div_up(B, 256) * g->L;
-  NOF_ARG(blocks < (1ll << 31));
-  hipLaunchKernelGGL(k_hash_bwd, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, *g, pts_w,
-                     (const float2*)table, (const float2*)dfeat, grad_table, dpts, B);
-  NOF_LAUNCH_OK();
+  hipStream_t st = (hipStream_t)stream;
+  if (dpts) {
+    hipLaunchKernelGGL(k_hash_dx, dim3((unsigned)nof_div_up(B, 256)), dim3(256), 0, st, *g, pts_w, (const float2*)table,
+                       (const float2*)dfeat, dpts, B);
+    NOF_LAUNCH_OK();
+  }
+  // split the levels: slices of <= 128 KiB are accumulated in LDS, the others go through wave-merged global atomics
+  const size_t lds_cap = 128 * 1024;
+  LevelList small, big;
+  small.n = big.n = 0;
+  size_t lds_need = 0;
+  for (int l = 0; l < g->L; ++l) {
+    const size_t bytes = (size_t)g->size[l] * 8;
+    if (bytes <= lds_cap) { small.level[small.n++] = l; if (bytes > lds_need) lds_need = bytes; }
+    else big.level[big.n++] = l;
+  }
+  if (small.n > 0) {
+    const int chunks = 64;
+    if (lds_need > 64 * 1024)
+      NOF_HIP(hipFuncSetAttribute((const void*)k_hash_bwd_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_need));
+    hipLaunchKernelGGL(k_hash_bwd_lds, dim3((unsigned)(chunks * small.n)), dim3(1024), lds_need, st, *g, small, chunks, pts_w,
+                       (const float2*)dfeat, grad_table, B);
+    NOF_LAUNCH_OK();
+  }
+  if (big.n > 0) {
+    const int64_t blocks = nof_div_up(B, 256) * big.n;
+    NOF_ARG(blocks < (1ll << 31));
+    hipLaunchKernelGGL(k_hash_bwd_agg, dim3((unsigned)blocks), dim3(256), 0, st, *g, big, pts_w, (const float2*)dfeat,
+                       grad_table, B, 1023u);
+    NOF_LAUNCH_OK();
+  }
   return 0;
 }
 

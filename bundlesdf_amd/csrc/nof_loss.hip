@@ -28,7 +28,7 @@ __global__ __launch_bounds__(64) void k_composite_loss(NofLossCfg c, const float
                                                         const float* __restrict__ z_vals, const uint8_t* __restrict__ valid,
                                                         const float* __restrict__ batch, int64_t R, int S,
                                                         float* __restrict__ rgb_map, float* __restrict__ weights,
-                                                        float4* __restrict__ draw, float* __restrict__ loss_out) {
+                                                        float4* __restrict__ draw, float* __restrict__ loss_rows) {
   const int64_t r = blockIdx.x;
   const int lane = threadIdx.x;
   const float* row = batch + r * NOF_RAY_COLS;
@@ -113,29 +113,48 @@ __global__ __launch_bounds__(64) void k_composite_loss(NofLossCfg c, const float
     draw[base + s] = g;
   }
   l_fs = wave_sum(l_fs); l_empty = wave_sum(l_empty); l_sdf = wave_sum(l_sdf); l_fsrgb = wave_sum(l_fsrgb);
-  if (lane == 0 && loss_out) {
+  if (lane == 0 && loss_rows) {
+    // per-ray terms go to their own row (plain stores); k_loss_reduce sums the rows.  (4096 rays x 7 atomics on ONE line
+    // cost 0.35 ms: gfx950 atomics execute memory-side and serialise per line.)
     const float rgb_loss = c.rgb_weight * (e0 * e0 + e1 * e1 + e2 * e2) * ray_w * inv3R;
     const float fs_loss = c.fs_weight * (0.5f * l_fs + c.empty_weight * l_empty) * invRS;
     const float sdf_loss = c.trunc_weight * 0.5f * l_sdf * invRS;
     const float fsrgb = c.fs_rgb_weight * l_fsrgb * invRS / 3.0f;
-    atomicAdd(&loss_out[0], rgb_loss + fs_loss + sdf_loss + fsrgb);
-    atomicAdd(&loss_out[1], rgb_loss);
-    atomicAdd(&loss_out[2], fs_loss);
-    atomicAdd(&loss_out[3], sdf_loss);
-    atomicAdd(&loss_out[4], fsrgb);
-    atomicAdd(&loss_out[5], nvalid);
-    atomicAdd(&loss_out[6], valid_ray ? 1.0f : 0.0f);
+    float4* row = (float4*)(loss_rows + r * 8);
+    row[0] = make_float4(rgb_loss + fs_loss + sdf_loss + fsrgb, rgb_loss, fs_loss, sdf_loss);
+    row[1] = make_float4(fsrgb, nvalid, valid_ray ? 1.0f : 0.0f, 0.0f);
   }
+}
+
+__global__ __launch_bounds__(256) void k_loss_reduce(const float* __restrict__ rows, int64_t R, float* __restrict__ loss_out) {
+  __shared__ float sm[4][8];
+  float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (int64_t r = threadIdx.x; r < R; r += blockDim.x)
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc[k] += rows[r * 8 + k];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) acc[k] = wave_sum(acc[k]);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0)
+#pragma unroll
+    for (int k = 0; k < 8; ++k) sm[wave][k] = acc[k];
+  __syncthreads();
+  if (threadIdx.x < 8) loss_out[threadIdx.x] += (sm[0][threadIdx.x] + sm[1][threadIdx.x]) + (sm[2][threadIdx.x] + sm[3][threadIdx.x]);
 }
 
 extern "C" int nof_composite_loss(const NofLossCfg* cfg, const float* raw, const float* z_vals, const uint8_t* valid,
                                    const float* batch, int64_t R, int32_t S, float* rgb_map, float* weights, float* draw,
-                                   float* loss_out, void* stream) {
+                                   float* loss_rows, float* loss_out, void* stream) {
   NOF_ARG(cfg && raw && z_vals && valid && batch && rgb_map && draw && R >= 0 && S >= 1);
+  NOF_ARG(loss_out == nullptr || loss_rows != nullptr);
   if (R == 0) return 0;
   hipLaunchKernelGGL(k_composite_loss, dim3((unsigned)R), dim3(64), 0, (hipStream_t)stream, *cfg, (const float4*)raw,
-                     z_vals, valid, batch, R, S, rgb_map, weights, (float4*)draw, loss_out);
+                     z_vals, valid, batch, R, S, rgb_map, weights, (float4*)draw, loss_out ? loss_rows : nullptr);
   NOF_LAUNCH_OK();
+  if (loss_out) {
+    hipLaunchKernelGGL(k_loss_reduce, dim3(1), dim3(256), 0, (hipStream_t)stream, loss_rows, R, loss_out);
+    NOF_LAUNCH_OK();
+  }
   return 0;
 }
 
@@ -176,17 +195,20 @@ extern "C" int nof_adam_step(float* params, float* grads, float* exp_avg, float*
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_reduce_partials(const float* __restrict__ partials, int n_rows, int n_cols,
                                                           float* __restrict__ out) {
-  const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= n_cols) return;
+  __shared__ float sm[4][64];
+  const int col = blockIdx.x * 64 + (threadIdx.x & 63), grp = threadIdx.x >> 6;      // 64 columns x 4 row groups
   float s = 0.0f;
-  for (int i = 0; i < n_rows; ++i) s += partials[(size_t)i * n_cols + j];
-  out[j] += s;
+  if (col < n_cols)
+    for (int i = grp; i < n_rows; i += 4) s += partials[(size_t)i * n_cols + col];
+  sm[grp][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (grp == 0 && col < n_cols) out[col] += (sm[0][threadIdx.x] + sm[1][threadIdx.x]) + (sm[2][threadIdx.x] + sm[3][threadIdx.x]);
 }
 
 extern "C" int nof_reduce_partials(const float* partials, int32_t n_rows, int32_t n_cols, float* out, void* stream) {
   NOF_ARG(partials && out && n_rows >= 0 && n_cols >= 0);
   if (n_cols == 0 || n_rows == 0) return 0;
-  hipLaunchKernelGGL(k_reduce_partials, dim3((unsigned)nof_div_up(n_cols, 256)), dim3(256), 0, (hipStream_t)stream,
+  hipLaunchKernelGGL(k_reduce_partials, dim3((unsigned)nof_div_up(n_cols, 64)), dim3(256), 0, (hipStream_t)stream,
                      partials, n_rows, n_cols, out);
   NOF_LAUNCH_OK();
   return 0;

@@ -92,27 +92,23 @@ __device__ __forceinline__ int inmap(const NofMlpDesc& d, int l, int q, int hi, 
   const int c = 32 * q + nloc(hi, r);
   return c < d.in_dim[l] ? c : -1;
 }
-// weight-matrix column of orientation-2 lane j of input block q (used when flushing dW)
-__device__ __forceinline__ int colmap(const NofMlpDesc& d, int l, int q, int j) {
-  if (l == 0) return j < d.in_feat ? j : -1;
-  if (l == d.n_sigma) {
-    if (q == 0) return (j >= 1 && j <= d.geo) ? d.n_view + j - 1 : -1;
-    return j < d.n_view ? j : -1;
-  }
-  const int c = 32 * q + j;
-  return c < d.in_dim[l] ? c : -1;
-}
-
-// Packs the fp32 PyTorch-layout weights into MFMA fragments in LDS.
+// Packs the fp32 PyTorch-layout weights into the MFMA fragment image the kernels keep in LDS (once per optimiser step,
+// by one small launch; every workgroup of the fwd/bwd kernels then just streams the image into LDS with 16-byte copies
+// -- packing inside each workgroup cost ~60 us of dependent global loads per workgroup and dominated the forward).
 //   fw[(pair_base(l) + p*QN + q)][step][lane][t] = W_l[32p + i][inmap(l,q,hi,KR*step+t)]                (lane = hi*32+i)
 //   bw[(pair_base(l) + q*PN + p)][step][lane][t] = W_l[32p + nloc(hi,KR*step+t)][inmap(l,q,hi(i),r(i))]
+//   image = [ fw : npair*1024 elems | bw : npair*1024 elems | bias : nob*32 floats ]
 template <class P>
-__device__ void pack_weights(const NofMlpDesc& d, const float* __restrict__ params, typename P::elem* fw,
-                             typename P::elem* bw, float* bias, int n_layers, bool want_bw) {
+__global__ __launch_bounds__(256) void k_mlp_pack(NofMlpDesc d, const float* __restrict__ params, char* __restrict__ image) {
   constexpr int KR = P::KR;
+  typedef typename P::elem elem;
+  const int n_layers = d.n_sigma + d.n_color;
   const int npair = pair_base(d, n_layers);
+  elem* fw = (elem*)image;
+  elem* bw = fw + (size_t)npair * 16 * 64;
+  float* bias = (float*)(bw + (size_t)npair * 16 * 64);
   const int total = npair * 16 * 64;
-  for (int e = threadIdx.x; e < total; e += blockDim.x) {
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
     const int lane = e & 63, r = (e >> 6) & 15;
     int pair = e >> 10, l = 0;
     for (;; ++l) {
@@ -128,18 +124,18 @@ __device__ void pack_weights(const NofMlpDesc& d, const float* __restrict__ para
       const int p = pair / qn, q = pair % qn;
       const int row = 32 * p + i, col = inmap(d, l, q, hi, r);
       const float v = (row < out_dim && col >= 0) ? W[row * in_dim + col] : 0.0f;
-      fw[(((size_t)(base + p * qn + q) * (16 / KR) + r / KR) * 64 + lane) * KR + r % KR] = (typename P::elem)v;
+      fw[(((size_t)(base + p * qn + q) * (16 / KR) + r / KR) * 64 + lane) * KR + r % KR] = (elem)v;
     }
-    if (want_bw) {
+    {
       const int q = pair / pn, p = pair % pn;
       const int hi_i = (i >> 2) & 1, r_i = (i & 3) + 4 * (i >> 3);
       const int row = 32 * p + nloc(hi, r), col = inmap(d, l, q, hi_i, r_i);
       const float v = (row < out_dim && col >= 0) ? W[row * in_dim + col] : 0.0f;
-      bw[(((size_t)(base + q * pn + p) * (16 / KR) + r / KR) * 64 + lane) * KR + r % KR] = (typename P::elem)v;
+      bw[(((size_t)(base + q * pn + p) * (16 / KR) + r / KR) * 64 + lane) * KR + r % KR] = (elem)v;
     }
   }
   const int nob = oblk_base(d, n_layers);
-  for (int e = threadIdx.x; e < nob * 32; e += blockDim.x) {
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < nob * 32; e += gridDim.x * blockDim.x) {
     int ob = e >> 5, l = 0;
     for (;; ++l) {
       const int pn = lay_pn(d, l);
@@ -149,6 +145,12 @@ __device__ void pack_weights(const NofMlpDesc& d, const float* __restrict__ para
     const int row = 32 * ob + (e & 31);
     bias[e] = row < d.out_dim[l] ? params[d.b_off[l] + row] : 0.0f;
   }
+}
+
+__device__ __forceinline__ void copy16(char* __restrict__ dst, const char* __restrict__ src, size_t bytes) {
+  const uint4* s4 = (const uint4*)src;
+  uint4* d4 = (uint4*)dst;
+  for (size_t e = threadIdx.x; e < bytes / 16; e += blockDim.x) d4[e] = s4[e];
 }
 
 // ---- one dense layer, both orientations -------------------------------------------------------------
@@ -178,31 +180,6 @@ __device__ __forceinline__ void dense_o1(const typename P::elem* fwl, const floa
     for (int r = 0; r < 16; ++r) out[p][r] = acc[r];
   }
 }
-// orientation 2: out[p][r] = neuron 32p + j at sample nloc(hi,r)          (lane = neuron)
-template <class P, int QN, int PN>
-__device__ __forceinline__ void dense_o2(const typename P::elem* fwl, const float* bl, const float (&in)[QN][16],
-                                         float (&out)[PN][16], int lane) {
-  constexpr int KR = P::KR, NSTEP = 16 / KR;
-  const int j = lane & 31;
-#pragma unroll
-  for (int p = 0; p < PN; ++p) {
-    const float bv = bl[32 * p + j];
-    f32x16 acc;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = bv;
-#pragma unroll
-    for (int q = 0; q < QN; ++q)
-#pragma unroll
-      for (int s = 0; s < NSTEP; ++s) {
-        const typename P::frag a = P::pack(&in[q][KR * s]);
-        const typename P::frag b = *(const typename P::frag*)&fwl[(((size_t)(p * QN + q) * NSTEP + s) * 64 + lane) * KR];
-        acc = P::mma(a, b, acc);
-      }
-#pragma unroll
-    for (int r = 0; r < 16; ++r) out[p][r] = acc[r];
-  }
-}
-
 template <int PN>
 __device__ __forceinline__ uint32_t relu_mask(float (&h)[PN][16]) {
   uint32_t m = 0;
@@ -260,16 +237,17 @@ __device__ __forceinline__ void load_view_o1(const float* __restrict__ view, int
 // forward: raw[b] = (rgb_raw[3], sdf)
 // =====================================================================================================
 template <class P, int NS, int NC, bool SDF_ONLY>
-__global__ __launch_bounds__(256) void k_mlp_fwd(NofMlpDesc d, const float* __restrict__ params,
+__global__ __launch_bounds__(256) void k_mlp_fwd(NofMlpDesc d, const char* __restrict__ image,
                                                   const float2* __restrict__ feat, int L, const float* __restrict__ view,
                                                   int S, float* __restrict__ out, int64_t B) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int NL = SDF_ONLY ? NS : NS + NC;
   typedef typename P::elem elem;
-  const int npair = pair_base(d, NL);
+  const int npair = pair_base(d, NL), npair_all = pair_base(d, NS + NC);
   elem* fw = (elem*)smem;
   float* bias = (float*)(smem + (size_t)npair * 16 * 64 * sizeof(elem));
-  pack_weights<P>(d, params, fw, nullptr, bias, NL, false);
+  copy16(smem, image, (size_t)npair * 16 * 64 * sizeof(elem));                       // forward fragments of the first NL layers
+  copy16((char*)bias, image + 2 * (size_t)npair_all * 16 * 64 * sizeof(elem), (size_t)oblk_base(d, NL) * 32 * 4);
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int hi = lane >> 5, j = lane & 31;
@@ -322,33 +300,45 @@ __global__ __launch_bounds__(256) void k_mlp_fwd(NofMlpDesc d, const float* __re
 // =====================================================================================================
 // backward (forward recomputed): dfeat, dview, per-workgroup dW/db partials
 // =====================================================================================================
+// dIn of input block q, orientation 1 (lane = sample, reg r = input slot (q,hi,r))
 template <class P, int PN>
-__device__ __forceinline__ void to_frags(const float (&h)[PN][16], typename P::frag (&f)[PN][16 / P::KR]) {
-#pragma unroll
-  for (int p = 0; p < PN; ++p)
-#pragma unroll
-    for (int s = 0; s < 16 / P::KR; ++s) f[p][s] = P::pack(&h[p][P::KR * s]);
-}
-
-// dIn for input block q, orientation 1 (lane = sample) and 2 (lane = input neuron)
-template <class P, int PN, bool O1, bool O2>
-__device__ __forceinline__ void bwd_data(const typename P::elem* bwl, int q, const float (&dout1)[PN][16],
-                                         float (&din1)[16], float (&din2)[16], int lane) {
+__device__ __forceinline__ void bwd_data(const typename P::elem* bwl, int q, const float (&dout1)[PN][16], float (&din1)[16],
+                                         int lane) {
   constexpr int KR = P::KR, NSTEP = 16 / KR;
-  f32x16 a1, a2;
+  f32x16 a1;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) { a1[r] = 0.0f; a2[r] = 0.0f; }
+  for (int r = 0; r < 16; ++r) a1[r] = 0.0f;
 #pragma unroll
   for (int p = 0; p < PN; ++p)
 #pragma unroll
     for (int s = 0; s < NSTEP; ++s) {
       const typename P::frag w = *(const typename P::frag*)&bwl[(((size_t)(q * PN + p) * NSTEP + s) * 64 + lane) * KR];
-      const typename P::frag g = P::pack(&dout1[p][KR * s]);
-      if constexpr (O1) a1 = P::mma(w, g, a1);
-      if constexpr (O2) a2 = P::mma(g, w, a2);
+      a1 = P::mma(w, P::pack(&dout1[p][KR * s]), a1);
     }
 #pragma unroll
-  for (int r = 0; r < 16; ++r) { din1[r] = a1[r]; din2[r] = a2[r]; }
+  for (int r = 0; r < 16; ++r) din1[r] = a1[r];
+}
+
+// The matrix core as a transpose engine: x is a 32-sample x 32-slot block held sample-per-lane (reg r = slot (hi,r));
+// D[sample][n] = sum_k X[sample][k] I[k][n] with I = identity returns it slot-per-lane (lane n = slot with
+// nloc(hi,r) == n, reg r' = sample nloc(hi',r')), i.e. exactly the A/B operand layout of the sample-contracted dW MFMA.
+// Multiplying by 1 and adding 0 is exact: y holds the operand-rounded values of x.
+template <class P>
+__device__ __forceinline__ void transpose32(const float (&x)[16], float (&y)[16], int lane) {
+  constexpr int KR = P::KR, NSTEP = 16 / KR;
+  const int hi = lane >> 5, j = lane & 31;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+#pragma unroll
+  for (int s = 0; s < NSTEP; ++s) {
+    float id[KR];
+#pragma unroll
+    for (int t = 0; t < KR; ++t) id[t] = (nloc(hi, KR * s + t) == j) ? 1.0f : 0.0f;
+    acc = P::mma(P::pack(&x[KR * s]), P::pack(id), acc);
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) y[r] = acc[r];
 }
 
 template <int NS, int NC>
@@ -360,32 +350,63 @@ struct Shp {                                       // compile-time layer shapes 
   static constexpr __host__ __device__ int nacc(int l) { return l == NS - 1 ? 8 : (l == NL - 1 ? 4 : 16); }
 };
 
-// db += sum_samples dOut ; dW += dOut (x) in   for one layer (orientation-2 operands, contraction over the 32 samples)
-template <class P, int PN, int QN, int NACC>
-__device__ __forceinline__ void dw_step(float (&dw)[2][2][16], float (&db)[2], const float (&g2)[2][16],
-                                        const typename P::frag (&in2l)[2][16 / P::KR]) {
+// Orientation-2 (slot-per-lane) copies of every layer INPUT = the B operands of the dW MFMAs.  In the 16-bit modes they
+// live in lane-private LDS slots (written and read by the same lane: no barrier); in fp32 (parity) mode in registers.
+template <class P, int NSLOT, bool IN_LDS>
+struct In2Store;
+template <class P, int NSLOT>
+struct In2Store<P, NSLOT, true> {
+  static constexpr int NSTEP = 16 / P::KR;
+  typename P::frag* base;                         // wave-private region, indexed [slot][step][lane]
+  int lane;
+  __device__ __forceinline__ void put(int slot, int s, typename P::frag f) { base[(slot * NSTEP + s) * 64 + lane] = f; }
+  __device__ __forceinline__ typename P::frag get(int slot, int s) const { return base[(slot * NSTEP + s) * 64 + lane]; }
+};
+template <class P, int NSLOT>
+struct In2Store<P, NSLOT, false> {
+  static constexpr int NSTEP = 16 / P::KR;
+  typename P::frag r[NSLOT][NSTEP];
+  __device__ __forceinline__ void put(int slot, int s, typename P::frag f) { r[slot][s] = f; }
+  __device__ __forceinline__ typename P::frag get(int slot, int s) const { return r[slot][s]; }
+};
+
+// transpose one sample-per-lane block and park it as MFMA operands in slot `slot`
+template <class P, class ST>
+__device__ __forceinline__ void park_o2(ST& st, int slot, const float (&x)[16], int lane) {
+  float y[16];
+  transpose32<P>(x, y, lane);
+#pragma unroll
+  for (int s = 0; s < 16 / P::KR; ++s) st.put(slot, s, P::pack(&y[P::KR * s]));
+}
+
+// one output block p of layer l:  g2 = T(g1[p]);  db += sum_samples g2;  dW[p][q] += g2 (x) in2(l,q)
+template <class P, int QN, int NACC, class ST>
+__device__ __forceinline__ void dw_block(float (&dw)[2][16], float& db, const float (&g1p)[16], const ST& st, int slot0,
+                                         int lane) {
   constexpr int KR = P::KR, NSTEP = 16 / KR;
+  float g2[16];
+  transpose32<P>(g1p, g2, lane);
+  float sdb = 0.0f;
 #pragma unroll
-  for (int p = 0; p < PN; ++p) {
-    float sdb = 0.0f;
+  for (int r = 0; r < 16; ++r) sdb += g2[r];
+  db += sdb;
+  typename P::frag ga[NSTEP];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) sdb += g2[p][r];
-    db[p] += sdb;
+  for (int s = 0; s < NSTEP; ++s) ga[s] = P::pack(&g2[KR * s]);
 #pragma unroll
-    for (int q = 0; q < QN; ++q) {
-      f32x16 acc;
+  for (int q = 0; q < QN; ++q) {
+    f32x16 acc;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[r] = r < NACC ? dw[p][q][r] : 0.0f;
+    for (int r = 0; r < 16; ++r) acc[r] = r < NACC ? dw[q][r] : 0.0f;
 #pragma unroll
-      for (int s = 0; s < NSTEP; ++s) acc = P::mma(P::pack(&g2[p][KR * s]), in2l[q][s], acc);
+    for (int s = 0; s < NSTEP; ++s) acc = P::mma(ga[s], st.get(slot0 + q, s), acc);
 #pragma unroll
-      for (int r = 0; r < NACC; ++r) dw[p][q][r] = acc[r];
-    }
+    for (int r = 0; r < NACC; ++r) dw[q][r] = acc[r];
   }
 }
 
 template <class P, int NS, int NC>
-__global__ __launch_bounds__(256) void k_mlp_bwd(NofMlpDesc d, const float* __restrict__ params,
+__global__ __launch_bounds__(256) void k_mlp_bwd(NofMlpDesc d, const char* __restrict__ image,
                                                   const float2* __restrict__ feat, int L, const float* __restrict__ view,
                                                   int S, const float4* __restrict__ draw, float2* __restrict__ dfeat,
                                                   float* __restrict__ dview, float* __restrict__ partials, int64_t B) {
@@ -394,16 +415,25 @@ __global__ __launch_bounds__(256) void k_mlp_bwd(NofMlpDesc d, const float* __re
   constexpr int KR = P::KR, NSTEP = 16 / KR;
   typedef typename P::elem elem;
   typedef typename P::frag frag;
+  typedef Shp<NS, NC> SH;
   const int npair = pair_base(d, NL);
   elem* fw = (elem*)smem;
   elem* bw = fw + (size_t)npair * 16 * 64;
   float* bias = (float*)(bw + (size_t)npair * 16 * 64);
-  pack_weights<P>(d, params, fw, bw, bias, NL, true);
+  copy16(smem, image, 2 * (size_t)npair * 16 * 64 * sizeof(elem) + (size_t)oblk_base(d, NL) * 32 * 4);
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int hi = lane >> 5, j = lane & 31;
+  constexpr bool IN2_LDS = (KR == 8);
+  constexpr int NSLOT = 2 * NL;                       // slot(l, q) = 2 l + q : input block q of layer l
+  typedef In2Store<P, NSLOT, IN2_LDS> Store;
+  Store st;
+  if constexpr (IN2_LDS) {
+    frag* in2_lds = (frag*)(bias + oblk_base(d, NL) * 32);
+    st.base = in2_lds + (size_t)wave * NSLOT * NSTEP * 64;
+    st.lane = lane;
+  }
 
-  typedef Shp<NS, NC> SH;
   float dw[NL][2][2][16];                             // persistent per-wave dW accumulators (only the live entries are touched)
   float db[NL][2];
 #pragma unroll
@@ -423,141 +453,101 @@ __global__ __launch_bounds__(256) void k_mlp_bwd(NofMlpDesc d, const float* __re
     asm volatile("" ::: "memory");                    // keep the weight fragments in LDS (no hoisting into VGPRs)
     const int64_t t0 = tile * 32;
     const int64_t b = t0 + j;
-    // ---------------- forward recompute, both orientations ----------------
-    float x[1][16];
-    load_feat_o1(feat, L, B, b, hi, x);
-    uint32_t m1[NL], m2[NL];                          // ReLU masks per layer output (hidden layers only)
-    frag in2[NL][2][NSTEP];                           // orientation-2 INPUT of layer l (l >= 1), as MFMA operands
+    // ---------------- forward recompute (sample-per-lane), parking the transposed layer inputs ----------------
+    uint32_t m1[NL];                                  // ReLU masks of the hidden layers' outputs
     float h[2][16];
     {
-      float h2[2][16];
+      float x[1][16];
+      load_feat_o1(feat, L, B, b, hi, x);
+      park_o2<P>(st, 0, x[0], lane);
       dense_o1<P, 1, 2>(LAYER_FW(0), LAYER_BIAS(0), x, h, lane);
-      dense_o2<P, 1, 2>(LAYER_FW(0), LAYER_BIAS(0), x, h2, lane);
       m1[0] = relu_mask<2>(h);
-      m2[0] = relu_mask<2>(h2);
-      to_frags<P, 2>(h2, in2[1]);
     }
 #pragma unroll
     for (int l = 1; l < NS - 1; ++l) {
-      float hn[2][16], h2[2][16];
+      park_o2<P>(st, 2 * l, h[0], lane);
+      park_o2<P>(st, 2 * l + 1, h[1], lane);
+      float hn[2][16];
       dense_o1<P, 2, 2>(LAYER_FW(l), LAYER_BIAS(l), h, hn, lane);
-      dense_o2<P, 2, 2>(LAYER_FW(l), LAYER_BIAS(l), h, h2, lane);
       m1[l] = relu_mask<2>(hn);
-      m2[l] = relu_mask<2>(h2);
-      to_frags<P, 2>(h2, in2[l + 1]);
 #pragma unroll
       for (int p = 0; p < 2; ++p)
 #pragma unroll
         for (int r = 0; r < 16; ++r) h[p][r] = hn[p][r];
     }
-    float cin[2][16];
+    park_o2<P>(st, 2 * (NS - 1), h[0], lane);
+    park_o2<P>(st, 2 * (NS - 1) + 1, h[1], lane);
     {
-      float so[1][16], so2[1][16];
+      float cin[2][16], so[1][16];
       dense_o1<P, 2, 1>(LAYER_FW(NS - 1), LAYER_BIAS(NS - 1), h, so, lane);
-      dense_o2<P, 2, 1>(LAYER_FW(NS - 1), LAYER_BIAS(NS - 1), h, so2, lane);
 #pragma unroll
       for (int r = 0; r < 16; ++r) cin[0][r] = so[0][r];
-      frag t[1][NSTEP];
-      to_frags<P, 1>(so2, t);
-#pragma unroll
-      for (int s = 0; s < NSTEP; ++s) in2[NS][0][s] = t[0][s];
-    }
-    load_view_o1(view, S, B, b, hi, cin[1]);
-    {                                                 // orientation-2 view block: lane u = j (< 16), reg r <-> sample nloc(hi,r)
-      float v2[1][16];
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int64_t bs = t0 + nloc(hi, r);
-        v2[0][r] = (j < NOF_VIEW_COLS && bs < B) ? view[(bs / S) * NOF_VIEW_COLS + j] : 0.0f;
-      }
-      frag t[1][NSTEP];
-      to_frags<P, 1>(v2, t);
-#pragma unroll
-      for (int s = 0; s < NSTEP; ++s) in2[NS][1][s] = t[0][s];
-    }
-    {
-      float h2[2][16];
+      load_view_o1(view, S, B, b, hi, cin[1]);
+      park_o2<P>(st, 2 * NS, cin[0], lane);
+      park_o2<P>(st, 2 * NS + 1, cin[1], lane);
       dense_o1<P, 2, 2>(LAYER_FW(NS), LAYER_BIAS(NS), cin, h, lane);
-      dense_o2<P, 2, 2>(LAYER_FW(NS), LAYER_BIAS(NS), cin, h2, lane);
       m1[NS] = relu_mask<2>(h);
-      m2[NS] = relu_mask<2>(h2);
-      to_frags<P, 2>(h2, in2[NS + 1]);
     }
 #pragma unroll
     for (int l = NS + 1; l < NL - 1; ++l) {
-      float hn[2][16], h2[2][16];
+      park_o2<P>(st, 2 * l, h[0], lane);
+      park_o2<P>(st, 2 * l + 1, h[1], lane);
+      float hn[2][16];
       dense_o1<P, 2, 2>(LAYER_FW(l), LAYER_BIAS(l), h, hn, lane);
-      dense_o2<P, 2, 2>(LAYER_FW(l), LAYER_BIAS(l), h, h2, lane);
       m1[l] = relu_mask<2>(hn);
-      m2[l] = relu_mask<2>(h2);
-      to_frags<P, 2>(h2, in2[l + 1]);
 #pragma unroll
       for (int p = 0; p < 2; ++p)
 #pragma unroll
         for (int r = 0; r < 16; ++r) h[p][r] = hn[p][r];
     }
+    park_o2<P>(st, 2 * (NL - 1), h[0], lane);
+    park_o2<P>(st, 2 * (NL - 1) + 1, h[1], lane);
     // (the last colour layer's output is not needed: its gradient comes from draw)
 
     // ---------------- backward ----------------
-    // top gradients: draw[b] = (d rgb_raw[3], d sdf)
-    float g1[2][16], g2[2][16];                       // dOut of the current layer (orientation 1 / 2); block 1 unused for PN = 1
+    float g1[2][16];                                  // dOut of the current layer, sample-per-lane (block 1 unused when PN = 1)
     float dsdf1 = 0.0f;
-    float dsdf2[16];
 #pragma unroll
     for (int p = 0; p < 2; ++p)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) { g1[p][r] = 0.0f; g2[p][r] = 0.0f; }
-    if (hi == 0 && b < B) {
+      for (int r = 0; r < 16; ++r) g1[p][r] = 0.0f;
+    if (hi == 0 && b < B) {                           // draw[b] = (d rgb_raw[3], d sdf)
       const float4 t = draw[b];
       g1[0][0] = t.x; g1[0][1] = t.y; g1[0][2] = t.z;
       dsdf1 = t.w;
     }
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int64_t bs = t0 + nloc(hi, r);
-      float v = 0.0f, w = 0.0f;
-      if (j < 4 && bs < B) {
-        const float* dr = (const float*)&draw[bs];
-        v = (j < 3) ? dr[j] : 0.0f;
-        w = (j == 0) ? dr[3] : 0.0f;
-      }
-      g2[0][r] = v;
-      dsdf2[r] = w;
-    }
-
-    // per layer: db, dW (needs in2[l]); dIn (both orientations) -> masked -> g1/g2 of layer l-1
-#define BWD_LAYER_COMMON(l, PN_, QN_, NACC_) dw_step<P, PN_, QN_, NACC_>(dw[l], db[l], g2, in2[l]);
-
-    // ---- colour net, last layer down to colour layer 1 ----
+    // ---- colour net: head down to colour layer 1 ----
 #pragma unroll
     for (int l = NL - 1; l > NS; --l) {
-      float d1[2][16], d2[2][16];
+      float d1[2][16];
       if (l == NL - 1) {
-        BWD_LAYER_COMMON(l, 1, 2, 4)
+        dw_block<P, 2, 4>(dw[l][0], db[l][0], g1[0], st, 2 * l, lane);
         float ga[1][16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) ga[0][r] = g1[0][r];
-        bwd_data<P, 1, true, true>(LAYER_BW(l), 0, ga, d1[0], d2[0], lane);
-        bwd_data<P, 1, true, true>(LAYER_BW(l), 1, ga, d1[1], d2[1], lane);
+        bwd_data<P, 1>(LAYER_BW(l), 0, ga, d1[0], lane);
+        bwd_data<P, 1>(LAYER_BW(l), 1, ga, d1[1], lane);
       } else {
-        BWD_LAYER_COMMON(l, 2, 2, 16)
-        bwd_data<P, 2, true, true>(LAYER_BW(l), 0, g1, d1[0], d2[0], lane);
-        bwd_data<P, 2, true, true>(LAYER_BW(l), 1, g1, d1[1], d2[1], lane);
+        dw_block<P, 2, 16>(dw[l][0], db[l][0], g1[0], st, 2 * l, lane);
+        dw_block<P, 2, 16>(dw[l][1], db[l][1], g1[1], st, 2 * l, lane);
+        bwd_data<P, 2>(LAYER_BW(l), 0, g1, d1[0], lane);
+        bwd_data<P, 2>(LAYER_BW(l), 1, g1, d1[1], lane);
       }
       apply_mask<2>(d1, m1[l - 1]);
-      apply_mask<2>(d2, m2[l - 1]);
 #pragma unroll
       for (int p = 0; p < 2; ++p)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { g1[p][r] = d1[p][r]; g2[p][r] = d2[p][r]; }
+        for (int r = 0; r < 16; ++r) g1[p][r] = d1[p][r];
     }
     // ---- colour layer 0: inputs = [sigma-out block | view block] ----
     {
-      float ds1[16], ds2[16], dv1[16], dv2[16];
-      BWD_LAYER_COMMON(NS, 2, 2, 16)
-      bwd_data<P, 2, true, true>(LAYER_BW(NS), 0, g1, ds1, ds2, lane);
-      bwd_data<P, 2, false, true>(LAYER_BW(NS), 1, g1, dv1, dv2, lane);
-      // dview[ray][u] += sum over the tile's samples (lane u = j, regs <-> samples; a tile may straddle two rays)
+      dw_block<P, 2, 16>(dw[NS][0], db[NS][0], g1[0], st, 2 * NS, lane);
+      dw_block<P, 2, 16>(dw[NS][1], db[NS][1], g1[1], st, 2 * NS, lane);
+      float ds1[16], dv1[16], dv2[16];
+      bwd_data<P, 2>(LAYER_BW(NS), 0, g1, ds1, lane);
+      bwd_data<P, 2>(LAYER_BW(NS), 1, g1, dv1, lane);
+      transpose32<P>(dv1, dv2, lane);
+      // dview[ray][u] += sum over the tile's samples (lane = view slot, regs <-> samples; a tile may straddle two rays)
       {
         const int64_t ray0 = t0 / S;
         float sa = 0.0f, sb = 0.0f;
@@ -571,65 +561,46 @@ __global__ __launch_bounds__(256) void k_mlp_bwd(NofMlpDesc d, const float* __re
         }
         sa += __shfl_xor(sa, 32, 64);
         sb += __shfl_xor(sb, 32, 64);
-        // orientation-2 lane j of a bwd_data result is input SLOT (hi_j, r_j); for the view block slot -> u = 16 hi_j + r_j
-        const int hi_j = (j >> 2) & 1, u = (j & 3) + 4 * (j >> 3);
+        const int hi_j = (j >> 2) & 1, u = (j & 3) + 4 * (j >> 3);   // lane j holds slot (hi_j, r_j) -> view column 16 hi_j + r_j
         if (hi == 0 && hi_j == 0 && u < d.n_view) {
           if (sa != 0.0f) atomicAdd(&dview[ray0 * NOF_VIEW_COLS + u], sa);
           if (sb != 0.0f) atomicAdd(&dview[(ray0 + 1) * NOF_VIEW_COLS + u], sb);
         }
       }
-      // gradient of the sigma net output block: geo_feat grads + the loss' own d sdf
+      // gradient of the sigma net output block: geo_feat grads + the loss' own d sdf (output 0 = hi 0, reg 0)
 #pragma unroll
-      for (int p = 0; p < 2; ++p)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { g1[p][r] = 0.0f; g2[p][r] = 0.0f; }
-#pragma unroll
-      for (int r = 0; r < 16; ++r) { g1[0][r] = ds1[r]; g2[0][r] = ds2[r]; }
+      for (int r = 0; r < 16; ++r) { g1[0][r] = ds1[r]; g1[1][r] = 0.0f; }
       if (hi == 0) g1[0][0] += dsdf1;
-      if (j == 0) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) g2[0][r] += dsdf2[r];
-      }
     }
-    // ---- sigma net: last layer down to layer 1 ----
+    // ---- sigma net: head down to layer 1 ----
 #pragma unroll
     for (int l = NS - 1; l >= 1; --l) {
-      float d1[2][16], d2[2][16];
+      float d1[2][16];
       if (l == NS - 1) {
-        BWD_LAYER_COMMON(l, 1, 2, 8)
+        dw_block<P, 2, 8>(dw[l][0], db[l][0], g1[0], st, 2 * l, lane);
         float ga[1][16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) ga[0][r] = g1[0][r];
-        bwd_data<P, 1, true, true>(LAYER_BW(l), 0, ga, d1[0], d2[0], lane);
-        bwd_data<P, 1, true, true>(LAYER_BW(l), 1, ga, d1[1], d2[1], lane);
+        bwd_data<P, 1>(LAYER_BW(l), 0, ga, d1[0], lane);
+        bwd_data<P, 1>(LAYER_BW(l), 1, ga, d1[1], lane);
       } else {
-        BWD_LAYER_COMMON(l, 2, 2, 16)
-        bwd_data<P, 2, true, true>(LAYER_BW(l), 0, g1, d1[0], d2[0], lane);
-        bwd_data<P, 2, true, true>(LAYER_BW(l), 1, g1, d1[1], d2[1], lane);
+        dw_block<P, 2, 16>(dw[l][0], db[l][0], g1[0], st, 2 * l, lane);
+        dw_block<P, 2, 16>(dw[l][1], db[l][1], g1[1], st, 2 * l, lane);
+        bwd_data<P, 2>(LAYER_BW(l), 0, g1, d1[0], lane);
+        bwd_data<P, 2>(LAYER_BW(l), 1, g1, d1[1], lane);
       }
       apply_mask<2>(d1, m1[l - 1]);
-      apply_mask<2>(d2, m2[l - 1]);
 #pragma unroll
       for (int p = 0; p < 2; ++p)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { g1[p][r] = d1[p][r]; g2[p][r] = d2[p][r]; }
+        for (int r = 0; r < 16; ++r) g1[p][r] = d1[p][r];
     }
-    // ---- sigma layer 0: dW needs the features in orientation 2 (lane = feature j, regs <-> samples) ----
+    // ---- sigma layer 0 ----
     {
-      float f2[1][16];
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int64_t bs = t0 + nloc(hi, r);
-        const int level = j >> 1;
-        f2[0][r] = (level < L && bs < B) ? ((const float*)&feat[(int64_t)level * B + bs])[j & 1] : 0.0f;
-      }
-      frag t[1][NSTEP];
-      to_frags<P, 1>(f2, t);
-#pragma unroll
-      for (int s = 0; s < NSTEP; ++s) in2[0][0][s] = t[0][s];
-      BWD_LAYER_COMMON(0, 2, 1, 16)
-      float df1[16], dummy[16];
-      bwd_data<P, 2, true, false>(LAYER_BW(0), 0, g1, df1, dummy, lane);
+      dw_block<P, 1, 16>(dw[0][0], db[0][0], g1[0], st, 0, lane);
+      dw_block<P, 1, 16>(dw[0][1], db[0][1], g1[1], st, 0, lane);
+      float df1[16];
+      bwd_data<P, 2>(LAYER_BW(0), 0, g1, df1, lane);
       if (b < B) {
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
@@ -638,7 +609,6 @@ __global__ __launch_bounds__(256) void k_mlp_bwd(NofMlpDesc d, const float* __re
         }
       }
     }
-#undef BWD_LAYER_COMMON
   }
 
   // ---------------- reduce the workgroup's dW/db and write its row of `partials` ----------------
@@ -646,6 +616,7 @@ __global__ __launch_bounds__(256) void k_mlp_bwd(NofMlpDesc d, const float* __re
   float* red = (float*)smem;
   for (int e = threadIdx.x; e < d.n_params; e += blockDim.x) red[e] = 0.0f;
   __syncthreads();
+  const int hi_j = (j >> 2) & 1, r_j = (j & 3) + 4 * (j >> 3);      // dW column lane j = input slot (hi_j, r_j)
 #pragma unroll
   for (int l = 0; l < NL; ++l) {
     const int in_dim = d.in_dim[l], out_dim = d.out_dim[l];
@@ -655,7 +626,7 @@ __global__ __launch_bounds__(256) void k_mlp_bwd(NofMlpDesc d, const float* __re
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
           if (q < SH::qn(l)) {
-            const int col = colmap(d, l, q, j);
+            const int col = inmap(d, l, q, hi_j, r_j);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
               if (r < SH::nacc(l)) {
@@ -721,6 +692,22 @@ static int set_smem(K kernel, size_t bytes) {
   else if (d->precision == 1) { DISPATCH_SHAPE(PrecBF16, FN, __VA_ARGS__) }                               \
   else { DISPATCH_SHAPE(PrecF16, FN, __VA_ARGS__) }
 
+extern "C" int64_t nof_mlp_packed_bytes(const NofMlpDesc* d) {
+  if (check_desc(d)) return -1;
+  const int nl = d->n_sigma + d->n_color;
+  return 2 * (int64_t)n_pairs(*d, nl) * 16 * 64 * (int64_t)elem_size(d->precision) + (int64_t)n_oblk(*d, nl) * 32 * 4;
+}
+
+extern "C" int nof_mlp_pack(const NofMlpDesc* d, const float* mlp_params, void* packed, void* stream) {
+  if (int e = check_desc(d)) return e;
+  NOF_ARG(mlp_params && packed);
+  if (d->precision == 0) hipLaunchKernelGGL(k_mlp_pack<PrecF32>, dim3(64), dim3(256), 0, (hipStream_t)stream, *d, mlp_params, (char*)packed);
+  else if (d->precision == 1) hipLaunchKernelGGL(k_mlp_pack<PrecBF16>, dim3(64), dim3(256), 0, (hipStream_t)stream, *d, mlp_params, (char*)packed);
+  else hipLaunchKernelGGL(k_mlp_pack<PrecF16>, dim3(64), dim3(256), 0, (hipStream_t)stream, *d, mlp_params, (char*)packed);
+  NOF_LAUNCH_OK();
+  return 0;
+}
+
 static int g_bwd_blocks = 0;
 extern "C" int nof_mlp_bwd_blocks(void) {
   if (g_bwd_blocks == 0) {
@@ -735,10 +722,10 @@ extern "C" int nof_mlp_bwd_blocks(void) {
   return g_bwd_blocks;
 }
 
-extern "C" int nof_mlp_fwd(const NofMlpDesc* d, const float* mlp_params, const float* feat, int32_t L, const float* view,
+extern "C" int nof_mlp_fwd(const NofMlpDesc* d, const void* packed, const float* feat, int32_t L, const float* view,
                             int32_t S, float* raw, int64_t B, void* stream) {
   if (int e = check_desc(d)) return e;
-  NOF_ARG(mlp_params && feat && view && raw && B >= 0 && S >= 1 && L >= 1 && L * 2 == d->in_feat);
+  NOF_ARG(packed && feat && view && raw && B >= 0 && S >= 1 && L >= 1 && L * 2 == d->in_feat);
   if (B == 0) return 0;
   const int nl = d->n_sigma + d->n_color;
   const size_t shm = (size_t)n_pairs(*d, nl) * 16 * 64 * elem_size(d->precision) + (size_t)n_oblk(*d, nl) * 32 * 4;
@@ -748,7 +735,7 @@ extern "C" int nof_mlp_fwd(const NofMlpDesc* d, const float* mlp_params, const f
   {                                                                                                       \
     auto kern = k_mlp_fwd<P, NS_, NC_, false>;                                                            \
     if (int e = set_smem(kern, shm)) return e;                                                            \
-    hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), shm, (hipStream_t)stream, *d, mlp_params,           \
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), shm, (hipStream_t)stream, *d, (const char*)packed,  \
                        (const float2*)feat, (int)L, view, (int)S, raw, B);                                \
   }
   DISPATCH_PREC(LAUNCH_FWD, 0)
@@ -757,10 +744,10 @@ extern "C" int nof_mlp_fwd(const NofMlpDesc* d, const float* mlp_params, const f
   return 0;
 }
 
-extern "C" int nof_mlp_sdf(const NofMlpDesc* d, const float* mlp_params, const float* feat, int32_t L, float* sdf,
+extern "C" int nof_mlp_sdf(const NofMlpDesc* d, const void* packed, const float* feat, int32_t L, float* sdf,
                             int64_t B, void* stream) {
   if (int e = check_desc(d)) return e;
-  NOF_ARG(mlp_params && feat && sdf && B >= 0 && L >= 1 && L * 2 == d->in_feat);
+  NOF_ARG(packed && feat && sdf && B >= 0 && L >= 1 && L * 2 == d->in_feat);
   if (B == 0) return 0;
   const int nl = d->n_sigma;
   const size_t shm = (size_t)n_pairs(*d, nl) * 16 * 64 * elem_size(d->precision) + (size_t)n_oblk(*d, nl) * 32 * 4;
@@ -770,7 +757,7 @@ extern "C" int nof_mlp_sdf(const NofMlpDesc* d, const float* mlp_params, const f
   {                                                                                                       \
     auto kern = k_mlp_fwd<P, NS_, NC_, true>;                                                             \
     if (int e = set_smem(kern, shm)) return e;                                                            \
-    hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), shm, (hipStream_t)stream, *d, mlp_params,           \
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), shm, (hipStream_t)stream, *d, (const char*)packed,  \
                        (const float2*)feat, (int)L, (const float*)nullptr, 1, sdf, B);                    \
   }
   DISPATCH_PREC(LAUNCH_SDF, 0)
@@ -779,20 +766,21 @@ extern "C" int nof_mlp_sdf(const NofMlpDesc* d, const float* mlp_params, const f
   return 0;
 }
 
-extern "C" int nof_mlp_bwd(const NofMlpDesc* d, const float* mlp_params, const float* feat, int32_t L, const float* view,
+extern "C" int nof_mlp_bwd(const NofMlpDesc* d, const void* packed, const float* feat, int32_t L, const float* view,
                             int32_t S, const float* draw, float* dfeat, float* dview, float* partials, int64_t B,
                             void* stream) {
   if (int e = check_desc(d)) return e;
-  NOF_ARG(mlp_params && feat && view && draw && dfeat && dview && partials && B >= 0 && S >= 32 && L * 2 == d->in_feat);
+  NOF_ARG(packed && feat && view && draw && dfeat && dview && partials && B >= 0 && S >= 32 && L * 2 == d->in_feat);
   const int nl = d->n_sigma + d->n_color;
   size_t shm = 2 * (size_t)n_pairs(*d, nl) * 16 * 64 * elem_size(d->precision) + (size_t)n_oblk(*d, nl) * 32 * 4;
+  if (d->precision != 0) shm += (size_t)4 * (2 * nl) * 2 * 64 * 16;      // lane-private orientation-2 slots (16-bit modes)
   if (shm < (size_t)d->n_params * 4) shm = (size_t)d->n_params * 4;
   const unsigned blocks = (unsigned)nof_mlp_bwd_blocks();
 #define LAUNCH_BWD(P, NS_, NC_, dummy)                                                                    \
   {                                                                                                       \
     auto kern = k_mlp_bwd<P, NS_, NC_>;                                                                   \
     if (int e = set_smem(kern, shm)) return e;                                                            \
-    hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), shm, (hipStream_t)stream, *d, mlp_params,           \
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), shm, (hipStream_t)stream, *d, (const char*)packed,  \
                        (const float2*)feat, (int)L, view, (int)S, (const float4*)draw, (float2*)dfeat,    \
                        dview, partials, B);                                                               \
   }

@@ -64,6 +64,8 @@ class NeuralObjectField:
         self.N_iters = cfg['n_step'] + 1
         self._bufs = {}
         self.nblk = lib.load().nof_mlp_bwd_blocks()
+        self.packed = torch.empty(int(lib.load().nof_mlp_packed_bytes(C.byref(self.desc))), dtype=torch.uint8, device=dev)
+        self._packed_step = None     # optimiser step the fragment image was built for
         self.profile = None          # dict name -> [(start_event, end_event)] when per-kernel timing is on (bench.py)
         self.profile_only = None
         if seed_init:
@@ -117,6 +119,7 @@ class NeuralObjectField:
                              pose=torch.zeros(self.F, 6) if self.optimize_poses else None)
 
     def load_parameters(self, table=None, mlp=None, feat=None, pose=None):
+        self._packed_step = None
         for name, val in (('table', table), ('mlp', mlp), ('feat', feat), ('pose', pose)):
             if val is not None:
                 seg = self._seg(self.params, name)
@@ -183,7 +186,7 @@ class NeuralObjectField:
                 batch=e(R, 12), rays_o_w=e(R, 3), viewdirs_w=e(R, 3), view=e(R, 16), t_in_out=e(R, self.max_hits, 2),
                 n_hits=e(R, dt=torch.int32), z_vals=e(R, S), pts_w=e(B, 3), valid=e(B, dt=torch.uint8),
                 feat=e(self.L, B, 2), raw=e(B, 4), draw=e(B, 4), dfeat=e(self.L, B, 2), dview=e(R, 16), dpts=e(B, 3),
-                rgb_map=e(R, 3), partials=e(self.nblk, self.n_mlp))
+                rgb_map=e(R, 3), partials=e(self.nblk, self.n_mlp), loss_rows=e(R, 8))
         return self._bufs[key]
 
     def _sample_cfg(self, seed, step):
@@ -199,6 +202,12 @@ class NeuralObjectField:
                               1.0 / self.world_size)
 
     # ---- forward pieces -----------------------------------------------------------------------------------
+    def pack_weights(self, force=False):
+        """fp32 PyTorch-layout MLP parameters -> MFMA fragment image (once per optimiser step)."""
+        if force or self._packed_step != self.global_step:
+            self._call('nof_mlp_pack', C.byref(self.desc), self.mlp, self.packed)
+            self._packed_step = self.global_step
+
     def update_poses(self):
         self._call('nof_pose_fwd', self.pose if self.optimize_poses else None, self.c2w, C.c_float(self.max_trans),
                  C.c_float(self.max_rot), self.tf, self.F)
@@ -209,6 +218,7 @@ class NeuralObjectField:
         S = cfg['N_samples'] + cfg['N_samples_around_depth']
         b = self._buffers(R, S)
         self.update_poses()
+        self.pack_weights()
         cid = None
         if want_cells:
             cid = b.setdefault('cell_ids', torch.empty(R, self.max_hits, dtype=torch.int32, device=self.device))
@@ -220,7 +230,7 @@ class NeuralObjectField:
                  u_occ, u_dep, b['z_vals'], b['pts_w'], b['valid'], self.flags)
         B = R * S
         self._call('nof_hash_encode_fwd', C.byref(self.grid), b['pts_w'], self.table, b['feat'], B)
-        self._call('nof_mlp_fwd', C.byref(self.desc), self.mlp, b['feat'], self.L, b['view'], S, b['raw'], B)
+        self._call('nof_mlp_fwd', C.byref(self.desc), self.packed, b['feat'], self.L, b['view'], S, b['raw'], B)
         return b, S
 
     def train_step(self, pool, ids, R, u_occ=None, u_dep=None, seed=0, do_step=True, want_cells=False,
@@ -233,9 +243,9 @@ class NeuralObjectField:
         lc = self._loss_cfg()
         self.loss_out.zero_()
         self._call('nof_composite_loss', C.byref(lc), b['raw'], b['z_vals'], b['valid'], b['batch'], R, S, b['rgb_map'],
-                 None, b['draw'], self.loss_out)
+                 None, b['draw'], b['loss_rows'], self.loss_out)
         b['dview'].zero_()
-        self._call('nof_mlp_bwd', C.byref(self.desc), self.mlp, b['feat'], self.L, b['view'], S, b['draw'], b['dfeat'],
+        self._call('nof_mlp_bwd', C.byref(self.desc), self.packed, b['feat'], self.L, b['view'], S, b['draw'], b['dfeat'],
                  b['dview'], b['partials'], B)
         self._call('nof_reduce_partials', b['partials'], self.nblk, self.n_mlp, self._seg(self.grads, 'mlp'))
         self._call('nof_hash_encode_bwd', C.byref(self.grid), b['pts_w'], self.table, b['dfeat'],
@@ -268,6 +278,7 @@ class NeuralObjectField:
     def query_sdf(self, pts, chunk=1 << 22):
         """run_network_density (nerf_runner.py:1307-1347): clip to [-1,1], hash encode, sigma_net -> sdf [N]."""
         pts = torch.clip(pts.to(self.device, torch.float32), -1, 1).contiguous()
+        self.pack_weights()
         N = pts.shape[0]
         out = torch.empty(N, device=self.device)
         for i in range(0, N, chunk):
@@ -275,7 +286,7 @@ class NeuralObjectField:
             feat = torch.empty(self.L, n, 2, device=self.device)
             p = pts[i:i + n].contiguous()
             lib.call('nof_hash_encode_fwd', C.byref(self.grid), p, self.table, feat, n)
-            lib.call('nof_mlp_sdf', C.byref(self.desc), self.mlp, feat, self.L, out[i:i + n], n)
+            lib.call('nof_mlp_sdf', C.byref(self.desc), self.packed, feat, self.L, out[i:i + n], n)
         return out
 
     def losses(self):

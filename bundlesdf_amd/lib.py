@@ -66,12 +66,14 @@ _SIGNATURES = {
     'nof_trace_rays': ([_P, _I32, _P, _P, _I64, _I32, _P, _P, _P, _P, _P], C.c_int),
     'nof_batch_trace': ([_P, _P, _P, _P, _I32, _I32, _P, _I32, _I64, _I32, _P, _P, _P, _P, _P, _P, _P, _P, _P], C.c_int),
     'nof_sample_points': ([C.POINTER(NofSampleCfg), _P, _P, _P, _P, _I64, _I32, _P, _P, _P, _P, _P, _P, _P], C.c_int),
+    'nof_mlp_packed_bytes': ([C.POINTER(NofMlpDesc)], C.c_int64),
+    'nof_mlp_pack': ([C.POINTER(NofMlpDesc), _P, _P, _P], C.c_int),
     'nof_mlp_fwd': ([C.POINTER(NofMlpDesc), _P, _P, _I32, _P, _I32, _P, _I64, _P], C.c_int),
     'nof_mlp_bwd_blocks': ([], C.c_int),
     'nof_mlp_bwd': ([C.POINTER(NofMlpDesc), _P, _P, _I32, _P, _I32, _P, _P, _P, _P, _I64, _P], C.c_int),
     'nof_reduce_partials': ([_P, _I32, _I32, _P, _P], C.c_int),
     'nof_mlp_sdf': ([C.POINTER(NofMlpDesc), _P, _P, _I32, _P, _I64, _P], C.c_int),
-    'nof_composite_loss': ([C.POINTER(NofLossCfg), _P, _P, _P, _P, _I64, _I32, _P, _P, _P, _P, _P], C.c_int),
+    'nof_composite_loss': ([C.POINTER(NofLossCfg), _P, _P, _P, _P, _I64, _I32, _P, _P, _P, _P, _P, _P], C.c_int),
     'nof_pose_grad_accum': ([_P, _P, _P, _P, _P, _P, _I32, _I32, _I64, _I32, _P, _P, _P], C.c_int),
     'nof_small_regs': ([_P, _P, _I32, _F, _F, _P], C.c_int),
     'nof_adam_step': ([_P, _P, _P, _P, _I64, _I64, _F, _F, _F, _F, _F, _I32, _P], C.c_int),

@@ -119,20 +119,24 @@ typedef struct {
   int32_t n_params;
   int32_t precision;                      /* 0: fp32 MFMA (exact), 1: bf16 MFMA, 2: fp16 MFMA */
 } NofMlpDesc;
+/* Weights are consumed as an MFMA-fragment image: nof_mlp_pack converts the fp32 PyTorch-layout parameters (once per
+ * optimiser step) into `packed` (nof_mlp_packed_bytes() bytes, caller-allocated); fwd / bwd / sdf read only the image. */
+int64_t nof_mlp_packed_bytes(const NofMlpDesc* h_desc);
+int nof_mlp_pack(const NofMlpDesc* h_desc, const float* mlp_params, void* packed, void* stream);
 /* feat [L,B,2]; view [R,16]; raw [B,4] = (rgb_raw[3], sdf)  (nerf_helpers.py:319). */
-int nof_mlp_fwd(const NofMlpDesc* h_desc, const float* mlp_params, const float* feat, int32_t L,
+int nof_mlp_fwd(const NofMlpDesc* h_desc, const void* packed, const float* feat, int32_t L,
                 const float* view, int32_t S, float* raw, int64_t B, void* stream);
 /* draw [B,4] -> dfeat [L,B,2] (overwritten), dview [R,16] ACCUMULATED, partials [n_blocks, n_params]
  * overwritten with per-workgroup weight-gradient partial sums (reduce with nof_reduce_partials).
  * n_blocks must equal nof_mlp_bwd_blocks(). */
 int nof_mlp_bwd_blocks(void);
-int nof_mlp_bwd(const NofMlpDesc* h_desc, const float* mlp_params, const float* feat, int32_t L,
+int nof_mlp_bwd(const NofMlpDesc* h_desc, const void* packed, const float* feat, int32_t L,
                 const float* view, int32_t S, const float* draw, float* dfeat, float* dview,
                 float* partials, int64_t B, void* stream);
 /* out[j] += sum_i partials[i,j] */
 int nof_reduce_partials(const float* partials, int32_t n_rows, int32_t n_cols, float* out, void* stream);
 /* sigma_net only: feat [L,B,2] -> sdf [B]  (NeRFSmall.forward_sdf, nerf_helpers.py:296-302) */
-int nof_mlp_sdf(const NofMlpDesc* h_desc, const float* mlp_params, const float* feat, int32_t L,
+int nof_mlp_sdf(const NofMlpDesc* h_desc, const void* packed, const float* feat, int32_t L,
                 float* sdf, int64_t B, void* stream);
 
 /* ---- compositing + losses + dL/draw (raw2outputs, train_loop, get_sdf_loss) ---------------------- */
@@ -144,11 +148,12 @@ typedef struct {
   float grad_scale;                       /* multiplies every gradient (1/world_size for DP averaging) */
 } NofLossCfg;
 /* raw [R,S,4], z_vals [R,S], valid [R,S] u8, batch [R,12] ->
- * rgb_map [R,3], weights [R,S] (may be NULL), draw [R,S,4], loss_out [8] ACCUMULATED:
- * 0 total, 1 rgb, 2 fs(+empty), 3 sdf, 4 fs_rgb, 5 n_valid_samples, 6 n_valid_rays. */
+ * rgb_map [R,3], weights [R,S] (may be NULL), draw [R,S,4], loss_out [8] ACCUMULATED (may be NULL):
+ * 0 total, 1 rgb, 2 fs(+empty), 3 sdf, 4 fs_rgb, 5 n_valid_samples, 6 n_valid_rays.
+ * loss_rows [R,8] is scratch for the per-ray terms (required when loss_out is given). */
 int nof_composite_loss(const NofLossCfg* h_cfg, const float* raw, const float* z_vals, const uint8_t* valid,
                        const float* batch, int64_t R, int32_t S, float* rgb_map, float* weights, float* draw,
-                       float* loss_out, void* stream);
+                       float* loss_rows, float* loss_out, void* stream);
 
 /* ---- pose / feature gradients of a batch ---------------------------------------------------------- */
 /* dpts [R*S,3] (from nof_hash_encode_bwd), dview [R,16] (from nof_mlp_bwd), batch, z_vals, c2w [F,16],

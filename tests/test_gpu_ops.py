@@ -272,6 +272,12 @@ def _mlp_setup(nof, ns, nc, ff, L, precision, seed=0):
     return shape, params, desc, flat
 
 
+def _pack(nof, desc, flat):
+    packed = torch.empty(int(nof.load().nof_mlp_packed_bytes(C.byref(desc))), dtype=torch.uint8, device='cuda')
+    nof.call('nof_mlp_pack', C.byref(desc), flat.cuda(), packed)
+    return packed
+
+
 TOL = {0: 2e-5, 1: 3e-2, 2: 4e-3}          # max |err| / max |ref| for the forward outputs
 # Gradients are checked against the oracle evaluated with the SAME operand rounding as the kernel (16-bit GEMM operands,
 # fp32 accumulate = the reference's autocast path): against a pure-fp32 oracle a ReLU whose pre-activation rounds across 0
@@ -304,9 +310,10 @@ def test_mlp_forward(nof, ns, nc, ff, L, precision):
     ref_m = O.mlp_forward(shape, params, x, ODT[precision]).detach().numpy()
     d_feat = feat.reshape(B, L, 2).permute(1, 0, 2).contiguous().cuda()
     raw = torch.zeros(B, 4, device='cuda')
-    nof.call('nof_mlp_fwd', C.byref(desc), flat.cuda(), d_feat, L, view.cuda(), S, raw, B)
+    packed = _pack(nof, desc, flat)
+    nof.call('nof_mlp_fwd', C.byref(desc), packed, d_feat, L, view.cuda(), S, raw, B)
     sdf = torch.zeros(B, device='cuda')
-    nof.call('nof_mlp_sdf', C.byref(desc), flat.cuda(), d_feat, L, sdf, B)
+    nof.call('nof_mlp_sdf', C.byref(desc), packed, d_feat, L, sdf, B)
     torch.cuda.synchronize()
     scale = np.abs(ref).max()
     assert np.abs(cpu(raw) - ref).max() / scale < TOL[precision]
@@ -337,7 +344,7 @@ def test_mlp_backward(nof, ns, nc, ff, L, precision):
     dfeat = torch.full((L, B, 2), 3.0, device='cuda')
     dview = torch.zeros(R, 16, device='cuda')
     partials = torch.full((nblk, desc.n_params), 5.0, device='cuda')
-    nof.call('nof_mlp_bwd', C.byref(desc), flat.cuda(), d_feat, L, view.cuda(), S, draw.cuda(), dfeat, dview, partials, B)
+    nof.call('nof_mlp_bwd', C.byref(desc), _pack(nof, desc, flat), d_feat, L, view.cuda(), S, draw.cuda(), dfeat, dview, partials, B)
     gflat = torch.zeros(desc.n_params, device='cuda')
     nof.call('nof_reduce_partials', partials, nblk, desc.n_params, gflat)
     torch.cuda.synchronize()
@@ -382,8 +389,9 @@ def test_composite_loss(nof, fs_rgb):
     g_w = torch.empty(R, S, device='cuda')
     g_draw = torch.empty(R, S, 4, device='cuda')
     g_loss = torch.zeros(8, device='cuda')
+    g_rows = torch.empty(R, 8, device='cuda')
     nof.call('nof_composite_loss', C.byref(lc), raw.detach().cuda(), U.dev(z), valid.to(torch.uint8).cuda(), tb.cuda(),
-             R, S, g_rgb, g_w, g_draw, g_loss)
+             R, S, g_rgb, g_w, g_draw, g_rows, g_loss)
     torch.cuda.synchronize()
     assert np.abs(cpu(g_rgb) - rgb_map.detach().numpy()).max() < 2e-6
     assert np.abs(cpu(g_w) - w.detach().numpy()).max() < 2e-6

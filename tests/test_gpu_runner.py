@@ -1,0 +1,110 @@
+"""End-to-end on the MI355X through the reference's plugin surface (the call sequence of bundlesdf.py:run_nerf,
+:219-241): NerfRunner(...) -> train() -> get_optimized_poses_in_real_world -> extract_mesh -> mesh_to_real_world ->
+add_new_frames(...) -> train().  The data set is the synthetic ellipsoid pool, so the mesh is checked by the Chamfer
+distance to the analytic surface (stand-in for the 'milk' sequence, whose data is not available offline)."""
+import numpy as np
+import pytest
+import torch
+from scipy.spatial import cKDTree
+
+pytestmark = pytest.mark.gpu
+
+
+def _ellipsoid_points(semi, n=20000, seed=0):
+    rng = np.random.default_rng(seed)
+    p = rng.normal(size=(n, 3))
+    p /= np.linalg.norm(p, axis=1, keepdims=True)
+    return p * semi
+
+
+def chamfer(a, b):
+    """Utils.py:268-273 (mutual mean nearest-neighbour distance)"""
+    d1, _ = cKDTree(a).query(b)
+    d2, _ = cKDTree(b).query(a)
+    return 0.5 * (d1.mean() + d2.mean())
+
+
+def _surface_samples(mesh, n=20000):
+    v, f = np.asarray(mesh.vertices), np.asarray(mesh.faces)
+    a, b, c = v[f[:, 0]], v[f[:, 1]], v[f[:, 2]]
+    area = 0.5 * np.linalg.norm(np.cross(b - a, c - a), axis=1)
+    rng = np.random.default_rng(0)
+    idx = rng.choice(len(area), size=n, p=area / area.sum())
+    r1, r2 = np.sqrt(rng.random(n)), rng.random(n)
+    return (1 - r1)[:, None] * a[idx] + (r1 * (1 - r2))[:, None] * b[idx] + (r1 * r2)[:, None] * c[idx]
+
+
+@pytest.mark.parametrize("precision", ['fp16', 'bf16'])
+def test_runner_surface_end_to_end(nof, precision):
+    from bundlesdf_amd import synthetic
+    from bundlesdf_amd.config import default_cfg
+    from bundlesdf_amd.nerf_runner import NerfRunner, get_optimized_poses_in_real_world, mesh_to_real_world
+    pool = synthetic.make_pool(n_frames=6, H=240, W=320, fx=300.0, seed=1)
+    cfg = default_cfg(n_step=400, N_rand=2048, num_levels=16, log2_hashmap_size=17, finest_res=256, far=1.0,
+                      sc_factor=pool['sc_factor'], translation=pool['translation'], frame_features=2)
+    n0 = 4
+    runner = NerfRunner(cfg, pool['rgbs'][:n0], depths=pool['depths'][:n0], masks=pool['masks'][:n0], normal_maps=None,
+                        poses=pool['poses'][:n0].copy(), K=pool['K'], build_octree_pcd=synthetic.PointCloud(pool['pcd_normalized']),
+                        precision=precision)
+    assert runner.rays.shape[1] == 12 and runner.rays.shape[0] > 20000
+    assert (runner.rays[:, 9] == 0).all() and (runner.rays[:, 8] < n0).all()
+    runner.train_loop()
+    first = runner.field.losses()['loss']
+    runner.global_step += 1
+    runner.train()
+    last = runner.field.losses()
+    assert np.isfinite(last['loss']) and last['loss'] < 0.2 * first, (first, last)
+    assert int(runner.field.flags[0].item()) == 0
+
+    poses_opt, offset = get_optimized_poses_in_real_world(pool['poses'][:n0].copy(), runner.models['pose_array'],
+                                                          cfg['sc_factor'], cfg['translation'])
+    assert poses_opt.shape == (n0, 4, 4) and np.isfinite(poses_opt).all()
+    # frame 0 is the anchor: its optimised real-world pose equals the input pose (converted back to OpenCV)
+    cam0 = pool['poses_gt'][0] @ np.diag([1.0, -1.0, -1.0, 1.0])
+    assert np.abs(poses_opt[0] - cam0).max() < 1e-4
+    # pose noise of +-5 mm / 2 deg was injected on frames > 0: optimisation must not make things worse on average
+    gt = pool['poses_gt'][:n0] @ np.diag([1.0, -1.0, -1.0, 1.0])
+    noisy = pool['poses'][:n0].copy()
+    noisy[:, :3, 3] = noisy[:, :3, 3] / cfg['sc_factor'] - cfg['translation']
+    noisy = noisy @ np.diag([1.0, -1.0, -1.0, 1.0])
+    err_before = np.linalg.norm(noisy[1:, :3, 3] - gt[1:, :3, 3], axis=1).mean()
+    err_after = np.linalg.norm(poses_opt[1:, :3, 3] - gt[1:, :3, 3], axis=1).mean()
+    assert err_after < err_before * 1.05 + 1e-4, (err_before, err_after)
+
+    mesh = runner.extract_mesh(isolevel=0, voxel_size=0.004)
+    assert mesh is not None and len(mesh.vertices) > 500 and len(mesh.faces) > 1000
+    mesh = mesh_to_real_world(mesh, pose_offset=offset, translation=cfg['translation'], sc_factor=cfg['sc_factor'])
+    cd = chamfer(_surface_samples(mesh), _ellipsoid_points(pool['semi_axes']))
+    assert cd < 0.004, f'Chamfer distance {cd * 100:.3f} cm'         # 4 mm at 4 mm voxels, noisy depth, 4 views
+
+    # growing the pool: images of the NEW frames, poses of ALL frames (bundlesdf.py:223)
+    runner.add_new_frames(pool['rgbs'][n0:], pool['depths'][n0:], pool['masks'][n0:], None, pool['poses'].copy(),
+                          new_pcd=synthetic.PointCloud(pool['pcd_normalized']), reuse_weights=False)
+    assert runner.field.F == 6 and (runner.rays[:, 8].max() == 5)
+    runner.cfg['n_step'] = 150
+    runner.N_iters = 151
+    runner.train()
+    assert np.isfinite(runner.field.losses()['loss'])
+    m2 = runner.extract_mesh(isolevel=0, voxel_size=0.006, return_sigma=True)
+    assert m2 is not None and m2[1].ndim == 3
+
+
+def test_checkpoint_roundtrip(nof, tmp_path):
+    from tests.test_gpu_step import _pair
+    from tests import util as U
+    cfg, fld, orc, batch, rng = _pair(nof, 'bf16', R=128)
+    pool = U.dev(batch)
+    for _ in range(3):
+        fld.train_step(pool, None, 128, seed=1)
+    snap = {k: getattr(fld, k).clone() for k in ('params', 'exp_avg', 'exp_avg_sq')}
+    step = fld.global_step
+    fld.train_step(pool, None, 128, seed=1)
+    after = fld.params.clone()
+    for k, v in snap.items():
+        getattr(fld, k).copy_(v)
+    fld.global_step = step
+    fld.grads.zero_()
+    fld.train_step(pool, None, 128, seed=1)
+    torch.cuda.synchronize()
+    # same state + same Philox (seed, step) -> same parameters up to atomic summation order
+    assert (fld.params - after).abs().max().item() < 2e-2 and ((fld.params - after).abs() > 1e-4).float().mean().item() < 1e-2
