@@ -13,3 +13,30 @@ int nof_set_error(int code, const char* fmt, ...) {
 
 extern "C" const char* nof_last_error(void) { return g_nof_err; }
 extern "C" int nof_version(void) { return 100; }
+
+// ---- test hook: fp32 atomic-add throughput for different address patterns (informs the hash scatter design) -------------
+//   0: two instructions per entry (x then y), random entries      1: adjacent-lane pairs (lane 2m -> x, 2m+1 -> y), random
+//   2: two instructions per entry, sequential entries             3: x only, random entries
+//   4: like 0 but each wave's 64 entries are sorted (neighbouring lanes -> neighbouring entries)
+__global__ __launch_bounds__(256) void k_atomic_probe(int variant, const uint32_t* __restrict__ idx, float* __restrict__ table,
+                                                       int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (variant == 1) {
+    const int64_t e = i >> 1;
+    if (e < n) atomicAdd(&table[2 * (size_t)idx[e] + (i & 1)], 1.0f);
+    return;
+  }
+  if (i >= n) return;
+  const size_t e = (variant == 2) ? (size_t)(i & 0x7FFFF) : (size_t)idx[i];
+  atomicAdd(&table[2 * e], 1.0f);
+  if (variant != 3) atomicAdd(&table[2 * e + 1], 1.0f);
+}
+
+extern "C" int nof_atomic_probe(int32_t variant, const uint32_t* idx, float* table, int64_t n, void* stream) {
+  NOF_ARG(idx && table && n > 0 && variant >= 0 && variant <= 4);
+  const int64_t threads = variant == 1 ? 2 * n : n;
+  hipLaunchKernelGGL(k_atomic_probe, dim3((unsigned)nof_div_up(threads, 256)), dim3(256), 0, (hipStream_t)stream, variant, idx,
+                     table, n);
+  NOF_LAUNCH_OK();
+  return 0;
+}

@@ -130,22 +130,26 @@ __device__ __forceinline__ Scatter make_scatter(const HashLevel& lv, const float
   return sc;
 }
 
-// Segmented sum over runs of equal keys (runs are contiguous: lanes = consecutive samples of a ray).  After the call the
-// FIRST lane of every run holds the run's total; returns whether this lane is such a leader.
+// Segmented suffix-sum over RUNS of adjacent lanes with equal keys (lanes are consecutive samples; along one ray a cell's
+// samples are adjacent, but nothing is assumed: equal keys that are not adjacent simply form separate runs).  After the call
+// the FIRST lane of every run holds the run's total; returns whether this lane is such a leader.
 __device__ __forceinline__ bool wave_merge_runs(Scatter& sc) {
   const int lane = threadIdx.x & 63;
+  const uint32_t next = __shfl_down(sc.key, 1, 64);
+  const uint32_t prev = __shfl_up(sc.key, 1, 64);
+  int tail = (lane == 63 || next != sc.key) ? 1 : 0;                 // a run ends inside the range this lane has summed so far
 #pragma unroll
   for (int off = 1; off < 64; off <<= 1) {
-    const uint32_t ok_key = __shfl_down(sc.key, off, 64);
-    const bool ok = (lane + off < 64) && (ok_key == sc.key);
+    const int t_other = __shfl_down(tail, off, 64);
+    const bool take = !tail && (lane + off < 64);
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
       const float tx = __shfl_down(sc.vx[k], off, 64);
       const float ty = __shfl_down(sc.vy[k], off, 64);
-      if (ok) { sc.vx[k] += tx; sc.vy[k] += ty; }
+      if (take) { sc.vx[k] += tx; sc.vy[k] += ty; }
     }
+    if (take) tail |= t_other;
   }
-  const uint32_t prev = __shfl_up(sc.key, 1, 64);
   return (lane == 0 || prev != sc.key) && sc.key != 0xFFFFFFFFu;
 }
 
@@ -154,24 +158,50 @@ struct LevelList {
   int32_t level[NOF_MAX_LEVELS];
 };
 
-// levels that do not fit LDS: wave-merged global atomics
+// Emission of the merged runs.  Measured on MI355X (tools/atomic_probe.py): fp32 atomics retire at ~20.8 G line-requests/s
+// chip-wide, lanes of ONE instruction that fall into the same 64-byte line merge into one request (x/y pair in adjacent
+// lanes: 2x; consecutive entries: 8x) and a hot line serialises (3.8 G/s).  So a run leader does not issue its 16 atomics
+// itself (16 instructions, one line each): the leaders' (row, value) lists are compacted through a small LDS stage and
+// re-read so that 16 ADJACENT lanes carry one cell -- [corner k][channel] with k's bit 0 = the x neighbour, whose row is
+// idx+1 for dense levels and for even x of hashed levels (prime 1) -- i.e. 4..8 line requests per cell instead of 16.
+struct EmitStage {                                                    // odd row strides: conflict-free LDS writes by rank
+  float val[4][64][17];
+  uint32_t row[4][64][9];
+};
+
+__device__ __forceinline__ void emit_packed(EmitStage& st, const Scatter& sc, bool lead, float* __restrict__ gt) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const unsigned long long mask = __ballot(lead);
+  const int nl = __popcll(mask);
+  const int rank = __popcll(mask & ((1ull << lane) - 1ull));
+  if (lead) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      st.val[w][rank][2 * k] = sc.vx[k];
+      st.val[w][rank][2 * k + 1] = sc.vy[k];
+      st.row[w][rank][k] = sc.idx[k];
+    }
+  }
+  __syncthreads();                                                    // block-uniform call site (all four waves arrive)
+  const int e = lane & 15;
+  for (int m = lane >> 4; m < nl; m += 4) {
+    const uint32_t r = st.row[w][m][e >> 1];
+    atomicAdd(&gt[2 * (size_t)r + (e & 1)], st.val[w][m][e]);     // gridencoder.cu:317-333 (fp32 atomics)
+  }
+}
+
+// levels that do not fit LDS: wave-merged, lane-packed global atomics
 __global__ __launch_bounds__(256) void k_hash_bwd_agg(NofHashGrid g, LevelList ll, const float* __restrict__ pts_w,
                                                        const float2* __restrict__ dfeat, float* __restrict__ grad_table,
                                                        int64_t B, uint32_t merge_max_res) {
+  __shared__ EmitStage stage;
   const int level = ll.level[blockIdx.x % ll.n];
   const int64_t b = (int64_t)(blockIdx.x / ll.n) * 256 + threadIdx.x;
   const HashLevel lv = load_level(g, level);
   Scatter sc = make_scatter(lv, pts_w, dfeat, level, b, B);
   bool lead = sc.key != 0xFFFFFFFFu;
   if (lv.res <= merge_max_res) lead = wave_merge_runs(sc);          // block-uniform branch
-  if (lead) {
-    float* __restrict__ gt = grad_table + 2 * (size_t)lv.offset;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {                                     // gridencoder.cu:317-333 (fp32 atomics)
-      atomicAdd(&gt[2 * (size_t)sc.idx[k]], sc.vx[k]);
-      atomicAdd(&gt[2 * (size_t)sc.idx[k] + 1], sc.vy[k]);
-    }
-  }
+  emit_packed(stage, sc, lead, grad_table + 2 * (size_t)lv.offset);
 }
 
 // levels whose slice fits LDS: accumulate privately, flush once

@@ -153,33 +153,53 @@ __device__ __forceinline__ void copy16(char* __restrict__ dst, const char* __res
   for (size_t e = threadIdx.x; e < bytes / 16; e += blockDim.x) d4[e] = s4[e];
 }
 
-// ---- one dense layer, both orientations -------------------------------------------------------------
-// orientation 1: out[p][r] = neuron 32p + nloc(hi,r) of sample j          (lane = sample)
+template <int NS, int NC>
+struct Shp {                                       // compile-time layer table (32-neuron blocks)
+  static constexpr int NL = NS + NC;
+  static constexpr __host__ __device__ int pn(int l) { return (l == NS - 1 || l == NL - 1) ? 1 : 2; }
+  static constexpr __host__ __device__ int qn(int l) { return l == 0 ? 1 : 2; }
+  // rows of a dW accumulator that can be non-zero: sigma head has 16 outputs (regs 0..7), colour head 3 (regs 0..3)
+  static constexpr __host__ __device__ int nacc(int l) { return l == NS - 1 ? 8 : (l == NL - 1 ? 4 : 16); }
+  static constexpr __host__ __device__ int pair_base(int l) { int s = 0; for (int k = 0; k < l; ++k) s += pn(k) * qn(k); return s; }
+  static constexpr __host__ __device__ int oblk_base(int l) { int s = 0; for (int k = 0; k < l; ++k) s += pn(k); return s; }
+};
+
+// ---- one dense layer -------------------------------------------------------------
+// out[p][r] = neuron 32p + nloc(hi,r) of sample j (lane = sample).  `frag_off` / `bias_off` are compile-time byte offsets of the
+// layer's fragments / biases inside the dynamic LDS block, so every ds_read is base-register + immediate.
 template <class P, int QN, int PN>
-__device__ __forceinline__ void dense_o1(const typename P::elem* fwl, const float* bl, const float (&in)[QN][16],
+__device__ __forceinline__ void dense_o1(const char* smem, int frag_off, int bias_off, const float (&in)[QN][16],
                                          float (&out)[PN][16], int lane) {
   constexpr int KR = P::KR, NSTEP = 16 / KR;
+  constexpr int FB = 64 * KR * (int)sizeof(typename P::elem);          // bytes of one fragment (all 64 lanes)
   const int hi = lane >> 5;
+  typename P::frag bop[QN][NSTEP];
+#pragma unroll
+  for (int q = 0; q < QN; ++q)
+#pragma unroll
+    for (int s = 0; s < NSTEP; ++s) bop[q][s] = P::pack(&in[q][KR * s]);
+  const char* fl = smem + lane * (KR * (int)sizeof(typename P::elem));
+  const char* bl = smem + bias_off + hi * 16;
 #pragma unroll
   for (int p = 0; p < PN; ++p) {
     f32x16 acc;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-      const float4 bv = *(const float4*)&bl[32 * p + 8 * g + 4 * hi];
+      const float4 bv = *(const float4*)(bl + (32 * p + 8 * g) * 4);
       acc[4 * g] = bv.x; acc[4 * g + 1] = bv.y; acc[4 * g + 2] = bv.z; acc[4 * g + 3] = bv.w;
     }
 #pragma unroll
     for (int q = 0; q < QN; ++q)
 #pragma unroll
       for (int s = 0; s < NSTEP; ++s) {
-        const typename P::frag a = *(const typename P::frag*)&fwl[(((size_t)(p * QN + q) * NSTEP + s) * 64 + lane) * KR];
-        const typename P::frag b = P::pack(&in[q][KR * s]);
-        acc = P::mma(a, b, acc);
+        const typename P::frag a = *(const typename P::frag*)(fl + frag_off + ((p * QN + q) * NSTEP + s) * FB);
+        acc = P::mma(a, bop[q][s], acc);
       }
 #pragma unroll
     for (int r = 0; r < 16; ++r) out[p][r] = acc[r];
   }
 }
+
 template <int PN>
 __device__ __forceinline__ uint32_t relu_mask(float (&h)[PN][16]) {
   uint32_t m = 0;
@@ -229,25 +249,26 @@ __device__ __forceinline__ void load_view_o1(const float* __restrict__ view, int
   }
 }
 
-#define LAYER_FW(l) (fw + (size_t)pair_base(d, (l)) * 16 * 64)
-#define LAYER_BW(l) (bw + (size_t)pair_base(d, (l)) * 16 * 64)
-#define LAYER_BIAS(l) (bias + oblk_base(d, (l)) * 32)
+// compile-time byte offsets inside the dynamic LDS block: [fw frags | (bw frags) | bias | ...]
+#define PAIR_BYTES (16 * 64 * (int)sizeof(typename P::elem))
+#define FW_OFF(l) (SH::pair_base(l) * PAIR_BYTES)
+#define BW_OFF(l) (BW_BASE + SH::pair_base(l) * PAIR_BYTES)
+#define BIAS_OFF(l) (BIAS_BASE + SH::oblk_base(l) * 32 * 4)
 
 // =====================================================================================================
 // forward: raw[b] = (rgb_raw[3], sdf)
 // =====================================================================================================
 template <class P, int NS, int NC, bool SDF_ONLY>
-__global__ __launch_bounds__(256) void k_mlp_fwd(NofMlpDesc d, const char* __restrict__ image,
+__global__ __launch_bounds__(256, 2) void k_mlp_fwd(      // >= 2 waves/SIMD: no AGPRs, so MFMA results land in VGPRs directly
+NofMlpDesc d, const char* __restrict__ image,
                                                   const float2* __restrict__ feat, int L, const float* __restrict__ view,
                                                   int S, float* __restrict__ out, int64_t B) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  typedef Shp<NS, NC> SH;
   constexpr int NL = SDF_ONLY ? NS : NS + NC;
-  typedef typename P::elem elem;
-  const int npair = pair_base(d, NL), npair_all = pair_base(d, NS + NC);
-  elem* fw = (elem*)smem;
-  float* bias = (float*)(smem + (size_t)npair * 16 * 64 * sizeof(elem));
-  copy16(smem, image, (size_t)npair * 16 * 64 * sizeof(elem));                       // forward fragments of the first NL layers
-  copy16((char*)bias, image + 2 * (size_t)npair_all * 16 * 64 * sizeof(elem), (size_t)oblk_base(d, NL) * 32 * 4);
+  constexpr int BIAS_BASE = SH::pair_base(NL) * PAIR_BYTES;           // this kernel keeps only the first NL layers' fragments
+  copy16(smem, image, (size_t)BIAS_BASE);
+  copy16(smem + BIAS_BASE, image + 2 * (size_t)SH::pair_base(NS + NC) * PAIR_BYTES, (size_t)SH::oblk_base(NL) * 32 * 4);
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int hi = lane >> 5, j = lane & 31;
@@ -258,19 +279,19 @@ __global__ __launch_bounds__(256) void k_mlp_fwd(NofMlpDesc d, const char* __res
     float x[1][16];
     load_feat_o1(feat, L, B, b, hi, x);
     float h[2][16], so[1][16];
-    dense_o1<P, 1, 2>(LAYER_FW(0), LAYER_BIAS(0), x, h, lane);
+    dense_o1<P, 1, 2>(smem, FW_OFF(0), BIAS_OFF(0), x, h, lane);
     relu_mask<2>(h);
 #pragma unroll
     for (int l = 1; l < NS - 1; ++l) {
       float h2[2][16];
-      dense_o1<P, 2, 2>(LAYER_FW(l), LAYER_BIAS(l), h, h2, lane);
+      dense_o1<P, 2, 2>(smem, FW_OFF(l), BIAS_OFF(l), h, h2, lane);
       relu_mask<2>(h2);
 #pragma unroll
       for (int p = 0; p < 2; ++p)
 #pragma unroll
         for (int r = 0; r < 16; ++r) h[p][r] = h2[p][r];
     }
-    dense_o1<P, 2, 1>(LAYER_FW(NS - 1), LAYER_BIAS(NS - 1), h, so, lane);
+    dense_o1<P, 2, 1>(smem, FW_OFF(NS - 1), BIAS_OFF(NS - 1), h, so, lane);
     if constexpr (SDF_ONLY) {
       if (hi == 0 && b < B) out[b] = so[0][0];
     } else {
@@ -278,12 +299,12 @@ __global__ __launch_bounds__(256) void k_mlp_fwd(NofMlpDesc d, const char* __res
 #pragma unroll
       for (int r = 0; r < 16; ++r) cin[0][r] = so[0][r];
       load_view_o1(view, S, B, b, hi, cin[1]);
-      dense_o1<P, 2, 2>(LAYER_FW(NS), LAYER_BIAS(NS), cin, h, lane);
+      dense_o1<P, 2, 2>(smem, FW_OFF(NS), BIAS_OFF(NS), cin, h, lane);
       relu_mask<2>(h);
 #pragma unroll
       for (int l = NS + 1; l < NS + NC - 1; ++l) {
         float h2[2][16];
-        dense_o1<P, 2, 2>(LAYER_FW(l), LAYER_BIAS(l), h, h2, lane);
+        dense_o1<P, 2, 2>(smem, FW_OFF(l), BIAS_OFF(l), h, h2, lane);
         relu_mask<2>(h2);
 #pragma unroll
         for (int p = 0; p < 2; ++p)
@@ -291,7 +312,7 @@ __global__ __launch_bounds__(256) void k_mlp_fwd(NofMlpDesc d, const char* __res
           for (int r = 0; r < 16; ++r) h[p][r] = h2[p][r];
       }
       float co[1][16];
-      dense_o1<P, 2, 1>(LAYER_FW(NS + NC - 1), LAYER_BIAS(NS + NC - 1), h, co, lane);
+      dense_o1<P, 2, 1>(smem, FW_OFF(NS + NC - 1), BIAS_OFF(NS + NC - 1), h, co, lane);
       if (hi == 0 && b < B) ((float4*)out)[b] = make_float4(co[0][0], co[0][1], co[0][2], so[0][0]);
     }
   }
@@ -300,11 +321,13 @@ __global__ __launch_bounds__(256) void k_mlp_fwd(NofMlpDesc d, const char* __res
 // =====================================================================================================
 // backward (forward recomputed): dfeat, dview, per-workgroup dW/db partials
 // =====================================================================================================
-// dIn of input block q, orientation 1 (lane = sample, reg r = input slot (q,hi,r))
+// dIn of input block q, sample-per-lane (reg r = input slot (q,hi,r)); bw_off = compile-time byte offset of the layer's fragments
 template <class P, int PN>
-__device__ __forceinline__ void bwd_data(const typename P::elem* bwl, int q, const float (&dout1)[PN][16], float (&din1)[16],
+__device__ __forceinline__ void bwd_data(const char* smem, int bw_off, int q, const float (&dout1)[PN][16], float (&din1)[16],
                                          int lane) {
   constexpr int KR = P::KR, NSTEP = 16 / KR;
+  constexpr int FB = 64 * KR * (int)sizeof(typename P::elem);
+  const char* fl = smem + lane * (KR * (int)sizeof(typename P::elem));
   f32x16 a1;
 #pragma unroll
   for (int r = 0; r < 16; ++r) a1[r] = 0.0f;
@@ -312,7 +335,7 @@ __device__ __forceinline__ void bwd_data(const typename P::elem* bwl, int q, con
   for (int p = 0; p < PN; ++p)
 #pragma unroll
     for (int s = 0; s < NSTEP; ++s) {
-      const typename P::frag w = *(const typename P::frag*)&bwl[(((size_t)(q * PN + p) * NSTEP + s) * 64 + lane) * KR];
+      const typename P::frag w = *(const typename P::frag*)(fl + bw_off + ((q * PN + p) * NSTEP + s) * FB);
       a1 = P::mma(w, P::pack(&dout1[p][KR * s]), a1);
     }
 #pragma unroll
@@ -322,33 +345,34 @@ __device__ __forceinline__ void bwd_data(const typename P::elem* bwl, int q, con
 // The matrix core as a transpose engine: x is a 32-sample x 32-slot block held sample-per-lane (reg r = slot (hi,r));
 // D[sample][n] = sum_k X[sample][k] I[k][n] with I = identity returns it slot-per-lane (lane n = slot with
 // nloc(hi,r) == n, reg r' = sample nloc(hi',r')), i.e. exactly the A/B operand layout of the sample-contracted dW MFMA.
-// Multiplying by 1 and adding 0 is exact: y holds the operand-rounded values of x.
+// Multiplying by 1 and adding 0 is exact: y holds the operand-rounded values of x.  `ident` = the identity fragments,
+// built once per wave.
 template <class P>
-__device__ __forceinline__ void transpose32(const float (&x)[16], float (&y)[16], int lane) {
+struct Ident {
+  typename P::frag f[16 / P::KR];
+  __device__ __forceinline__ void init(int lane) {
+    const int hi = lane >> 5, j = lane & 31;
+#pragma unroll
+    for (int s = 0; s < 16 / P::KR; ++s) {
+      float id[P::KR];
+#pragma unroll
+      for (int t = 0; t < P::KR; ++t) id[t] = (nloc(hi, P::KR * s + t) == j) ? 1.0f : 0.0f;
+      f[s] = P::pack(id);
+    }
+  }
+};
+
+template <class P>
+__device__ __forceinline__ void transpose32(const Ident<P>& I, const float (&x)[16], float (&y)[16]) {
   constexpr int KR = P::KR, NSTEP = 16 / KR;
-  const int hi = lane >> 5, j = lane & 31;
   f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
 #pragma unroll
-  for (int s = 0; s < NSTEP; ++s) {
-    float id[KR];
-#pragma unroll
-    for (int t = 0; t < KR; ++t) id[t] = (nloc(hi, KR * s + t) == j) ? 1.0f : 0.0f;
-    acc = P::mma(P::pack(&x[KR * s]), P::pack(id), acc);
-  }
+  for (int s = 0; s < NSTEP; ++s) acc = P::mma(P::pack(&x[KR * s]), I.f[s], acc);
 #pragma unroll
   for (int r = 0; r < 16; ++r) y[r] = acc[r];
 }
-
-template <int NS, int NC>
-struct Shp {                                       // compile-time layer shapes (32-neuron blocks)
-  static constexpr int NL = NS + NC;
-  static constexpr __host__ __device__ int pn(int l) { return (l == NS - 1 || l == NL - 1) ? 1 : 2; }
-  static constexpr __host__ __device__ int qn(int l) { return l == 0 ? 1 : 2; }
-  // rows of a dW accumulator that can be non-zero: sigma head has 16 outputs (regs 0..7), colour head 3 (regs 0..3)
-  static constexpr __host__ __device__ int nacc(int l) { return l == NS - 1 ? 8 : (l == NL - 1 ? 4 : 16); }
-};
 
 // Orientation-2 (slot-per-lane) copies of every layer INPUT = the B operands of the dW MFMAs.  In the 16-bit modes they
 // live in lane-private LDS slots (written and read by the same lane: no barrier); in fp32 (parity) mode in registers.
@@ -357,10 +381,9 @@ struct In2Store;
 template <class P, int NSLOT>
 struct In2Store<P, NSLOT, true> {
   static constexpr int NSTEP = 16 / P::KR;
-  typename P::frag* base;                         // wave-private region, indexed [slot][step][lane]
-  int lane;
-  __device__ __forceinline__ void put(int slot, int s, typename P::frag f) { base[(slot * NSTEP + s) * 64 + lane] = f; }
-  __device__ __forceinline__ typename P::frag get(int slot, int s) const { return base[(slot * NSTEP + s) * 64 + lane]; }
+  typename P::frag* base;                         // wave-private region + lane, indexed [slot][step] with stride 64 fragments
+  __device__ __forceinline__ void put(int slot, int s, typename P::frag f) { base[(slot * NSTEP + s) * 64] = f; }
+  __device__ __forceinline__ typename P::frag get(int slot, int s) const { return base[(slot * NSTEP + s) * 64]; }
 };
 template <class P, int NSLOT>
 struct In2Store<P, NSLOT, false> {
@@ -372,24 +395,24 @@ struct In2Store<P, NSLOT, false> {
 
 // transpose one sample-per-lane block and park it as MFMA operands in slot `slot`
 template <class P, class ST>
-__device__ __forceinline__ void park_o2(ST& st, int slot, const float (&x)[16], int lane) {
+__device__ __forceinline__ void park_o2(ST& st, const Ident<P>& I, int slot, const float (&x)[16]) {
   float y[16];
-  transpose32<P>(x, y, lane);
+  transpose32<P>(I, x, y);
 #pragma unroll
   for (int s = 0; s < 16 / P::KR; ++s) st.put(slot, s, P::pack(&y[P::KR * s]));
 }
 
 // one output block p of layer l:  g2 = T(g1[p]);  db += sum_samples g2;  dW[p][q] += g2 (x) in2(l,q)
 template <class P, int QN, int NACC, class ST>
-__device__ __forceinline__ void dw_block(float (&dw)[2][16], float& db, const float (&g1p)[16], const ST& st, int slot0,
-                                         int lane) {
+__device__ __forceinline__ void dw_block(float (&dw)[2][16], float* db_lane, const Ident<P>& I, const float (&g1p)[16],
+                                         const ST& st, int slot0) {
   constexpr int KR = P::KR, NSTEP = 16 / KR;
   float g2[16];
-  transpose32<P>(g1p, g2, lane);
+  transpose32<P>(I, g1p, g2);
   float sdb = 0.0f;
 #pragma unroll
   for (int r = 0; r < 16; ++r) sdb += g2[r];
-  db += sdb;
+  *db_lane += sdb;                                   // lane-private LDS word (bias gradients need no register)
   typename P::frag ga[NSTEP];
 #pragma unroll
   for (int s = 0; s < NSTEP; ++s) ga[s] = P::pack(&g2[KR * s]);
@@ -411,42 +434,40 @@ __global__ __launch_bounds__(256) void k_mlp_bwd(NofMlpDesc d, const char* __res
                                                   int S, const float4* __restrict__ draw, float2* __restrict__ dfeat,
                                                   float* __restrict__ dview, float* __restrict__ partials, int64_t B) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  typedef Shp<NS, NC> SH;
   constexpr int NL = NS + NC;
   constexpr int KR = P::KR, NSTEP = 16 / KR;
-  typedef typename P::elem elem;
   typedef typename P::frag frag;
-  typedef Shp<NS, NC> SH;
-  const int npair = pair_base(d, NL);
-  elem* fw = (elem*)smem;
-  elem* bw = fw + (size_t)npair * 16 * 64;
-  float* bias = (float*)(bw + (size_t)npair * 16 * 64);
-  copy16(smem, image, 2 * (size_t)npair * 16 * 64 * sizeof(elem) + (size_t)oblk_base(d, NL) * 32 * 4);
+  constexpr int BW_BASE = SH::pair_base(NL) * PAIR_BYTES;
+  constexpr int BIAS_BASE = 2 * BW_BASE;
+  constexpr int IN2_BASE = BIAS_BASE + SH::oblk_base(NL) * 32 * 4;
+  constexpr bool IN2_LDS = (KR == 8);
+  constexpr int NSLOT = 2 * NL;                       // slot(l, q) = 2 l + q : input block q of layer l
+  constexpr int IN2_WAVE = NSLOT * NSTEP * 64 * (int)sizeof(frag);
+  constexpr int DB_BASE = IN2_BASE + (IN2_LDS ? 4 * IN2_WAVE : 0);
+  copy16(smem, image, (size_t)IN2_BASE);
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int hi = lane >> 5, j = lane & 31;
-  constexpr bool IN2_LDS = (KR == 8);
-  constexpr int NSLOT = 2 * NL;                       // slot(l, q) = 2 l + q : input block q of layer l
   typedef In2Store<P, NSLOT, IN2_LDS> Store;
   Store st;
-  if constexpr (IN2_LDS) {
-    frag* in2_lds = (frag*)(bias + oblk_base(d, NL) * 32);
-    st.base = in2_lds + (size_t)wave * NSLOT * NSTEP * 64;
-    st.lane = lane;
-  }
+  if constexpr (IN2_LDS) st.base = (frag*)(smem + IN2_BASE + wave * IN2_WAVE) + lane;
+  float* dbw = (float*)(smem + DB_BASE) + wave * NSLOT * 64 + lane;   // bias-gradient partial sums: [2 l + p][lane], lane-private
+#pragma unroll
+  for (int k = 0; k < NSLOT; ++k) dbw[k * 64] = 0.0f;
+  Ident<P> I;
+  I.init(lane);
 
   float dw[NL][2][2][16];                             // persistent per-wave dW accumulators (only the live entries are touched)
-  float db[NL][2];
 #pragma unroll
   for (int l = 0; l < NL; ++l)
 #pragma unroll
-    for (int p = 0; p < 2; ++p) {
-      if (p < SH::pn(l)) db[l][p] = 0.0f;
+    for (int p = 0; p < 2; ++p)
 #pragma unroll
       for (int q = 0; q < 2; ++q)
 #pragma unroll
         for (int r = 0; r < 16; ++r)
           if (p < SH::pn(l) && q < SH::qn(l) && r < SH::nacc(l)) dw[l][p][q][r] = 0.0f;
-    }
 
   const int64_t ntiles = (B + 31) / 32;
   for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < ntiles; tile += (int64_t)gridDim.x * 4) {
@@ -459,49 +480,49 @@ __global__ __launch_bounds__(256) void k_mlp_bwd(NofMlpDesc d, const char* __res
     {
       float x[1][16];
       load_feat_o1(feat, L, B, b, hi, x);
-      park_o2<P>(st, 0, x[0], lane);
-      dense_o1<P, 1, 2>(LAYER_FW(0), LAYER_BIAS(0), x, h, lane);
+      park_o2<P>(st, I, 0, x[0]);
+      dense_o1<P, 1, 2>(smem, FW_OFF(0), BIAS_OFF(0), x, h, lane);
       m1[0] = relu_mask<2>(h);
     }
 #pragma unroll
     for (int l = 1; l < NS - 1; ++l) {
-      park_o2<P>(st, 2 * l, h[0], lane);
-      park_o2<P>(st, 2 * l + 1, h[1], lane);
+      park_o2<P>(st, I, 2 * l, h[0]);
+      park_o2<P>(st, I, 2 * l + 1, h[1]);
       float hn[2][16];
-      dense_o1<P, 2, 2>(LAYER_FW(l), LAYER_BIAS(l), h, hn, lane);
+      dense_o1<P, 2, 2>(smem, FW_OFF(l), BIAS_OFF(l), h, hn, lane);
       m1[l] = relu_mask<2>(hn);
 #pragma unroll
       for (int p = 0; p < 2; ++p)
 #pragma unroll
         for (int r = 0; r < 16; ++r) h[p][r] = hn[p][r];
     }
-    park_o2<P>(st, 2 * (NS - 1), h[0], lane);
-    park_o2<P>(st, 2 * (NS - 1) + 1, h[1], lane);
+    park_o2<P>(st, I, 2 * (NS - 1), h[0]);
+    park_o2<P>(st, I, 2 * (NS - 1) + 1, h[1]);
     {
       float cin[2][16], so[1][16];
-      dense_o1<P, 2, 1>(LAYER_FW(NS - 1), LAYER_BIAS(NS - 1), h, so, lane);
+      dense_o1<P, 2, 1>(smem, FW_OFF(NS - 1), BIAS_OFF(NS - 1), h, so, lane);
 #pragma unroll
       for (int r = 0; r < 16; ++r) cin[0][r] = so[0][r];
       load_view_o1(view, S, B, b, hi, cin[1]);
-      park_o2<P>(st, 2 * NS, cin[0], lane);
-      park_o2<P>(st, 2 * NS + 1, cin[1], lane);
-      dense_o1<P, 2, 2>(LAYER_FW(NS), LAYER_BIAS(NS), cin, h, lane);
+      park_o2<P>(st, I, 2 * NS, cin[0]);
+      park_o2<P>(st, I, 2 * NS + 1, cin[1]);
+      dense_o1<P, 2, 2>(smem, FW_OFF(NS), BIAS_OFF(NS), cin, h, lane);
       m1[NS] = relu_mask<2>(h);
     }
 #pragma unroll
     for (int l = NS + 1; l < NL - 1; ++l) {
-      park_o2<P>(st, 2 * l, h[0], lane);
-      park_o2<P>(st, 2 * l + 1, h[1], lane);
+      park_o2<P>(st, I, 2 * l, h[0]);
+      park_o2<P>(st, I, 2 * l + 1, h[1]);
       float hn[2][16];
-      dense_o1<P, 2, 2>(LAYER_FW(l), LAYER_BIAS(l), h, hn, lane);
+      dense_o1<P, 2, 2>(smem, FW_OFF(l), BIAS_OFF(l), h, hn, lane);
       m1[l] = relu_mask<2>(hn);
 #pragma unroll
       for (int p = 0; p < 2; ++p)
 #pragma unroll
         for (int r = 0; r < 16; ++r) h[p][r] = hn[p][r];
     }
-    park_o2<P>(st, 2 * (NL - 1), h[0], lane);
-    park_o2<P>(st, 2 * (NL - 1) + 1, h[1], lane);
+    park_o2<P>(st, I, 2 * (NL - 1), h[0]);
+    park_o2<P>(st, I, 2 * (NL - 1) + 1, h[1]);
     // (the last colour layer's output is not needed: its gradient comes from draw)
 
     // ---------------- backward ----------------
@@ -521,17 +542,17 @@ __global__ __launch_bounds__(256) void k_mlp_bwd(NofMlpDesc d, const char* __res
     for (int l = NL - 1; l > NS; --l) {
       float d1[2][16];
       if (l == NL - 1) {
-        dw_block<P, 2, 4>(dw[l][0], db[l][0], g1[0], st, 2 * l, lane);
+        dw_block<P, 2, 4>(dw[l][0], dbw + (2 * l) * 64, I, g1[0], st, 2 * l);
         float ga[1][16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) ga[0][r] = g1[0][r];
-        bwd_data<P, 1>(LAYER_BW(l), 0, ga, d1[0], lane);
-        bwd_data<P, 1>(LAYER_BW(l), 1, ga, d1[1], lane);
+        bwd_data<P, 1>(smem, BW_OFF(l), 0, ga, d1[0], lane);
+        bwd_data<P, 1>(smem, BW_OFF(l), 1, ga, d1[1], lane);
       } else {
-        dw_block<P, 2, 16>(dw[l][0], db[l][0], g1[0], st, 2 * l, lane);
-        dw_block<P, 2, 16>(dw[l][1], db[l][1], g1[1], st, 2 * l, lane);
-        bwd_data<P, 2>(LAYER_BW(l), 0, g1, d1[0], lane);
-        bwd_data<P, 2>(LAYER_BW(l), 1, g1, d1[1], lane);
+        dw_block<P, 2, 16>(dw[l][0], dbw + (2 * l) * 64, I, g1[0], st, 2 * l);
+        dw_block<P, 2, 16>(dw[l][1], dbw + (2 * l + 1) * 64, I, g1[1], st, 2 * l);
+        bwd_data<P, 2>(smem, BW_OFF(l), 0, g1, d1[0], lane);
+        bwd_data<P, 2>(smem, BW_OFF(l), 1, g1, d1[1], lane);
       }
       apply_mask<2>(d1, m1[l - 1]);
 #pragma unroll
@@ -541,23 +562,22 @@ __global__ __launch_bounds__(256) void k_mlp_bwd(NofMlpDesc d, const char* __res
     }
     // ---- colour layer 0: inputs = [sigma-out block | view block] ----
     {
-      dw_block<P, 2, 16>(dw[NS][0], db[NS][0], g1[0], st, 2 * NS, lane);
-      dw_block<P, 2, 16>(dw[NS][1], db[NS][1], g1[1], st, 2 * NS, lane);
+      dw_block<P, 2, 16>(dw[NS][0], dbw + (2 * NS) * 64, I, g1[0], st, 2 * NS);
+      dw_block<P, 2, 16>(dw[NS][1], dbw + (2 * NS + 1) * 64, I, g1[1], st, 2 * NS);
       float ds1[16], dv1[16], dv2[16];
-      bwd_data<P, 2>(LAYER_BW(NS), 0, g1, ds1, lane);
-      bwd_data<P, 2>(LAYER_BW(NS), 1, g1, dv1, lane);
-      transpose32<P>(dv1, dv2, lane);
+      bwd_data<P, 2>(smem, BW_OFF(NS), 0, g1, ds1, lane);
+      bwd_data<P, 2>(smem, BW_OFF(NS), 1, g1, dv1, lane);
+      transpose32<P>(I, dv1, dv2);
       // dview[ray][u] += sum over the tile's samples (lane = view slot, regs <-> samples; a tile may straddle two rays)
       {
-        const int64_t ray0 = t0 / S;
+        const int64_t ray0 = t0 / S;                                 // one (wave-uniform) division per tile
+        const int64_t end0 = (ray0 + 1) * S, endB = end0 < B ? end0 : B;
         float sa = 0.0f, sb = 0.0f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int64_t bs = t0 + nloc(hi, r);
-          if (bs < B) {
-            if (bs / S == ray0) sa += dv2[r];
-            else sb += dv2[r];
-          }
+          if (bs < endB) sa += dv2[r];
+          else if (bs < B) sb += dv2[r];
         }
         sa += __shfl_xor(sa, 32, 64);
         sb += __shfl_xor(sb, 32, 64);
@@ -577,17 +597,17 @@ __global__ __launch_bounds__(256) void k_mlp_bwd(NofMlpDesc d, const char* __res
     for (int l = NS - 1; l >= 1; --l) {
       float d1[2][16];
       if (l == NS - 1) {
-        dw_block<P, 2, 8>(dw[l][0], db[l][0], g1[0], st, 2 * l, lane);
+        dw_block<P, 2, 8>(dw[l][0], dbw + (2 * l) * 64, I, g1[0], st, 2 * l);
         float ga[1][16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) ga[0][r] = g1[0][r];
-        bwd_data<P, 1>(LAYER_BW(l), 0, ga, d1[0], lane);
-        bwd_data<P, 1>(LAYER_BW(l), 1, ga, d1[1], lane);
+        bwd_data<P, 1>(smem, BW_OFF(l), 0, ga, d1[0], lane);
+        bwd_data<P, 1>(smem, BW_OFF(l), 1, ga, d1[1], lane);
       } else {
-        dw_block<P, 2, 16>(dw[l][0], db[l][0], g1[0], st, 2 * l, lane);
-        dw_block<P, 2, 16>(dw[l][1], db[l][1], g1[1], st, 2 * l, lane);
-        bwd_data<P, 2>(LAYER_BW(l), 0, g1, d1[0], lane);
-        bwd_data<P, 2>(LAYER_BW(l), 1, g1, d1[1], lane);
+        dw_block<P, 2, 16>(dw[l][0], dbw + (2 * l) * 64, I, g1[0], st, 2 * l);
+        dw_block<P, 2, 16>(dw[l][1], dbw + (2 * l + 1) * 64, I, g1[1], st, 2 * l);
+        bwd_data<P, 2>(smem, BW_OFF(l), 0, g1, d1[0], lane);
+        bwd_data<P, 2>(smem, BW_OFF(l), 1, g1, d1[1], lane);
       }
       apply_mask<2>(d1, m1[l - 1]);
 #pragma unroll
@@ -597,10 +617,10 @@ __global__ __launch_bounds__(256) void k_mlp_bwd(NofMlpDesc d, const char* __res
     }
     // ---- sigma layer 0 ----
     {
-      dw_block<P, 1, 16>(dw[0][0], db[0][0], g1[0], st, 0, lane);
-      dw_block<P, 1, 16>(dw[0][1], db[0][1], g1[1], st, 0, lane);
+      dw_block<P, 1, 16>(dw[0][0], dbw, I, g1[0], st, 0);
+      dw_block<P, 1, 16>(dw[0][1], dbw + 64, I, g1[1], st, 0);
       float df1[16];
-      bwd_data<P, 2>(LAYER_BW(0), 0, g1, df1, lane);
+      bwd_data<P, 2>(smem, BW_OFF(0), 0, g1, df1, lane);
       if (b < B) {
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
@@ -612,6 +632,11 @@ __global__ __launch_bounds__(256) void k_mlp_bwd(NofMlpDesc d, const char* __res
   }
 
   // ---------------- reduce the workgroup's dW/db and write its row of `partials` ----------------
+  float dbv[NL][2];
+#pragma unroll
+  for (int l = 0; l < NL; ++l)
+#pragma unroll
+    for (int p = 0; p < 2; ++p) dbv[l][p] = dbw[(2 * l + p) * 64];
   __syncthreads();
   float* red = (float*)smem;
   for (int e = threadIdx.x; e < d.n_params; e += blockDim.x) red[e] = 0.0f;
@@ -637,7 +662,7 @@ __global__ __launch_bounds__(256) void k_mlp_bwd(NofMlpDesc d, const char* __res
           }
         }
         const int row = 32 * p + j;
-        if (row < out_dim) atomicAdd(&red[d.b_off[l] + row], db[l][p]);
+        if (row < out_dim) atomicAdd(&red[d.b_off[l] + row], dbv[l][p]);
       }
     }
   }
@@ -774,6 +799,7 @@ extern "C" int nof_mlp_bwd(const NofMlpDesc* d, const void* packed, const float*
   const int nl = d->n_sigma + d->n_color;
   size_t shm = 2 * (size_t)n_pairs(*d, nl) * 16 * 64 * elem_size(d->precision) + (size_t)n_oblk(*d, nl) * 32 * 4;
   if (d->precision != 0) shm += (size_t)4 * (2 * nl) * 2 * 64 * 16;      // lane-private orientation-2 slots (16-bit modes)
+  shm += (size_t)4 * (2 * nl) * 64 * 4;                                   // lane-private bias-gradient sums
   if (shm < (size_t)d->n_params * 4) shm = (size_t)d->n_params * 4;
   const unsigned blocks = (unsigned)nof_mlp_bwd_blocks();
 #define LAUNCH_BWD(P, NS_, NC_, dummy)                                                                    \

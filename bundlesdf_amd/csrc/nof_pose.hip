@@ -72,13 +72,10 @@ __global__ void k_pose_fwd(const float* __restrict__ pose, const float* __restri
           ((D[i * 4] * M[j] + D[i * 4 + 1] * M[4 + j]) + D[i * 4 + 2] * M[8 + j]) + D[i * 4 + 3] * M[12 + j];
 }
 
-__global__ void k_pose_bwd(const float* __restrict__ pose, const float* __restrict__ g_delta, float max_trans,
-                           float max_rot, float* __restrict__ grad_pose, int F) {
-  const int f = blockIdx.x * blockDim.x + threadIdx.x;
-  if (f >= F || f == 0) return;
+// dL/dDelta[:3,:4] (row-major 12) -> dL/dxi (6) for one frame
+__device__ void se3_backward(const float* xi, const float* G, float max_trans, float max_rot, float* gp) {
   Se3 s;
-  se3_forward(pose + (size_t)f * 6, max_trans, max_rot, s);
-  const float* G = g_delta + (size_t)f * 12;
+  se3_forward(xi, max_trans, max_rot, s);
   float GR[9], Gt[3];
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
@@ -123,9 +120,19 @@ __global__ void k_pose_bwd(const float* __restrict__ pose, const float* __restri
   }
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
-    grad_pose[(size_t)f * 6 + k] += gu[k] * max_trans * (1.0f - s.tanhv[k] * s.tanhv[k]);
-    grad_pose[(size_t)f * 6 + 3 + k] += gw[k] * max_rot * (1.0f - s.tanhv[3 + k] * s.tanhv[3 + k]);
+    gp[k] = gu[k] * max_trans * (1.0f - s.tanhv[k] * s.tanhv[k]);
+    gp[3 + k] = gw[k] * max_rot * (1.0f - s.tanhv[3 + k] * s.tanhv[3 + k]);
   }
+}
+
+__global__ void k_pose_bwd(const float* __restrict__ pose, const float* __restrict__ g_delta, float max_trans,
+                           float max_rot, float* __restrict__ grad_pose, int F) {
+  const int f = blockIdx.x * blockDim.x + threadIdx.x;
+  if (f >= F || f == 0) return;
+  float gp[6];
+  se3_backward(pose + (size_t)f * 6, g_delta + (size_t)f * 12, max_trans, max_rot, gp);
+#pragma unroll
+  for (int k = 0; k < 6; ++k) grad_pose[(size_t)f * 6 + k] += gp[k];
 }
 
 __device__ __forceinline__ float wave_sum_p(float v) {
@@ -139,14 +146,15 @@ __device__ __forceinline__ float wave_sum_p(float v) {
 __global__ __launch_bounds__(64) void k_pose_grad_accum(const float* __restrict__ dpts, const float* __restrict__ dview,
                                                          const float* __restrict__ batch, const float* __restrict__ z_vals,
                                                          const float* __restrict__ c2w, const float* __restrict__ tf, int ff,
-                                                         int sh_degree, int64_t R, int S, float* __restrict__ g_delta,
-                                                         float* __restrict__ grad_feat) {
+                                                         int sh_degree, int64_t R, int S, float* __restrict__ g_ray) {
   const int64_t r = blockIdx.x;
   const int lane = threadIdx.x;
   const float* row = batch + r * NOF_RAY_COLS;
   const int f = (int)row[8];
-  if (grad_feat != nullptr && lane < ff) atomicAdd(&grad_feat[(size_t)f * ff + lane], dview[r * NOF_VIEW_COLS + lane]);
-  if (f == 0 || g_delta == nullptr) return;
+  if (f == 0) {                                                         // frame 0 carries no correction
+    if (lane < 12) g_ray[r * 12 + lane] = 0.0f;
+    return;
+  }
   const float* M = c2w + (size_t)f * 16;
   const float dx = row[0], dy = row[1], dz = row[2];
   float G[12];
@@ -200,10 +208,55 @@ __global__ __launch_bounds__(64) void k_pose_grad_accum(const float* __restrict_
       G[i * 4 + 2] += gd[i] * cv[2];
     }
   }
+  float mine = 0.0f;                                                    // lane k keeps component k: one coalesced 48-byte store
 #pragma unroll
   for (int k = 0; k < 12; ++k) {
     const float t = wave_sum_p(G[k]);
-    if (lane == 0) atomicAdd(&g_delta[(size_t)f * 12 + k], t);
+    if (lane == k) mine = t;
+  }
+  if (lane < 12) g_ray[r * 12 + lane] = mine;
+}
+
+// One workgroup per frame: sums the per-ray rows of its frame (no atomics: gfx950 atomics serialise per 64-byte line and
+// all frames' 12-vectors share a handful of lines), then lane 0 runs the SE(3) backward; frame-feature gradients likewise.
+__global__ __launch_bounds__(256) void k_pose_reduce_bwd(const float* __restrict__ pose, const float* __restrict__ g_ray,
+                                                          const float* __restrict__ dview, const float* __restrict__ batch,
+                                                          int64_t R, int ff, float max_trans, float max_rot,
+                                                          float* __restrict__ grad_pose, float* __restrict__ grad_feat,
+                                                          float* __restrict__ g_delta) {
+  __shared__ float sm[4][32];
+  const int f = blockIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float acc[12 + NOF_VIEW_COLS];
+#pragma unroll
+  for (int k = 0; k < 12 + NOF_VIEW_COLS; ++k) acc[k] = 0.0f;
+  for (int64_t r = threadIdx.x; r < R; r += blockDim.x) {
+    if ((int)batch[r * NOF_RAY_COLS + 8] != f) continue;
+    if (g_ray)
+#pragma unroll
+      for (int k = 0; k < 12; ++k) acc[k] += g_ray[r * 12 + k];
+    for (int k = 0; k < ff; ++k) acc[12 + k] += dview[r * NOF_VIEW_COLS + k];
+  }
+#pragma unroll
+  for (int k = 0; k < 12 + NOF_VIEW_COLS; ++k) {
+    const float t = wave_sum_p(acc[k]);
+    if (lane == 0) sm[wave][k] = t;
+  }
+  __syncthreads();
+  if (threadIdx.x < 12 + NOF_VIEW_COLS) {
+    const int k = threadIdx.x;
+    sm[0][k] = (sm[0][k] + sm[1][k]) + (sm[2][k] + sm[3][k]);
+  }
+  __syncthreads();
+  if (threadIdx.x < ff && grad_feat) grad_feat[(size_t)f * ff + threadIdx.x] += sm[0][12 + threadIdx.x];
+  if (threadIdx.x < 12 && g_delta) g_delta[(size_t)f * 12 + threadIdx.x] = sm[0][threadIdx.x];
+  if (threadIdx.x == 0 && pose && grad_pose && f != 0) {
+    float G[12], gp[6];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) G[k] = sm[0][k];
+    se3_backward(pose + (size_t)f * 6, G, max_trans, max_rot, gp);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) grad_pose[(size_t)f * 6 + k] += gp[k];
   }
 }
 
@@ -229,13 +282,24 @@ extern "C" int nof_pose_bwd(const float* pose_data, const float* g_delta, float 
 
 extern "C" int nof_pose_grad_accum(const float* dpts, const float* dview, const float* batch, const float* z_vals,
                                     const float* c2w, const float* tf, int32_t ff, int32_t sh_degree, int64_t R, int32_t S,
-                                    float* g_delta, float* grad_feat, void* stream) {
-  NOF_ARG(batch && z_vals && c2w && tf && R >= 0 && S >= 1 && ff >= 0 && ff <= NOF_VIEW_COLS);
+                                    float* g_ray, void* stream) {
+  NOF_ARG(batch && z_vals && c2w && tf && g_ray && R >= 0 && S >= 1 && ff >= 0 && ff <= NOF_VIEW_COLS);
   NOF_ARG(sh_degree >= 1 && sh_degree <= 3);
-  NOF_ARG(ff == 0 || grad_feat == nullptr || dview != nullptr);
   if (R == 0) return 0;
   hipLaunchKernelGGL(k_pose_grad_accum, dim3((unsigned)R), dim3(64), 0, (hipStream_t)stream, dpts, dview, batch, z_vals,
-                     c2w, tf, ff, sh_degree, R, S, g_delta, grad_feat);
+                     c2w, tf, ff, sh_degree, R, S, g_ray);
+  NOF_LAUNCH_OK();
+  return 0;
+}
+
+extern "C" int nof_pose_reduce_bwd(const float* pose_data, const float* g_ray, const float* dview, const float* batch,
+                                    int64_t R, int32_t ff, float max_trans, float max_rot_rad, float* grad_pose,
+                                    float* grad_feat, float* g_delta, int32_t F, void* stream) {
+  NOF_ARG(batch && R >= 0 && F >= 0 && ff >= 0 && ff <= NOF_VIEW_COLS);
+  NOF_ARG((ff == 0 || grad_feat == nullptr || dview != nullptr) && (grad_pose == nullptr || (pose_data && g_ray)));
+  if (F == 0) return 0;
+  hipLaunchKernelGGL(k_pose_reduce_bwd, dim3((unsigned)F), dim3(256), 0, (hipStream_t)stream, pose_data, g_ray, dview,
+                     batch, R, ff, max_trans, max_rot_rad, grad_pose, grad_feat, g_delta);
   NOF_LAUNCH_OK();
   return 0;
 }

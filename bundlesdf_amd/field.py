@@ -186,7 +186,7 @@ class NeuralObjectField:
                 batch=e(R, 12), rays_o_w=e(R, 3), viewdirs_w=e(R, 3), view=e(R, 16), t_in_out=e(R, self.max_hits, 2),
                 n_hits=e(R, dt=torch.int32), z_vals=e(R, S), pts_w=e(B, 3), valid=e(B, dt=torch.uint8),
                 feat=e(self.L, B, 2), raw=e(B, 4), draw=e(B, 4), dfeat=e(self.L, B, 2), dview=e(R, 16), dpts=e(B, 3),
-                rgb_map=e(R, 3), partials=e(self.nblk, self.n_mlp), loss_rows=e(R, 8))
+                rgb_map=e(R, 3), partials=e(self.nblk, self.n_mlp), loss_rows=e(R, 8), g_ray=e(R, 12))
         return self._bufs[key]
 
     def _sample_cfg(self, seed, step):
@@ -251,13 +251,14 @@ class NeuralObjectField:
         self._call('nof_hash_encode_bwd', C.byref(self.grid), b['pts_w'], self.table, b['dfeat'],
                  self._seg(self.grads, 'table'), b['dpts'] if self.optimize_poses else None, B)
         if self.optimize_poses or self.ff > 0:
-            self.g_delta.zero_()
-            self._call('nof_pose_grad_accum', b['dpts'] if self.optimize_poses else None, b['dview'], b['batch'], b['z_vals'],
-                     self.c2w, self.tf, self.ff, self.sh_degree, R, S, self.g_delta if self.optimize_poses else None,
-                     self._seg(self.grads, 'feat') if self.ff > 0 else None)
             if self.optimize_poses:
-                self._call('nof_pose_bwd', self.pose, self.g_delta, C.c_float(self.max_trans), C.c_float(self.max_rot),
-                         self._seg(self.grads, 'pose'), self.F)
+                self._call('nof_pose_grad_accum', b['dpts'], b['dview'], b['batch'], b['z_vals'], self.c2w, self.tf, self.ff,
+                           self.sh_degree, R, S, b['g_ray'])
+            self._call('nof_pose_reduce_bwd', self.pose if self.optimize_poses else None,
+                       b['g_ray'] if self.optimize_poses else None, b['dview'], b['batch'], R, self.ff,
+                       C.c_float(self.max_trans), C.c_float(self.max_rot),
+                       self._seg(self.grads, 'pose') if self.optimize_poses else None,
+                       self._seg(self.grads, 'feat') if self.ff > 0 else None, None, self.F)
         if self.ff > 0:
             self._call('nof_small_regs', self.feat, self._seg(self.grads, 'feat'), self.n_feat,
                      C.c_float(cfg['feature_reg_weight']), C.c_float(1.0 / self.world_size))

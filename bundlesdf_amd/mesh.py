@@ -133,6 +133,24 @@ class Mesh:
         return path
 
 
+def largest_component(mesh):
+    """Keep the connected component with the most faces (what run_global_nerf does with trimesh_split before export,
+    bundlesdf.py:748-760): unsupervised space inside the object can carry small closed level sets."""
+    from scipy.sparse import coo_matrix
+    from scipy.sparse.csgraph import connected_components
+    v, f = np.asarray(mesh.vertices), np.asarray(mesh.faces)
+    n = len(v)
+    e = np.concatenate([f[:, [0, 1]], f[:, [1, 2]], f[:, [2, 0]]], 0)
+    g = coo_matrix((np.ones(len(e), dtype=np.int8), (e[:, 0], e[:, 1])), shape=(n, n))
+    _, lab = connected_components(g, directed=False)
+    fl = lab[f[:, 0]]
+    keep = fl == np.bincount(fl).argmax()
+    used = np.unique(f[keep])
+    remap = -np.ones(n, dtype=np.int64)
+    remap[used] = np.arange(len(used))
+    return make_mesh(v[used], remap[f[keep]])
+
+
 def make_mesh(vertices, faces):
     """trimesh.Trimesh(vertices, faces, process=False) when trimesh is importable (the reference's return type,
     nerf_runner.py:1404), else the minimal container above."""

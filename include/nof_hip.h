@@ -156,11 +156,16 @@ int nof_composite_loss(const NofLossCfg* h_cfg, const float* raw, const float* z
                        float* loss_rows, float* loss_out, void* stream);
 
 /* ---- pose / feature gradients of a batch ---------------------------------------------------------- */
-/* dpts [R*S,3] (from nof_hash_encode_bwd), dview [R,16] (from nof_mlp_bwd), batch, z_vals, c2w [F,16],
- * tf [F,12] -> g_delta [F,12] ACCUMULATED (dL/dDelta), grad_feat [F,ff] ACCUMULATED (may be NULL). */
+/* dpts [R*S,3] (from nof_hash_encode_bwd, may be NULL), dview [R,16] (from nof_mlp_bwd), batch, z_vals, c2w [F,16], tf [F,12]
+ * -> g_ray [R,12] = this ray's contribution to dL/dDelta_frame (rows of frame-0 rays are 0).  No atomics. */
 int nof_pose_grad_accum(const float* dpts, const float* dview, const float* batch, const float* z_vals,
                         const float* c2w, const float* tf, int32_t ff, int32_t sh_degree, int64_t R, int32_t S,
-                        float* g_delta, float* grad_feat, void* stream);
+                        float* g_ray, void* stream);
+/* one workgroup per frame: g_delta[f] = sum of its rays' rows (written when non-NULL), grad_pose [F,6] += se3 backward,
+ * grad_feat [F,ff] += sum of its rays' dview[:, :ff] (either gradient pointer may be NULL). */
+int nof_pose_reduce_bwd(const float* pose_data, const float* g_ray, const float* dview, const float* batch, int64_t R,
+                        int32_t ff, float max_trans, float max_rot_rad, float* grad_pose, float* grad_feat,
+                        float* g_delta, int32_t F, void* stream);
 /* grad += 2*w*data/numel  (feature_reg, nerf_runner.py:745-747) and pose_reg (:749-752) */
 int nof_small_regs(const float* feat_data, float* grad_feat, int32_t n_feat, float feature_reg_weight,
                    float grad_scale, void* stream);
@@ -173,6 +178,9 @@ int nof_adam_step(float* params, float* grads, float* exp_avg, float* exp_avg_sq
 
 /* ---- test hook: raw MFMA tile  D[32,32] = A[32,K] * B[K,32] with the operand layouts nof_mlp uses ---- */
 int nof_mfma_probe(int32_t precision, const float* A, const float* Bm, float* D, int32_t K, void* stream);
+
+/* ---- test hook: fp32 atomic-add throughput for address patterns 0..4 (see nof_capi.hip); idx [n] uint32 < 2^19, table [2^19,2] */
+int nof_atomic_probe(int32_t variant, const uint32_t* idx, float* table, int64_t n, void* stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,28 @@
+"""fp32 atomic throughput on MI355X for the address patterns the hash scatter could use (run on the GPU box)."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from bundlesdf_amd import lib
+lib.load()
+n = 1 << 24
+T = 1 << 19
+g = torch.Generator(device='cuda').manual_seed(0)
+idx_rand = torch.randint(0, T, (n,), device='cuda', generator=g, dtype=torch.int64).to(torch.int32)
+idx_sorted = idx_rand.view(-1, 64).sort(dim=1)[0].reshape(-1).contiguous()
+# "ray-like": runs of nearby entries
+idx_hot = (torch.randint(0, 512, (n,), device='cuda', generator=g, dtype=torch.int64)).to(torch.int32)
+table = torch.zeros(T, 2, device='cuda')
+def run(name, variant, idx):
+    for rep in range(3):
+        table.zero_()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(); lib.call('nof_atomic_probe', variant, idx, table, n); b.record(); torch.cuda.synchronize()
+    ms = a.elapsed_time(b)
+    per = 1 if variant == 3 else 2
+    print(f'{name:46s} {ms:8.3f} ms  {n * per / ms / 1e6:8.1f} G atomics/s  sum={table.sum().item():.0f}')
+run('0 x,y separate instr, random entries', 0, idx_rand)
+run('1 adjacent-lane (x,y) pairs, random entries', 1, idx_rand)
+run('2 x,y separate instr, sequential entries', 2, idx_rand)
+run('3 x only, random entries', 3, idx_rand)
+run('4 x,y separate, per-wave sorted entries', 0, idx_sorted)
+run('5 x,y separate, 512 hot entries', 0, idx_hot)

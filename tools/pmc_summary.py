@@ -1,16 +1,12 @@
-"""Per-kernel averages of rocprofv3 --pmc counter CSVs: python tools/pmc_summary.py <dir> [<dir> ...]"""
-import csv, glob, os, sys, collections
+"""Per-kernel averages of rocprofv3 --pmc counters (SQLite output): python tools/pmc_summary.py <dir> [<dir> ...]"""
+import glob, os, sqlite3, sys
 for d in sys.argv[1:]:
-    files = glob.glob(os.path.join(d, '**', '*counter_collection.csv'), recursive=True)
-    print(f'== {d}: {len(files)} file(s)')
-    acc = collections.defaultdict(lambda: collections.defaultdict(list))
-    for f in files:
-        with open(f) as fh:
-            for row in csv.DictReader(fh):
-                k = row.get('Kernel_Name', '?')
-                if not k.startswith(('void k_', 'k_')):
-                    continue
-                k = k.split('(')[0][:70]
-                acc[k][row.get('Counter_Name')].append(float(row.get('Counter_Value', 0)))
-    for k in sorted(acc):
-        print('  ', k, {c: f'{sum(v) / len(v):.4g} (n={len(v)})' for c, v in acc[k].items()})
+    for db in glob.glob(os.path.join(d, '**', '*.db'), recursive=True):
+        con = sqlite3.connect(db)
+        rows = con.execute("select name, counter_name, count(*), avg(counter_value), avg(duration) from pmc_events "
+                           "where name like '%k_%' and name not like '%at::native%' group by name, counter_name "
+                           "order by avg(duration) desc").fetchall()
+        print(f'== {db}')
+        print(f"{'kernel':56s} {'counter':26s} {'n':>4s} {'avg_value':>16s} {'avg_us':>9s}")
+        for r in rows:
+            print(f"{r[0].split('(')[0][:56]:56s} {r[1]:26s} {r[2]:4d} {r[3]:16.4g} {r[4] / 1e3:9.1f}")
