@@ -55,7 +55,7 @@ def build_runner(args, rank, world, device):
         dist.all_gather(cs, c)
         cloud = torch.cat(cs, 0).cpu().numpy()
     sync = None
-    if world > 1:
+    if dist.is_initialized():
         def sync(flat):
             dist.all_reduce(flat)           # RCCL sum; gradients are pre-scaled by 1/world_size
     ns, nc = (3, 2) if args.mlp == 'baseline' else (2, 3)
@@ -147,7 +147,7 @@ def main():
         raise SystemExit('bench.py needs an MI355X (no CPU fallback for the product path)')
     torch.cuda.set_device(local_rank)
     device = torch.device('cuda', local_rank)
-    if world > 1:
+    if world > 1 or ('RANK' in os.environ and 'MASTER_PORT' in os.environ):     # launched by torch.distributed.run
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         dist.init_process_group('nccl', device_id=device)
     assert world == args.gpus or world == 1, f'--gpus {args.gpus} but WORLD_SIZE={world}'
@@ -172,7 +172,7 @@ def main():
     fld.profile_only = dominant
 
     def barrier():
-        if world > 1:
+        if dist.is_initialized():
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -206,17 +206,24 @@ def main():
             'nof_mlp_bwd': ('mfma', B * 3.0 * fl_fwd),
             'nof_adam_step': ('hbm', fld.n_total * 32.0),
         }
+        traffic = None          # HBM bytes per launch from the committed PMC passes (profiles/pmc_traffic.json), same workload only
+        try:
+            if args.precision == 'bf16' and args.mlp == 'baseline' and R == 4096 and args.log2_T == 19:
+                pm = json.load(open(os.path.join(ROOT, 'profiles', 'pmc_traffic.json')))
+                traffic = pm.get(dominant, {}).get('traffic_bytes')
+        except Exception:
+            traffic = None
         roof = None
         if dominant in work and dom_ms:
             kind, amount = work[dominant]
             if kind == 'hbm':
                 ach = amount / (dom_ms * 1e-3) / 1e9
                 roof = {"kernel": dominant, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": ach / HBM_PEAK_GBS, "traffic": None, "avg_ms": dom_ms}
+                        "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes": amount, "avg_ms": dom_ms}
             else:
                 ach = amount / (dom_ms * 1e-3) / 1e12
                 roof = {"kernel": dominant, "bound": "mfma", "achieved": ach, "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s",
-                        "frac": ach / MFMA_BF16_PEAK_TF, "traffic": None, "avg_ms": dom_ms}
+                        "frac": ach / MFMA_BF16_PEAK_TF, "traffic": traffic, "algorithmic_flop": amount, "avg_ms": dom_ms}
         elif dominant:
             roof = {"kernel": dominant, "bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None,
                     "traffic": None, "avg_ms": dom_ms}
@@ -238,7 +245,7 @@ def main():
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

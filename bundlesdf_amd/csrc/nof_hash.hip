@@ -315,17 +315,36 @@ extern "C" int nof_hash_encode_fwd(const NofHashGrid* g, const float* pts_w, con
   return 0;
 }
 
+// Fork/join helper: the three backward kernels are independent of each other (they only share read-only inputs and write
+// disjoint outputs / disjoint levels of grad_table).  k_hash_bwd_agg is bound by memory-side atomic throughput and leaves the
+// CUs mostly idle, so the gather-bound k_hash_dx and the LDS-bound k_hash_bwd_lds run beside it on an internal stream.
+// Event record/wait pairs are legal during stream capture (they become graph edges).
+struct SideStream {
+  hipStream_t stream = nullptr;
+  hipEvent_t fork = nullptr, join = nullptr;
+  int device = -1;
+};
+static thread_local SideStream g_side;
+
+static int side_stream(SideStream** out) {
+  int dev = 0;
+  NOF_HIP(hipGetDevice(&dev));
+  if (g_side.stream == nullptr || g_side.device != dev) {
+    NOF_HIP(hipStreamCreateWithFlags(&g_side.stream, hipStreamNonBlocking));
+    NOF_HIP(hipEventCreateWithFlags(&g_side.fork, hipEventDisableTiming));
+    NOF_HIP(hipEventCreateWithFlags(&g_side.join, hipEventDisableTiming));
+    g_side.device = dev;
+  }
+  *out = &g_side;
+  return 0;
+}
+
 extern "C" int nof_hash_encode_bwd(const NofHashGrid* g, const float* pts_w, const float* table, const float* dfeat,
                                     float* grad_table, float* dpts, int64_t B, void* stream) {
   if (int e = check_grid(g)) return e;
   NOF_ARG(pts_w && table && dfeat && grad_table && B >= 0);
   if (B == 0) return 0;
   hipStream_t st = (hipStream_t)stream;
-  if (dpts) {
-    hipLaunchKernelGGL(k_hash_dx, dim3((unsigned)nof_div_up(B, 256)), dim3(256), 0, st, *g, pts_w, (const float2*)table,
-                       (const float2*)dfeat, dpts, B);
-    NOF_LAUNCH_OK();
-  }
   // split the levels: slices of <= 128 KiB are accumulated in LDS, the others go through wave-merged global atomics
   const size_t lds_cap = 128 * 1024;
   LevelList small, big;
@@ -336,13 +355,14 @@ extern "C" int nof_hash_encode_bwd(const NofHashGrid* g, const float* pts_w, con
     if (bytes <= lds_cap) { small.level[small.n++] = l; if (bytes > lds_need) lds_need = bytes; }
     else big.level[big.n++] = l;
   }
-  if (small.n > 0) {
-    const int chunks = 64;
-    if (lds_need > 64 * 1024)
-      NOF_HIP(hipFuncSetAttribute((const void*)k_hash_bwd_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_need));
-    hipLaunchKernelGGL(k_hash_bwd_lds, dim3((unsigned)(chunks * small.n)), dim3(1024), lds_need, st, *g, small, chunks, pts_w,
-                       (const float2*)dfeat, grad_table, B);
-    NOF_LAUNCH_OK();
+  SideStream* side = nullptr;
+  const bool fork = big.n > 0 && (dpts != nullptr || small.n > 0);
+  hipStream_t s2 = st;
+  if (fork) {
+    if (int e = side_stream(&side)) return e;
+    s2 = side->stream;
+    NOF_HIP(hipEventRecord(side->fork, st));
+    NOF_HIP(hipStreamWaitEvent(s2, side->fork, 0));
   }
   if (big.n > 0) {
     const int64_t blocks = nof_div_up(B, 256) * big.n;
@@ -350,6 +370,23 @@ extern "C" int nof_hash_encode_bwd(const NofHashGrid* g, const float* pts_w, con
     hipLaunchKernelGGL(k_hash_bwd_agg, dim3((unsigned)blocks), dim3(256), 0, st, *g, big, pts_w, (const float2*)dfeat,
                        grad_table, B, 1023u);
     NOF_LAUNCH_OK();
+  }
+  if (dpts) {
+    hipLaunchKernelGGL(k_hash_dx, dim3((unsigned)nof_div_up(B, 256)), dim3(256), 0, s2, *g, pts_w, (const float2*)table,
+                       (const float2*)dfeat, dpts, B);
+    NOF_LAUNCH_OK();
+  }
+  if (small.n > 0) {
+    const int chunks = 64;
+    if (lds_need > 64 * 1024)
+      NOF_HIP(hipFuncSetAttribute((const void*)k_hash_bwd_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_need));
+    hipLaunchKernelGGL(k_hash_bwd_lds, dim3((unsigned)(chunks * small.n)), dim3(1024), lds_need, s2, *g, small, chunks, pts_w,
+                       (const float2*)dfeat, grad_table, B);
+    NOF_LAUNCH_OK();
+  }
+  if (fork) {
+    NOF_HIP(hipEventRecord(side->join, s2));
+    NOF_HIP(hipStreamWaitEvent(st, side->join, 0));
   }
   return 0;
 }

@@ -1,0 +1,61 @@
+"""CPU tests of the iso-surface extraction used by NerfRunner.extract_mesh (bundlesdf_amd/mesh.py)."""
+import numpy as np
+
+from bundlesdf_amd.mesh import Mesh, largest_component, make_mesh, marching_tetrahedra
+
+
+def _ellipsoid_volume(n=48, semi=(0.6, 0.8, 0.5)):
+    ax = (np.arange(n) + 0.5) / n * 2 - 1
+    X, Y, Z = np.meshgrid(ax, ax, ax, indexing='ij')
+    return np.sqrt((X / semi[0]) ** 2 + (Y / semi[1]) ** 2 + (Z / semi[2]) ** 2) - 1, ax
+
+
+def test_marching_tetrahedra_on_analytic_sdf():
+    vol, ax = _ellipsoid_volume()
+    v, f = marching_tetrahedra(vol.astype(np.float32), 0.0)
+    p = ax[0] + v * (ax[1] - ax[0])
+    r = np.sqrt((p[:, 0] / 0.6) ** 2 + (p[:, 1] / 0.8) ** 2 + (p[:, 2] / 0.5) ** 2)
+    assert np.abs(r - 1).max() < 5e-3                      # vertices sit on the level set (linear interpolation error only)
+    # closed, consistently oriented 2-manifold: every undirected edge is shared by exactly two faces, in opposite directions
+    e = np.concatenate([f[:, [0, 1]], f[:, [1, 2]], f[:, [2, 0]]], 0)
+    und = np.sort(e, 1)
+    _, cnt = np.unique(und, axis=0, return_counts=True)
+    assert (cnt == 2).all()
+    key = e[:, 0] * (len(v) + 1) + e[:, 1]
+    assert len(np.unique(key)) == len(key)                  # no directed edge appears twice
+    # outward normals (towards increasing SDF)
+    c = p[f].mean(1)
+    nrm = np.cross(p[f[:, 1]] - p[f[:, 0]], p[f[:, 2]] - p[f[:, 0]])
+    grad = np.stack([c[:, 0] / 0.36, c[:, 1] / 0.64, c[:, 2] / 0.25], -1)
+    assert ((nrm * grad).sum(1) > 0).mean() > 0.999
+    # enclosed volume = 4/3 pi a b c within 2 %
+    vol_mesh = np.abs(np.einsum('ij,ij->i', p[f[:, 0]], np.cross(p[f[:, 1]], p[f[:, 2]])).sum()) / 6
+    assert abs(vol_mesh - 4 / 3 * np.pi * 0.6 * 0.8 * 0.5) / (4 / 3 * np.pi * 0.24) < 0.02
+
+
+def test_empty_level_set_raises_like_skimage():
+    import pytest
+    with pytest.raises(ValueError):
+        marching_tetrahedra(np.ones((8, 8, 8), np.float32), 0.0)
+
+
+def test_largest_component_and_mesh_container(tmp_path):
+    vol, ax = _ellipsoid_volume()
+    n = len(ax)
+    X, Y, Z = np.meshgrid(ax, ax, ax, indexing='ij')
+    bubble = np.sqrt((X - 0.1) ** 2 + Y ** 2 + Z ** 2) - 0.12
+    vol = np.where(bubble < 0.03, -bubble, vol)             # a positive bubble inside the object -> a second closed surface
+    v, f = marching_tetrahedra(vol.astype(np.float32), 0.0)
+    m = Mesh(v, f)
+    big = largest_component(m)
+    assert len(big.faces) < len(m.faces) and len(big.faces) > 0.8 * len(m.faces)
+    T = np.eye(4)
+    T[:3, 3] = [1, 2, 3]
+    c0 = np.asarray(big.vertices).mean(0)
+    big.apply_transform(T)
+    assert np.allclose(np.asarray(big.vertices).mean(0), c0 + [1, 2, 3])
+    big.vertices = np.asarray(big.vertices) / 2.0            # Utils.py:512 assigns .vertices
+    out = Mesh(np.asarray(big.vertices), np.asarray(big.faces)).export(str(tmp_path / 'm.obj'))
+    txt = open(out).read().splitlines()
+    assert sum(l.startswith('v ') for l in txt) == len(big.vertices) and sum(l.startswith('f ') for l in txt) == len(big.faces)
+    assert make_mesh(v, f) is not None

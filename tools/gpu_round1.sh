@@ -14,3 +14,8 @@ rm -rf gpurun_out/prof
 cd /tmp && timeout 420 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof -o bench -- python $R/bench.py --steps 30 --warmup 3 --no-cpu-baseline > $R/gpurun_out/prof.log 2>&1
 cd $R; python tools/prof_summary.py gpurun_out/prof/bench_results.db 2>&1 | head -14 | cut -c1-150
 if [ "$PMC" = "1" ]; then KF=16 bash tools/gpu_pmc.sh; fi
+if [ "$DIST" = "1" ]; then
+  HSA_ENABLE_IPC_MODE_LEGACY=0 timeout 240 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29517 \
+    bench.py --gpus 1 --steps 30 --warmup 5 --no-cpu-baseline > gpurun_out/bench_dist.log 2> gpurun_out/bench_dist.err
+  tail -1 gpurun_out/bench_dist.log | cut -c1-600; tail -3 gpurun_out/bench_dist.err
+fi
