@@ -26,6 +26,20 @@ __global__ __launch_bounds__(256) void k_atomic_probe(int variant, const uint32_
     if (e < n) atomicAdd(&table[2 * (size_t)idx[e] + (i & 1)], 1.0f);
     return;
   }
+  if (variant == 6 || variant == 7 || variant == 8) {
+    // 16 lines per instruction, 4 lanes each: 6 = same ADDRESS from lanes l, l+16, l+32, l+48; 7 = same line, different words,
+    // lanes 16 apart; 8 = same line, different words, ADJACENT lanes
+    if (i >= n) return;
+    const int l = threadIdx.x & 63;
+    const int grp = variant == 8 ? (l >> 2) : (l & 15), sub = variant == 8 ? (l & 3) : (l >> 4);
+    const size_t base = (size_t)(idx[(i >> 6) * 16 + grp] & ~3u);
+    atomicAdd(&table[2 * (base + (variant == 6 ? 0 : sub))], 1.0f);
+    return;
+  }
+  if (variant == 9) {                       // plain 4-byte stores, random entries (what an atomic-free scatter would cost)
+    if (i < n) table[2 * (size_t)idx[i]] = 1.0f;
+    return;
+  }
   if (i >= n) return;
   const size_t e = (variant == 2) ? (size_t)(i & 0x7FFFF) : (size_t)idx[i];
   atomicAdd(&table[2 * e], 1.0f);
@@ -33,7 +47,7 @@ __global__ __launch_bounds__(256) void k_atomic_probe(int variant, const uint32_
 }
 
 extern "C" int nof_atomic_probe(int32_t variant, const uint32_t* idx, float* table, int64_t n, void* stream) {
-  NOF_ARG(idx && table && n > 0 && variant >= 0 && variant <= 4);
+  NOF_ARG(idx && table && n > 0 && variant >= 0 && variant <= 9);
   const int64_t threads = variant == 1 ? 2 * n : n;
   hipLaunchKernelGGL(k_atomic_probe, dim3((unsigned)nof_div_up(threads, 256)), dim3(256), 0, (hipStream_t)stream, variant, idx,
                      table, n);

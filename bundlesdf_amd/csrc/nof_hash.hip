@@ -14,8 +14,8 @@
 //       k_hash_bwd_lds levels whose whole slice fits in LDS accumulate there (ds_add_f32) and are flushed once per
 //                      workgroup, skipping untouched entries;
 //       k_hash_bwd_agg all other levels: lanes of a wave are consecutive samples of ONE ray, so lanes falling into the
-//                      same cell form contiguous runs; a segmented shuffle-sum merges each run and only its first lane
-//                      issues the 16 atomics (16x fewer at the coarsest hashed level, 1x at the finest).
+//                      same cell form contiguous runs; each run is summed out of an LDS stage and emitted once by 16
+//                      adjacent lanes (cfg2: 3..15 samples per run at the hashed levels).
 #include "nof_common.h"
 #pragma clang fp contract(off)
 
@@ -158,50 +158,113 @@ struct LevelList {
   int32_t level[NOF_MAX_LEVELS];
 };
 
-// Emission of the merged runs.  Measured on MI355X (tools/atomic_probe.py): fp32 atomics retire at ~20.8 G line-requests/s
-// chip-wide, lanes of ONE instruction that fall into the same 64-byte line merge into one request (x/y pair in adjacent
-// lanes: 2x; consecutive entries: 8x) and a hot line serialises (3.8 G/s).  So a run leader does not issue its 16 atomics
-// itself (16 instructions, one line each): the leaders' (row, value) lists are compacted through a small LDS stage and
-// re-read so that 16 ADJACENT lanes carry one cell -- [corner k][channel] with k's bit 0 = the x neighbour, whose row is
-// idx+1 for dense levels and for even x of hashed levels (prime 1) -- i.e. 4..8 line requests per cell instead of 16.
-struct EmitStage {                                                    // odd row strides: conflict-free LDS writes by rank
-  float val[4][64][17];
-  uint32_t row[4][64][9];
+// Merge + emission for the levels that do not fit LDS.  Measured on MI355X (tools/atomic_probe.py): fp32 atomics retire at
+// ~20.8 G line-requests/s chip-wide, lanes of ONE instruction that fall into the same 64-byte line merge into one request
+// (x/y pair in adjacent lanes: 2x; consecutive entries: 8x) and a hot line serialises (3.8 G/s).  Two consequences:
+//   * runs of adjacent lanes in the same cell are merged before anything leaves the CU.  Two merges were measured and
+//     dropped: a segmented shuffle scan (16 values x 6 steps of ds_bpermute + select + add: ~45% of the kernel's
+//     instructions and all of its LDS round-trip latency) and ds_add_f32 into one LDS slot per run (LDS float atomics
+//     retire ~1 lane per 4.5 cycles on gfx950, 92 us per level regardless of the run structure).  Instead every lane parks
+//     its 16 products in LDS with plain 16-byte stores and the run is summed by the lanes that emit it;
+//   * a run is emitted by 16 ADJACENT lanes -- [corner k][channel] with k's bit 0 = the x neighbour, whose row is
+//     idx+1 for dense levels and for even x of hashed levels (prime 1) -- i.e. 4..8 line requests per cell instead of 16
+//     (different words of one line merge into one request from anywhere in the instruction, variants 7/8 of the probe).
+//     Lane (q, e) of a wave walks the runs q, q+4, ... and adds up element e of their lanes in lane order (deterministic).
+#define AGG_STRIDE 20                                                  // floats per lane slot: 16-byte aligned, conflict-free b128
+#define AGG_ROWS 12                                                    // words per run in the row list (8 used), same reason
+struct AggStage {
+  float val[4][64 * AGG_STRIDE];                                      // [wave][lane * 20 + corner * 2 + channel]
+  uint32_t row[4][64 * AGG_ROWS];                                     // [wave][run * 12 + corner]
+  uint32_t span[4][64];                                               // [wave][run] = first lane | (length << 8)
 };
 
-__device__ __forceinline__ void emit_packed(EmitStage& st, const Scatter& sc, bool lead, float* __restrict__ gt) {
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const unsigned long long mask = __ballot(lead);
-  const int nl = __popcll(mask);
-  const int rank = __popcll(mask & ((1ull << lane) - 1ull));
-  if (lead) {
+struct Rows8 {
+  uint32_t r[8];
+};
+__device__ __forceinline__ Rows8 load_rows(const uint32_t* p) {
+  const uint4 a = *reinterpret_cast<const uint4*>(p), b = *reinterpret_cast<const uint4*>(p + 4);
+  Rows8 o;
+  o.r[0] = a.x; o.r[1] = a.y; o.r[2] = a.z; o.r[3] = a.w; o.r[4] = b.x; o.r[5] = b.y; o.r[6] = b.z; o.r[7] = b.w;
+  return o;
+}
+__device__ __forceinline__ uint32_t match_mask(const Rows8& rs, uint32_t row) {
+  uint32_t m = 0;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      st.val[w][rank][2 * k] = sc.vx[k];
-      st.val[w][rank][2 * k + 1] = sc.vy[k];
-      st.row[w][rank][k] = sc.idx[k];
-    }
-  }
-  __syncthreads();                                                    // block-uniform call site (all four waves arrive)
-  const int e = lane & 15;
-  for (int m = lane >> 4; m < nl; m += 4) {
-    const uint32_t r = st.row[w][m][e >> 1];
-    atomicAdd(&gt[2 * (size_t)r + (e & 1)], st.val[w][m][e]);     // gridencoder.cu:317-333 (fp32 atomics)
-  }
+  for (int k = 0; k < 8; ++k) m |= (rs.r[k] == row ? 1u : 0u) << k;
+  return m;
 }
 
-// levels that do not fit LDS: wave-merged, lane-packed global atomics
+// A third measured fact shapes the last step: lanes of one instruction that hit the SAME ADDRESS are not merged (4 lanes on
+// one word cost 4 requests, tools/atomic_probe.py variant 6), and consecutive cells along a ray share a face, i.e. 4 of
+// their 8 table rows.  So rows are de-duplicated across the runs of a wave before emission: the first run of a chain of
+// consecutive runs containing a row owns it and adds up the chain's contributions (exact for any collision pattern: a
+// run that also lists the row earlier in itself, or whose predecessor lists it, is not an owner).
 __global__ __launch_bounds__(256) void k_hash_bwd_agg(NofHashGrid g, LevelList ll, const float* __restrict__ pts_w,
                                                        const float2* __restrict__ dfeat, float* __restrict__ grad_table,
-                                                       int64_t B, uint32_t merge_max_res) {
-  __shared__ EmitStage stage;
+                                                       int64_t B) {
+  __shared__ __attribute__((aligned(16))) AggStage st;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int level = ll.level[blockIdx.x % ll.n];
   const int64_t b = (int64_t)(blockIdx.x / ll.n) * 256 + threadIdx.x;
   const HashLevel lv = load_level(g, level);
-  Scatter sc = make_scatter(lv, pts_w, dfeat, level, b, B);
-  bool lead = sc.key != 0xFFFFFFFFu;
-  if (lv.res <= merge_max_res) lead = wave_merge_runs(sc);          // block-uniform branch
-  emit_packed(stage, sc, lead, grad_table + 2 * (size_t)lv.offset);
+  const Scatter sc = make_scatter(lv, pts_w, dfeat, level, b, B);
+  const bool valid = sc.key != 0xFFFFFFFFu;
+  const uint32_t prev = __shfl_up(sc.key, 1, 64);
+  const bool head = valid && (lane == 0 || prev != sc.key);           // lanes are consecutive samples of one ray
+  const unsigned long long heads = __ballot(head);
+  const unsigned long long breaks = heads | ~__ballot(valid);         // a run ends before the next head or invalid lane
+  const int nl = __popcll(heads);
+  float* val = st.val[w];
+  uint32_t* row = st.row[w];
+  float4* v4 = reinterpret_cast<float4*>(&val[lane * AGG_STRIDE]);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) v4[k] = make_float4(sc.vx[2 * k], sc.vy[2 * k], sc.vx[2 * k + 1], sc.vy[2 * k + 1]);
+  if (head) {
+    const int slot = __popcll(heads & ((1ull << lane) - 1ull));
+    const unsigned long long after = lane == 63 ? 0ull : (breaks >> (lane + 1));
+    const int len = after ? __builtin_ctzll(after) + 1 : 64 - lane;
+    st.span[w][slot] = (uint32_t)lane | ((uint32_t)len << 8);
+    uint4* r4 = reinterpret_cast<uint4*>(&row[slot * AGG_ROWS]);
+    r4[0] = make_uint4(sc.idx[0], sc.idx[1], sc.idx[2], sc.idx[3]);
+    r4[1] = make_uint4(sc.idx[4], sc.idx[5], sc.idx[6], sc.idx[7]);
+  }
+  __syncthreads();
+  // phase 1: lane (q, e) sums element e over the lanes of runs q, q+4, ... (lane order); the total replaces the head's slot
+  const int e = lane & 15, q = lane >> 4;
+  for (int m = q; m < nl; m += 4) {
+    const uint32_t sp = st.span[w][m];
+    float* src = &val[(sp & 0xFF) * AGG_STRIDE + e];
+    const int len = (int)(sp >> 8);
+    float acc = src[0];
+    for (int i = 1; i < len; ++i) acc += src[i * AGG_STRIDE];
+    if (len > 1) src[0] = acc;
+  }
+  __syncthreads();
+  // phase 2: row owners collect their chain and emit
+  float* __restrict__ gt = grad_table + 2 * (size_t)lv.offset;
+  const int k = e >> 1, ch = e & 1;
+  for (int m = q; m < nl; m += 4) {
+    const Rows8 mine = load_rows(&row[m * AGG_ROWS]);
+    const uint32_t r = row[m * AGG_ROWS + k];
+    uint32_t mm = match_mask(mine, r);
+    bool owner = (mm & ((1u << k) - 1u)) == 0u;                       // no earlier corner of this run has the same row
+    if (m > 0 && match_mask(load_rows(&row[(m - 1) * AGG_ROWS]), r) != 0u) owner = false;
+    if (!owner) continue;
+    float acc = 0.0f;
+    int j = m;
+    while (true) {
+      const float* sv = &val[(st.span[w][j] & 0xFF) * AGG_STRIDE + ch];
+      while (mm) {
+        const int kk = __builtin_ctz(mm);
+        mm &= mm - 1u;
+        acc += sv[2 * kk];
+      }
+      if (++j >= nl) break;
+      mm = match_mask(load_rows(&row[j * AGG_ROWS]), r);
+      if (mm == 0u) break;
+    }
+    atomicAdd(&gt[2 * (size_t)r + ch], acc);                          // gridencoder.cu:317-333 (fp32 atomics)
+  }
 }
 
 // levels whose slice fits LDS: accumulate privately, flush once
@@ -330,7 +393,7 @@ static int side_stream(SideStream** out) {
   int dev = 0;
   NOF_HIP(hipGetDevice(&dev));
   if (g_side.stream == nullptr || g_side.device != dev) {
-    NOF_HIP(hipStreamCreateWithFlags(&g_side.stream, hipStreamNonBlocking));
+    NOF_HIP(hipStreamCreateWithFlags(&g_side.stream, hipStreamNonBlocking));   // (stream priority made no measurable difference)
     NOF_HIP(hipEventCreateWithFlags(&g_side.fork, hipEventDisableTiming));
     NOF_HIP(hipEventCreateWithFlags(&g_side.join, hipEventDisableTiming));
     g_side.device = dev;
@@ -345,8 +408,11 @@ extern "C" int nof_hash_encode_bwd(const NofHashGrid* g, const float* pts_w, con
   NOF_ARG(pts_w && table && dfeat && grad_table && B >= 0);
   if (B == 0) return 0;
   hipStream_t st = (hipStream_t)stream;
-  // split the levels: slices of <= 128 KiB are accumulated in LDS, the others go through wave-merged global atomics
-  const size_t lds_cap = 128 * 1024;
+  // split the levels: slices of <= 48 KiB are accumulated in LDS (their few hundred rows would be hot lines for global
+  // atomics), the others go through wave-merged global atomics.  Measured at cfg2: a 128 KiB cap (levels 0-2 in LDS) makes
+  // the LDS kernel's 1024-thread / 125 KiB blocks wait for empty CUs beside k_hash_bwd_agg (501 us overlapped vs 85 us
+  // alone) and the whole call 75 us slower than with level 0 alone in LDS; no LDS level at all is 230 us slower.
+  const size_t lds_cap = 48 * 1024;
   LevelList small, big;
   small.n = big.n = 0;
   size_t lds_need = 0;
@@ -368,7 +434,7 @@ extern "C" int nof_hash_encode_bwd(const NofHashGrid* g, const float* pts_w, con
     const int64_t blocks = nof_div_up(B, 256) * big.n;
     NOF_ARG(blocks < (1ll << 31));
     hipLaunchKernelGGL(k_hash_bwd_agg, dim3((unsigned)blocks), dim3(256), 0, st, *g, big, pts_w, (const float2*)dfeat,
-                       grad_table, B, 1023u);
+                       grad_table, B);
     NOF_LAUNCH_OK();
   }
   if (dpts) {

@@ -26,3 +26,15 @@ run('2 x,y separate instr, sequential entries', 2, idx_rand)
 run('3 x only, random entries', 3, idx_rand)
 run('4 x,y separate, per-wave sorted entries', 0, idx_sorted)
 run('5 x,y separate, 512 hot entries', 0, idx_hot)
+run('6 same address from lanes 16 apart (16 lines/instr)', 3, idx_rand) if False else None
+def run1(name, variant, idx):
+    for rep in range(3):
+        table.zero_()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(); lib.call('nof_atomic_probe', variant, idx, table, n); b.record(); torch.cuda.synchronize()
+    ms = a.elapsed_time(b)
+    print(f'{name:58s} {ms:8.3f} ms  {n / ms / 1e6:8.1f} G lane-ops/s  {n / 4 / ms / 1e6:8.1f} G lines/s  sum={table.sum().item():.0f}')
+run1('6 same ADDRESS, lanes 16 apart, 16 lines/instr', 6, idx_rand)
+run1('7 same line diff words, lanes 16 apart, 16 lines/instr', 7, idx_rand)
+run1('8 same line diff words, adjacent lanes, 16 lines/instr', 8, idx_rand)
+run1('9 plain 4-byte stores, random entries (64 lines/instr)', 9, idx_rand)
