@@ -16,51 +16,8 @@
 //       k_hash_bwd_agg all other levels: lanes of a wave are consecutive samples of ONE ray, so lanes falling into the
 //                      same cell form contiguous runs; each run is summed out of an LDS stage and emitted once by 16
 //                      adjacent lanes (cfg2: 3..15 samples per run at the hashed levels).
-#include "nof_common.h"
+#include "nof_hash_dev.h"
 #pragma clang fp contract(off)
-
-struct HashLevel {
-  float scale;
-  uint32_t res, offset, size, hashed;
-};
-
-__device__ __forceinline__ uint32_t grid_index(const HashLevel& lv, uint32_t x, uint32_t y, uint32_t z) {
-  uint32_t index;
-  if (lv.hashed) {
-    index = (x * 1u) ^ (y * 2654435761u) ^ (z * 805459861u);      // fast_hash, gridencoder.cu:47-62
-  } else {
-    const uint32_t r1 = lv.res + 1u;                                // align_corners == false
-    index = x + y * r1 + z * r1 * r1;                               // gridencoder.cu:70-74
-  }
-  return index % lv.size;
-}
-
-struct CellPos {
-  uint32_t g[3];
-  float f[3];
-  bool oob;
-};
-
-__device__ __forceinline__ CellPos locate(const float* __restrict__ pts_w, int64_t b, float scale) {
-  CellPos c;
-  c.oob = false;
-#pragma unroll
-  for (int d = 0; d < 3; ++d) {
-    const float x01 = (pts_w[b * 3 + d] + 1.0f) * 0.5f;            // grid.py:160
-    if (x01 < 0.0f || x01 > 1.0f) c.oob = true;                     // gridencoder.cu:131
-    const float pos = x01 * scale + 0.5f;                           // gridencoder.cu:164
-    const float fl = floorf(pos);
-    c.g[d] = (uint32_t)fl;
-    c.f[d] = pos - fl;
-  }
-  return c;
-}
-
-__device__ __forceinline__ HashLevel load_level(const NofHashGrid& g, int l) {
-  HashLevel lv;
-  lv.scale = g.scale[l]; lv.res = g.resolution[l]; lv.offset = g.offset[l]; lv.size = g.size[l]; lv.hashed = g.hashed[l];
-  return lv;
-}
 
 __global__ __launch_bounds__(256) void k_hash_fwd(NofHashGrid g, const float* __restrict__ pts_w,
                                                    const float2* __restrict__ table, float2* __restrict__ feat,
@@ -70,29 +27,7 @@ __global__ __launch_bounds__(256) void k_hash_fwd(NofHashGrid g, const float* __
   if (b >= B) return;
   const HashLevel lv = load_level(g, level);
   const CellPos c = locate(pts_w, b, lv.scale);
-  float2 acc = make_float2(0.f, 0.f);
-  if (!c.oob) {
-    const float2* __restrict__ tl = table + lv.offset;
-    uint32_t idx[8];
-    float w[8];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      float wk = 1.0f;
-      uint32_t p[3];
-#pragma unroll
-      for (int d = 0; d < 3; ++d) {
-        if (k & (1 << d)) { wk *= c.f[d]; p[d] = c.g[d] + 1u; }
-        else              { wk *= 1.0f - c.f[d]; p[d] = c.g[d]; }
-      }
-      w[k] = wk;
-      idx[k] = grid_index(lv, p[0], p[1], p[2]);
-    }
-    float2 v[8];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) v[k] = tl[idx[k]];                  // 8 independent 8-byte gathers in flight
-#pragma unroll
-    for (int k = 0; k < 8; ++k) { acc.x += w[k] * v[k].x; acc.y += w[k] * v[k].y; }
-  }
+  const float2 acc = encode_level(lv, table, c);
   feat[(int64_t)level * B + b] = acc;
 }
 

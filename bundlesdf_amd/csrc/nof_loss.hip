@@ -158,6 +158,13 @@ extern "C" int nof_composite_loss(const NofLossCfg* cfg, const float* raw, const
   return 0;
 }
 
+// the name SURVEY.md 8b lists for the same entry point (forward compositing + losses + dL/draw in one launch)
+extern "C" int nof_composite_loss_fwd_bwd(const NofLossCfg* cfg, const float* raw, const float* z_vals, const uint8_t* valid,
+                                           const float* batch, int64_t R, int32_t S, float* rgb_map, float* weights,
+                                           float* draw, float* loss_rows, float* loss_out, void* stream) {
+  return nof_composite_loss(cfg, raw, z_vals, valid, batch, R, S, rgb_map, weights, draw, loss_rows, loss_out, stream);
+}
+
 // ------------------------------------------------------------------------------------------------
 // torch.optim.Adam, single tensor form: m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2;
 // p -= (lr/bc1) * m / (sqrt(v)/sqrt(bc2) + eps).  HBM streaming: 16 B read + 16 B written per parameter.

@@ -16,6 +16,7 @@
 //     ever goes to HBM.
 // Accumulator layout of v_mfma_f32_32x32x*: lane l = (hi = l>>5, j = l&31) holds column j, rows (r&3)+8(r>>2)+4hi.
 #include "nof_common.h"
+#include "nof_hash_dev.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -315,6 +316,75 @@ NofMlpDesc d, const char* __restrict__ image,
       dense_o1<P, 2, 1>(smem, FW_OFF(NS + NC - 1), BIAS_OFF(NS + NC - 1), h, co, lane);
       if (hi == 0 && b < B) ((float4*)out)[b] = make_float4(co[0][0], co[0][1], co[0][2], so[0][0]);
     }
+  }
+}
+
+// =====================================================================================================
+// dense SDF grid for mesh extraction (extract_mesh + run_network_density, nerf_runner.py:1307-1386), fused:
+// voxel centre -> octree mask -> hash encode in registers -> sigma net on MFMA -> sdf[nx,ny,nz].  Nothing per point ever goes
+// to HBM except the 4-byte result (the reference materialises query_pts, the [N,32] embedding and every activation).
+// A wave owns 32 consecutive voxels of one z column (lane = (voxel, hi), hi picks which 8 levels the lane encodes = exactly
+// the B-operand layout of the first layer); occupancy is spatially coherent (level <= 6 cells vs 1/512 voxels), so a
+// wave-uniform skip of all-empty tiles is the whole compaction that is needed.
+// =====================================================================================================
+template <class P, int NS, int NC>
+__global__ __launch_bounds__(256, 2) void k_sdf_grid(NofMlpDesc d, const char* __restrict__ image, NofHashGrid g,
+                                                      const float2* __restrict__ table, const uint32_t* __restrict__ occ_bits,
+                                                      int occ_n, const float* __restrict__ tx, const float* __restrict__ ty,
+                                                      const float* __restrict__ tz, int nx, int ny, int nz, float outside,
+                                                      float* __restrict__ sdf) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  typedef Shp<NS, NC> SH;
+  constexpr int BIAS_BASE = SH::pair_base(NS) * PAIR_BYTES;
+  copy16(smem, image, (size_t)BIAS_BASE);
+  copy16(smem + BIAS_BASE, image + 2 * (size_t)SH::pair_base(NS + NC) * PAIR_BYTES, (size_t)SH::oblk_base(NS) * 32 * 4);
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int hi = lane >> 5, j = lane & 31;
+  const int ntz = (nz + 31) / 32;
+  const int64_t ntiles = (int64_t)nx * ny * ntz;
+  for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < ntiles; tile += (int64_t)gridDim.x * 4) {
+    asm volatile("" ::: "memory");
+    const int64_t col = tile / ntz;
+    const int k = (int)(tile - col * ntz) * 32 + j;
+    const int ix = (int)(col / ny), iy = (int)(col - (int64_t)ix * ny);
+    const bool in_range = k < nz;
+    float p[3] = {tx[ix], ty[iy], in_range ? tz[k] : 0.0f};
+    const bool inside = in_range && (occ_bits == nullptr || occ_point_test(occ_bits, occ_n, p[0], p[1], p[2]));
+    const int64_t vox = col * nz + k;
+    if (__ballot(inside) == 0ull) {
+      if (hi == 0 && in_range) sdf[vox] = outside;
+      continue;
+    }
+#pragma unroll
+    for (int dd = 0; dd < 3; ++dd) p[dd] = fminf(fmaxf(p[dd], -1.0f), 1.0f);      // run_network_density clips (nerf_runner.py:1313)
+    float x[1][16];
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) {
+      const int level = 8 * hi + kk;
+      float2 v = make_float2(0.f, 0.f);
+      if (inside && level < g.L) {
+        const HashLevel lv = load_level(g, level);
+        v = encode_level(lv, table, locate3(p, lv.scale));
+      }
+      x[0][2 * kk] = v.x;
+      x[0][2 * kk + 1] = v.y;
+    }
+    float h[2][16], so[1][16];
+    dense_o1<P, 1, 2>(smem, FW_OFF(0), BIAS_OFF(0), x, h, lane);
+    relu_mask<2>(h);
+#pragma unroll
+    for (int l = 1; l < NS - 1; ++l) {
+      float h2[2][16];
+      dense_o1<P, 2, 2>(smem, FW_OFF(l), BIAS_OFF(l), h, h2, lane);
+      relu_mask<2>(h2);
+#pragma unroll
+      for (int pp = 0; pp < 2; ++pp)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) h[pp][r] = h2[pp][r];
+    }
+    dense_o1<P, 2, 1>(smem, FW_OFF(NS - 1), BIAS_OFF(NS - 1), h, so, lane);
+    if (hi == 0 && in_range) sdf[vox] = inside ? so[0][0] : outside;
   }
 }
 
@@ -814,6 +884,36 @@ extern "C" int nof_mlp_bwd(const NofMlpDesc* d, const void* packed, const float*
 #undef LAUNCH_BWD
   NOF_LAUNCH_OK();
   return 0;
+}
+
+extern "C" int nof_sdf_grid_query(const NofHashGrid* g, const NofMlpDesc* d, const void* packed, const float* table,
+                                   const uint32_t* occ_bits, int32_t level, const float* tx, const float* ty, const float* tz,
+                                   int32_t nx, int32_t ny, int32_t nz, float outside_value, float* sdf, void* stream) {
+  if (int e = check_desc(d)) return e;
+  NOF_ARG(g && g->C == 2 && g->L >= 1 && g->L <= NOF_MAX_LEVELS && g->L * 2 == d->in_feat);
+  NOF_ARG(packed && table && tx && ty && tz && sdf && nx >= 0 && ny >= 0 && nz >= 0 && level >= 0 && level <= 8);
+  if (nx == 0 || ny == 0 || nz == 0) return 0;
+  const int nl = d->n_sigma;
+  const size_t shm = (size_t)n_pairs(*d, nl) * 16 * 64 * elem_size(d->precision) + (size_t)n_oblk(*d, nl) * 32 * 4;
+  const int64_t ntiles = (int64_t)nx * ny * ((nz + 31) / 32);
+  const unsigned blocks = (unsigned)(nof_div_up(ntiles, 4) < 2048 ? nof_div_up(ntiles, 4) : 2048);
+#define LAUNCH_GRID(P, NS_, NC_, dummy)                                                                   \
+  {                                                                                                       \
+    auto kern = k_sdf_grid<P, NS_, NC_>;                                                                  \
+    if (int e = set_smem(kern, shm)) return e;                                                            \
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), shm, (hipStream_t)stream, *d, (const char*)packed, *g, \
+                       (const float2*)table, occ_bits, 1 << level, tx, ty, tz, (int)nx, (int)ny, (int)nz, \
+                       outside_value, sdf);                                                               \
+  }
+  DISPATCH_PREC(LAUNCH_GRID, 0)
+#undef LAUNCH_GRID
+  NOF_LAUNCH_OK();
+  return 0;
+}
+
+extern "C" int64_t nof_mlp_bwd_workspace_bytes(const NofMlpDesc* d) {
+  if (check_desc(d)) return -1;
+  return (int64_t)nof_mlp_bwd_blocks() * d->n_params * 4;
 }
 
 // ---- test hook: one 32x32 output tile with the operand layouts used above -----------------------------

@@ -441,3 +441,17 @@ extern "C" int nof_sample_points(const NofSampleCfg* cfg, const float* batch, co
   NOF_LAUNCH_OK();
   return 0;
 }
+
+// render_rays up to the sample points in ONE call (SURVEY.md 8b `nof_raymarch_sample`): ray gather + pose transform + SH +
+// occupancy DDA (k_batch_trace) and stratified z sampling + point generation (k_sample_points), launched back to back.
+extern "C" int nof_raymarch_sample(const NofSampleCfg* cfg, const float* pool, const int64_t* ids, const float* tf,
+                                    const float* frame_feat, int32_t ff, int32_t sh_degree, const uint32_t* occ_bits,
+                                    int32_t level, int64_t R, int32_t max_hits, const float* u_occ, const float* u_dep,
+                                    float* batch, float* rays_o_w, float* viewdirs_w, float* view, float* t_in_out,
+                                    int32_t* cell_ids, int32_t* n_hits, float* z_vals, float* pts_w, uint8_t* valid,
+                                    int32_t* flags, void* stream) {
+  if (int e = nof_batch_trace(pool, ids, tf, frame_feat, ff, sh_degree, occ_bits, level, R, max_hits, batch, rays_o_w,
+                              viewdirs_w, view, t_in_out, cell_ids, n_hits, flags, stream))
+    return e;
+  return nof_sample_points(cfg, batch, tf, t_in_out, n_hits, R, max_hits, u_occ, u_dep, z_vals, pts_w, valid, flags, stream);
+}

@@ -222,12 +222,11 @@ class NeuralObjectField:
         cid = None
         if want_cells:
             cid = b.setdefault('cell_ids', torch.empty(R, self.max_hits, dtype=torch.int32, device=self.device))
-        self._call('nof_batch_trace', pool, ids, self.tf, self.feat if self.ff > 0 else None, self.ff, self.sh_degree,
-                 self.occ_bits, self.level, R, self.max_hits, b['batch'], b['rays_o_w'], b['viewdirs_w'], b['view'],
-                 b['t_in_out'], cid, b['n_hits'], self.flags)
         sc = self._sample_cfg(seed, self.global_step)
-        self._call('nof_sample_points', C.byref(sc), b['batch'], self.tf, b['t_in_out'], b['n_hits'], R, self.max_hits,
-                 u_occ, u_dep, b['z_vals'], b['pts_w'], b['valid'], self.flags)
+        self._call('nof_raymarch_sample', C.byref(sc), pool, ids, self.tf, self.feat if self.ff > 0 else None, self.ff,
+                   self.sh_degree, self.occ_bits, self.level, R, self.max_hits, u_occ, u_dep, b['batch'], b['rays_o_w'],
+                   b['viewdirs_w'], b['view'], b['t_in_out'], cid, b['n_hits'], b['z_vals'], b['pts_w'], b['valid'],
+                   self.flags)
         B = R * S
         self._call('nof_hash_encode_fwd', C.byref(self.grid), b['pts_w'], self.table, b['feat'], B)
         self._call('nof_mlp_fwd', C.byref(self.desc), self.packed, b['feat'], self.L, b['view'], S, b['raw'], B)
@@ -288,6 +287,18 @@ class NeuralObjectField:
             p = pts[i:i + n].contiguous()
             lib.call('nof_hash_encode_fwd', C.byref(self.grid), p, self.table, feat, n)
             lib.call('nof_mlp_sdf', C.byref(self.desc), self.packed, feat, self.L, out[i:i + n], n)
+        return out
+
+    def query_sdf_grid(self, tx, ty, tz, outside_value=1.0, use_octree=True):
+        """extract_mesh's dense query (nerf_runner.py:1351-1386) fused into one launch: sdf [nx,ny,nz] on the device for the
+        voxel centres (tx[i], ty[j], tz[k]); voxels outside the octree get `outside_value`."""
+        self.pack_weights()
+        ax = [torch.as_tensor(np.asarray(a, dtype=np.float32)).to(self.device).contiguous() for a in (tx, ty, tz)]
+        nx, ny, nz = (int(a.numel()) for a in ax)
+        out = torch.empty(nx, ny, nz, device=self.device)
+        occ = self.occ_bits if use_octree else None
+        lib.call('nof_sdf_grid_query', C.byref(self.grid), C.byref(self.desc), self.packed, self.table, occ, self.level,
+                 ax[0], ax[1], ax[2], nx, ny, nz, C.c_float(outside_value), out)
         return out
 
     def losses(self):

@@ -78,6 +78,15 @@ _SIGNATURES = {
     'nof_pose_reduce_bwd': ([_P, _P, _P, _P, _I64, _I32, _F, _F, _P, _P, _P, _I32, _P], C.c_int),
     'nof_small_regs': ([_P, _P, _I32, _F, _F, _P], C.c_int),
     'nof_adam_step': ([_P, _P, _P, _P, _I64, _I64, _F, _F, _F, _F, _F, _I32, _P], C.c_int),
+    'nof_raymarch_sample': ([C.POINTER(NofSampleCfg), _P, _P, _P, _P, _I32, _I32, _P, _I32, _I64, _I32, _P, _P,
+                             _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P], C.c_int),
+    'nof_composite_loss_fwd_bwd': ([C.POINTER(NofLossCfg), _P, _P, _P, _P, _I64, _I32, _P, _P, _P, _P, _P, _P], C.c_int),
+    'nof_mlp_bwd_workspace_bytes': ([C.POINTER(NofMlpDesc)], C.c_int64),
+    'nof_sdf_grid_query': ([C.POINTER(NofHashGrid), C.POINTER(NofMlpDesc), _P, _P, _P, _I32, _P, _P, _P, _I32, _I32, _I32,
+                            _F, _P, _P], C.c_int),
+    'nof_mt_count': ([_P, _I32, _I32, _I32, _F, _P, _P], C.c_int),
+    'nof_mt_emit': ([_P, _I32, _I32, _I32, _F, _P, _P, _P], C.c_int),
+    'nof_mt_vertices': ([_P, _I32, _I32, _I32, _F, _P, _I64, _P, _P], C.c_int),
     'nof_mfma_probe': ([_I32, _P, _P, _P, _I32, _P], C.c_int),
     'nof_atomic_probe': ([_I32, _P, _P, _I64, _P], C.c_int),
 }

@@ -32,11 +32,13 @@ def marching_tetrahedra(vol, iso=0.0):
     tf = flat[tv]
     tin = tf < iso
     cnt = tin.sum(1)
-    tris_a, tris_b = [], []                                             # triangles as edge endpoints (a_k, b_k), k = 0..2
+    tris_a, tris_b, tris_d = [], [], []                                 # triangles as edge endpoints (a_k, b_k), k = 0..2
+    unlin = lambda i: np.stack([i // (ny * nz), (i // nz) % ny, i % nz], -1).astype(np.float64)
 
-    def emit(sel, e):
+    def emit(sel, e, d):
         tris_a.append(np.stack([sel[:, e[0][0]], sel[:, e[1][0]], sel[:, e[2][0]]], 1))
         tris_b.append(np.stack([sel[:, e[0][1]], sel[:, e[1][1]], sel[:, e[2][1]]], 1))
+        tris_d.append(d)                                                # inside -> outside direction of the tetrahedron
 
     for want in (1, 3):                                                 # one vertex on its own side -> one triangle
         m = cnt == want
@@ -45,14 +47,16 @@ def marching_tetrahedra(vol, iso=0.0):
             lone = s.argmax(1)
             order = (lone[:, None] + np.arange(4)[None]) % 4
             vs = np.take_along_axis(v, order, 1)                        # vs[:,0] is the lone vertex
-            emit(vs, [(0, 1), (0, 2), (0, 3)])
+            d = (unlin(vs[:, 1]) + unlin(vs[:, 2]) + unlin(vs[:, 3])) / 3.0 - unlin(vs[:, 0])
+            emit(vs, [(0, 1), (0, 2), (0, 3)], d if want == 1 else -d)
     m = cnt == 2                                                        # two / two -> a quad (two triangles)
     if m.any():
         v, s = tv[m], tin[m]
         order = np.argsort(~s, axis=1, kind='stable')                   # inside vertices first
         vs = np.take_along_axis(v, order, 1)                            # (i0, i1, o0, o1)
-        emit(vs, [(0, 2), (0, 3), (1, 3)])
-        emit(vs, [(0, 2), (1, 3), (1, 2)])
+        d = (unlin(vs[:, 2]) + unlin(vs[:, 3])) / 2.0 - (unlin(vs[:, 0]) + unlin(vs[:, 1])) / 2.0
+        emit(vs, [(0, 2), (0, 3), (1, 3)], d)
+        emit(vs, [(0, 2), (1, 3), (1, 2)], d)
     A = np.concatenate(tris_a, 0)
     Bv = np.concatenate(tris_b, 0)
     lo, hi = np.minimum(A, Bv), np.maximum(A, Bv)
@@ -63,15 +67,12 @@ def marching_tetrahedra(vol, iso=0.0):
     ua, ub = uniq // npts, uniq % npts
     fa, fb = flat[ua].astype(np.float64), flat[ub].astype(np.float64)
     t = np.where(fb != fa, (iso - fa) / np.where(fb != fa, fb - fa, 1.0), 0.5)
-    unlin = lambda i: np.stack([i // (ny * nz), (i // nz) % ny, i % nz], -1).astype(np.float64)
     verts = unlin(ua) + t[:, None] * (unlin(ub) - unlin(ua))
-    # orient every triangle so that its normal points towards increasing value (out of the object for an SDF)
-    g = np.stack(np.gradient(vol.astype(np.float32)), -1)
-    ctr = verts[faces].mean(1)
-    ci = np.clip(np.round(ctr).astype(np.int64), 0, [nx - 1, ny - 1, nz - 1])
-    gn = g[ci[:, 0], ci[:, 1], ci[:, 2]]
+    # orient every triangle so that its normal points from the inside (value < iso) vertices of its tetrahedron to the
+    # outside ones, i.e. out of the object for an SDF (a purely local rule: the GPU extractor applies the same one)
+    D = np.concatenate(tris_d, 0)
     nrm = np.cross(verts[faces[:, 1]] - verts[faces[:, 0]], verts[faces[:, 2]] - verts[faces[:, 0]])
-    flip = (nrm * gn).sum(1) < 0
+    flip = (nrm * D).sum(1) < 0
     faces[flip] = faces[flip][:, [0, 2, 1]]
     faces = faces[(faces[:, 0] != faces[:, 1]) & (faces[:, 1] != faces[:, 2]) & (faces[:, 0] != faces[:, 2])]
     return verts, faces.astype(np.int64)

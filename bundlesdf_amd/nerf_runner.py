@@ -22,6 +22,7 @@ import torch
 
 from . import lib
 from .field import NeuralObjectField
+from .mesh_gpu import marching_tetrahedra_gpu
 from .mesh import make_mesh, marching_tetrahedra
 from .nerf_helpers import *          # noqa: F401,F403  (re-exported on purpose, like the reference module does)
 from .nerf_helpers import set_seed, get_optimized_poses_in_real_world, mesh_to_real_world
@@ -241,24 +242,13 @@ class NerfRunner:
         tx = np.arange(bounds[0, 0] + 0.5 * voxel_size, bounds[1, 0], voxel_size)
         ty = np.arange(bounds[0, 1] + 0.5 * voxel_size, bounds[1, 1], voxel_size)
         tz = np.arange(bounds[0, 2] + 0.5 * voxel_size, bounds[1, 2], voxel_size)
-        N = len(tx)
-        gx, gy, gz = torch.meshgrid(torch.tensor(tx, dtype=torch.float32), torch.tensor(ty, dtype=torch.float32),
-                                    torch.tensor(tz, dtype=torch.float32), indexing='ij')
-        query_pts = torch.stack([gx, gy, gz], -1).reshape(-1, 3).to(self.device)
         f = self.field
-        if f.occ_bits is not None:
-            inside = torch.empty(query_pts.shape[0], dtype=torch.uint8, device=self.device)
-            lib.call('nof_occgrid_query', f.occ_bits, f.level, query_pts, inside, query_pts.shape[0])
-            valid = inside > 0
-        else:
-            valid = torch.ones(query_pts.shape[0], dtype=torch.bool, device=self.device)
-        logging.info(f'query_pts:{query_pts.shape}, valid:{valid.sum()}')
-        sigma_ = torch.ones(query_pts.shape[0], device=self.device)
-        sigma_[valid] = f.query_sdf(query_pts[valid])
-        sigma = sigma_.reshape(len(tx), len(ty), len(tz)).cpu().numpy()
+        # fused dense query on the device: voxel centres, octree mask, hash encode, sigma net (nerf_runner.py:1363-1386)
+        sigma_dev = f.query_sdf_grid(tx, ty, tz, outside_value=1.0, use_octree=f.occ_bits is not None)
+        logging.info(f'query grid:{tuple(sigma_dev.shape)}, valid:{int((sigma_dev != 1.0).sum().item())}')
         logging.info('Running iso-surface extraction')
         try:
-            vertices, triangles = marching_tetrahedra(sigma, isolevel)
+            vertices, triangles = marching_tetrahedra_gpu(sigma_dev, isolevel)
         except Exception as e:
             logging.info(f"ERROR Marching Cubes {e}")
             return None
@@ -268,7 +258,9 @@ class NerfRunner:
         vertices = step.reshape(1, 3) * vertices + offset.reshape(1, 3)
         mesh = make_mesh(vertices, triangles)
         if return_sigma:
-            return mesh, sigma, query_pts
+            gx, gy, gz = np.meshgrid(tx, ty, tz, indexing='ij')
+            query_pts = torch.tensor(np.stack([gx, gy, gz], -1).astype(np.float32).reshape(-1, 3), device=self.device)
+            return mesh, sigma_dev.cpu().numpy(), query_pts
         return mesh
 
     def mesh_texture_from_train_images(self, mesh, rgbs_raw, train_texture=False, tex_res=1024):

@@ -106,6 +106,15 @@ int nof_sample_points(const NofSampleCfg* h_cfg, const float* batch, const float
                       const int32_t* n_hits, int64_t R, int32_t max_hits, const float* u_occ, const float* u_dep,
                       float* z_vals, float* pts_w, uint8_t* valid, int32_t* flags, void* stream);
 
+/* The two calls above as one entry point (render_rays up to the sample points, nerf_runner.py:1044-1083): this is what the
+ * training step calls.  Arguments as in nof_batch_trace / nof_sample_points. */
+int nof_raymarch_sample(const NofSampleCfg* h_cfg, const float* pool, const int64_t* ids, const float* tf,
+                        const float* frame_feat, int32_t ff, int32_t sh_degree, const uint32_t* occ_bits, int32_t level,
+                        int64_t R, int32_t max_hits, const float* u_occ, const float* u_dep,
+                        float* batch, float* rays_o_w, float* viewdirs_w, float* view, float* t_in_out,
+                        int32_t* cell_ids, int32_t* n_hits, float* z_vals, float* pts_w, uint8_t* valid,
+                        int32_t* flags, void* stream);
+
 /* ---- SDF + colour tiny-MLPs on MFMA (replaces NeRFSmall's cuBLAS GEMMs) ------------------------ */
 typedef struct {
   int32_t n_sigma, n_color;               /* NeRFSmall(num_layers, num_layers_color) nerf_helpers.py:244 */
@@ -139,6 +148,32 @@ int nof_reduce_partials(const float* partials, int32_t n_rows, int32_t n_cols, f
 int nof_mlp_sdf(const NofMlpDesc* h_desc, const void* packed, const float* feat, int32_t L,
                 float* sdf, int64_t B, void* stream);
 
+/* bytes of the `partials` workspace of nof_mlp_bwd (= nof_mlp_bwd_blocks() * n_params * 4); -1 on a bad descriptor */
+int64_t nof_mlp_bwd_workspace_bytes(const NofMlpDesc* h_desc);
+
+/* ---- dense SDF grid for mesh extraction (extract_mesh + run_network_density, nerf_runner.py:1307-1386) ------------
+ * Fused: voxel centre (tx[i], ty[j], tz[k]) -> occupancy mask (get_center_ids >= 0, Utils.py:393-398; occ_bits may be NULL =
+ * every voxel valid) -> clip to [-1,1] -> hash encode -> sigma net -> sdf[(i*ny + j)*nz + k]; voxels outside the octree get
+ * `outside_value` (1.0 in the reference, nerf_runner.py:1384-1385).  tx/ty/tz are the float32 device copies of the host's
+ * np.arange axes, so the query points are bit-identical to the reference's meshgrid.  No per-point buffer in HBM. */
+int nof_sdf_grid_query(const NofHashGrid* h_grid, const NofMlpDesc* h_desc, const void* packed, const float* table,
+                       const uint32_t* occ_bits, int32_t level, const float* tx, const float* ty, const float* tz,
+                       int32_t nx, int32_t ny, int32_t nz, float outside_value, float* sdf, void* stream);
+
+/* ---- iso-surface extraction on the device (replaces skimage.measure.marching_cubes, nerf_runner.py:1388-1394) -----
+ * Marching tetrahedra, 6 per cell.  vol [nx,ny,nz]; cells are (nx-1)(ny-1)(nz-1), z fastest.
+ *   nof_mt_count     counts [ncell] int32 = triangles per cell;
+ *   (caller: exclusive prefix sum of counts -> offsets [ncell] int64, T = total)
+ *   nof_mt_emit      keys [T,3] int64, one EDGE KEY per triangle corner: lo * (nx*ny*nz) + hi of the edge's two grid points;
+ *                    triangles are oriented from value < iso towards value >= iso;
+ *   (caller: sort/unique of the keys -> V unique keys, faces = inverse indices)
+ *   nof_mt_vertices  verts [V,3] float64 = interpolated vertex of each unique key, in index coordinates. */
+int nof_mt_count(const float* vol, int32_t nx, int32_t ny, int32_t nz, float iso, int32_t* counts, void* stream);
+int nof_mt_emit(const float* vol, int32_t nx, int32_t ny, int32_t nz, float iso, const int64_t* offsets, int64_t* keys,
+                void* stream);
+int nof_mt_vertices(const float* vol, int32_t nx, int32_t ny, int32_t nz, float iso, const int64_t* keys, int64_t V,
+                    double* verts, void* stream);
+
 /* ---- compositing + losses + dL/draw (raw2outputs, train_loop, get_sdf_loss) ---------------------- */
 typedef struct {
   float trunc, neg_trunc_ratio, sdf_lambda;
@@ -154,6 +189,11 @@ typedef struct {
 int nof_composite_loss(const NofLossCfg* h_cfg, const float* raw, const float* z_vals, const uint8_t* valid,
                        const float* batch, int64_t R, int32_t S, float* rgb_map, float* weights, float* draw,
                        float* loss_rows, float* loss_out, void* stream);
+
+/* same entry point under the name SURVEY.md 8b lists */
+int nof_composite_loss_fwd_bwd(const NofLossCfg* h_cfg, const float* raw, const float* z_vals, const uint8_t* valid,
+                               const float* batch, int64_t R, int32_t S, float* rgb_map, float* weights, float* draw,
+                               float* loss_rows, float* loss_out, void* stream);
 
 /* ---- pose / feature gradients of a batch ---------------------------------------------------------- */
 /* dpts [R*S,3] (from nof_hash_encode_bwd, may be NULL), dview [R,16] (from nof_mlp_bwd), batch, z_vals, c2w [F,16], tf [F,12]
