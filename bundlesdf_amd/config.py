@@ -30,3 +30,27 @@ def load_yaml(path, **over):
         cfg = yaml.safe_load(f)
     cfg.update(over)
     return cfg
+
+
+def validate_cfg(cfg):
+    """Options of the reference's config the MI355X path does not implement are rejected loudly, never ignored.
+    (All of them are 0 / off in the reference's own config.yml; two are dead code there)"""
+    bad = []
+    if float(cfg.get('eikonal_weight', 0)) > 0:
+        bad.append("eikonal_weight > 0 (dead code in the reference: train_loop renders with get_normals=False, nerf_runner.py:686,734-738)")
+    if float(cfg.get('depth_weight', 0)) > 0:
+        bad.append("depth_weight > 0 (references an undefined name in the reference, nerf_runner.py:718)")
+    if int(cfg.get('N_importance', 0)) > 0:
+        bad.append("N_importance > 0 (broken in the reference, nerf_runner.py:1106)")
+    if int(cfg.get('N_samples_around_depth', 0)) < 2:
+        bad.append("N_samples_around_depth < 2 (the reference requires the depth-guided branch, nerf_runner.py:1081)")
+    if not int(cfg.get('use_viewdirs', 1)):
+        bad.append("use_viewdirs = 0")
+    if float(cfg.get('raw_noise_std', 0)) > 0:
+        bad.append("raw_noise_std > 0")
+    if float(cfg.get('pose_reg_weight', 0)) > 0:
+        bad.append("pose_reg_weight > 0")
+    if int(cfg.get('feature_grid_dim', 2)) != 2:
+        bad.append("feature_grid_dim != 2")
+    if bad:
+        raise NotImplementedError('Neural Object Field (MI355X): unsupported configuration: ' + '; '.join(bad))

@@ -7,9 +7,9 @@ streaming pass and the data-parallel gradient exchange is a single all-reduce):
     [ hash table rows*2 | MLP (PyTorch parameter order) | frame features F*ff | pose corrections F*6 ]
       `------------------------- param group 'basic' -------------------------' `--- 'pose_array' ---'
 
-Step (train_loop nerf_runner.py:679-763), 11 launches, no host synchronisation:
-    pose_fwd -> batch_trace -> sample_points -> hash_fwd -> mlp_fwd -> composite_loss -> mlp_bwd -> reduce_partials
-    -> hash_bwd -> pose_grad_accum -> pose_bwd (+small_regs) -> [all-reduce] -> adam
+Step (train_loop nerf_runner.py:679-763), 12 C-ABI calls = 16 kernel launches, no host synchronisation:
+    pose_fwd -> mlp_pack -> raymarch_sample -> hash_fwd -> mlp_fwd -> composite_loss -> mlp_bwd -> reduce_partials
+    -> hash_bwd -> pose_grad_accum -> pose_reduce_bwd (+small_regs) -> [all-reduce] -> adam
 """
 import ctypes as C
 import math
@@ -18,6 +18,7 @@ import numpy as np
 import torch
 
 from . import lib
+from .config import validate_cfg
 
 PRECISIONS = {'fp32': 0, 'bf16': 1, 'fp16': 2}
 
@@ -30,6 +31,7 @@ class NeuralObjectField:
         self.device = torch.device(device)
         self.F = int(n_frames)
         self.ff = int(cfg.get('frame_features', 0))
+        validate_cfg(cfg)
         self.sh_degree = int(cfg['multires_views'])
         self.n_view = self.ff + self.sh_degree ** 2
         self.world_size, self.rank = world_size, rank
