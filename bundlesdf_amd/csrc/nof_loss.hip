@@ -200,22 +200,36 @@ extern "C" int nof_adam_step(float* params, float* grads, float* exp_avg, float*
 }
 
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_reduce_partials(const float* __restrict__ partials, int n_rows, int n_cols,
-                                                          float* __restrict__ out) {
-  __shared__ float sm[4][64];
-  const int col = blockIdx.x * 64 + (threadIdx.x & 63), grp = threadIdx.x >> 6;      // 64 columns x 4 row groups
-  float s = 0.0f;
-  if (col < n_cols)
-    for (int i = grp; i < n_rows; i += 4) s += partials[(size_t)i * n_cols + col];
-  sm[grp][threadIdx.x & 63] = s;
+// out[col] += sum over rows.  32 columns (one 128-byte line per row) x 32 row groups per workgroup, so that every CU streams
+// its share of the rows with 8 independent loads in flight per lane (n_rows = 4 x CUs = 1024 on MI355X).
+__global__ __launch_bounds__(1024) void k_reduce_partials(const float* __restrict__ partials, int n_rows, int n_cols,
+                                                           float* __restrict__ out) {
+  __shared__ float sm[32][33];
+  const int c = threadIdx.x & 31, grp = threadIdx.x >> 5;
+  const int col = blockIdx.x * 32 + c;
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (col < n_cols) {
+    int i = grp;
+    for (; i + 32 * 7 < n_rows; i += 32 * 8) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc[u] += partials[(size_t)(i + 32 * u) * n_cols + col];
+    }
+    for (; i < n_rows; i += 32) acc[0] += partials[(size_t)i * n_cols + col];
+  }
+  sm[grp][c] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
   __syncthreads();
-  if (grp == 0 && col < n_cols) out[col] += (sm[0][threadIdx.x] + sm[1][threadIdx.x]) + (sm[2][threadIdx.x] + sm[3][threadIdx.x]);
+  if (grp == 0 && col < n_cols) {
+    float s = 0.0f;
+#pragma unroll
+    for (int g = 0; g < 32; ++g) s += sm[g][c];
+    out[col] += s;
+  }
 }
 
 extern "C" int nof_reduce_partials(const float* partials, int32_t n_rows, int32_t n_cols, float* out, void* stream) {
   NOF_ARG(partials && out && n_rows >= 0 && n_cols >= 0);
   if (n_cols == 0 || n_rows == 0) return 0;
-  hipLaunchKernelGGL(k_reduce_partials, dim3((unsigned)nof_div_up(n_cols, 64)), dim3(256), 0, (hipStream_t)stream,
+  hipLaunchKernelGGL(k_reduce_partials, dim3((unsigned)nof_div_up(n_cols, 32)), dim3(1024), 0, (hipStream_t)stream,
                      partials, n_rows, n_cols, out);
   NOF_LAUNCH_OK();
   return 0;

@@ -498,6 +498,46 @@ __device__ __forceinline__ void dw_block(float (&dw)[2][16], float* db_lane, con
   }
 }
 
+// Every wave writes its dW / db accumulators of layers [LA, LB) as ITS OWN row of `partials` (row = 4 * workgroup + wave) with
+// plain global stores: for one register every lane owns a distinct (row, column) and the (lane, register) pairs cover every
+// parameter exactly once, so no zero-fill, no LDS and no atomics are needed (reducing the four waves in LDS with
+// ds_add_f32 cost ~70 us per workgroup: LDS float atomics retire ~1 lane per 4.5 cycles on gfx950).  nof_reduce_partials
+// sums the 4 * n_workgroups rows.
+template <class SH, int LA, int LB>
+__device__ __forceinline__ void flush_dw(const NofMlpDesc& d, const float (&dw)[SH::NL][2][2][16], const float* dbw,
+                                         float* __restrict__ partials) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int hi = lane >> 5, j = lane & 31;
+  const int hi_j = (j >> 2) & 1, r_j = (j & 3) + 4 * (j >> 3);      // dW column lane j = input slot (hi_j, r_j)
+  float* __restrict__ dst = partials + ((size_t)blockIdx.x * 4 + wave) * d.n_params;
+#pragma unroll
+  for (int l = LA; l < LB; ++l) {
+    const int in_dim = d.in_dim[l], out_dim = d.out_dim[l];
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      if (p < SH::pn(l)) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          if (q < SH::qn(l)) {
+            const int col = inmap(d, l, q, hi_j, r_j);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              if (r < SH::nacc(l)) {
+                const int row = 32 * p + nloc(hi, r);
+                if (col >= 0 && row < out_dim) dst[d.w_off[l] + row * in_dim + col] = dw[l][p][q][r];
+              }
+            }
+          }
+        }
+        float v = dbw[(2 * l + p) * 64];                               // lane-private sums of lanes (hi, j): the pair shares row j
+        v += __shfl_xor(v, 32, 64);
+        const int row = 32 * p + j;
+        if (hi == 0 && row < out_dim) dst[d.b_off[l] + row] = v;
+      }
+    }
+  }
+}
+
 template <class P, int NS, int NC>
 __global__ __launch_bounds__(256) void k_mlp_bwd(NofMlpDesc d, const char* __restrict__ image,
                                                   const float2* __restrict__ feat, int L, const float* __restrict__ view,
@@ -702,43 +742,7 @@ __global__ __launch_bounds__(256) void k_mlp_bwd(NofMlpDesc d, const char* __res
   }
 
   // ---------------- reduce the workgroup's dW/db and write its row of `partials` ----------------
-  float dbv[NL][2];
-#pragma unroll
-  for (int l = 0; l < NL; ++l)
-#pragma unroll
-    for (int p = 0; p < 2; ++p) dbv[l][p] = dbw[(2 * l + p) * 64];
-  __syncthreads();
-  float* red = (float*)smem;
-  for (int e = threadIdx.x; e < d.n_params; e += blockDim.x) red[e] = 0.0f;
-  __syncthreads();
-  const int hi_j = (j >> 2) & 1, r_j = (j & 3) + 4 * (j >> 3);      // dW column lane j = input slot (hi_j, r_j)
-#pragma unroll
-  for (int l = 0; l < NL; ++l) {
-    const int in_dim = d.in_dim[l], out_dim = d.out_dim[l];
-#pragma unroll
-    for (int p = 0; p < 2; ++p) {
-      if (p < SH::pn(l)) {
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-          if (q < SH::qn(l)) {
-            const int col = inmap(d, l, q, hi_j, r_j);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-              if (r < SH::nacc(l)) {
-                const int row = 32 * p + nloc(hi, r);
-                if (col >= 0 && row < out_dim) atomicAdd(&red[d.w_off[l] + row * in_dim + col], dw[l][p][q][r]);
-              }
-            }
-          }
-        }
-        const int row = 32 * p + j;
-        if (row < out_dim) atomicAdd(&red[d.b_off[l] + row], dbv[l][p]);
-      }
-    }
-  }
-  __syncthreads();
-  float* dst = partials + (size_t)blockIdx.x * d.n_params;
-  for (int e = threadIdx.x; e < d.n_params; e += blockDim.x) dst[e] = red[e];
+  flush_dw<SH, 0, NL>(d, dw, dbw, partials);
 }
 
 // =====================================================================================================
@@ -812,7 +816,7 @@ extern "C" int nof_mlp_bwd_blocks(void) {
       if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
     }
     (void)hipGetLastError();
-    g_bwd_blocks = cus;
+    g_bwd_blocks = 4 * cus;                                           // one partial row per wave of the persistent grid
   }
   return g_bwd_blocks;
 }
@@ -870,8 +874,7 @@ extern "C" int nof_mlp_bwd(const NofMlpDesc* d, const void* packed, const float*
   size_t shm = 2 * (size_t)n_pairs(*d, nl) * 16 * 64 * elem_size(d->precision) + (size_t)n_oblk(*d, nl) * 32 * 4;
   if (d->precision != 0) shm += (size_t)4 * (2 * nl) * 2 * 64 * 16;      // lane-private orientation-2 slots (16-bit modes)
   shm += (size_t)4 * (2 * nl) * 64 * 4;                                   // lane-private bias-gradient sums
-  if (shm < (size_t)d->n_params * 4) shm = (size_t)d->n_params * 4;
-  const unsigned blocks = (unsigned)nof_mlp_bwd_blocks();
+  const unsigned blocks = (unsigned)nof_mlp_bwd_blocks() / 4;
 #define LAUNCH_BWD(P, NS_, NC_, dummy)                                                                    \
   {                                                                                                       \
     auto kern = k_mlp_bwd<P, NS_, NC_>;                                                                   \

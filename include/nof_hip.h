@@ -135,9 +135,9 @@ int nof_mlp_pack(const NofMlpDesc* h_desc, const float* mlp_params, void* packed
 /* feat [L,B,2]; view [R,16]; raw [B,4] = (rgb_raw[3], sdf)  (nerf_helpers.py:319). */
 int nof_mlp_fwd(const NofMlpDesc* h_desc, const void* packed, const float* feat, int32_t L,
                 const float* view, int32_t S, float* raw, int64_t B, void* stream);
-/* draw [B,4] -> dfeat [L,B,2] (overwritten), dview [R,16] ACCUMULATED, partials [n_blocks, n_params]
- * overwritten with per-workgroup weight-gradient partial sums (reduce with nof_reduce_partials).
- * n_blocks must equal nof_mlp_bwd_blocks(). */
+/* draw [B,4] -> dfeat [L,B,2] (overwritten), dview [R,16] ACCUMULATED, partials [n_rows, n_params]
+ * overwritten with per-wave weight-gradient partial sums (reduce with nof_reduce_partials).
+ * n_rows must equal nof_mlp_bwd_blocks() (= 4 waves x the persistent grid of one workgroup per CU). */
 int nof_mlp_bwd_blocks(void);
 int nof_mlp_bwd(const NofMlpDesc* h_desc, const void* packed, const float* feat, int32_t L,
                 const float* view, int32_t S, const float* draw, float* dfeat, float* dview,
