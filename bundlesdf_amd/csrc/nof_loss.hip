@@ -200,21 +200,25 @@ extern "C" int nof_adam_step(float* params, float* grads, float* exp_avg, float*
 }
 
 // ------------------------------------------------------------------------------------------------
-// out[col] += sum over rows.  32 columns (one 128-byte line per row) x 32 row groups per workgroup, so that every CU streams
-// its share of the rows with 8 independent loads in flight per lane (n_rows = 4 x CUs = 1024 on MI355X).
+// out[col] += sum over rows of partials [n_rows, n_cols] (n_rows = 8 x CUs = 2048 on MI355X: 75 MB at cfg2).
+// A workgroup owns 32 columns (one 128-byte line per row) and one of RSPLIT row ranges; 32 row groups x 8 independent
+// loads in flight per lane; one fp32 atomic per (column, row range) at the end.
+#define RED_RSPLIT 4
 __global__ __launch_bounds__(1024) void k_reduce_partials(const float* __restrict__ partials, int n_rows, int n_cols,
                                                            float* __restrict__ out) {
   __shared__ float sm[32][33];
   const int c = threadIdx.x & 31, grp = threadIdx.x >> 5;
   const int col = blockIdx.x * 32 + c;
+  const int per = (n_rows + RED_RSPLIT - 1) / RED_RSPLIT;
+  const int r0 = blockIdx.y * per, r1 = r0 + per < n_rows ? r0 + per : n_rows;
   float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   if (col < n_cols) {
-    int i = grp;
-    for (; i + 32 * 7 < n_rows; i += 32 * 8) {
+    int i = r0 + grp;
+    for (; i + 32 * 7 < r1; i += 32 * 8) {
 #pragma unroll
       for (int u = 0; u < 8; ++u) acc[u] += partials[(size_t)(i + 32 * u) * n_cols + col];
     }
-    for (; i < n_rows; i += 32) acc[0] += partials[(size_t)i * n_cols + col];
+    for (; i < r1; i += 32) acc[0] += partials[(size_t)i * n_cols + col];
   }
   sm[grp][c] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
   __syncthreads();
@@ -222,14 +226,14 @@ __global__ __launch_bounds__(1024) void k_reduce_partials(const float* __restric
     float s = 0.0f;
 #pragma unroll
     for (int g = 0; g < 32; ++g) s += sm[g][c];
-    out[col] += s;
+    atomicAdd(&out[col], s);
   }
 }
 
 extern "C" int nof_reduce_partials(const float* partials, int32_t n_rows, int32_t n_cols, float* out, void* stream) {
   NOF_ARG(partials && out && n_rows >= 0 && n_cols >= 0);
   if (n_cols == 0 || n_rows == 0) return 0;
-  hipLaunchKernelGGL(k_reduce_partials, dim3((unsigned)nof_div_up(n_cols, 32)), dim3(1024), 0, (hipStream_t)stream,
+  hipLaunchKernelGGL(k_reduce_partials, dim3((unsigned)nof_div_up(n_cols, 32), RED_RSPLIT), dim3(1024), 0, (hipStream_t)stream,
                      partials, n_rows, n_cols, out);
   NOF_LAUNCH_OK();
   return 0;

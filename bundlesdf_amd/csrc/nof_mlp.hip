@@ -250,6 +250,25 @@ __device__ __forceinline__ void load_view_o1(const float* __restrict__ view, int
   }
 }
 
+// The sigma head's 16 outputs (sdf + geo_feat) of a sample in operand precision: [B][hi][8] elements; lane (j, hi) holds
+// rows nloc(hi, r), r < 8 (r >= 8 are the padded rows >= 16, structurally zero).  Written by the forward kernel and read back
+// as the colour net's input by the split backward; the same layout carries dL/d(sigma out) between its two kernels.  The
+// values are rounded exactly where the fused kernel rounds them (P::pack of the MFMA operand), so nothing changes numerically.
+template <class P>
+__device__ __forceinline__ void store_sig_o1(typename P::elem* __restrict__ sig, int64_t B, int64_t b, int hi, const float (&x)[16]) {
+  if (b < B) *reinterpret_cast<typename P::frag*>(sig + (b * 2 + hi) * 8) = P::pack(&x[0]);
+}
+template <class P>
+__device__ __forceinline__ void load_sig_o1(const typename P::elem* __restrict__ sig, int64_t B, int64_t b, int hi, float (&x)[16]) {
+#pragma unroll
+  for (int r = 0; r < 16; ++r) x[r] = 0.0f;
+  if (b < B) {
+    const typename P::frag f = *reinterpret_cast<const typename P::frag*>(sig + (b * 2 + hi) * 8);
+#pragma unroll
+    for (int t = 0; t < 8; ++t) x[t] = (float)f[t];
+  }
+}
+
 // compile-time byte offsets inside the dynamic LDS block: [fw frags | (bw frags) | bias | ...]
 #define PAIR_BYTES (16 * 64 * (int)sizeof(typename P::elem))
 #define FW_OFF(l) (SH::pair_base(l) * PAIR_BYTES)
@@ -263,7 +282,7 @@ template <class P, int NS, int NC, bool SDF_ONLY>
 __global__ __launch_bounds__(256, 2) void k_mlp_fwd(      // >= 2 waves/SIMD: no AGPRs, so MFMA results land in VGPRs directly
 NofMlpDesc d, const char* __restrict__ image,
                                                   const float2* __restrict__ feat, int L, const float* __restrict__ view,
-                                                  int S, float* __restrict__ out, int64_t B) {
+                                                  int S, float* __restrict__ out, typename P::elem* __restrict__ sig, int64_t B) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   typedef Shp<NS, NC> SH;
   constexpr int NL = SDF_ONLY ? NS : NS + NC;
@@ -299,6 +318,9 @@ NofMlpDesc d, const char* __restrict__ image,
       float cin[2][16];
 #pragma unroll
       for (int r = 0; r < 16; ++r) cin[0][r] = so[0][r];
+      if constexpr (P::KR == 8) {
+        if (sig != nullptr) store_sig_o1<P>(sig, B, b, hi, so[0]);     // the colour net's operand, kept for the split backward
+      }
       load_view_o1(view, S, B, b, hi, cin[1]);
       dense_o1<P, 2, 2>(smem, FW_OFF(NS), BIAS_OFF(NS), cin, h, lane);
       relu_mask<2>(h);
@@ -746,6 +768,279 @@ __global__ __launch_bounds__(256) void k_mlp_bwd(NofMlpDesc d, const char* __res
 }
 
 // =====================================================================================================
+// backward split by network (16-bit modes): k_mlp_bwd_color then k_mlp_bwd_sigma.
+// The fused kernel above keeps all 150 dW registers of both networks and therefore runs 1 wave/SIMD, where hipcc puts every
+// MFMA result in AGPRs (824 of the 3450 instructions per tile were AGPR<->VGPR moves) and nothing overlaps a wave's LDS
+// round trips.  Each half needs fewer accumulators (colour 72, sigma 112 for 3x64 + 2x64), fits 256 registers and runs
+// 2 waves/SIMD with the MFMA results in VGPRs.  The halves exchange two [B,16] operand-precision arrays: the sigma head's
+// output (written by the forward kernel) and its gradient -- 64 B/sample of extra traffic against ~300 B/sample saved
+// instructions' worth of time.  Numerically identical to the fused kernel (same operand roundings, same MFMA chains).
+// =====================================================================================================
+template <class P, int NS, int NC>
+__global__ __launch_bounds__(256, 2) void k_mlp_bwd_color(NofMlpDesc d, const char* __restrict__ image,
+                                                           const typename P::elem* __restrict__ sig,
+                                                           const float* __restrict__ view, int S,
+                                                           const float4* __restrict__ draw, typename P::elem* __restrict__ dsig,
+                                                           float* __restrict__ dview, float* __restrict__ partials, int64_t B) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  typedef Shp<NS, NC> SH;
+  constexpr int NL = NS + NC;
+  constexpr int KR = P::KR, NSTEP = 16 / KR;
+  typedef typename P::frag frag;
+  constexpr int PA = SH::pair_base(NS), PB = SH::pair_base(NL), NP = PB - PA;       // the colour layers' fragment pairs
+  constexpr int OA = SH::oblk_base(NS), OB = SH::oblk_base(NL);
+  constexpr int BWB = NP * PAIR_BYTES, BIASB = 2 * NP * PAIR_BYTES;
+  constexpr int IN2_BASE = BIASB + (OB - OA) * 128;
+  constexpr int NSLOT = 2 * NC;                                                     // slot(l, q) = 2 (l - NS) + q
+  constexpr int IN2_WAVE = NSLOT * NSTEP * 64 * (int)sizeof(frag);
+  constexpr int DB_BASE = IN2_BASE + 4 * IN2_WAVE;
+  copy16(smem, image + (size_t)PA * PAIR_BYTES, (size_t)NP * PAIR_BYTES);
+  copy16(smem + BWB, image + (size_t)(PB + PA) * PAIR_BYTES, (size_t)NP * PAIR_BYTES);
+  copy16(smem + BIASB, image + 2 * (size_t)PB * PAIR_BYTES + OA * 128, (size_t)(OB - OA) * 128);
+  __syncthreads();
+#define CFW(l) ((SH::pair_base(l) - PA) * PAIR_BYTES)
+#define CBW(l) (BWB + (SH::pair_base(l) - PA) * PAIR_BYTES)
+#define CBIAS(l) (BIASB + (SH::oblk_base(l) - OA) * 128)
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int hi = lane >> 5, j = lane & 31;
+  typedef In2Store<P, NSLOT, true> Store;
+  Store st;
+  st.base = (frag*)(smem + IN2_BASE + wave * IN2_WAVE) + lane;
+  float* dbl = (float*)(smem + DB_BASE) + wave * (2 * NC) * 64 + lane;              // [2 (l - NS) + p][lane]
+#pragma unroll
+  for (int k = 0; k < 2 * NC; ++k) dbl[k * 64] = 0.0f;
+  float* dbw = dbl - (2 * NS) * 64;                                                 // so that [2 l + p] addresses it (never dereferenced below 2 NS)
+  Ident<P> I;
+  I.init(lane);
+  float dw[NL][2][2][16];
+#pragma unroll
+  for (int l = NS; l < NL; ++l)
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+      for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (p < SH::pn(l) && q < SH::qn(l) && r < SH::nacc(l)) dw[l][p][q][r] = 0.0f;
+
+  const int64_t ntiles = (B + 31) / 32;
+  for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < ntiles; tile += (int64_t)gridDim.x * 4) {
+    asm volatile("" ::: "memory");
+    const int64_t t0 = tile * 32;
+    const int64_t b = t0 + j;
+    uint32_t m1[NL];
+    float h[2][16];
+    {
+      float cin[2][16];
+      load_sig_o1<P>(sig, B, b, hi, cin[0]);
+      load_view_o1(view, S, B, b, hi, cin[1]);
+      park_o2<P>(st, I, 0, cin[0]);
+      park_o2<P>(st, I, 1, cin[1]);
+      dense_o1<P, 2, 2>(smem, CFW(NS), CBIAS(NS), cin, h, lane);
+      m1[NS] = relu_mask<2>(h);
+    }
+#pragma unroll
+    for (int l = NS + 1; l < NL - 1; ++l) {
+      park_o2<P>(st, I, 2 * (l - NS), h[0]);
+      park_o2<P>(st, I, 2 * (l - NS) + 1, h[1]);
+      float hn[2][16];
+      dense_o1<P, 2, 2>(smem, CFW(l), CBIAS(l), h, hn, lane);
+      m1[l] = relu_mask<2>(hn);
+#pragma unroll
+      for (int p = 0; p < 2; ++p)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) h[p][r] = hn[p][r];
+    }
+    park_o2<P>(st, I, 2 * (NL - 1 - NS), h[0]);
+    park_o2<P>(st, I, 2 * (NL - 1 - NS) + 1, h[1]);
+
+    float g1[2][16];
+    float dsdf1 = 0.0f;
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) g1[p][r] = 0.0f;
+    if (hi == 0 && b < B) {                           // draw[b] = (d rgb_raw[3], d sdf)
+      const float4 t = draw[b];
+      g1[0][0] = t.x; g1[0][1] = t.y; g1[0][2] = t.z;
+      dsdf1 = t.w;
+    }
+#pragma unroll
+    for (int l = NL - 1; l > NS; --l) {
+      float d1[2][16];
+      if (l == NL - 1) {
+        dw_block<P, 2, 4>(dw[l][0], dbw + (2 * l) * 64, I, g1[0], st, 2 * (l - NS));
+        float ga[1][16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ga[0][r] = g1[0][r];
+        bwd_data<P, 1>(smem, CBW(l), 0, ga, d1[0], lane);
+        bwd_data<P, 1>(smem, CBW(l), 1, ga, d1[1], lane);
+      } else {
+        dw_block<P, 2, 16>(dw[l][0], dbw + (2 * l) * 64, I, g1[0], st, 2 * (l - NS));
+        dw_block<P, 2, 16>(dw[l][1], dbw + (2 * l + 1) * 64, I, g1[1], st, 2 * (l - NS));
+        bwd_data<P, 2>(smem, CBW(l), 0, g1, d1[0], lane);
+        bwd_data<P, 2>(smem, CBW(l), 1, g1, d1[1], lane);
+      }
+      apply_mask<2>(d1, m1[l - 1]);
+#pragma unroll
+      for (int p = 0; p < 2; ++p)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) g1[p][r] = d1[p][r];
+    }
+    {
+      dw_block<P, 2, 16>(dw[NS][0], dbw + (2 * NS) * 64, I, g1[0], st, 0);
+      dw_block<P, 2, 16>(dw[NS][1], dbw + (2 * NS + 1) * 64, I, g1[1], st, 0);
+      float ds1[16], dv1[16], dv2[16];
+      bwd_data<P, 2>(smem, CBW(NS), 0, g1, ds1, lane);
+      bwd_data<P, 2>(smem, CBW(NS), 1, g1, dv1, lane);
+      transpose32<P>(I, dv1, dv2);
+      {
+        const int64_t ray0 = t0 / S;
+        const int64_t end0 = (ray0 + 1) * S, endB = end0 < B ? end0 : B;
+        float sa = 0.0f, sb = 0.0f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int64_t bs = t0 + nloc(hi, r);
+          if (bs < endB) sa += dv2[r];
+          else if (bs < B) sb += dv2[r];
+        }
+        sa += __shfl_xor(sa, 32, 64);
+        sb += __shfl_xor(sb, 32, 64);
+        const int hi_j = (j >> 2) & 1, u = (j & 3) + 4 * (j >> 3);
+        if (hi == 0 && hi_j == 0 && u < d.n_view) {
+          if (sa != 0.0f) atomicAdd(&dview[ray0 * NOF_VIEW_COLS + u], sa);
+          if (sb != 0.0f) atomicAdd(&dview[(ray0 + 1) * NOF_VIEW_COLS + u], sb);
+        }
+      }
+      if (hi == 0) ds1[0] += dsdf1;                    // the loss' own d sdf joins the geo_feat gradients (output 0 = hi 0, reg 0)
+      store_sig_o1<P>(dsig, B, b, hi, ds1);
+    }
+  }
+  flush_dw<SH, NS, NL>(d, dw, dbw, partials);
+#undef CFW
+#undef CBW
+#undef CBIAS
+}
+
+template <class P, int NS, int NC>
+__global__ __launch_bounds__(256, 2) void k_mlp_bwd_sigma(NofMlpDesc d, const char* __restrict__ image,
+                                                           const float2* __restrict__ feat, int L,
+                                                           const typename P::elem* __restrict__ dsig, float2* __restrict__ dfeat,
+                                                           float* __restrict__ partials, int64_t B) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  typedef Shp<NS, NC> SH;
+  constexpr int NL = NS + NC;
+  constexpr int KR = P::KR, NSTEP = 16 / KR;
+  typedef typename P::frag frag;
+  constexpr int FWN = SH::pair_base(NS - 1), NP = SH::pair_base(NS);               // the head's forward is not recomputed
+  constexpr int BWB = FWN * PAIR_BYTES, BIASB = BWB + NP * PAIR_BYTES;
+  constexpr int IN2_BASE = BIASB + SH::oblk_base(NS - 1) * 128;
+  constexpr int NSLOT = 2 * NS - 1;                                                 // slot(0, 0) = 0, slot(l, q) = 2 l + q - 1
+  constexpr int IN2_WAVE = NSLOT * NSTEP * 64 * (int)sizeof(frag);
+  constexpr int DB_BASE = IN2_BASE + 4 * IN2_WAVE;
+  copy16(smem, image, (size_t)FWN * PAIR_BYTES);
+  copy16(smem + BWB, image + (size_t)SH::pair_base(NL) * PAIR_BYTES, (size_t)NP * PAIR_BYTES);
+  copy16(smem + BIASB, image + 2 * (size_t)SH::pair_base(NL) * PAIR_BYTES, (size_t)SH::oblk_base(NS - 1) * 128);
+  __syncthreads();
+#define SFW(l) (SH::pair_base(l) * PAIR_BYTES)
+#define SBW(l) (BWB + SH::pair_base(l) * PAIR_BYTES)
+#define SBIAS(l) (BIASB + SH::oblk_base(l) * 128)
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int hi = lane >> 5, j = lane & 31;
+  typedef In2Store<P, NSLOT, true> Store;
+  Store st;
+  st.base = (frag*)(smem + IN2_BASE + wave * IN2_WAVE) + lane;
+  float* dbw = (float*)(smem + DB_BASE) + wave * (2 * NS) * 64 + lane;              // [2 l + p][lane]
+#pragma unroll
+  for (int k = 0; k < 2 * NS; ++k) dbw[k * 64] = 0.0f;
+  Ident<P> I;
+  I.init(lane);
+  float dw[NL][2][2][16];
+#pragma unroll
+  for (int l = 0; l < NS; ++l)
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+      for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (p < SH::pn(l) && q < SH::qn(l) && r < SH::nacc(l)) dw[l][p][q][r] = 0.0f;
+
+  const int64_t ntiles = (B + 31) / 32;
+  for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < ntiles; tile += (int64_t)gridDim.x * 4) {
+    asm volatile("" ::: "memory");
+    const int64_t b = tile * 32 + j;
+    uint32_t m1[NS];
+    float h[2][16];
+    {
+      float x[1][16];
+      load_feat_o1(feat, L, B, b, hi, x);
+      park_o2<P>(st, I, 0, x[0]);
+      dense_o1<P, 1, 2>(smem, SFW(0), SBIAS(0), x, h, lane);
+      m1[0] = relu_mask<2>(h);
+    }
+#pragma unroll
+    for (int l = 1; l < NS - 1; ++l) {
+      park_o2<P>(st, I, 2 * l - 1, h[0]);
+      park_o2<P>(st, I, 2 * l, h[1]);
+      float hn[2][16];
+      dense_o1<P, 2, 2>(smem, SFW(l), SBIAS(l), h, hn, lane);
+      m1[l] = relu_mask<2>(hn);
+#pragma unroll
+      for (int p = 0; p < 2; ++p)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) h[p][r] = hn[p][r];
+    }
+    park_o2<P>(st, I, 2 * (NS - 1) - 1, h[0]);
+    park_o2<P>(st, I, 2 * (NS - 1), h[1]);
+
+    float g1[2][16];
+    load_sig_o1<P>(dsig, B, b, hi, g1[0]);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) g1[1][r] = 0.0f;
+#pragma unroll
+    for (int l = NS - 1; l >= 1; --l) {
+      float d1[2][16];
+      if (l == NS - 1) {
+        dw_block<P, 2, 8>(dw[l][0], dbw + (2 * l) * 64, I, g1[0], st, 2 * l - 1);
+        float ga[1][16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ga[0][r] = g1[0][r];
+        bwd_data<P, 1>(smem, SBW(l), 0, ga, d1[0], lane);
+        bwd_data<P, 1>(smem, SBW(l), 1, ga, d1[1], lane);
+      } else {
+        dw_block<P, 2, 16>(dw[l][0], dbw + (2 * l) * 64, I, g1[0], st, 2 * l - 1);
+        dw_block<P, 2, 16>(dw[l][1], dbw + (2 * l + 1) * 64, I, g1[1], st, 2 * l - 1);
+        bwd_data<P, 2>(smem, SBW(l), 0, g1, d1[0], lane);
+        bwd_data<P, 2>(smem, SBW(l), 1, g1, d1[1], lane);
+      }
+      apply_mask<2>(d1, m1[l - 1]);
+#pragma unroll
+      for (int p = 0; p < 2; ++p)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) g1[p][r] = d1[p][r];
+    }
+    {
+      dw_block<P, 1, 16>(dw[0][0], dbw, I, g1[0], st, 0);
+      dw_block<P, 1, 16>(dw[0][1], dbw + 64, I, g1[1], st, 0);
+      float df1[16];
+      bwd_data<P, 2>(smem, SBW(0), 0, g1, df1, lane);
+      if (b < B) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const int level = 8 * hi + k;
+          if (level < L) dfeat[(int64_t)level * B + b] = make_float2(df1[2 * k], df1[2 * k + 1]);
+        }
+      }
+    }
+  }
+  flush_dw<SH, 0, NS>(d, dw, dbw, partials);
+#undef SFW
+#undef SBW
+#undef SBIAS
+}
+
+// =====================================================================================================
 // host side
 // =====================================================================================================
 static int check_desc(const NofMlpDesc* d) {
@@ -774,9 +1069,14 @@ static int n_oblk(const NofMlpDesc& d, int nl) { return oblk_base(d, nl); }
 
 template <class K>
 static int set_smem(K kernel, size_t bytes) {
+  if (bytes > 160 * 1024)                                              // gfx950: 160 KB LDS per CU; refuse before HIP sees it
+    return nof_set_error(-1, "mlp: this shape/precision needs %zu bytes of LDS per workgroup (limit 163840)", bytes);
   if (bytes > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-    if (e != hipSuccess) return nof_set_error((int)e, "hipFuncSetAttribute(%zu B LDS): %s", bytes, hipGetErrorString(e));
+    if (e != hipSuccess) {
+      (void)hipGetLastError();                                         // do not leave a sticky error for the caller's next HIP call
+      return nof_set_error((int)e, "hipFuncSetAttribute(%zu B LDS): %s", bytes, hipGetErrorString(e));
+    }
   }
   return 0;
 }
@@ -816,13 +1116,13 @@ extern "C" int nof_mlp_bwd_blocks(void) {
       if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
     }
     (void)hipGetLastError();
-    g_bwd_blocks = 4 * cus;                                           // one partial row per wave of the persistent grid
+    g_bwd_blocks = 8 * cus;                                           // one partial row per wave: 2 workgroups x 4 waves per CU
   }
   return g_bwd_blocks;
 }
 
 extern "C" int nof_mlp_fwd(const NofMlpDesc* d, const void* packed, const float* feat, int32_t L, const float* view,
-                            int32_t S, float* raw, int64_t B, void* stream) {
+                            int32_t S, float* raw, void* sigma_out, int64_t B, void* stream) {
   if (int e = check_desc(d)) return e;
   NOF_ARG(packed && feat && view && raw && B >= 0 && S >= 1 && L >= 1 && L * 2 == d->in_feat);
   if (B == 0) return 0;
@@ -835,7 +1135,7 @@ extern "C" int nof_mlp_fwd(const NofMlpDesc* d, const void* packed, const float*
     auto kern = k_mlp_fwd<P, NS_, NC_, false>;                                                            \
     if (int e = set_smem(kern, shm)) return e;                                                            \
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), shm, (hipStream_t)stream, *d, (const char*)packed,  \
-                       (const float2*)feat, (int)L, view, (int)S, raw, B);                                \
+                       (const float2*)feat, (int)L, view, (int)S, raw, (typename P::elem*)sigma_out, B);  \
   }
   DISPATCH_PREC(LAUNCH_FWD, 0)
 #undef LAUNCH_FWD
@@ -857,7 +1157,7 @@ extern "C" int nof_mlp_sdf(const NofMlpDesc* d, const void* packed, const float*
     auto kern = k_mlp_fwd<P, NS_, NC_, true>;                                                             \
     if (int e = set_smem(kern, shm)) return e;                                                            \
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), shm, (hipStream_t)stream, *d, (const char*)packed,  \
-                       (const float2*)feat, (int)L, (const float*)nullptr, 1, sdf, B);                    \
+                       (const float2*)feat, (int)L, (const float*)nullptr, 1, sdf, (typename P::elem*)nullptr, B); \
   }
   DISPATCH_PREC(LAUNCH_SDF, 0)
 #undef LAUNCH_SDF
@@ -866,15 +1166,43 @@ extern "C" int nof_mlp_sdf(const NofMlpDesc* d, const void* packed, const float*
 }
 
 extern "C" int nof_mlp_bwd(const NofMlpDesc* d, const void* packed, const float* feat, int32_t L, const float* view,
-                            int32_t S, const float* draw, float* dfeat, float* dview, float* partials, int64_t B,
-                            void* stream) {
+                            int32_t S, const float* draw, const void* sigma_out, void* dsigma_ws, float* dfeat, float* dview,
+                            float* partials, int64_t B, void* stream) {
   if (int e = check_desc(d)) return e;
   NOF_ARG(packed && feat && view && draw && dfeat && dview && partials && B >= 0 && S >= 32 && L * 2 == d->in_feat);
-  const int nl = d->n_sigma + d->n_color;
-  size_t shm = 2 * (size_t)n_pairs(*d, nl) * 16 * 64 * elem_size(d->precision) + (size_t)n_oblk(*d, nl) * 32 * 4;
+  const int nl = d->n_sigma + d->n_color, ns = d->n_sigma;
+  const size_t es = elem_size(d->precision), pair_bytes = 16 * 64 * es;
+  const unsigned rows = (unsigned)nof_mlp_bwd_blocks();
+  if (d->precision != 0 && sigma_out != nullptr && dsigma_ws != nullptr) {
+    // split path: colour net, then sigma net; 2 workgroups per CU each, one partial row per wave
+    const size_t shm_c = 2 * (size_t)(n_pairs(*d, nl) - n_pairs(*d, ns)) * pair_bytes + (size_t)(n_oblk(*d, nl) - n_oblk(*d, ns)) * 128 +
+                         (size_t)4 * (2 * d->n_color) * 2 * 64 * 16 + (size_t)4 * (2 * d->n_color) * 64 * 4;
+    const size_t shm_s = (size_t)(n_pairs(*d, ns - 1) + n_pairs(*d, ns)) * pair_bytes + (size_t)n_oblk(*d, ns - 1) * 128 +
+                         (size_t)4 * (2 * ns - 1) * 2 * 64 * 16 + (size_t)4 * (2 * ns) * 64 * 4;
+    const unsigned blocks = rows / 4;
+#define LAUNCH_SPLIT(P, NS_, NC_, dummy)                                                                  \
+  {                                                                                                       \
+    auto kc = k_mlp_bwd_color<P, NS_, NC_>;                                                               \
+    auto ks = k_mlp_bwd_sigma<P, NS_, NC_>;                                                               \
+    if (int e = set_smem(kc, shm_c)) return e;                                                            \
+    if (int e = set_smem(ks, shm_s)) return e;                                                            \
+    hipLaunchKernelGGL(kc, dim3(blocks), dim3(256), shm_c, (hipStream_t)stream, *d, (const char*)packed,  \
+                       (const typename P::elem*)sigma_out, view, (int)S, (const float4*)draw,             \
+                       (typename P::elem*)dsigma_ws, dview, partials, B);                                 \
+    hipLaunchKernelGGL(ks, dim3(blocks), dim3(256), shm_s, (hipStream_t)stream, *d, (const char*)packed,  \
+                       (const float2*)feat, (int)L, (const typename P::elem*)dsigma_ws, (float2*)dfeat,   \
+                       partials, B);                                                                      \
+  }
+    if (d->precision == 1) { DISPATCH_SHAPE(PrecBF16, LAUNCH_SPLIT, 0) }
+    else { DISPATCH_SHAPE(PrecF16, LAUNCH_SPLIT, 0) }
+#undef LAUNCH_SPLIT
+    NOF_LAUNCH_OK();
+    return 0;
+  }
+  size_t shm = 2 * (size_t)n_pairs(*d, nl) * pair_bytes + (size_t)n_oblk(*d, nl) * 32 * 4;
   if (d->precision != 0) shm += (size_t)4 * (2 * nl) * 2 * 64 * 16;      // lane-private orientation-2 slots (16-bit modes)
   shm += (size_t)4 * (2 * nl) * 64 * 4;                                   // lane-private bias-gradient sums
-  const unsigned blocks = (unsigned)nof_mlp_bwd_blocks() / 4;
+  const unsigned blocks = rows / 4;
 #define LAUNCH_BWD(P, NS_, NC_, dummy)                                                                    \
   {                                                                                                       \
     auto kern = k_mlp_bwd<P, NS_, NC_>;                                                                   \

@@ -188,7 +188,10 @@ class NeuralObjectField:
                 batch=e(R, 12), rays_o_w=e(R, 3), viewdirs_w=e(R, 3), view=e(R, 16), t_in_out=e(R, self.max_hits, 2),
                 n_hits=e(R, dt=torch.int32), z_vals=e(R, S), pts_w=e(B, 3), valid=e(B, dt=torch.uint8),
                 feat=e(self.L, B, 2), raw=e(B, 4), draw=e(B, 4), dfeat=e(self.L, B, 2), dview=e(R, 16), dpts=e(B, 3),
-                rgb_map=e(R, 3), partials=e(self.nblk, self.n_mlp), loss_rows=e(R, 8), g_ray=e(R, 12))
+                rgb_map=e(R, 3), partials=e(self.nblk, self.n_mlp), loss_rows=e(R, 8), g_ray=e(R, 12),
+                # sigma-head output / its gradient in MFMA operand precision: the hand-off of the split MLP backward
+                sig=e(B, 16, dt=torch.int16) if self.desc.precision != 0 else None,
+                dsig=e(B, 16, dt=torch.int16) if self.desc.precision != 0 else None)
         return self._bufs[key]
 
     def _sample_cfg(self, seed, step):
@@ -231,7 +234,7 @@ class NeuralObjectField:
                    self.flags)
         B = R * S
         self._call('nof_hash_encode_fwd', C.byref(self.grid), b['pts_w'], self.table, b['feat'], B)
-        self._call('nof_mlp_fwd', C.byref(self.desc), self.packed, b['feat'], self.L, b['view'], S, b['raw'], B)
+        self._call('nof_mlp_fwd', C.byref(self.desc), self.packed, b['feat'], self.L, b['view'], S, b['raw'], b['sig'], B)
         return b, S
 
     def train_step(self, pool, ids, R, u_occ=None, u_dep=None, seed=0, do_step=True, want_cells=False,
@@ -246,7 +249,8 @@ class NeuralObjectField:
         self._call('nof_composite_loss', C.byref(lc), b['raw'], b['z_vals'], b['valid'], b['batch'], R, S, b['rgb_map'],
                  None, b['draw'], b['loss_rows'], self.loss_out)
         b['dview'].zero_()
-        self._call('nof_mlp_bwd', C.byref(self.desc), self.packed, b['feat'], self.L, b['view'], S, b['draw'], b['dfeat'],
+        self._call('nof_mlp_bwd', C.byref(self.desc), self.packed, b['feat'], self.L, b['view'], S, b['draw'], b['sig'],
+                   b['dsig'], b['dfeat'],
                  b['dview'], b['partials'], B)
         self._call('nof_reduce_partials', b['partials'], self.nblk, self.n_mlp, self._seg(self.grads, 'mlp'))
         self._call('nof_hash_encode_bwd', C.byref(self.grid), b['pts_w'], self.table, b['dfeat'],

@@ -132,16 +132,21 @@ typedef struct {
  * optimiser step) into `packed` (nof_mlp_packed_bytes() bytes, caller-allocated); fwd / bwd / sdf read only the image. */
 int64_t nof_mlp_packed_bytes(const NofMlpDesc* h_desc);
 int nof_mlp_pack(const NofMlpDesc* h_desc, const float* mlp_params, void* packed, void* stream);
-/* feat [L,B,2]; view [R,16]; raw [B,4] = (rgb_raw[3], sdf)  (nerf_helpers.py:319). */
+/* feat [L,B,2]; view [R,16]; raw [B,4] = (rgb_raw[3], sdf)  (nerf_helpers.py:319).
+ * sigma_out (may be NULL; ignored in fp32 mode): [B,16] elements of the MFMA operand type (2 bytes) = the sigma head's
+ * output as the colour net consumes it; nof_mlp_bwd's split path reads it back instead of recomputing the sigma net twice. */
 int nof_mlp_fwd(const NofMlpDesc* h_desc, const void* packed, const float* feat, int32_t L,
-                const float* view, int32_t S, float* raw, int64_t B, void* stream);
+                const float* view, int32_t S, float* raw, void* sigma_out, int64_t B, void* stream);
 /* draw [B,4] -> dfeat [L,B,2] (overwritten), dview [R,16] ACCUMULATED, partials [n_rows, n_params]
  * overwritten with per-wave weight-gradient partial sums (reduce with nof_reduce_partials).
- * n_rows must equal nof_mlp_bwd_blocks() (= 4 waves x the persistent grid of one workgroup per CU). */
+ * n_rows must equal nof_mlp_bwd_blocks() (= 4 waves x 2 workgroups per CU of the persistent grid).
+ * 16-bit modes: with sigma_out (as written by nof_mlp_fwd) and dsigma_ws (scratch of the same size, [B,16] x 2 bytes) the
+ * backward runs as two kernels (colour net, sigma net) at twice the occupancy; with either NULL, and always in fp32 mode,
+ * one fused kernel recomputes everything.  Both paths produce the same values. */
 int nof_mlp_bwd_blocks(void);
 int nof_mlp_bwd(const NofMlpDesc* h_desc, const void* packed, const float* feat, int32_t L,
-                const float* view, int32_t S, const float* draw, float* dfeat, float* dview,
-                float* partials, int64_t B, void* stream);
+                const float* view, int32_t S, const float* draw, const void* sigma_out, void* dsigma_ws,
+                float* dfeat, float* dview, float* partials, int64_t B, void* stream);
 /* out[j] += sum_i partials[i,j] */
 int nof_reduce_partials(const float* partials, int32_t n_rows, int32_t n_cols, float* out, void* stream);
 /* sigma_net only: feat [L,B,2] -> sdf [B]  (NeRFSmall.forward_sdf, nerf_helpers.py:296-302) */

@@ -45,7 +45,7 @@ def test_argument_errors_are_reported_not_crashing():
     assert rc < 0 and b'C == 2' in so.nof_last_error()
     d, _ = lib.make_mlp_desc(2, 3, 32, 9)
     d.hidden = 128
-    rc = so.nof_mlp_fwd(ctypes.byref(d), None, None, 16, None, 192, None, 0, None)
+    rc = so.nof_mlp_fwd(ctypes.byref(d), None, None, 16, None, 192, None, None, 0, None)
     assert rc < 0 and b'hidden' in so.nof_last_error()
     assert so.nof_version() >= 100
 

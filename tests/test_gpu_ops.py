@@ -311,7 +311,7 @@ def test_mlp_forward(nof, ns, nc, ff, L, precision):
     d_feat = feat.reshape(B, L, 2).permute(1, 0, 2).contiguous().cuda()
     raw = torch.zeros(B, 4, device='cuda')
     packed = _pack(nof, desc, flat)
-    nof.call('nof_mlp_fwd', C.byref(desc), packed, d_feat, L, view.cuda(), S, raw, B)
+    nof.call('nof_mlp_fwd', C.byref(desc), packed, d_feat, L, view.cuda(), S, raw, None, B)
     sdf = torch.zeros(B, device='cuda')
     nof.call('nof_mlp_sdf', C.byref(desc), packed, d_feat, L, sdf, B)
     torch.cuda.synchronize()
@@ -323,9 +323,11 @@ def test_mlp_forward(nof, ns, nc, ff, L, precision):
     assert np.abs(cpu(raw) - ref_m).max() / scale < {0: 2e-5, 1: 4e-3, 2: 5e-4}[precision]
 
 
-@pytest.mark.parametrize("ns,nc,ff,L", [(2, 3, 0, 16), (3, 2, 2, 16), (2, 3, 2, 4)])
-@pytest.mark.parametrize("precision", [0, 1, 2])
-def test_mlp_backward(nof, ns, nc, ff, L, precision):
+@pytest.mark.parametrize("ns,nc,ff,L", [(2, 3, 0, 16), (3, 2, 2, 16), (2, 3, 2, 4), (3, 3, 0, 16)])
+@pytest.mark.parametrize("precision,split", [(0, False), (1, False), (2, False), (1, True), (2, True)])
+def test_mlp_backward(nof, ns, nc, ff, L, precision, split):
+    """split=True: the two-kernel path (colour net, sigma net) fed by the forward kernel's sigma-head output;
+    split=False: the fused kernel.  Both must match the oracle."""
     shape, params, desc, flat = _mlp_setup(nof, ns, nc, ff, L, precision, seed=2)
     R, S = 21, 48                                        # S not a multiple of 32: tiles straddle rays
     B = R * S
@@ -344,7 +346,19 @@ def test_mlp_backward(nof, ns, nc, ff, L, precision):
     dfeat = torch.full((L, B, 2), 3.0, device='cuda')
     dview = torch.zeros(R, 16, device='cuda')
     partials = torch.full((nblk, desc.n_params), 5.0, device='cuda')
-    nof.call('nof_mlp_bwd', C.byref(desc), _pack(nof, desc, flat), d_feat, L, view.cuda(), S, draw.cuda(), dfeat, dview, partials, B)
+    packed = _pack(nof, desc, flat)
+    sig = dsig = None
+    if (ns, nc) == (3, 3) and precision != 0 and not split:
+        # the fused kernel's fragments + operand slots for six 16-bit layers exceed the 160 KB LDS: loud error, not a crash
+        with pytest.raises(nof.NofError):
+            nof.call('nof_mlp_bwd', C.byref(desc), packed, d_feat, L, view.cuda(), S, draw.cuda(), None, None, dfeat, dview, partials, B)
+        return
+    if split:
+        sig = torch.zeros(B, 16, dtype=torch.int16, device='cuda')
+        dsig = torch.zeros(B, 16, dtype=torch.int16, device='cuda')
+        raw = torch.zeros(B, 4, device='cuda')
+        nof.call('nof_mlp_fwd', C.byref(desc), packed, d_feat, L, view.cuda(), S, raw, sig, B)
+    nof.call('nof_mlp_bwd', C.byref(desc), packed, d_feat, L, view.cuda(), S, draw.cuda(), sig, dsig, dfeat, dview, partials, B)
     gflat = torch.zeros(desc.n_params, device='cuda')
     nof.call('nof_reduce_partials', partials, nblk, desc.n_params, gflat)
     torch.cuda.synchronize()
