@@ -9,15 +9,20 @@ struct HashLevel {
   uint32_t res, offset, size, hashed;
 };
 
+// `index % size` without the division sequence on the hot paths: a hashed level has size 2^T (mask), a dense level's linear
+// index is below its size except for the float32 resolution quirk of exact-power levels (SURVEY 8a notes), where the
+// reference's modulo wrap must be kept -- so the general `%` stays as the rare branch.  Same values as gridencoder.cu:82.
 __device__ __forceinline__ uint32_t grid_index(const HashLevel& lv, uint32_t x, uint32_t y, uint32_t z) {
   uint32_t index;
   if (lv.hashed) {
     index = (x * 1u) ^ (y * 2654435761u) ^ (z * 805459861u);      // fast_hash, gridencoder.cu:47-62
-  } else {
-    const uint32_t r1 = lv.res + 1u;                                // align_corners == false
-    index = x + y * r1 + z * r1 * r1;                               // gridencoder.cu:70-74
+    if ((lv.size & (lv.size - 1u)) == 0u) return index & (lv.size - 1u);
+    return index % lv.size;
   }
-  return index % lv.size;
+  const uint32_t r1 = lv.res + 1u;                                  // align_corners == false
+  index = x + y * r1 + z * r1 * r1;                                 // gridencoder.cu:70-74
+  if (index >= lv.size) index %= lv.size;
+  return index;
 }
 
 struct CellPos {
