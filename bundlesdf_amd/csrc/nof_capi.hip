@@ -11,6 +11,19 @@ int nof_set_error(int code, const char* fmt, ...) {
   return code;
 }
 
+int nof_cu_count(void) {
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0, n = 256;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+      n = prop.multiProcessorCount;
+    (void)hipGetLastError();
+    cus = n;
+  }
+  return cus;
+}
+
 extern "C" const char* nof_last_error(void) { return g_nof_err; }
 extern "C" int nof_version(void) { return 100; }
 

@@ -23,3 +23,5 @@ int nof_set_error(int code, const char* fmt, ...);
 static inline int64_t nof_div_up(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
 #define NOF_INF __builtin_huge_valf()
+
+int nof_cu_count(void);                     // compute units of the current device (cached; 256 on MI355X)
