@@ -145,11 +145,16 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X (no CPU fallback for the product path)')
-    torch.cuda.set_device(local_rank)
-    device = torch.device('cuda', local_rank)
+    dev_index = local_rank % torch.cuda.device_count()      # (== local_rank on a real node; the 1-GPU gloo test wraps around)
+    torch.cuda.set_device(dev_index)
+    device = torch.device('cuda', dev_index)
     if world > 1 or ('RANK' in os.environ and 'MASTER_PORT' in os.environ):     # launched by torch.distributed.run
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', device_id=device)
+        backend = os.environ.get('NOF_DIST_BACKEND', 'nccl')                    # 'nccl' is RCCL; 'gloo' only for the 1-GPU test
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=device)
+        else:
+            dist.init_process_group(backend)
     assert world == args.gpus or world == 1, f'--gpus {args.gpus} but WORLD_SIZE={world}'
 
     log(f'rank {rank}/{world}: building the keyframe pool and ray table')
@@ -191,6 +196,13 @@ def main():
     dom_ms = fld.kernel_times_ms().get(dominant) if dominant else None
     flags = int(fld.flags[0].item())
     losses = fld.losses()
+    dp_spread = None
+    if dist.is_initialized():               # replicas must hold bit-identical parameters after K synchronised steps
+        chk = torch.stack([fld.params.double().sum(), fld.params.double().abs().sum()]).to(device)
+        allc = [torch.empty_like(chk) for _ in range(dist.get_world_size())]
+        dist.all_gather(allc, chk)
+        allc = torch.stack(allc)
+        dp_spread = float((allc.max(0).values - allc.min(0).values).abs().max().item())
 
     if rank == 0:
         ms = dt / args.steps * 1e3
@@ -239,7 +251,7 @@ def main():
                        "pool_rays": int(runner.rays.shape[0]), "parallelism": f"dp{world}"},
             "train_iters_per_sec": it_s * 1.0,
             "kernel_ms_warmup": {k: round(v, 4) for k, v in sorted(ktimes.items(), key=lambda kv: -kv[1])},
-            "loss": losses['loss'], "flags": flags,
+            "loss": losses['loss'], "flags": flags, "dp_param_checksum_spread": dp_spread,
             "roofline": roof,
         }
         if not args.no_cpu_baseline:

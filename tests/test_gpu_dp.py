@@ -1,0 +1,30 @@
+"""The N > 1 launch path of bench.py on ONE GPU: two processes started by torch.distributed.run share cuda:0 and talk
+through gloo (RCCL refuses two ranks on one device), so everything except the transport is the product path: keyframe
+sharding by rank, all-gather of the pose table / octree cloud, the per-step all-reduce of the flat gradient buffer through
+the grad_sync hook, barrier + MAX-over-ranks timing, rank-0 JSON line.  After the synchronised steps both replicas must
+hold bit-identical parameters."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_bench_two_ranks_one_gpu_gloo(nof):
+    env = dict(os.environ, NOF_DIST_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', '29533', os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '6', '--warmup', '2',
+           '--keyframes', '3', '--no-cpu-baseline']
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith('{"metric"')]
+    assert len(line) == 1, out.stdout[-2000:]                          # rank 0 only
+    d = json.loads(line[0])
+    assert d['n_gpus'] == 2 and d['scaling'] == 'weak' and d['config']['parallelism'] == 'dp2'
+    assert d['flags'] == 0 and d['loss'] == d['loss']                  # finite
+    assert d['dp_param_checksum_spread'] == 0.0
+    assert d['value'] > 0 and abs(d['value'] - 2 * 4096 * 192 * 1e3 / d['ms_per_step']) < 1e-3 * d['value']
