@@ -128,3 +128,40 @@ def test_philox_training_reduces_loss(nof):
     last = fld.losses()['loss']
     assert np.isfinite(last) and last < 0.7 * first, (first, last)
     assert cpu(fld.flags)[0] == 0
+
+
+def test_train_step_is_graph_capturable(nof):
+    """Every launch of a step goes to the caller's stream (the hash backward forks onto an internal stream and joins by
+    events), nothing allocates or synchronises: the whole step can be captured into a HIP graph and replayed.  Scalars
+    (learning rate, Philox step) are baked into the captured launches, so the replay is compared with an eager step that
+    uses the same ones."""
+    cfg, fld, orc, batch, rng = _pair(nof, 'bf16', R=256)
+    R = batch.shape[0]
+    pool = U.dev(batch)
+    for _ in range(2):                                   # warm up: module load, LDS attributes, side stream, buffers
+        fld.train_step(pool, None, R, seed=3, do_step=False)
+        fld.grads.zero_()
+    torch.cuda.synchronize()
+    p0 = fld.params.clone()
+    fld.train_step(pool, None, R, seed=3, do_step=False)
+    torch.cuda.synchronize()
+    g_eager = fld.grads.clone()
+    loss_eager = fld.losses()['loss']
+    fld.grads.zero_()
+    fld.params.copy_(p0)
+    graph = torch.cuda.CUDAGraph()
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        with torch.cuda.graph(graph, stream=s):
+            fld.train_step(pool, None, R, seed=3, do_step=False)
+    torch.cuda.current_stream().wait_stream(s)
+    torch.cuda.synchronize()
+    fld.grads.zero_()
+    graph.replay()
+    torch.cuda.synchronize()
+    g_replay = fld.grads.clone()
+    assert abs(fld.losses()['loss'] - loss_eager) <= 1e-5 * abs(loss_eager)
+    d = (g_replay - g_eager).abs().max().item()
+    assert d <= 1e-3 * g_eager.abs().max().item(), d          # atomics: summation order only
+    assert torch.isfinite(g_replay).all() and g_replay.abs().sum().item() > 0
