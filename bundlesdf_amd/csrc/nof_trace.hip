@@ -71,7 +71,7 @@ __device__ __forceinline__ void cell_slab(const Axis& a, int i, float cs, float&
 }
 
 // Walks the occupied cells of one ray; writes at most max_hits intervals. Returns the number written.
-__device__ int trace_one(const uint32_t* __restrict__ bits, int n, const float o[3], const float d[3], int max_hits,
+__device__ __forceinline__ int trace_one(const uint32_t* __restrict__ bits, int n, const float o[3], const float d[3], int max_hits,
                          float* __restrict__ tio, int32_t* __restrict__ cid, int* overflow) {
   const float cs = 2.0f / (float)n;
   Axis ax[3];
@@ -140,10 +140,24 @@ __device__ int trace_one(const uint32_t* __restrict__ bits, int n, const float o
   return nh;
 }
 
+// The occupancy bitfield of the ray-tracing level is tiny (level 4: 512 B, level 6: 32 KB): every workgroup stages it in LDS
+// so that the DDA's dependent occupancy tests cost an LDS read instead of a global round trip (the kernel is one latency
+// chain per ray: 64 waves for 4096 rays).  Levels above 6 read the global copy.
+#define OCC_LDS_WORDS 8192
+__device__ __forceinline__ const uint32_t* stage_occ(const uint32_t* __restrict__ bits, int n, uint32_t* lds) {
+  const int words = (n * n * n + 31) / 32;
+  if (words > OCC_LDS_WORDS) return bits;
+  for (int i = threadIdx.x; i < words; i += blockDim.x) lds[i] = bits[i];
+  __syncthreads();
+  return lds;
+}
+
 __global__ __launch_bounds__(64) void k_trace_rays(const uint32_t* __restrict__ bits, int n, const float* __restrict__ rays_o,
                                                     const float* __restrict__ rays_d, int64_t R, int max_hits,
                                                     float* __restrict__ t_in_out, int32_t* __restrict__ cell_ids,
                                                     int32_t* __restrict__ n_hits, int32_t* __restrict__ flags) {
+  extern __shared__ uint32_t occ_lds[];
+  const uint32_t* occ = stage_occ(bits, n, occ_lds);
   const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= R) return;
   const float o[3] = {rays_o[r * 3], rays_o[r * 3 + 1], rays_o[r * 3 + 2]};
@@ -151,12 +165,9 @@ __global__ __launch_bounds__(64) void k_trace_rays(const uint32_t* __restrict__ 
   float* tio = t_in_out + r * max_hits * 2;
   int32_t* cid = cell_ids ? cell_ids + r * max_hits : nullptr;
   int overflow = 0;
-  const int nh = trace_one(bits, n, o, d, max_hits, tio, cid, &overflow);
-  for (int k = nh; k < max_hits; ++k) {                              // zero padding = at::zeros in common.cu:158
-    tio[2 * k] = 0.0f;
-    tio[2 * k + 1] = 0.0f;
-    if (cid) cid[k] = -1;
-  }
+  const int nh = trace_one(occ, n, o, d, max_hits, tio, cid, &overflow);
+  if (cid)                                                            // (t_in_out's zero padding = at::zeros in common.cu:158
+    for (int k = nh; k < max_hits; ++k) cid[k] = -1;                  //  is one memset before the launch)
   n_hits[r] = nh;
   if (overflow && flags) atomicOr(&flags[0], 1);
 }
@@ -196,6 +207,8 @@ __global__ __launch_bounds__(64) void k_batch_trace(const float* __restrict__ po
                                                      float* __restrict__ viewdirs_w, float* __restrict__ view,
                                                      float* __restrict__ t_in_out, int32_t* __restrict__ cell_ids,
                                                      int32_t* __restrict__ n_hits, int32_t* __restrict__ flags) {
+  extern __shared__ uint32_t occ_lds[];
+  const uint32_t* occ = stage_occ(bits, n, occ_lds);
   const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= R) return;
   const int64_t src = ids ? ids[r] : r;
@@ -232,12 +245,9 @@ __global__ __launch_bounds__(64) void k_batch_trace(const float* __restrict__ po
   float* tio = t_in_out + r * max_hits * 2;
   int32_t* cid = cell_ids ? cell_ids + r * max_hits : nullptr;
   int overflow = 0;
-  const int nh = trace_one(bits, n, o, d, max_hits, tio, cid, &overflow);
-  for (int k = nh; k < max_hits; ++k) {
-    tio[2 * k] = 0.0f;
-    tio[2 * k + 1] = 0.0f;
-    if (cid) cid[k] = -1;
-  }
+  const int nh = trace_one(occ, n, o, d, max_hits, tio, cid, &overflow);
+  if (cid)
+    for (int k = nh; k < max_hits; ++k) cid[k] = -1;
   n_hits[r] = nh;
   if (overflow && flags) atomicOr(&flags[0], 1);
 }
@@ -376,6 +386,12 @@ __global__ void k_sample_points(NofSampleCfg cfg, const float* __restrict__ batc
 }
 
 // ------------------------------------------------------------------------------------------------
+static size_t occ_lds_bytes(int level) {
+  const size_t n = (size_t)1 << level;
+  const size_t words = (n * n * n + 31) / 32;
+  return words <= OCC_LDS_WORDS ? words * 4 : 0;
+}
+
 extern "C" int nof_occgrid_build(const int32_t* coords, int64_t P, int32_t max_level, int32_t level,
                                   uint32_t* occ_bits, void* stream) {
   NOF_ARG(occ_bits && level >= 0 && level <= 8 && max_level >= level && max_level <= 10 && P >= 0);
@@ -405,7 +421,8 @@ extern "C" int nof_trace_rays(const uint32_t* occ_bits, int32_t level, const flo
                                void* stream) {
   NOF_ARG(occ_bits && rays_o && rays_d && t_in_out && n_hits && level >= 0 && level <= 8 && max_hits >= 1 && R >= 0);
   if (R == 0) return 0;
-  hipLaunchKernelGGL(k_trace_rays, dim3((unsigned)nof_div_up(R, 64)), dim3(64), 0, (hipStream_t)stream, occ_bits,
+  NOF_HIP(hipMemsetAsync(t_in_out, 0, (size_t)R * max_hits * 2 * sizeof(float), (hipStream_t)stream));
+  hipLaunchKernelGGL(k_trace_rays, dim3((unsigned)nof_div_up(R, 64)), dim3(64), occ_lds_bytes(level), (hipStream_t)stream, occ_bits,
                      1 << level, rays_o, rays_d, R, max_hits, t_in_out, cell_ids, n_hits, flags);
   NOF_LAUNCH_OK();
   return 0;
@@ -419,7 +436,8 @@ extern "C" int nof_batch_trace(const float* pool, const int64_t* ids, const floa
   NOF_ARG(level >= 0 && level <= 8 && max_hits >= 1 && R >= 0 && sh_degree >= 1 && sh_degree <= 4);
   NOF_ARG(ff >= 0 && ff + sh_degree * sh_degree <= NOF_VIEW_COLS && (ff == 0 || frame_feat));
   if (R == 0) return 0;
-  hipLaunchKernelGGL(k_batch_trace, dim3((unsigned)nof_div_up(R, 64)), dim3(64), 0, (hipStream_t)stream, pool, ids, tf,
+  NOF_HIP(hipMemsetAsync(t_in_out, 0, (size_t)R * max_hits * 2 * sizeof(float), (hipStream_t)stream));
+  hipLaunchKernelGGL(k_batch_trace, dim3((unsigned)nof_div_up(R, 64)), dim3(64), occ_lds_bytes(level), (hipStream_t)stream, pool, ids, tf,
                      frame_feat, ff, sh_degree, occ_bits, 1 << level, R, max_hits, batch, rays_o_w, viewdirs_w, view,
                      t_in_out, cell_ids, n_hits, flags);
   NOF_LAUNCH_OK();
