@@ -55,9 +55,11 @@ def build_runner(args, rank, world, device):
         dist.all_gather(cs, c)
         cloud = torch.cat(cs, 0).cpu().numpy()
     sync = None
-    if dist.is_initialized():
-        def sync(flat):
-            dist.all_reduce(flat)           # RCCL sum; gradients are pre-scaled by 1/world_size
+    if dist.is_initialized():               # RCCL sum; gradients are pre-scaled by 1/world_size on the device
+        from bundlesdf_amd.dist import GradSync
+        sync = GradSync()                   # bucketed: the fine hash levels' slice is reduced beside the rest of the backward
+        if os.environ.get('NOF_DP_OVERLAP', '1') == '0':
+            sync = sync.__call__            # one blocking all-reduce of the whole buffer
     ns, nc = (3, 2) if args.mlp == 'baseline' else (2, 3)
     runner = NerfRunner(cfg, pool['rgbs'], depths=pool['depths'], masks=pool['masks'], normal_maps=None, poses=poses,
                         K=pool['K'], build_octree_pcd=synthetic.PointCloud(cloud), precision=args.precision, n_sigma=ns,
@@ -196,7 +198,7 @@ def main():
     dom_ms = fld.kernel_times_ms().get(dominant) if dominant else None
     flags = int(fld.flags[0].item())
     losses = fld.losses()
-    dp_spread = None
+    dp_spread, checksum = None, float(fld.params.double().abs().sum().item())
     if dist.is_initialized():               # replicas must hold bit-identical parameters after K synchronised steps
         chk = torch.stack([fld.params.double().sum(), fld.params.double().abs().sum()]).to(device)
         allc = [torch.empty_like(chk) for _ in range(dist.get_world_size())]
@@ -251,7 +253,7 @@ def main():
                        "pool_rays": int(runner.rays.shape[0]), "parallelism": f"dp{world}"},
             "train_iters_per_sec": it_s * 1.0,
             "kernel_ms_warmup": {k: round(v, 4) for k, v in sorted(ktimes.items(), key=lambda kv: -kv[1])},
-            "loss": losses['loss'], "flags": flags, "dp_param_checksum_spread": dp_spread,
+            "loss": losses['loss'], "flags": flags, "dp_param_checksum_spread": dp_spread, "param_checksum": checksum,
             "roofline": roof,
         }
         if not args.no_cpu_baseline:

@@ -356,7 +356,17 @@ static int side_stream(SideStream** out) {
 extern "C" int nof_hash_encode_bwd(const NofHashGrid* g, const float* pts_w, const float* table, const float* dfeat,
                                     float* grad_table, float* dpts, int64_t B, void* stream) {
   if (int e = check_grid(g)) return e;
-  NOF_ARG(pts_w && table && dfeat && grad_table && B >= 0);
+  return nof_hash_encode_bwd_levels(g, pts_w, table, dfeat, grad_table, dpts, 0, g->L, B, stream);
+}
+
+// The table gradient of levels [level_lo, level_hi) only (+ the input gradient over ALL levels when dpts is given).  The
+// data-parallel step calls it twice, fine levels first, so that the all-reduce of their (large) slice of the gradient
+// buffer runs beside the scatter of the coarse levels and the pose kernels.
+extern "C" int nof_hash_encode_bwd_levels(const NofHashGrid* g, const float* pts_w, const float* table, const float* dfeat,
+                                           float* grad_table, float* dpts, int32_t level_lo, int32_t level_hi, int64_t B,
+                                           void* stream) {
+  if (int e = check_grid(g)) return e;
+  NOF_ARG(pts_w && table && dfeat && grad_table && B >= 0 && level_lo >= 0 && level_lo <= level_hi && level_hi <= g->L);
   if (B == 0) return 0;
   hipStream_t st = (hipStream_t)stream;
   // split the levels: slices of <= 48 KiB are accumulated in LDS (their few hundred rows would be hot lines for global
@@ -367,13 +377,14 @@ extern "C" int nof_hash_encode_bwd(const NofHashGrid* g, const float* pts_w, con
   LevelList small, big;
   small.n = big.n = 0;
   size_t lds_need = 0;
-  for (int l = 0; l < g->L; ++l) {
+  for (int l = level_lo; l < level_hi; ++l) {
     const size_t bytes = (size_t)g->size[l] * 8;
     if (bytes <= lds_cap) { small.level[small.n++] = l; if (bytes > lds_need) lds_need = bytes; }
     else big.level[big.n++] = l;
   }
   SideStream* side = nullptr;
   const bool fork = big.n > 0 && (dpts != nullptr || small.n > 0);
+  if (big.n == 0 && small.n == 0 && dpts == nullptr) return 0;
   hipStream_t s2 = st;
   if (fork) {
     if (int e = side_stream(&side)) return e;

@@ -34,14 +34,37 @@ def all_gather_cat(t):
     return torch.cat(parts, 0)
 
 
-def make_grad_sync():
-    """hook for NeuralObjectField.train_step: sum the (pre-scaled) flat gradients of all ranks."""
+class GradSync:
+    """Hook for NeuralObjectField.train_step: sums the (pre-scaled) flat gradients of all ranks.
+
+    Called as a function it is one blocking all-reduce of the whole buffer.  `start(slice)` / `finish()` is the bucketed
+    form the step uses: the fine hash levels' slice (80 % of the bytes) is reduced asynchronously -- torch's process group runs
+    the collective on its own stream, ordered after the launches already enqueued on the current one -- while the scatter
+    of the coarse levels and the pose kernels still run; `finish()` makes the current stream wait before Adam.  Sums are
+    element-wise, so bucketing does not change a single bit of the result."""
+
+    def __init__(self):
+        self.pending = []
+
+    def __call__(self, flat):
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+
+    def start(self, part):
+        if part.numel():
+            self.pending.append(dist.all_reduce(part, op=dist.ReduceOp.SUM, async_op=True))
+
+    def finish(self):
+        for w in self.pending:
+            w.wait()
+        self.pending = []
+
+
+def make_grad_sync(overlap=True):
+    """GradSync when a process group with more than one rank exists, else None."""
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return None
-
-    def sync(flat):
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
-    return sync
+    g = GradSync()
+    return g if overlap else g.__call__
 
 
 def shard_frames(n_total, rank, world):

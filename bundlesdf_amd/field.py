@@ -253,8 +253,22 @@ class NeuralObjectField:
                    b['dsig'], b['dfeat'],
                  b['dview'], b['partials'], B)
         self._call('nof_reduce_partials', b['partials'], self.nblk, self.n_mlp, self._seg(self.grads, 'mlp'))
-        self._call('nof_hash_encode_bwd', C.byref(self.grid), b['pts_w'], self.table, b['dfeat'],
-                 self._seg(self.grads, 'table'), b['dpts'] if self.optimize_poses else None, B)
+        dpts = b['dpts'] if self.optimize_poses else None
+        gtab = self._seg(self.grads, 'table')
+        hashed = [l for l in range(self.L) if self.grid.hashed[l]]
+        split = hashed[0] if hashed and 0 < hashed[0] < self.L else None
+        bucketed = grad_sync is not None and hasattr(grad_sync, 'start') and split is not None
+        if bucketed:
+            # data parallel: the fine (hashed) levels first; their slice [rows of level `split` .., MLP] of the flat gradient
+            # buffer (80 % of its bytes at cfg2) is all-reduced while the coarse levels, dL/dx and the pose kernels still run
+            a = 2 * int(self.offsets[split])
+            self._call('nof_hash_encode_bwd_levels', C.byref(self.grid), b['pts_w'], self.table, b['dfeat'], gtab, None,
+                       split, self.L, B)
+            grad_sync.start(self.grads[a:self.n_table + self.n_mlp])
+            self._call('nof_hash_encode_bwd_levels', C.byref(self.grid), b['pts_w'], self.table, b['dfeat'], gtab, dpts,
+                       0, split, B)
+        else:
+            self._call('nof_hash_encode_bwd', C.byref(self.grid), b['pts_w'], self.table, b['dfeat'], gtab, dpts, B)
         if self.optimize_poses or self.ff > 0:
             if self.optimize_poses:
                 self._call('nof_pose_grad_accum', b['dpts'], b['dview'], b['batch'], b['z_vals'], self.c2w, self.tf, self.ff,
@@ -267,7 +281,11 @@ class NeuralObjectField:
         if self.ff > 0:
             self._call('nof_small_regs', self.feat, self._seg(self.grads, 'feat'), self.n_feat,
                      C.c_float(cfg['feature_reg_weight']), C.c_float(1.0 / self.world_size))
-        if grad_sync is not None:
+        if bucketed:
+            grad_sync.start(self.grads[:a])
+            grad_sync.start(self.grads[self.n_table + self.n_mlp:])
+            grad_sync.finish()
+        elif grad_sync is not None:
             grad_sync(self.grads)
         if do_step:
             self.adam_step()

@@ -58,6 +58,7 @@ _SIGNATURES = {
     'nof_version': ([], C.c_int),
     'nof_hash_encode_fwd': ([C.POINTER(NofHashGrid), _P, _P, _P, _I64, _P], C.c_int),
     'nof_hash_encode_bwd': ([C.POINTER(NofHashGrid), _P, _P, _P, _P, _P, _I64, _P], C.c_int),
+    'nof_hash_encode_bwd_levels': ([C.POINTER(NofHashGrid), _P, _P, _P, _P, _P, _I32, _I32, _I64, _P], C.c_int),
     'nof_hash_corner_indices': ([C.POINTER(NofHashGrid), _P, _P, _I64, _P], C.c_int),
     'nof_pose_fwd': ([_P, _P, _F, _F, _P, _I32, _P], C.c_int),
     'nof_pose_bwd': ([_P, _P, _F, _F, _P, _I32, _P], C.c_int),

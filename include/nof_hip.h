@@ -54,6 +54,9 @@ int nof_hash_encode_fwd(const NofHashGrid* h_grid, const float* pts_w, const flo
 int nof_hash_encode_bwd(const NofHashGrid* h_grid, const float* pts_w, const float* table, const float* dfeat,
                         float* grad_table, float* dpts, int64_t B, void* stream);
 /* debug/parity: the 8 absolute table rows each (point, level) touches -> idx [B,L,8] int32 (-1 if out of range) */
+/* Same, restricted to the table rows of levels [level_lo, level_hi); dpts (if given) still covers all levels. */
+int nof_hash_encode_bwd_levels(const NofHashGrid* h_grid, const float* pts_w, const float* table, const float* dfeat,
+                               float* grad_table, float* dpts, int32_t level_lo, int32_t level_hi, int64_t B, void* stream);
 int nof_hash_corner_indices(const NofHashGrid* h_grid, const float* pts_w, int32_t* idx, int64_t B, void* stream);
 
 /* ---- pose corrections (replaces PoseArray.get_matrices + pytorch3d se3_exp_map) ---------------- */

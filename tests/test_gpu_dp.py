@@ -14,16 +14,24 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_bench_two_ranks_one_gpu_gloo(nof):
-    env = dict(os.environ, NOF_DIST_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0')
+def _run(overlap, port):
+    env = dict(os.environ, NOF_DIST_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0', NOF_DP_OVERLAP=overlap)
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
-           '--master-port', '29533', os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '6', '--warmup', '2',
+           '--master-port', str(port), os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '6', '--warmup', '2',
            '--keyframes', '3', '--no-cpu-baseline']
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-3000:]
     line = [l for l in out.stdout.splitlines() if l.startswith('{"metric"')]
     assert len(line) == 1, out.stdout[-2000:]                          # rank 0 only
-    d = json.loads(line[0])
+    return json.loads(line[0])
+
+
+def test_bench_two_ranks_one_gpu_gloo(nof):
+    d = _run('1', 29533)               # bucketed: fine hash levels reduced asynchronously beside the rest of the backward
+    d0 = _run('0', 29534)              # one blocking all-reduce of the whole buffer
+    assert d0['dp_param_checksum_spread'] == 0.0
+    # element-wise sums: bucketing cannot change the result beyond the atomics' summation order inside each rank
+    assert abs(d['param_checksum'] - d0['param_checksum']) <= 1e-6 * d0['param_checksum']
     assert d['n_gpus'] == 2 and d['scaling'] == 'weak' and d['config']['parallelism'] == 'dp2'
     assert d['flags'] == 0 and d['loss'] == d['loss']                  # finite
     assert d['dp_param_checksum_spread'] == 0.0
