@@ -227,7 +227,7 @@ int nof_adam_step(float* params, float* grads, float* exp_avg, float* exp_avg_sq
 /* ---- test hook: raw MFMA tile  D[32,32] = A[32,K] * B[K,32] with the operand layouts nof_mlp uses ---- */
 int nof_mfma_probe(int32_t precision, const float* A, const float* Bm, float* D, int32_t K, void* stream);
 
-/* ---- test hook: fp32 atomic-add throughput for address patterns 0..4 (see nof_capi.hip); idx [n] uint32 < 2^19, table [2^19,2] */
+/* ---- test hook: fp32 atomic-add throughput for address patterns 0..9 (see nof_capi.hip); idx [n] uint32 < 2^19, table [2^19,2] */
 int nof_atomic_probe(int32_t variant, const uint32_t* idx, float* table, int64_t n, void* stream);
 
 #ifdef __cplusplus

@@ -25,9 +25,10 @@ R, S, L, T = 4096, 192, 16, 19
 B = R * S
 
 
-def _ray_like_points(seed=0):
+def _ray_like_points(seed=0, R=R):
     """samples along rays through the cube (consecutive samples of a ray are spatially coherent, like training batches),
     a few of them outside [-1,1]"""
+    B = R * S
     g = torch.Generator(device='cuda').manual_seed(seed)
     o = torch.randn(R, 3, device='cuda', generator=g)
     o = o / o.norm(dim=1, keepdim=True) * 1.6
@@ -38,9 +39,13 @@ def _ray_like_points(seed=0):
     return (o[:, None, :] + t * d[:, None, :]).reshape(B, 3).contiguous()
 
 
-def test_hash_partition_of_unity_and_mass_conservation(nof):
-    g, geo = U.make_grids(nof, L=L, T=T)
-    pts = _ray_like_points()
+@pytest.mark.parametrize("R,T,finest", [(4096, 19, 256),        # BASELINE cfg2 / cfg3 (per GPU)
+                                        (8192, 19, 512),        # cfg4: 8192 rays per step, finest 512
+                                        (16384, 22, 512)])      # cfg5: 16384 rays, T = 2^22 (237 MB table), finest 512
+def test_hash_partition_of_unity_and_mass_conservation(nof, R, T, finest):
+    B = R * S
+    g, geo = U.make_grids(nof, L=L, T=T, finest=finest)
+    pts = _ray_like_points(R=R)
     inside = ((pts >= -1) & (pts <= 1)).all(1)
     assert 0.3 < inside.float().mean().item() < 0.99
     table = torch.empty(geo.n_entries, 2, device='cuda')
