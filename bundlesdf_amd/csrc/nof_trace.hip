@@ -473,3 +473,202 @@ extern "C" int nof_raymarch_sample(const NofSampleCfg* cfg, const float* pool, c
     return e;
   return nof_sample_points(cfg, batch, tf, t_in_out, n_hits, R, max_hits, u_occ, u_dep, z_vals, pts_w, valid, flags, stream);
 }
+
+// ================================================================================================================
+// Ray-pool construction on the device: the per-keyframe ray table of
+// NerfRunner.make_frame_rays (nerf_runner.py:246-316) + compute_near_far_and_filter_rays (:39-65) +
+// ray_box_intersection_batch (nerf_helpers.py:403-446) + the octree-miss filter (:302-314) + the cloud-based depth
+// denoise (:178-195).  The reference does all of it in float64 NumPy on the host for every pixel of every keyframe; here
+// it is one pass per frame in float64 on the GPU (same operations, same order -- bundlesdf_amd/rays.py is the host
+// restatement the tests compare against), a brute-force nearest-cloud-point test, and a stable compaction.
+// ================================================================================================================
+// does the ray hit any occupied cell (n_hits > 0 of the tracer, with its terminator / minimum-length filters)?
+__device__ __forceinline__ bool trace_hits_any(const uint32_t* __restrict__ occ, int n, const float (&o)[3], const float (&d)[3]) {
+  float tio[2];
+  int overflow = 0;
+  return trace_one(occ, n, o, d, 1, tio, nullptr, &overflow) > 0;
+}
+
+// cv2.dilate with a k x k all-ones kernel (anchor k/2): window offsets -k/2 ... k-1-k/2, borders ignored; separable.
+__global__ __launch_bounds__(256) void k_dilate_1d(const uint8_t* __restrict__ in, int H, int W, int k, int horizontal,
+                                                    uint8_t* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (int64_t)H * W) return;
+  const int v = (int)(i / W), u = (int)(i % W);
+  const int lo = -(k / 2), hi = k - 1 - k / 2;
+  uint8_t m = 0;
+  if (horizontal) {
+    for (int d = lo; d <= hi; ++d) {
+      const int uu = u + d;
+      if (uu >= 0 && uu < W) { const uint8_t x = in[(int64_t)v * W + uu]; m = x > m ? x : m; }
+    }
+  } else {
+    for (int d = lo; d <= hi; ++d) {
+      const int vv = v + d;
+      if (vv >= 0 && vv < H) { const uint8_t x = in[(int64_t)vv * W + u]; m = x > m ? x : m; }
+    }
+  }
+  out[i] = m;
+}
+
+__device__ __forceinline__ void box_axis(double o, double inv, bool neg, double lo, double hi, double& tn, double& tf_) {
+  const double near_plane = neg ? hi : lo, far_plane = neg ? lo : hi;      // nerf_helpers.py:414-420
+  tn = (near_plane - o) * inv;
+  if (tn < 0.0) tn = 0.0;
+  tf_ = (far_plane - o) * inv;
+}
+
+__global__ __launch_bounds__(64) void k_frame_rays(NofFrameRaysCfg c, const float* __restrict__ image,
+                                                    const float* __restrict__ depth, const uint8_t* __restrict__ mask_in,
+                                                    const uint8_t* __restrict__ mask_sel, const uint8_t* __restrict__ occ_mask,
+                                                    const uint32_t* __restrict__ bits, int n, int H, int W,
+                                                    float* __restrict__ rows, uint8_t* __restrict__ keep) {
+  extern __shared__ uint32_t occ_lds[];
+  const uint32_t* occ = bits ? stage_occ(bits, n, occ_lds) : nullptr;
+  const int64_t i = (int64_t)blockIdx.x * 64 + threadIdx.x;
+  if (i >= (int64_t)H * W) return;
+  const int v = (int)(i / W), u = (int)(i % W);
+  const float d32 = depth[i];
+  const bool min_ = mask_in[i] > 0;
+  const bool invalid_depth = (((double)d32 < c.near_thr) || ((double)d32 > c.far_thr)) && min_;   // nerf_runner.py:268
+  bool sel = mask_sel[i] > 0;
+  if (occ_mask && occ_mask[i] > 0) sel = false;
+  if (c.valid_depth_only && invalid_depth) sel = false;
+  sel = sel && !invalid_depth;                                                     // ray type 0 only (:296)
+  // get_camera_rays_np: float32 pixel grid, float64 intrinsics
+  const double dx = ((double)(float)u - c.cx) / c.fx, dy = -((double)(float)v - c.cy) / c.fy, dz = -1.0;
+  float* r = rows + i * NOF_RAY_COLS;
+  r[0] = (float)dx; r[1] = (float)dy; r[2] = (float)dz;
+  r[3] = image[i * 3]; r[4] = image[i * 3 + 1]; r[5] = image[i * 3 + 2];
+  r[6] = d32; r[7] = min_ ? 1.0f : 0.0f; r[8] = (float)c.frame_id; r[9] = 0.0f;
+  bool ok = sel;
+  float nearf = 0.0f, farf = 0.0f;
+  if (sel) {
+    const double nrm = sqrt((dx * dx + dy * dy) + dz * dz);
+    const double ux = dx / nrm, uy = dy / nrm, uz = dz / nrm;                      // dirs_unit (:44)
+    const double* P = c.pose;
+    double dw[3], ow[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      dw[a] = (P[a * 4] * dx + P[a * 4 + 1] * dy) + P[a * 4 + 2] * dz;            // cam_in_world[:3,:3] @ dir (:45)
+      ow[a] = P[a * 4 + 3];
+    }
+    const double n2 = sqrt((dw[0] * dw[0] + dw[1] * dw[1]) + dw[2] * dw[2]) + 1e-10;   // nerf_helpers.py:408
+    double inv[3];
+    bool neg[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { inv[a] = 1.0 / (dw[a] / n2); neg[a] = inv[a] < 0.0; }
+    double tmin, tmax, tymin, tymax, tzmin, tzmax;
+    box_axis(ow[0], inv[0], neg[0], c.box_lo[0], c.box_hi[0], tmin, tmax);
+    box_axis(ow[1], inv[1], neg[1], c.box_lo[1], c.box_hi[1], tymin, tymax);
+    bool ishit = !((tmin > tymax) || (tymin > tmax));
+    if (tymin > tmin) tmin = tymin;
+    if (tymax < tmax) tmax = tymax;
+    box_axis(ow[2], inv[2], neg[2], c.box_lo[2], c.box_hi[2], tzmin, tzmax);
+    ishit = ishit && !((tmin > tzmax) || (tzmin > tmax));
+    if (tzmin > tmin) tmin = tzmin;
+    if (tzmax < tmax) tmax = tzmax;
+    if (!ishit) { tmin = -1.0; tmax = -1.0; }
+    ok = tmin >= 0.0;                                                              // nerf_runner.py:57
+    nearf = (float)fabs(uz * tmin);                                                // |z| of the entry / exit point (:59-62)
+    farf = (float)fabs(uz * tmax);
+    if (ok && occ) {                                                               // rays that miss the octree (:302-314)
+      const double wx = (P[0] * ux + P[1] * uy) + P[2] * uz, wy = (P[4] * ux + P[5] * uy) + P[6] * uz,
+                   wz = (P[8] * ux + P[9] * uy) + P[10] * uz;
+      const float o32[3] = {(float)ow[0], (float)ow[1], (float)ow[2]}, d32v[3] = {(float)wx, (float)wy, (float)wz};
+      ok = trace_hits_any(occ, n, o32, d32v);
+    }
+  }
+  r[10] = nearf; r[11] = farf;
+  keep[i] = ok ? 1 : 0;
+}
+
+// depth denoise (nerf_runner.py:178-195): a kept ray with mask > 0 and depth <= far whose back-projected point is farther
+// than dist_thr from every cloud point is dropped.  Brute force over the (voxel-down-sampled, <= a few 10^4 points) cloud,
+// staged through LDS in tiles; float64 like cKDTree.
+__global__ __launch_bounds__(256) void k_cloud_filter(const float* __restrict__ rows, int64_t N, uint8_t* __restrict__ keep,
+                                                       const double* __restrict__ poses, const double* __restrict__ cloud,
+                                                       int64_t P, double far_thr, double dist_thr) {
+  __shared__ double tile[256 * 3];
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  bool active = false;
+  double pw[3] = {0.0, 0.0, 0.0};
+  if (i < N && keep[i]) {
+    const float* r = rows + i * NOF_RAY_COLS;
+    if (r[7] > 0.0f && (double)r[6] <= far_thr) {
+      active = true;
+      const double dep = (double)r[6];
+      const double px = (double)r[0] * dep, py = (double)r[1] * dep, pz = (double)r[2] * dep;
+      const double* T = poses + (int64_t)r[8] * 16;
+#pragma unroll
+      for (int a = 0; a < 3; ++a) pw[a] = ((T[a * 4] * px + T[a * 4 + 1] * py) + T[a * 4 + 2] * pz) + T[a * 4 + 3];
+    }
+  }
+  double best = 1e300;
+  for (int64_t base = 0; base < P; base += 256) {
+    const int64_t j = base + threadIdx.x;
+    if (j < P) { tile[threadIdx.x * 3] = cloud[j * 3]; tile[threadIdx.x * 3 + 1] = cloud[j * 3 + 1]; tile[threadIdx.x * 3 + 2] = cloud[j * 3 + 2]; }
+    __syncthreads();
+    const int cnt = (int)((P - base) < 256 ? (P - base) : 256);
+    if (active) {
+      for (int t = 0; t < cnt; ++t) {
+        const double ax = pw[0] - tile[t * 3], ay = pw[1] - tile[t * 3 + 1], az = pw[2] - tile[t * 3 + 2];
+        const double d2 = (ax * ax + ay * ay) + az * az;
+        best = d2 < best ? d2 : best;
+      }
+    }
+    __syncthreads();
+  }
+  if (active && sqrt(best) > dist_thr) keep[i] = 0;
+}
+
+__global__ __launch_bounds__(256) void k_compact_rows(const float* __restrict__ rows, const uint8_t* __restrict__ keep,
+                                                       const int64_t* __restrict__ offsets, int64_t N, float* __restrict__ out) {
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t i = t / NOF_RAY_COLS;
+  const int cidx = (int)(t % NOF_RAY_COLS);
+  if (i >= N || !keep[i]) return;
+  out[offsets[i] * NOF_RAY_COLS + cidx] = rows[t];
+}
+
+extern "C" int nof_mask_dilate(const uint8_t* mask, int32_t H, int32_t W, int32_t k, uint8_t* tmp, uint8_t* out, void* stream) {
+  NOF_ARG(mask && tmp && out && H > 0 && W > 0 && k >= 1 && k <= 1024);
+  const unsigned blocks = (unsigned)nof_div_up((int64_t)H * W, 256);
+  hipLaunchKernelGGL(k_dilate_1d, dim3(blocks), dim3(256), 0, (hipStream_t)stream, mask, H, W, k, 1, tmp);
+  hipLaunchKernelGGL(k_dilate_1d, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const uint8_t*)tmp, H, W, k, 0, out);
+  NOF_LAUNCH_OK();
+  return 0;
+}
+
+extern "C" int nof_frame_rays(const NofFrameRaysCfg* cfg, const float* image, const float* depth, const uint8_t* mask_in,
+                               const uint8_t* mask_sel, const uint8_t* occ_mask, const uint32_t* occ_bits, int32_t level,
+                               int32_t H, int32_t W, float* rows, uint8_t* keep, void* stream) {
+  NOF_ARG(cfg && image && depth && mask_in && mask_sel && rows && keep && H > 0 && W > 0 && level >= 0 && level <= 8);
+  const unsigned blocks = (unsigned)nof_div_up((int64_t)H * W, 64);
+  hipLaunchKernelGGL(k_frame_rays, dim3(blocks), dim3(64), occ_bits ? occ_lds_bytes(level) : 0, (hipStream_t)stream, *cfg, image,
+                     depth, mask_in, mask_sel, occ_mask, occ_bits, 1 << level, (int)H, (int)W, rows, keep);
+  NOF_LAUNCH_OK();
+  return 0;
+}
+
+extern "C" int nof_cloud_filter(const float* rows, int64_t N, uint8_t* keep, const double* poses, const double* cloud, int64_t P,
+                                 double far_thr, double dist_thr, void* stream) {
+  NOF_ARG(N >= 0 && P >= 0);
+  if (N == 0 || P == 0) return 0;
+  NOF_ARG(rows && keep && poses && cloud);
+  hipLaunchKernelGGL(k_cloud_filter, dim3((unsigned)nof_div_up(N, 256)), dim3(256), 0, (hipStream_t)stream, rows, N, keep, poses,
+                     cloud, P, far_thr, dist_thr);
+  NOF_LAUNCH_OK();
+  return 0;
+}
+
+extern "C" int nof_compact_rows(const float* rows, const uint8_t* keep, const int64_t* offsets, int64_t N, float* out,
+                                 void* stream) {
+  NOF_ARG(N >= 0);
+  if (N == 0) return 0;
+  NOF_ARG(rows && keep && offsets && out);
+  hipLaunchKernelGGL(k_compact_rows, dim3((unsigned)nof_div_up(N * NOF_RAY_COLS, 256)), dim3(256), 0, (hipStream_t)stream, rows,
+                     keep, offsets, N, out);
+  NOF_LAUNCH_OK();
+  return 0;
+}

@@ -32,6 +32,13 @@ class NofHashGrid(C.Structure):
                 ('hashed', C.c_uint32 * NOF_MAX_LEVELS)]
 
 
+class NofFrameRaysCfg(C.Structure):
+    _fields_ = [('fx', C.c_double), ('fy', C.c_double), ('cx', C.c_double), ('cy', C.c_double),
+                ('near_thr', C.c_double), ('far_thr', C.c_double),
+                ('box_lo', C.c_double * 3), ('box_hi', C.c_double * 3), ('pose', C.c_double * 16),
+                ('frame_id', C.c_int32), ('valid_depth_only', C.c_int32)]
+
+
 class NofSampleCfg(C.Structure):
     _fields_ = [('n_samples', C.c_int32), ('n_around', C.c_int32),
                 ('near_sc', C.c_float), ('far_sc', C.c_float), ('trunc', C.c_float), ('neg_trunc_ratio', C.c_float),
@@ -88,6 +95,10 @@ _SIGNATURES = {
     'nof_mt_count': ([_P, _I32, _I32, _I32, _F, _P, _P], C.c_int),
     'nof_mt_emit': ([_P, _I32, _I32, _I32, _F, _P, _P, _P], C.c_int),
     'nof_mt_vertices': ([_P, _I32, _I32, _I32, _F, _P, _I64, _P, _P], C.c_int),
+    'nof_mask_dilate': ([_P, _I32, _I32, _I32, _P, _P, _P], C.c_int),
+    'nof_frame_rays': ([C.POINTER(NofFrameRaysCfg), _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _P, _P, _P], C.c_int),
+    'nof_cloud_filter': ([_P, _I64, _P, _P, _P, _I64, C.c_double, C.c_double, _P], C.c_int),
+    'nof_compact_rows': ([_P, _P, _P, _I64, _P, _P], C.c_int),
     'nof_mfma_probe': ([_I32, _P, _P, _P, _I32, _P], C.c_int),
     'nof_atomic_probe': ([_I32, _P, _P, _I64, _P], C.c_int),
 }

@@ -27,6 +27,7 @@ from .mesh import make_mesh, marching_tetrahedra
 from .nerf_helpers import *          # noqa: F401,F403  (re-exported on purpose, like the reference module does)
 from .nerf_helpers import set_seed, get_optimized_poses_in_real_world, mesh_to_real_world
 from .rays import DataLoader, denoise_rays, make_frame_rays
+from .rays_gpu import frame_rays_device
 
 __all__ = ['NerfRunner', 'PoseArrayView', 'preprocess_data', 'get_optimized_poses_in_real_world', 'mesh_to_real_world',
            'glcam_in_cvcam', 'BAD_DEPTH', 'BAD_COLOR', 'set_seed', 'get_camera_rays_np', 'ray_box_intersection_batch',
@@ -106,8 +107,7 @@ class NerfRunner:
         self.global_step = 0
         print("sc_factor", self.cfg['sc_factor'])
         print("translation", self.cfg['translation'])
-        rays = self._frame_rays(range(len(self.masks)))
-        self.rays = torch.tensor(rays, dtype=torch.float).to(self.device)
+        self.rays = self._frame_rays_tensor(range(len(self.masks)))
         print("rays", self.rays.shape)
         self.data_loader = DataLoader(rays=self.rays, batch_size=self.cfg['N_rand'])
 
@@ -163,6 +163,16 @@ class NerfRunner:
         _, _, nh = self.field.trace(torch.from_numpy(o).to(self.device), torch.from_numpy(d).to(self.device))
         return (nh > 0).cpu().numpy()
 
+    def _frame_rays_tensor(self, frame_ids):
+        """[N,12] float32 CUDA tensor of the rays of the local frames `frame_ids`: built on the device
+        (bundlesdf_amd/rays_gpu.py) unless cfg['device_ray_pool'] is false, in which case the NumPy path of rays.py (what
+        the reference does on the host) is used and uploaded."""
+        if self.cfg.get('device_ray_pool', True):
+            cloud = self.build_octree_pts if self.cfg['denoise_depth_use_octree_cloud'] else None
+            return frame_rays_device(self.field, list(frame_ids), self.images, self.depths, self.masks, self.poses, self.K,
+                                     self.cfg, frame_offset=self.frame_offset, occ_masks=self.occ_masks, cloud_pts=cloud)
+        return torch.tensor(self._frame_rays(frame_ids), dtype=torch.float, device=self.device)
+
     def _frame_rays(self, frame_ids):
         rays_ = []
         for i in frame_ids:
@@ -201,8 +211,7 @@ class NerfRunner:
             self.build_octree()
         self.create_optimizer()
         self.global_step = 0
-        rays = self._frame_rays(range(prev, len(self.masks)))
-        self.rays = torch.cat((self.rays, torch.tensor(rays, dtype=torch.float, device=self.device)), dim=0)
+        self.rays = torch.cat((self.rays, self._frame_rays_tensor(range(prev, len(self.masks)))), dim=0)
         self.data_loader = DataLoader(rays=self.rays, batch_size=self.cfg['N_rand'])
 
     # ---- training (nerf_runner.py:679-763, 855-863) --------------------------------------------------------

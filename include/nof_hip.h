@@ -85,6 +85,31 @@ int nof_trace_rays(const uint32_t* occ_bits, int32_t level, const float* rays_o,
                    int64_t R, int32_t max_hits, float* t_in_out, int32_t* cell_ids, int32_t* n_hits,
                    int32_t* flags, void* stream);
 
+/* ---- ray-pool construction on the device (make_frame_rays nerf_runner.py:246-316, compute_near_far_and_filter_rays :39-65,
+ *      ray_box_intersection_batch nerf_helpers.py:403-446, octree-miss filter :302-314, cloud denoise :178-195) ------------ */
+/* cv2.dilate(mask, ones(k,k)): window offsets -k/2 .. k-1-k/2, borders ignored.  mask/tmp/out [H,W] uint8. */
+int nof_mask_dilate(const uint8_t* mask, int32_t H, int32_t W, int32_t k, uint8_t* tmp, uint8_t* out, void* stream);
+typedef struct {
+  double  fx, fy, cx, cy;                 /* K (float64 like the reference's numpy path) */
+  double  near_thr, far_thr;              /* near*sc, far*sc, already rounded to the dtype numpy would compare in */
+  double  box_lo[3], box_hi[3];           /* cfg['bounding_box'] */
+  double  pose[16];                       /* cam_in_world of this frame, row-major 4x4 */
+  int32_t frame_id;                       /* written to column 8 */
+  int32_t valid_depth_only;               /* cfg['rays_valid_depth_only'] */
+} NofFrameRaysCfg;
+/* One row per pixel, rows [H*W,12] (column layout above), keep [H*W] = 1 for the rays make_frame_rays returns: selected by
+ * mask_sel (the dilated mask; occ_mask [H,W] may be NULL), usable depth, inside the bounding box, and -- when occ_bits is
+ * given -- hitting an occupied octree cell.  image [H,W,3] f32, depth [H,W] f32, mask_in [H,W] u8. */
+int nof_frame_rays(const NofFrameRaysCfg* h_cfg, const float* image, const float* depth, const uint8_t* mask_in,
+                   const uint8_t* mask_sel, const uint8_t* occ_mask, const uint32_t* occ_bits, int32_t level,
+                   int32_t H, int32_t W, float* rows, uint8_t* keep, void* stream);
+/* clears keep[i] for kept rays (mask > 0, depth <= far_thr) whose back-projected point is farther than dist_thr from every
+ * cloud point; poses [F,16] f64, cloud [P,3] f64. */
+int nof_cloud_filter(const float* rows, int64_t N, uint8_t* keep, const double* poses, const double* cloud, int64_t P,
+                     double far_thr, double dist_thr, void* stream);
+/* out[offsets[i]] = rows[i] for keep[i] != 0 (offsets = exclusive prefix sum of keep, supplied by the caller). */
+int nof_compact_rows(const float* rows, const uint8_t* keep, const int64_t* offsets, int64_t N, float* out, void* stream);
+
 /* ---- one training batch: gather + ray setup + trace (render_rays nerf_runner.py:1044-1060) ------ */
 /* pool [N,12]; ids [R] int64 rows of the pool (NULL: rows 0..R-1); tf [F,12].
  * Outputs: batch [R,12] gathered rows; rays_o_w [R,3]; viewdirs_w [R,3]; view [R,16] = [ff|SH9|0];
