@@ -38,6 +38,9 @@ def _stale(target, deps):
 
 
 def build(force=False, verbose=True):
+    srcs = [os.path.join(CSRC, x) for x in SOURCES if os.path.exists(os.path.join(CSRC, x))]
+    if not force and not _stale(LIB, srcs + HEADERS):
+        return LIB                  # e.g. on the GPU box: the snapshot ships the .so but not the object cache
     os.makedirs(OBJ, exist_ok=True)
     cc = hipcc()
     objs, procs = [], []
