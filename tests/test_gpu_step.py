@@ -1,4 +1,4 @@
-"""Whole-step parity: NeuralObjectField.train_step (11 HIP launches through the C ABI) against the CPU oracle's
+"""Whole-step parity: NeuralObjectField.train_step (12 C-ABI calls, 16 kernel launches) against the CPU oracle's
 train_loop restatement (oracle/nof_oracle.py:OracleField.train_step) on identical rays, identical injected uniforms
 and identical initial parameters: z samples, ray-hit indices, raw outputs, loss terms, every gradient group, and the
 parameters after several Adam steps."""
