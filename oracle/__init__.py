@@ -1,10 +1,10 @@
 """CPU oracle for the Neural Object Field hot path -- TEST INFRASTRUCTURE ONLY.
 
-This package is a CPU restatement (PyTorch fp32 + NumPy + a small C library) of the
+This package is a CPU restatement (PyTorch fp32 + NumPy) of the
 reference algorithm on the path named by BASELINE.json:north_star.  Every function
 cites the reference file:line it follows.
 
-Rules (enforced by tests/test_no_oracle_in_product.py):
+Rules (enforced by tests/test_capi.py::test_product_never_imports_the_oracle):
   * only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg
     may import anything from here -- and there only as the checker, never as the thing
     being measured or shipped;
