@@ -196,3 +196,58 @@ extern "C" int nof_mt_vertices(const float* vol, int32_t nx, int32_t ny, int32_t
   NOF_LAUNCH_OK();
   return 0;
 }
+
+// ---- texture bake helper: UV of every ray/mesh hit (replaces common.rayColorToTextureImageCUDA, common.cu:171-238) -------
+// Barycentric weights of the hit point in its triangle from signed-area ratios projected on the triangle normal
+// (w0 = [P,B,C]/[A,B,C], w1 = [P,C,A]/[A,B,C], w2 = 1 - w0 - w1), then the vertices' texture coordinates blended with them.
+__device__ __forceinline__ void cross3(const float (&a)[3], const float (&b)[3], float (&o)[3]) {
+  o[0] = a[1] * b[2] - a[2] * b[1];
+  o[1] = a[2] * b[0] - a[0] * b[2];
+  o[2] = a[0] * b[1] - a[1] * b[0];
+}
+__device__ __forceinline__ float dot3(const float (&a)[3], const float (&b)[3]) { return (a[0] * b[0] + a[1] * b[1]) + a[2] * b[2]; }
+
+__global__ __launch_bounds__(256) void k_bary_uv(const int64_t* __restrict__ faces, const float* __restrict__ verts,
+                                                  const float* __restrict__ hit_locations, const int64_t* __restrict__ hit_face_ids,
+                                                  const float* __restrict__ uvs_tex, int64_t n_hits, float* __restrict__ uvs) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n_hits) return;
+  const int64_t* f = faces + hit_face_ids[i] * 3;
+  float A[3], Bv[3], Cv[3], p[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    A[c] = verts[f[0] * 3 + c];
+    Bv[c] = verts[f[1] * 3 + c];
+    Cv[c] = verts[f[2] * 3 + c];
+    p[c] = hit_locations[i * 3 + c];
+  }
+  float bc[3], ba[3], ca[3], pb[3], pc[3], pa[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    bc[c] = Bv[c] - Cv[c]; ba[c] = Bv[c] - A[c]; ca[c] = Cv[c] - A[c];
+    pb[c] = Bv[c] - p[c]; pc[c] = Cv[c] - p[c]; pa[c] = A[c] - p[c];
+  }
+  float nrm[3], t[3];
+  cross3(bc, ba, nrm);
+  cross3(ba, ca, t);
+  const float area = dot3(nrm, t);
+  cross3(pb, pc, t);
+  const float w0 = dot3(nrm, t) / area;
+  cross3(pc, pa, t);
+  const float w1 = dot3(nrm, t) / area;
+  const float w2 = 1.0f - w0 - w1;
+#pragma unroll
+  for (int c = 0; c < 2; ++c)
+    uvs[i * 2 + c] = (uvs_tex[f[0] * 2 + c] * w0 + uvs_tex[f[1] * 2 + c] * w1) + uvs_tex[f[2] * 2 + c] * w2;
+}
+
+extern "C" int nof_bary_uv(const int64_t* faces, const float* verts, const float* hit_locations, const int64_t* hit_face_ids,
+                            const float* uvs_tex, int64_t n_hits, float* uvs, void* stream) {
+  NOF_ARG(n_hits >= 0);
+  if (n_hits == 0) return 0;
+  NOF_ARG(faces && verts && hit_locations && hit_face_ids && uvs_tex && uvs);
+  hipLaunchKernelGGL(k_bary_uv, dim3((unsigned)nof_div_up(n_hits, 256)), dim3(256), 0, (hipStream_t)stream, faces, verts,
+                     hit_locations, hit_face_ids, uvs_tex, n_hits, uvs);
+  NOF_LAUNCH_OK();
+  return 0;
+}

@@ -99,6 +99,7 @@ _SIGNATURES = {
     'nof_frame_rays': ([C.POINTER(NofFrameRaysCfg), _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _P, _P, _P], C.c_int),
     'nof_cloud_filter': ([_P, _I64, _P, _P, _P, _I64, C.c_double, C.c_double, _P], C.c_int),
     'nof_compact_rows': ([_P, _P, _P, _I64, _P, _P], C.c_int),
+    'nof_bary_uv': ([_P, _P, _P, _P, _P, _I64, _P, _P], C.c_int),
     'nof_mfma_probe': ([_I32, _P, _P, _P, _I32, _P], C.c_int),
     'nof_atomic_probe': ([_I32, _P, _P, _I64, _P], C.c_int),
 }

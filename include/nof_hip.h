@@ -207,6 +207,12 @@ int nof_mt_emit(const float* vol, int32_t nx, int32_t ny, int32_t nz, float iso,
 int nof_mt_vertices(const float* vol, int32_t nx, int32_t ny, int32_t nz, float iso, const int64_t* keys, int64_t V,
                     double* verts, void* stream);
 
+/* ---- texture bake helper (replaces common.rayColorToTextureImageCUDA, mycuda/common.h:30, common.cu:171-238) ----------
+ * faces [nf,3] int64, verts [nv,3] f32, hit_locations [n,3] f32 (points on the mesh), hit_face_ids [n] int64,
+ * uvs_tex [nv,2] f32 per-vertex texture coordinates -> uvs [n,2]: barycentric blend of the hit triangle's uvs. */
+int nof_bary_uv(const int64_t* faces, const float* verts, const float* hit_locations, const int64_t* hit_face_ids,
+                const float* uvs_tex, int64_t n_hits, float* uvs, void* stream);
+
 /* ---- compositing + losses + dL/draw (raw2outputs, train_loop, get_sdf_loss) ---------------------- */
 typedef struct {
   float trunc, neg_trunc_ratio, sdf_lambda;

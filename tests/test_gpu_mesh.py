@@ -103,3 +103,29 @@ def test_extract_mesh_sphere_end_to_end(nof):
     assert len(np.unique(key)) == len(key) and np.isin(rkey, key).all()
     nrm = np.cross(p[f[:, 1]] - p[f[:, 0]], p[f[:, 2]] - p[f[:, 0]])
     assert ((nrm * p[f].mean(1)).sum(1) > 0).mean() > 0.999
+
+
+def test_bary_uv_matches_numpy(nof):
+    """common.rayColorToTextureImageCUDA's arithmetic (common.cu:171-216) restated in NumPy float64: points sampled inside
+    random triangles must get the barycentric blend of the triangle's texture coordinates."""
+    rng = np.random.default_rng(4)
+    nv, nf, n = 500, 900, 20000
+    V = rng.normal(size=(nv, 3)).astype(np.float32)
+    F = np.stack([rng.permutation(nv)[:3] for _ in range(nf)]).astype(np.int64)
+    uv = rng.random((nv, 2)).astype(np.float32)
+    fid = rng.integers(0, nf, size=n).astype(np.int64)
+    w = rng.dirichlet([1, 1, 1], size=n)
+    tri = V[F[fid]].astype(np.float64)                               # [n,3,3]
+    P = (w[:, :, None] * tri).sum(1).astype(np.float32)
+    out = torch.zeros(n, 2, device='cuda')
+    nof.call('nof_bary_uv', U.dev(F), U.dev(V), U.dev(P), U.dev(fid), U.dev(uv), n, out)
+    A, B, Cc = tri[:, 0], tri[:, 1], tri[:, 2]
+    p = P.astype(np.float64)
+    nrm = np.cross(B - Cc, B - A)
+    area = (nrm * np.cross(B - A, Cc - A)).sum(1)
+    w0 = (nrm * np.cross(B - p, Cc - p)).sum(1) / area
+    w1 = (nrm * np.cross(Cc - p, A - p)).sum(1) / area
+    ww = np.stack([w0, w1, 1 - w0 - w1], 1)
+    ref = (ww[:, :, None] * uv[F[fid]].astype(np.float64)).sum(1)
+    assert np.abs(ww - w).max() < 1e-4                                # the restatement recovers the sampling weights
+    assert np.abs(out.cpu().numpy() - ref).max() < 2e-4
