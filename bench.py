@@ -256,7 +256,7 @@ def main():
             "loss": losses['loss'], "flags": flags, "dp_param_checksum_spread": dp_spread, "param_checksum": checksum,
             "roofline": roof,
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:          # the CPU leg is timed on rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
         print(json.dumps(out), flush=True)
     if dist.is_initialized():
