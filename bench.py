@@ -241,11 +241,14 @@ def main():
         elif dominant:
             roof = {"kernel": dominant, "bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None,
                     "traffic": None, "avg_ms": dom_ms}
+        shape_key = (args.keyframes, R, args.log2_T, args.mlp, args.width, args.height)
+        cfg_name = {(64, 4096, 19, 'baseline', 640, 480): 'cfg2' if world == 1 else 'cfg3',
+                    (4, 1024, 14, 'reference', 640, 480): 'cfg1 shapes'}.get(shape_key, 'custom')
         out = {
             "metric": "ray_samples_per_sec", "value": value, "unit": "ray-samples/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.precision, "data": "synthetic",
-            "config": {"workload": f"cfg2: {args.keyframes} synthetic {args.width}x{args.height} RGBD keyframes per GPU, "
+            "config": {"workload": f"{cfg_name}: {args.keyframes} synthetic {args.width}x{args.height} RGBD keyframes per GPU, "
                                    f"{R} rays/step x {S} samples, hash L=16 T=2^{args.log2_T} base16->256, "
                                    f"MLP {'SDF 3x64 + colour 2x64' if args.mlp == 'baseline' else 'SDF 2x64 + colour 3x64'}, "
                                    f"{args.precision} MFMA, fp32 table/Adam",
