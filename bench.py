@@ -67,9 +67,11 @@ def build_runner(args, rank, world, device):
     return runner, cfg
 
 
-def cpu_baseline(seconds=20.0):
-    """The oracle (CPU PyTorch fp32 restatement of nerf_runner's step) on BASELINE.json configs[0]: 4 keyframes
-    640x480, 1024 rays/step, L=16 T=2^14, MLP 2x64 -- timed on this box's host cores."""
+def cpu_baseline(seconds=20.0, rays_per_step=4096, log2_T=19, mlp='baseline'):
+    """The oracle (CPU PyTorch fp32 restatement of nerf_runner's step = "nerf_runner's CPU PyTorch path": the reference itself
+    has none) on the SAME step as the GPU workload -- same rays per step, samples per ray, hash grid and MLP shape -- for a
+    bounded number of steps on this box's host cores.  The pool holds 4 keyframes instead of 64: the cost of a step does not
+    depend on how many rows the ray table has."""
     from bundlesdf_amd import synthetic
     from bundlesdf_amd.config import default_cfg
     from bundlesdf_amd.rays import make_frame_rays
@@ -80,7 +82,7 @@ def cpu_baseline(seconds=20.0):
     torch.set_num_threads(ncores)
     log(f'cpu_baseline: {ncores} threads of {os.cpu_count()} cores')
     pool = synthetic.make_pool(n_frames=4, H=480, W=640, seed=0, analytic_bounds=True)
-    cfg = default_cfg(n_step=500, N_rand=1024, num_levels=16, log2_hashmap_size=14, finest_res=256, base_res=16,
+    cfg = default_cfg(n_step=500, N_rand=rays_per_step, num_levels=16, log2_hashmap_size=log2_T, finest_res=256, base_res=16,
                       N_samples=128, N_samples_around_depth=64, far=1.0, sc_factor=pool['sc_factor'],
                       translation=pool['translation'], use_octree=1)
     occ, occ_l, max_level, level = O.build_occupancy(pool['pcd_normalized'], cfg)
@@ -90,7 +92,7 @@ def cpu_baseline(seconds=20.0):
     rows = []
     for f in range(4):
         r = make_frame_rays(f, pool['rgbs'][f], pool['depths'][f], pool['masks'][f], pool['poses'][f], pool['K'], cfg)
-        sel = np.random.default_rng(f).choice(len(r), size=min(len(r), 4096), replace=False)
+        sel = np.random.default_rng(f).choice(len(r), size=min(len(r), 2 * rays_per_step), replace=False)
         r = r[sel]
         o = np.tile(pool['poses'][f][:3, 3], (len(r), 1)).astype(np.float32)
         unit = r[:, :3] / np.linalg.norm(r[:, :3], axis=-1, keepdims=True)
@@ -98,10 +100,11 @@ def cpu_baseline(seconds=20.0):
         rows.append(r[trace_fn(o, d)])
     rays = np.concatenate(rows, 0).astype(np.float32)
     torch.manual_seed(0)
-    geo = O.HashGeometry(16, 2, 16, 14, 256)
-    field = O.OracleField(cfg, geo, O.FieldShape(), 4, pool['poses'], occ_l)
+    geo = O.HashGeometry(16, 2, 16, log2_T, 256)
+    ns, nc = (3, 2) if mlp == 'baseline' else (2, 3)
+    field = O.OracleField(cfg, geo, O.FieldShape(num_layers=ns, num_layers_color=nc), 4, pool['poses'], occ_l)
     rng = np.random.default_rng(0)
-    R, S = 1024, 192
+    R, S = rays_per_step, 192
     times = []
     t_start = time.time()
     it = 0
@@ -120,8 +123,9 @@ def cpu_baseline(seconds=20.0):
     med = float(np.median(times))
     return {"value": R * S / med, "unit": "ray-samples/s", "cores": ncores, "kind": "port",
             "iters_per_s": 1.0 / med,
-            "sample": f"{len(times)} timed steps (1 warm-up) of oracle/nof_oracle.py OracleField.train_step, cfg1: 4 keyframes "
-                      f"640x480, 1024 rays x 192 samples, L=16 T=2^14, MLP 2x64+3x64 fp32, torch threads={ncores}"}
+            "sample": f"{len(times)} timed steps (1 warm-up) of oracle/nof_oracle.py OracleField.train_step on the workload's own "
+                      f"step: {R} rays x {S} samples, L=16 T=2^{log2_T}, MLP SDF {ns}x64 + colour {nc}x64, fp32, rays of 4 "
+                      f"keyframes 640x480, torch threads={ncores}"}
 
 
 def main():
@@ -138,7 +142,7 @@ def main():
     ap.add_argument('--mlp', default='baseline', choices=['baseline', 'reference'],
                     help='baseline: SDF 3x64 + colour 2x64 (BASELINE.json cfg2); reference: NeRFSmall(2,3) nerf_runner.py:221')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cpu-seconds', type=float, default=20.0)
+    ap.add_argument('--cpu-seconds', type=float, default=25.0)
     args = ap.parse_args()
 
     import torch.distributed as dist
@@ -260,7 +264,7 @@ def main():
             "roofline": roof,
         }
         if not args.no_cpu_baseline and world == 1:          # the CPU leg is timed on rank 0 at N = 1 only
-            out["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
+            out["cpu_baseline"] = cpu_baseline(args.cpu_seconds, R, args.log2_T, args.mlp)
         print(json.dumps(out), flush=True)
     if dist.is_initialized():
         dist.barrier()
