@@ -306,11 +306,16 @@ NofMlpDesc d, const char* __restrict__ image,
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int hi = lane >> 5, j = lane & 31;
   const int64_t ntiles = (B + 31) / 32;
-  for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < ntiles; tile += (int64_t)gridDim.x * 4) {
+  const int64_t tstride = (int64_t)gridDim.x * 4;
+  float xn[1][16];                                    // the NEXT tile's features: loaded a whole tile ahead (latency hidden)
+  load_feat_o1(feat, L, B, ((int64_t)blockIdx.x * 4 + wave) * 32 + j, hi, xn);
+  for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < ntiles; tile += tstride) {
     asm volatile("" ::: "memory");                    // keep the weight fragments in LDS (no hoisting into VGPRs)
     const int64_t b = tile * 32 + j;
     float x[1][16];
-    load_feat_o1(feat, L, B, b, hi, x);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) x[0][r] = xn[0][r];
+    load_feat_o1(feat, L, B, (tile + tstride) * 32 + j, hi, xn);      // out-of-range tiles load nothing (b >= B -> zeros)
     float h[2][16], so[1][16];
     dense_o1<P, 1, 2>(smem, FW_OFF(0), BIAS_OFF(0), x, h, lane);
     relu_mask<2>(h);
