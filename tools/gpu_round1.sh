@@ -3,7 +3,7 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
 R=$GRAFT_REPO_ROOT
-timeout 500 python -m pytest tests/test_gpu_ops.py tests/test_gpu_step.py tests/test_gpu_mesh.py tests/test_gpu_fullsize.py tests/test_gpu_rays.py -m gpu -q > gpurun_out/tests.log 2>&1
+timeout 500 python -m pytest tests/test_gpu_ops.py tests/test_gpu_step.py tests/test_gpu_mesh.py tests/test_gpu_fullsize.py tests/test_gpu_rays.py tests/test_gpu_dp.py -m gpu -q > gpurun_out/tests.log 2>&1
 tail -4 gpurun_out/tests.log | cut -c1-300
 if [ "$RUNNER" = "1" ]; then timeout 400 python -m pytest tests/test_gpu_runner.py -m gpu -q -x -s > gpurun_out/tests_runner.log 2>&1; grep -E "runner losses|pose translation|Chamfer|passed|failed|^E  " gpurun_out/tests_runner.log | head -12 | cut -c1-400; fi
 timeout 200 python __graft_entry__.py smoke > gpurun_out/smoke.log 2>&1; tail -1 gpurun_out/smoke.log

@@ -1,0 +1,29 @@
+"""profiles/pmc_traffic.json from the FETCH_SIZE / WRITE_SIZE passes of tools/gpu_pmc.sh (run on the GPU box, where the
+rocprofv3 databases are): HBM-side bytes per launch of every C-ABI entry point bench.py can name as dominant."""
+import glob, json, sqlite3, sys
+
+out_path = sys.argv[1] if len(sys.argv) > 1 else 'gpurun_out/pmc_traffic.json'
+
+
+def per_kernel(dbdir, counter):
+    db = glob.glob(f'gpurun_out/{dbdir}/*.db')[0]
+    rows = sqlite3.connect(db).execute(
+        "select name, avg(counter_value) from pmc_events where counter_name=? group by name", (counter,)).fetchall()
+    return {r[0].split('(')[0].replace('void ', ''): r[1] for r in rows}
+
+
+fetch, write = per_kernel('pmc_fetch', 'FETCH_SIZE'), per_kernel('pmc_write', 'WRITE_SIZE')
+groups = {'nof_hash_encode_bwd': ['k_hash_bwd_agg', 'k_hash_dx', 'k_hash_bwd_lds'], 'nof_hash_encode_fwd': ['k_hash_fwd'],
+          'nof_mlp_bwd': ['k_mlp_bwd_color<PrecBF16, 3, 2>', 'k_mlp_bwd_sigma<PrecBF16, 3, 2>'],
+          'nof_mlp_fwd': ['k_mlp_fwd<PrecBF16, 3, 2, false>'], 'nof_adam_step': ['k_adam']}
+out = {'_note': 'HBM-side bytes per launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, KiB * 1024), cfg2 batch '
+                '(4096 rays x 192 samples, L=16, T=2^19), summed over the kernels of each C-ABI entry point. RAW counter values: '
+                'on gfx950 FETCH_SIZE under-reports wide coalesced streaming reads by 2x (MI355X_MICROARCH.md, HBM section); for '
+                '8-byte gathers and atomics it is uncalibrated. Source: the pmc_counters file of the same round in profiles/',
+       'workload': 'cfg2-bf16-baseline'}
+for k, names in groups.items():
+    f = sum(fetch.get(n, 0) for n in names) * 1024
+    w = sum(write.get(n, 0) for n in names) * 1024
+    out[k] = {'fetch_bytes': f, 'write_bytes': w, 'traffic_bytes': f + w}
+json.dump(out, open(out_path, 'w'), indent=1)
+print(json.dumps({k: v['traffic_bytes'] for k, v in out.items() if isinstance(v, dict)}))
