@@ -1,0 +1,148 @@
+"""Host-side logic of the product that needs no GPU: the level table handed to the kernels, the MLP descriptor / parameter
+layout, configuration validation, schedules, the NumPy ray-pool helpers and the mesh container."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from bundlesdf_amd import lib
+from bundlesdf_amd.config import default_cfg, validate_cfg
+from oracle import nof_oracle as O
+
+
+@pytest.mark.parametrize("L,T,base,finest", [(16, 19, 16, 256), (16, 14, 16, 256), (16, 22, 16, 512), (4, 22, 16, 128),
+                                              (8, 14, 16, 128), (16, 19, 16, 512)])
+def test_level_table_matches_oracle_and_reference_rule(L, T, base, finest):
+    """grid.py:110,127-134 (allocation, float64) + gridencoder.cu:154-156 (indexing constants, float32): the struct the
+    kernels receive and the oracle's geometry must be the same numbers, bit for bit."""
+    g, offsets, n, pls = lib.make_hash_grid(L, 2, base, T, finest)
+    geo = O.HashGeometry(n_levels=L, level_dim=2, base_resolution=base, log2_hashmap_size=T, desired_resolution=finest)
+    assert n == geo.n_entries and np.array_equal(offsets, geo.offsets)
+    for l in range(L):
+        assert np.float32(g.scale[l]) == geo.scale[l] and g.resolution[l] == geo.resolution[l]
+        assert g.size[l] == geo.size[l] and g.offset[l] == geo.offsets[l] and bool(g.hashed[l]) == bool(geo.hashed[l])
+        assert g.size[l] % 8 == 0 and g.size[l] <= 2 ** T
+        if g.hashed[l]:
+            assert g.size[l] == 2 ** T                    # the kernels mask instead of dividing for hashed levels
+    # the documented cfg2 / cfg5 table sizes
+    if (L, T, finest) == (16, 19, 256):
+        assert n == 4555440
+    if (L, T, finest) == (16, 22, 512):
+        assert n == 29580312
+
+
+@pytest.mark.parametrize("ns,nc,ff", [(2, 3, 0), (3, 2, 2), (2, 2, 0), (3, 3, 4)])
+def test_mlp_descriptor_is_pytorch_parameter_order(ns, nc, ff):
+    """NeRFSmall.parameters() order: sigma_net W,b per layer, then color_net W,b (nerf_helpers.py:243-321)."""
+    n_view = 9 + ff
+    desc, dims = lib.make_mlp_desc(ns, nc, 32, n_view, 1)
+    shape = O.FieldShape(input_ch=32, input_ch_views=n_view, num_layers=ns, num_layers_color=nc)
+    s, c = shape.layer_dims()
+    assert [tuple(d) for d in dims] == [tuple(x) for x in list(s) + list(c)]
+    off = 0
+    for l, (o, i) in enumerate(dims):
+        assert desc.w_off[l] == off and desc.out_dim[l] == o and desc.in_dim[l] == i
+        off += o * i
+        assert desc.b_off[l] == off
+        off += o
+    assert desc.n_params == off == shape.n_params()
+    assert dims[ns - 1][0] == 16 and dims[-1][0] == 3 and dims[ns][1] == n_view + 15
+
+
+def test_unsupported_configuration_is_rejected_loudly():
+    validate_cfg(default_cfg())
+    for key, val in (('eikonal_weight', 0.1), ('depth_weight', 1.0), ('N_importance', 64), ('N_samples_around_depth', 0),
+                     ('use_viewdirs', 0), ('raw_noise_std', 1.0), ('pose_reg_weight', 0.1), ('feature_grid_dim', 4)):
+        with pytest.raises(NotImplementedError, match=key.split('_')[0]):
+            validate_cfg(default_cfg(**{key: val}))
+
+
+def test_runner_needs_the_gpu_and_the_library():
+    """no CPU fallback: constructing the runner without an MI355X is an error, not a slow path"""
+    if torch.cuda.is_available():
+        pytest.skip('a GPU is present')
+    from bundlesdf_amd.nerf_runner import NerfRunner
+    from bundlesdf_amd import synthetic
+    pool = synthetic.make_pool(n_frames=1, H=24, W=32, fx=30.0, seed=0, pose_noise=False)
+    cfg = default_cfg(sc_factor=pool['sc_factor'], translation=pool['translation'])
+    with pytest.raises(lib.NofError, match='no CPU'):
+        NerfRunner(cfg, pool['rgbs'], depths=pool['depths'], masks=pool['masks'], normal_maps=None, poses=pool['poses'],
+                   K=pool['K'], build_octree_pcd=synthetic.PointCloud(pool['pcd_normalized']))
+
+
+def test_dilate_mask_window_convention():
+    """cv2.dilate with an even k x k kernel anchors at k//2: window offsets -k//2 .. k-1-k//2 (nerf_runner.py:275-283 uses
+    100 and 60); checked against a brute-force loop on an asymmetric mask."""
+    from bundlesdf_amd.rays import dilate_mask
+    rng = np.random.default_rng(0)
+    m = (rng.random((23, 31)) < 0.03).astype(np.uint8)
+    for k in (2, 3, 6, 9):
+        ref = np.zeros_like(m)
+        lo, hi = -(k // 2), k - 1 - k // 2
+        for v in range(m.shape[0]):
+            for u in range(m.shape[1]):
+                v0, v1 = max(v + lo, 0), min(v + hi, m.shape[0] - 1)
+                u0, u1 = max(u + lo, 0), min(u + hi, m.shape[1] - 1)
+                ref[v, u] = m[v0:v1 + 1, u0:u1 + 1].max()
+        assert np.array_equal(dilate_mask(m, k), ref), k
+    assert np.array_equal(dilate_mask(m, 1), m)
+
+
+def test_data_loader_epochs():
+    """nerf_runner.py:90-107: consecutive slices of one permutation; a new permutation when fewer than batch+1 ids remain"""
+    from bundlesdf_amd.rays import DataLoader
+    torch.manual_seed(0)
+    rays = torch.arange(10 * 12, dtype=torch.float32).reshape(10, 12)
+    dl = DataLoader(rays, batch_size=4)
+    first = dl.ids.clone()
+    a, b = dl.next_ids(), dl.next_ids()
+    assert torch.equal(a, first[:4]) and torch.equal(b, first[4:8])
+    c = dl.next_ids()                                    # 2 left < 4 + 1 -> reshuffle, the tail is dropped
+    assert dl.pos == 4 and torch.equal(c, dl.ids[:4]) and sorted(dl.ids.tolist()) == list(range(10))
+    assert torch.equal(next(dl), rays[dl.batch_ray_ids])
+
+
+def test_learning_rate_and_truncation_schedules():
+    """schedule_lr every 10 steps after step 0 (nerf_runner.py:579-583,762-763); get_truncation (:663-676)"""
+    from bundlesdf_amd.field import NeuralObjectField
+
+    class Stub:
+        learning_rates = NeuralObjectField.learning_rates
+        truncation = NeuralObjectField.truncation
+    s = Stub()
+    s.cfg = default_cfg(n_step=100, lrate=0.01, lrate_pose=0.02, decay_rate=0.1, trunc=0.01, trunc_start=0.04, sc_factor=2.0)
+    s.N_iters = 101
+    for step, g in ((0, 0), (10, 0), (11, 10), (20, 10), (21, 20), (100, 90)):
+        s.global_step = step
+        k = 1.0 if g == 0 else 0.1 ** (g / 101)
+        lr, lrp = s.learning_rates()
+        assert abs(lr - 0.01 * k) < 1e-12 and abs(lrp - 0.02 * k) < 1e-12, step
+    s.global_step = 50
+    assert s.truncation() == pytest.approx(0.01 * 2.0)
+    s.cfg['trunc_decay_type'] = 'linear'
+    assert s.truncation() == pytest.approx((0.04 - 0.03 * 0.5) * 2.0)
+    s.cfg['trunc_decay_type'] = 'exp'
+    lamb = np.log(0.01 / 0.04) / 25
+    assert s.truncation() == pytest.approx(max(0.04 * np.exp(50 * lamb), 0.01) * 2.0)
+
+
+def test_mesh_container_operations(tmp_path):
+    from bundlesdf_amd.mesh import Mesh, largest_component
+    v = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0], [0, 0, 1], [5, 5, 5], [6, 5, 5], [5, 6, 5]], dtype=np.float64)
+    f = np.array([[0, 1, 2], [0, 1, 3], [0, 2, 3], [1, 2, 3], [4, 5, 6]])
+    m = Mesh(v, f)
+    big = largest_component(m)
+    assert len(big.faces) == 4 and len(big.vertices) == 4
+    T = np.eye(4)
+    T[:3, 3] = [1, 2, 3]
+    m2 = m.copy().apply_transform(T)
+    assert np.allclose(m2.vertices, v + [1, 2, 3]) and np.allclose(m.vertices, v)
+    for ext in ('obj', 'ply'):
+        p = m.export(str(tmp_path / f'm.{ext}'))
+        txt = open(p).read()
+        assert ('f 1 2 3' in txt) if ext == 'obj' else ('element face 5' in txt)
+    dup = Mesh(np.concatenate([v, v[:1]]), np.concatenate([f, [[7, 1, 2]]]))
+    dup.merge_vertices()
+    dup.remove_duplicate_faces()
+    assert len(dup.vertices) == 7 and len(dup.faces) == 5
