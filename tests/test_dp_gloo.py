@@ -58,7 +58,16 @@ def _worker(rank, world, port, R, out):
     flat = torch.cat([g.reshape(-1) for g in res['grads']]) / world          # NofLossCfg.grad_scale = 1/world
     sync = D.make_grad_sync()
     assert sync is not None
-    sync(flat)
+    bucketed = flat.clone()
+    sync(flat)                                           # one blocking all-reduce of the whole buffer
+    # the bucketed asynchronous form the device step uses (three slices, the middle one first): same bits
+    a, b = flat.numel() // 3, 2 * flat.numel() // 3
+    sync.start(bucketed[a:b])
+    sync.start(bucketed[:a])
+    sync.start(bucketed[b:])
+    sync.start(bucketed[:0])                             # empty slices are skipped
+    sync.finish()
+    assert not sync.pending and torch.equal(bucketed, flat)
     if rank == 0:
         out.put(flat.numpy())
     dist.barrier()
