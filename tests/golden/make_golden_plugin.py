@@ -1,0 +1,112 @@
+"""Golden vectors for the plugin-surface helpers the tracking loop calls around the Neural Object Field
+(bundlesdf.py:148-170,231-235): the reference's OWN functions are cut out of the read-only mount with `ast` and executed on
+CPU (pure NumPy, no CUDA):
+
+    preprocess_data                       nerf_helpers.py:218-240
+    get_optimized_poses_in_real_world     Utils.py:479-505
+    mesh_to_real_world                    Utils.py:508-514
+    glcam_in_cvcam, BAD_DEPTH, BAD_COLOR  Utils.py:34-40
+
+Run here (needs /root/reference):  python tests/golden/make_golden_plugin.py  ->  tests/golden/plugin_vectors.npz
+The fixture travels; the generator does not need to."""
+import ast
+import os
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF = '/root/reference'
+
+
+def cut(path, names):
+    src = open(os.path.join(REF, path)).read()
+    tree = ast.parse(src)
+    out = []
+    for n in tree.body:
+        if isinstance(n, ast.FunctionDef) and n.name in names:
+            out.append('\n'.join(src.splitlines()[n.lineno - 1:n.end_lineno]))
+    assert len(out) == len(names), (path, names)
+    return out
+
+
+def constants(path, names):
+    """top-level `NAME = <literal expression>` assignments"""
+    src = open(os.path.join(REF, path)).read()
+    out = {}
+    for n in ast.parse(src).body:
+        if isinstance(n, ast.Assign) and len(n.targets) == 1 and isinstance(n.targets[0], ast.Name) and n.targets[0].id in names:
+            out[n.targets[0].id] = '\n'.join(src.splitlines()[n.lineno - 1:n.end_lineno])
+    assert set(out) == set(names), (path, names, list(out))
+    return out
+
+
+class PoseStub:
+    """stands in for PoseArray: get_matrices(ids) -> torch [n,4,4] (nerf_helpers.py:143-154)"""
+
+    def __init__(self, mats):
+        self.mats = torch.as_tensor(mats)
+
+    def get_matrices(self, ids):
+        return self.mats[torch.as_tensor(ids).long()]
+
+
+class MeshStub:
+    def __init__(self, v):
+        self.vertices = v
+
+    def apply_transform(self, T):
+        self.vertices = self.vertices @ T[:3, :3].T + T[:3, 3]
+
+
+def main():
+    ns = {'np': np, 'torch': torch}
+    for code in constants('Utils.py', ['BAD_DEPTH', 'BAD_COLOR', 'glcam_in_cvcam']).values():
+        exec(code, ns)
+    for code in cut('nerf_helpers.py', ['preprocess_data']) + cut('Utils.py', ['get_optimized_poses_in_real_world', 'mesh_to_real_world']):
+        exec(code, ns)
+    rng = np.random.default_rng(0)
+    out = {'BAD_DEPTH': np.float64(ns['BAD_DEPTH']), 'BAD_COLOR': np.asarray(ns['BAD_COLOR'], dtype=np.float64),
+           'glcam_in_cvcam': np.asarray(ns['glcam_in_cvcam'], dtype=np.float64)}
+    # ---- preprocess_data ----
+    N, H, W = 3, 6, 8
+    rgbs = rng.integers(0, 256, size=(N, H, W, 3)).astype(np.float32)
+    depths = rng.uniform(0.0, 1.5, size=(N, H, W)).astype(np.float32)
+    depths[0, 0, :3] = 0.05                                   # below the 0.1 m validity threshold
+    masks = (rng.random((N, H, W)) < 0.7).astype(np.uint8)
+    normals = rng.normal(size=(N, H, W, 3)).astype(np.float32)
+    poses = np.tile(np.eye(4), (N, 1, 1))
+    poses[:, :3, 3] = rng.normal(size=(N, 3))
+    sc, tr = 3.7, np.array([0.01, -0.02, 0.3])
+    out.update(pp_rgbs=rgbs.copy(), pp_depths=depths.copy(), pp_masks=masks.copy(), pp_normals=normals.copy(), pp_poses=poses.copy(),
+               pp_sc=np.float64(sc), pp_tr=tr)
+    r = ns['preprocess_data'](rgbs.copy(), depths.copy(), masks.copy(), normals.copy(), poses.copy(), sc, tr)
+    for k, v in zip(('rgbs', 'depths', 'masks', 'normals', 'poses'), r):
+        out['pp_out_' + k] = np.asarray(v)
+    # ---- get_optimized_poses_in_real_world ----
+    F = 5
+    pn = np.tile(np.eye(4), (F, 1, 1))
+    for i in range(F):
+        w = rng.normal(size=3)
+        w /= np.linalg.norm(w)
+        th = rng.uniform(0, 1.0)
+        Kx = np.array([[0, -w[2], w[1]], [w[2], 0, -w[0]], [-w[1], w[0], 0]])
+        pn[i, :3, :3] = np.eye(3) + np.sin(th) * Kx + (1 - np.cos(th)) * Kx @ Kx
+        pn[i, :3, 3] = rng.uniform(-0.6, 0.6, 3)
+    delta = np.tile(np.eye(4), (F, 1, 1)).astype(np.float32)
+    delta[1:, :3, 3] = rng.uniform(-0.02, 0.02, (F - 1, 3))
+    for i in range(1, F):
+        a = rng.uniform(-0.05, 0.05)
+        delta[i, :2, :2] = [[np.cos(a), -np.sin(a)], [np.sin(a), np.cos(a)]]
+    opt, offset = ns['get_optimized_poses_in_real_world'](pn.copy(), PoseStub(delta), sc, tr)
+    out.update(gp_poses=pn, gp_delta=delta, gp_out=np.asarray(opt), gp_offset=np.asarray(offset))
+    # ---- mesh_to_real_world ----
+    V = rng.normal(size=(50, 3))
+    m = ns['mesh_to_real_world'](MeshStub(V.copy()), np.asarray(offset, dtype=np.float64), tr, sc)
+    out.update(mw_v=V, mw_out=np.asarray(m.vertices))
+    np.savez_compressed(os.path.join(HERE, 'plugin_vectors.npz'), **out)
+    print('wrote', len(out), 'arrays')
+
+
+if __name__ == '__main__':
+    main()

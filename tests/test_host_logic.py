@@ -146,3 +146,44 @@ def test_mesh_container_operations(tmp_path):
     dup.merge_vertices()
     dup.remove_duplicate_faces()
     assert len(dup.vertices) == 7 and len(dup.faces) == 5
+
+
+# ---- plugin-surface helpers pinned against the reference's own code (tests/golden/make_golden_plugin.py) ----------------
+def _plugin_golden():
+    import os
+    return np.load(os.path.join(os.path.dirname(__file__), 'golden', 'plugin_vectors.npz'))
+
+
+def test_constants_match_reference():
+    from bundlesdf_amd import nerf_helpers as H
+    g = _plugin_golden()
+    assert H.BAD_DEPTH == float(g['BAD_DEPTH']) and np.array_equal(np.asarray(H.BAD_COLOR, dtype=np.float64), g['BAD_COLOR'])
+    assert np.array_equal(np.asarray(H.glcam_in_cvcam, dtype=np.float64), g['glcam_in_cvcam'])
+
+
+def test_preprocess_data_matches_reference():
+    from bundlesdf_amd.nerf_helpers import preprocess_data
+    g = _plugin_golden()
+    r = preprocess_data(g['pp_rgbs'].copy(), g['pp_depths'].copy(), g['pp_masks'].copy(), g['pp_normals'].copy(),
+                        g['pp_poses'].copy(), float(g['pp_sc']), g['pp_tr'])
+    for k, v in zip(('rgbs', 'depths', 'masks', 'normals', 'poses'), r):
+        ref = g['pp_out_' + k]
+        assert np.asarray(v).shape == ref.shape and np.asarray(v).dtype == ref.dtype, k
+        assert np.array_equal(np.asarray(v), ref), k
+
+
+def test_pose_hand_back_and_mesh_to_real_world_match_reference():
+    """bundlesdf.py:231-235: optimised poses back in real-world OpenCV convention, mesh back to metres"""
+    from bundlesdf_amd.nerf_helpers import get_optimized_poses_in_real_world, mesh_to_real_world
+    from bundlesdf_amd.mesh import Mesh
+    g = _plugin_golden()
+
+    class Poses:
+        def get_matrices(self, ids):
+            return torch.as_tensor(g['gp_delta'])[torch.as_tensor(ids).long()]
+    opt, offset = get_optimized_poses_in_real_world(g['gp_poses'].copy(), Poses(), float(g['pp_sc']), g['pp_tr'])
+    assert opt.dtype == g['gp_out'].dtype and np.array_equal(opt, g['gp_out'])
+    assert np.array_equal(np.asarray(offset), g['gp_offset'])
+    m = mesh_to_real_world(Mesh(g['mw_v'].copy(), np.zeros((0, 3), dtype=np.int64)), np.asarray(offset, dtype=np.float64),
+                           g['pp_tr'], float(g['pp_sc']))
+    assert np.allclose(np.asarray(m.vertices), g['mw_out'], rtol=0, atol=1e-12)
