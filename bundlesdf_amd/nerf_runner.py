@@ -26,7 +26,7 @@ from .mesh_gpu import marching_tetrahedra_gpu
 from .mesh import make_mesh, marching_tetrahedra
 from .nerf_helpers import *          # noqa: F401,F403  (re-exported on purpose, like the reference module does)
 from .nerf_helpers import set_seed, get_optimized_poses_in_real_world, mesh_to_real_world
-from .rays import DataLoader, denoise_rays, make_frame_rays
+from .rays import DataLoader, denoise_rays, make_frame_rays, octree_cells
 from .rays_gpu import frame_rays_device
 
 __all__ = ['NerfRunner', 'PoseArrayView', 'preprocess_data', 'get_optimized_poses_in_real_world', 'mesh_to_real_world',
@@ -136,23 +136,7 @@ class NerfRunner:
         """nerf_runner.py:436-489: occupied cells = 27-neighbour dilation of the cloud's cells at max_level; the ray
         tracing level is floor(log2(2/(octree_raytracing_voxel_size*sc)))."""
         cfg = self.cfg
-        sv = cfg['octree_smallest_voxel_size'] * cfg['sc_factor']
-        max_level = int(np.ceil(np.log2(2.0 / sv)))
-        vs = 2.0 / (2 ** max_level)
-        radius = max(1, int(np.ceil(cfg['octree_dilate_size'] / cfg['octree_smallest_voxel_size'])))
-        logging.info(f"Octree voxel dilate_radius:{radius}")
-        pts = np.asarray(self.build_octree_pts, dtype=np.float32)
-        assert pts.min() >= -1 and pts.max() <= 1
-        coords = np.floor((pts + 1) / np.float32(vs)).astype(np.int64)
-        shifts = np.array([[dx, dy, dz] for dx in (-1, 0, 1) for dy in (-1, 0, 1) for dz in (-1, 0, 1)], dtype=np.int64)
-        for _ in range(radius):
-            coords = np.unique((coords[None] + shifts[:, None]).reshape(-1, 3), axis=0)
-        # centres are clipped to [-1,1] and re-quantised (kaolin quantize_points clamps to [0, 2^l - 1])
-        n = 2 ** max_level
-        centres = np.clip(((coords + 0.5) * vs - 1).astype(np.float32), -1, 1)
-        q = np.floor(np.clip(n * (centres + 1.0) / 2.0, 0, n - 1.0)).astype(np.int32)
-        rv = cfg['octree_raytracing_voxel_size'] * cfg['sc_factor']
-        level = int(np.floor(np.log2(2.0 / rv)))
+        q, centres, max_level, level = octree_cells(self.build_octree_pts, cfg)
         self.octree_levels = (max_level, level)
         self.field.set_occupancy(q, max_level, level)
         if cfg.get('save_octree_clouds', False) and cfg.get('save_dir'):

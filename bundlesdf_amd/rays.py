@@ -97,6 +97,30 @@ def denoise_rays(rays, poses, cloud_pts, cfg):
     return rays[rays[:, RAY_TYPE] == 0]
 
 
+def octree_cells(points, cfg):
+    """build_octree's host arithmetic (nerf_runner.py:443-476): occupied cells at max_level = 27-neighbour dilation of the
+    cloud's cells, `radius` times; centres clipped to [-1,1] and re-quantised the way kaolin's quantize_points does
+    (floor(clamp(n (x+1)/2, 0, n-1))).  Returns (cells [P,3] int32 at max_level, centres [P,3] float32 = the points the
+    reference hands to OctreeManager, max_level, ray-tracing level)."""
+    sv = cfg['octree_smallest_voxel_size'] * cfg['sc_factor']
+    max_level = int(np.ceil(np.log2(2.0 / sv)))
+    vs = 2.0 / (2 ** max_level)
+    radius = max(1, int(np.ceil(cfg['octree_dilate_size'] / cfg['octree_smallest_voxel_size'])))
+    logging.info(f"Octree voxel dilate_radius:{radius}")
+    pts = np.asarray(points, dtype=np.float32)
+    assert pts.min() >= -1 and pts.max() <= 1
+    coords = np.floor((pts + 1) / np.float32(vs)).astype(np.int64)
+    shifts = np.array([[dx, dy, dz] for dx in (-1, 0, 1) for dy in (-1, 0, 1) for dz in (-1, 0, 1)], dtype=np.int64)
+    for _ in range(radius):
+        coords = np.unique((coords[None] + shifts[:, None]).reshape(-1, 3), axis=0)
+    n = 2 ** max_level
+    centres = np.clip(((coords + 0.5) * vs - 1).astype(np.float32), -1, 1)
+    q = np.floor(np.clip(n * (centres + 1.0) / 2.0, 0, n - 1.0)).astype(np.int32)
+    rv = cfg['octree_raytracing_voxel_size'] * cfg['sc_factor']
+    level = int(np.floor(np.log2(2.0 / rv)))
+    return q, centres, max_level, level
+
+
 class DataLoader:
     """nerf_runner.py:90-107: epoch permutation from torch.randperm (CPU generator); a batch is the next
     `batch_size` ids, and when fewer than batch_size+1 remain the permutation is redrawn (the tail is dropped).

@@ -5,6 +5,7 @@ CPU (pure NumPy, no CUDA):
     preprocess_data                       nerf_helpers.py:218-240
     get_optimized_poses_in_real_world     Utils.py:479-505
     mesh_to_real_world                    Utils.py:508-514
+    NerfRunner.build_octree               nerf_runner.py:436-489 (reference-driven: kaolin's OctreeManager stubbed)
     glcam_in_cvcam, BAD_DEPTH, BAD_COLOR  Utils.py:34-40
 
 Run here (needs /root/reference):  python tests/golden/make_golden_plugin.py  ->  tests/golden/plugin_vectors.npz
@@ -104,6 +105,41 @@ def main():
     V = rng.normal(size=(50, 3))
     m = ns['mesh_to_real_world'](MeshStub(V.copy()), np.asarray(offset, dtype=np.float64), tr, sc)
     out.update(mw_v=V, mw_out=np.asarray(m.vertices))
+    # ---- NerfRunner.build_octree (nerf_runner.py:436-489), reference-driven: the method itself runs on CPU with
+    #      .cuda() patched to identity and a stub OctreeManager that records what kaolin would have been given ----
+    src = open(os.path.join(REF, 'nerf_runner.py')).read()
+    tree = ast.parse(src)
+    cls = next(n for n in tree.body if isinstance(n, ast.ClassDef) and n.name == 'NerfRunner')
+    fn = next(n for n in cls.body if isinstance(n, ast.FunctionDef) and n.name == 'build_octree')
+    import textwrap
+    code = textwrap.dedent('\n'.join(src.splitlines()[fn.lineno - 1:fn.end_lineno]))
+    captured = {}
+
+    class OctreeManager:
+        def __init__(self, pts, max_level):
+            captured['pts'], captured['max_level'] = pts.detach().cpu().numpy().copy(), int(max_level)
+
+        def draw_boxes(self, **kw):
+            pass
+    import logging
+    ns2 = {'np': np, 'torch': torch, 'logging': logging, 'OctreeManager': OctreeManager}
+    exec(code, ns2)
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    for tag, (npts, sv, dil, rv, scf) in {'a': (400, 0.02, 0.02, 0.02, 5.25), 'b': (150, 0.01, 0.03, 0.04, 3.1)}.items():
+        cloud = (rng.normal(size=(npts, 3)) * 0.25).clip(-1, 1).astype(np.float64)
+        cloud[0] = [1.0, -1.0, 0.999]                          # corner: the dilation leaves the cube and is clipped back
+
+        class Stub:
+            pass
+        st = Stub()
+        st.cfg = dict(save_octree_clouds=False, save_dir=None, octree_smallest_voxel_size=sv, octree_dilate_size=dil,
+                      octree_raytracing_voxel_size=rv, sc_factor=scf)
+        st.build_octree_pts, st._run = cloud, None
+        ns2['build_octree'](st)
+        out[f'oct_{tag}_cfg'] = np.array([sv, dil, rv, scf])
+        out[f'oct_{tag}_cloud'] = cloud
+        out[f'oct_{tag}_pts'] = captured['pts']
+        out[f'oct_{tag}_max_level'] = np.int64(captured['max_level'])
     np.savez_compressed(os.path.join(HERE, 'plugin_vectors.npz'), **out)
     print('wrote', len(out), 'arrays')
 

@@ -187,3 +187,22 @@ def test_pose_hand_back_and_mesh_to_real_world_match_reference():
     m = mesh_to_real_world(Mesh(g['mw_v'].copy(), np.zeros((0, 3), dtype=np.int64)), np.asarray(offset, dtype=np.float64),
                            g['pp_tr'], float(g['pp_sc']))
     assert np.allclose(np.asarray(m.vertices), g['mw_out'], rtol=0, atol=1e-12)
+
+
+@pytest.mark.parametrize("tag", ['a', 'b'])
+def test_octree_cells_match_reference_build_octree(tag):
+    """the points the reference's build_octree hands to kaolin (dilated cell centres, clipped) and its max_level, from a
+    reference-driven run of the method itself; the product's cell list must be exactly their quantisation"""
+    from bundlesdf_amd.rays import octree_cells
+    g = _plugin_golden()
+    sv, dil, rv, scf = g[f'oct_{tag}_cfg']
+    cfg = dict(octree_smallest_voxel_size=float(sv), octree_dilate_size=float(dil), octree_raytracing_voxel_size=float(rv),
+               sc_factor=float(scf))
+    q, centres, max_level, level = octree_cells(g[f'oct_{tag}_cloud'], cfg)
+    ref = g[f'oct_{tag}_pts']
+    assert max_level == int(g[f'oct_{tag}_max_level']) and level == int(np.floor(np.log2(2.0 / (rv * scf))))
+    key = lambda a: a[np.lexsort((a[:, 2], a[:, 1], a[:, 0]))]
+    assert centres.dtype == ref.dtype and np.array_equal(key(centres), key(ref))
+    n = 2 ** max_level
+    q_ref = np.floor(np.clip(n * (ref.astype(np.float32) + 1.0) / 2.0, 0, n - 1.0)).astype(np.int32)
+    assert np.array_equal(np.unique(q, axis=0), np.unique(q_ref, axis=0))
