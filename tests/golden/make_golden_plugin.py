@@ -6,12 +6,14 @@ CPU (pure NumPy, no CUDA):
     get_optimized_poses_in_real_world     Utils.py:479-505
     mesh_to_real_world                    Utils.py:508-514
     NerfRunner.build_octree               nerf_runner.py:436-489 (reference-driven: kaolin's OctreeManager stubbed)
+    NerfRunner.make_frame_rays            nerf_runner.py:246-316 (reference-driven: cv2.dilate stubbed, use_octree off)
     glcam_in_cvcam, BAD_DEPTH, BAD_COLOR  Utils.py:34-40
 
 Run here (needs /root/reference):  python tests/golden/make_golden_plugin.py  ->  tests/golden/plugin_vectors.npz
 The fixture travels; the generator does not need to."""
 import ast
 import os
+import textwrap
 
 import numpy as np
 import torch
@@ -111,7 +113,6 @@ def main():
     tree = ast.parse(src)
     cls = next(n for n in tree.body if isinstance(n, ast.ClassDef) and n.name == 'NerfRunner')
     fn = next(n for n in cls.body if isinstance(n, ast.FunctionDef) and n.name == 'build_octree')
-    import textwrap
     code = textwrap.dedent('\n'.join(src.splitlines()[fn.lineno - 1:fn.end_lineno]))
     captured = {}
 
@@ -140,6 +141,56 @@ def main():
         out[f'oct_{tag}_cloud'] = cloud
         out[f'oct_{tag}_pts'] = captured['pts']
         out[f'oct_{tag}_max_level'] = np.int64(captured['max_level'])
+    # ---- NerfRunner.make_frame_rays (nerf_runner.py:246-316), reference-driven: the method and its helpers run on CPU.
+    #      cv2.dilate is the one stub (cv2 is not installed): all-ones k x k kernel anchored at k//2, borders ignored, written
+    #      here as a plain double loop; use_octree is off (the kaolin tracer cannot run here) ----
+    import types
+    import sys
+    sys.path.insert(0, HERE)
+    import make_golden as MG
+    ns3 = MG.build_namespace()
+
+    def cv2_dilate(mask, kernel, iterations=1):
+        k = kernel.shape[0]
+        lo, hi = -(k // 2), k - 1 - k // 2
+        Hh, Ww = mask.shape
+        outm = np.zeros_like(mask)
+        for v in range(Hh):
+            v0, v1 = max(v + lo, 0), min(v + hi, Hh - 1)
+            for u in range(Ww):
+                u0, u1 = max(u + lo, 0), min(u + hi, Ww - 1)
+                outm[v, u] = mask[v0:v1 + 1, u0:u1 + 1].max()
+        return outm
+    ns3['cv2'] = types.SimpleNamespace(dilate=cv2_dilate)
+    code = textwrap.dedent('\n'.join(src.splitlines()[
+        next(n for n in cls.body if isinstance(n, ast.FunctionDef) and n.name == 'make_frame_rays').lineno - 1:
+        next(n for n in cls.body if isinstance(n, ast.FunctionDef) and n.name == 'make_frame_rays').end_lineno]))
+    exec(code, ns3)
+    Hh, Ww, Fn = 36, 48, 2
+    imgs = rng.random((Fn, Hh, Ww, 3)).astype(np.float32)
+    msk = np.zeros((Fn, Hh, Ww, 1), dtype=np.uint8)
+    msk[0, 10:22, 14:30] = 1
+    msk[1, 5:30, 20:40] = 1
+    scf = 2.5
+    dep = (rng.uniform(0.3, 0.9, (Fn, Hh, Ww, 1)) * scf).astype(np.float32)
+    dep[0, 12:14, 16:20] = 99 * scf                            # invalid depth inside the mask -> ray type 1
+    dep[1, 6, 21] = 0.01 * scf
+    Kc = np.array([[40.0, 0, 24.0], [0, 40.0, 18.0], [0, 0, 1]])
+    ps = np.tile(np.eye(4), (Fn, 1, 1))
+    ps[0, :3, 3] = [0.1, -0.2, 1.6]
+    ps[1, :3, :3] = pn[1, :3, :3]
+    ps[1, :3, 3] = [-0.3, 0.2, 1.4]
+
+    class Stub2:
+        pass
+    for valid_only in (1, 0):
+        st = Stub2()
+        st.images, st.depths, st.masks, st.normal_maps, st.occ_masks, st.poses, st.K, st.H, st.W = imgs, dep, msk, None, None, ps, Kc, Hh, Ww
+        st.cfg = dict(near=0.1, far=1.0, sc_factor=scf, down_scale_ratio=4, rays_valid_depth_only=valid_only, use_octree=0,
+                      bounding_box=[[-1, -1, -1], [1, 1, 1]])
+        for fid in range(Fn):
+            out[f'mfr_{valid_only}_{fid}'] = np.asarray(ns3['make_frame_rays'](st, fid))
+    out.update(mfr_images=imgs, mfr_depths=dep, mfr_masks=msk, mfr_poses=ps, mfr_K=Kc, mfr_sc=np.float64(scf))
     np.savez_compressed(os.path.join(HERE, 'plugin_vectors.npz'), **out)
     print('wrote', len(out), 'arrays')
 

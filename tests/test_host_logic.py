@@ -206,3 +206,21 @@ def test_octree_cells_match_reference_build_octree(tag):
     n = 2 ** max_level
     q_ref = np.floor(np.clip(n * (ref.astype(np.float32) + 1.0) / 2.0, 0, n - 1.0)).astype(np.int32)
     assert np.array_equal(np.unique(q, axis=0), np.unique(q_ref, axis=0))
+
+
+@pytest.mark.parametrize("valid_only", [1, 0])
+def test_make_frame_rays_matches_reference_driven_run(valid_only):
+    """the reference's NerfRunner.make_frame_rays executed on CPU (only cv2.dilate stubbed, octree filter off) against
+    bundlesdf_amd/rays.py: same rays, same order, same 12 float64 columns (mask dilation 100 / 60//down, ray types, depth
+    validity, bounding-box near / far)"""
+    from bundlesdf_amd.rays import make_frame_rays
+    g = _plugin_golden()
+    cfg = default_cfg(near=0.1, far=1.0, sc_factor=float(g['mfr_sc']), down_scale_ratio=4, rays_valid_depth_only=valid_only,
+                      use_octree=0, bounding_box=[[-1, -1, -1], [1, 1, 1]])
+    for fid in range(2):
+        ref = g[f'mfr_{valid_only}_{fid}']
+        got = make_frame_rays(fid, g['mfr_images'][fid], g['mfr_depths'][fid], g['mfr_masks'][fid], g['mfr_poses'][fid],
+                              g['mfr_K'], cfg)
+        assert got.shape == ref.shape and got.dtype == ref.dtype, (got.shape, ref.shape)
+        assert np.array_equal(got[:, :10], ref[:, :10])
+        assert np.allclose(got[:, 10:], ref[:, 10:], rtol=1e-12, atol=0)
