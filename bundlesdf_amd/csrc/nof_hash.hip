@@ -19,10 +19,15 @@
 #include "nof_hash_dev.h"
 #pragma clang fp contract(off)
 
-__global__ __launch_bounds__(256) void k_hash_fwd(NofHashGrid g, const float* __restrict__ pts_w,
+struct LevelList {
+  int32_t n;
+  int32_t level[NOF_MAX_LEVELS];
+};
+
+__global__ __launch_bounds__(256) void k_hash_fwd(NofHashGrid g, LevelList slots, const float* __restrict__ pts_w,
                                                    const float2* __restrict__ table, float2* __restrict__ feat,
                                                    int64_t B) {
-  const int level = blockIdx.x % g.L;
+  const int level = slots.level[blockIdx.x % g.L];                   // slot -> level: see xcd_level_slots()
   const int64_t b = (int64_t)(blockIdx.x / g.L) * 256 + threadIdx.x;
   if (b >= B) return;
   const HashLevel lv = load_level(g, level);
@@ -88,10 +93,6 @@ __device__ __forceinline__ bool wave_merge_runs(Scatter& sc) {
   return (lane == 0 || prev != sc.key) && sc.key != 0xFFFFFFFFu;
 }
 
-struct LevelList {
-  int32_t n;
-  int32_t level[NOF_MAX_LEVELS];
-};
 
 // Merge + emission for the levels that do not fit LDS.  Measured on MI355X (tools/atomic_probe.py): fp32 atomics retire at
 // ~20.8 G line-requests/s chip-wide, lanes of ONE instruction that fall into the same 64-byte line merge into one request
@@ -316,6 +317,28 @@ static int check_grid(const NofHashGrid* g) {
   return 0;
 }
 
+// Block b runs on XCD b % 8 and handles the level in slot b % L, so slots with equal (slot % 8) share one XCD's 4 MiB L2.
+// Levels are dealt to the slots largest first in snake order (0..7, 7..0, ...): every XCD gets one large hashed level and
+// one small dense level instead of levels l and l + 8 (at cfg2 that paired the two 4 MB levels 7/15 ... on one L2).
+// Placement is a speed assumption only.
+static LevelList xcd_level_slots(const NofHashGrid* g) {
+  int order[NOF_MAX_LEVELS];
+  for (int l = 0; l < g->L; ++l) order[l] = l;
+  for (int i = 1; i < g->L; ++i)                                       // insertion sort by size, descending (stable)
+    for (int j = i; j > 0 && g->size[order[j]] > g->size[order[j - 1]]; --j) { const int t = order[j]; order[j] = order[j - 1]; order[j - 1] = t; }
+  LevelList s;
+  s.n = g->L;
+  for (int i = 0; i < g->L; ++i) {
+    const int grp = i / 8, r = (grp & 1) ? 7 - (i % 8) : (i % 8);
+    int slot = grp * 8 + r;
+    if (slot >= g->L) slot = i;                                        // ragged last group: keep it simple
+    s.level[slot] = order[i];
+  }
+  if (g->L % 8 != 0)                                                   // ragged: fall back to the identity permutation
+    for (int i = 0; i < g->L; ++i) s.level[i] = i;
+  return s;
+}
+
 extern "C" int nof_hash_encode_fwd(const NofHashGrid* g, const float* pts_w, const float* table, float* feat,
                                     int64_t B, void* stream) {
   if (int e = check_grid(g)) return e;
@@ -323,7 +346,7 @@ extern "C" int nof_hash_encode_fwd(const NofHashGrid* g, const float* pts_w, con
   if (B == 0) return 0;
   const int64_t blocks = nof_div_up(B, 256) * g->L;
   NOF_ARG(blocks < (1ll << 31));
-  hipLaunchKernelGGL(k_hash_fwd, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, *g, pts_w,
+  hipLaunchKernelGGL(k_hash_fwd, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, *g, xcd_level_slots(g), pts_w,
                      (const float2*)table, (float2*)feat, B);
   NOF_LAUNCH_OK();
   return 0;
