@@ -21,6 +21,7 @@ import numpy as np
 import torch
 
 from . import lib
+from .checkpoint import load_reference_checkpoint, to_reference_checkpoint
 from .field import NeuralObjectField
 from .mesh_gpu import marching_tetrahedra_gpu
 from .mesh import make_mesh, marching_tetrahedra
@@ -261,16 +262,27 @@ class NerfRunner:
                                   'SURVEY.md 8f rank 4 (not on the hot path)')
 
     # ---- checkpoint (nerf_runner.py:528-577) ----------------------------------------------------------------
-    def save_weights(self, out_file, models=None):
+    def save_weights(self, out_file, models=None, reference_format=False):
+        """native: the flat buffers + Adam moments + occupancy bitfield; reference_format=True: the reference's own layout
+        (nerf_runner.py:546-566: 'model' / 'embed_fn' / 'pose_array' / 'feature_array' state_dicts), loadable by it"""
         f = self.field
-        torch.save({'global_step': self.global_step, 'params': f.params.cpu(), 'exp_avg': f.exp_avg.cpu(),
-                    'exp_avg_sq': f.exp_avg_sq.cpu(), 'field_step': f.global_step,
-                    'octree': (f.occ_bits.cpu() if f.occ_bits is not None else None, f.level, f.max_level)}, out_file)
+        if reference_format:
+            torch.save(to_reference_checkpoint(f, self.global_step), out_file)
+        else:
+            torch.save({'global_step': self.global_step, 'params': f.params.cpu(), 'exp_avg': f.exp_avg.cpu(),
+                        'exp_avg_sq': f.exp_avg_sq.cpu(), 'field_step': f.global_step,
+                        'octree': (f.occ_bits.cpu() if f.occ_bits is not None else None, f.level, f.max_level)}, out_file)
         print('Saved checkpoints at', out_file)
 
     def load_weights(self, ckpt_path):
+        """accepts both layouts: this implementation's, and checkpoints written by the reference's save_weights (parameters
+        only: its optimiser state and kaolin octree bytes have no counterpart here)"""
         ck = torch.load(ckpt_path)
         f = self.field
+        if 'params' not in ck and 'model' in ck:
+            self.global_step = load_reference_checkpoint(f, ck)
+            f.global_step = self.global_step
+            return
         f.params.copy_(ck['params'].to(f.device))
         f.exp_avg.copy_(ck['exp_avg'].to(f.device))
         f.exp_avg_sq.copy_(ck['exp_avg_sq'].to(f.device))

@@ -7,6 +7,7 @@ CPU (pure NumPy, no CUDA):
     mesh_to_real_world                    Utils.py:508-514
     NerfRunner.build_octree               nerf_runner.py:436-489 (reference-driven: kaolin's OctreeManager stubbed)
     NerfRunner.make_frame_rays            nerf_runner.py:246-316 (reference-driven: cv2.dilate stubbed, use_octree off)
+    NeRFSmall.state_dict()                nerf_helpers.py:243-294: key names, order, shapes (the checkpoint layout)
     glcam_in_cvcam, BAD_DEPTH, BAD_COLOR  Utils.py:34-40
 
 Run here (needs /root/reference):  python tests/golden/make_golden_plugin.py  ->  tests/golden/plugin_vectors.npz
@@ -191,6 +192,19 @@ def main():
         for fid in range(Fn):
             out[f'mfr_{valid_only}_{fid}'] = np.asarray(ns3['make_frame_rays'](st, fid))
     out.update(mfr_images=imgs, mfr_depths=dep, mfr_masks=msk, mfr_poses=ps, mfr_K=Kc, mfr_sc=np.float64(scf))
+    # ---- NeRFSmall.state_dict(): the key names / shapes / order a reference checkpoint carries (nerf_runner.py:546-550) ----
+    for tag, (nl, nlc, ichv) in {'ref': (2, 3, 9), 'base': (3, 2, 11)}.items():
+        torch.manual_seed(3)
+        net = ns3['NeRFSmall'](num_layers=nl, hidden_dim=64, geo_feat_dim=15, num_layers_color=nlc, hidden_dim_color=64,
+                               input_ch=32, input_ch_views=ichv)
+        sd = net.state_dict()
+        out[f'sd_{tag}_keys'] = np.array(list(sd.keys()))
+        out[f'sd_{tag}_flat'] = torch.cat([p.detach().reshape(-1) for p in net.parameters()]).numpy()
+        out[f'sd_{tag}_cat'] = torch.cat([sd[k].reshape(-1) for k in sd.keys()]).numpy()     # state_dict order
+        out[f'sd_{tag}_shapes'] = np.array([list(sd[k].shape) + [0] * (2 - sd[k].dim()) for k in sd.keys()])
+        xin = torch.from_numpy(rng.normal(size=(7, 32 + ichv)).astype(np.float32))
+        out[f'sd_{tag}_x'] = xin.numpy()
+        out[f'sd_{tag}_y'] = net(xin).detach().numpy()
     np.savez_compressed(os.path.join(HERE, 'plugin_vectors.npz'), **out)
     print('wrote', len(out), 'arrays')
 

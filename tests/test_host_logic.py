@@ -224,3 +224,35 @@ def test_make_frame_rays_matches_reference_driven_run(valid_only):
         assert got.shape == ref.shape and got.dtype == ref.dtype, (got.shape, ref.shape)
         assert np.array_equal(got[:, :10], ref[:, :10])
         assert np.allclose(got[:, 10:], ref[:, 10:], rtol=1e-12, atol=0)
+
+
+@pytest.mark.parametrize("tag,ns,nc,n_view", [('ref', 2, 3, 9), ('base', 3, 2, 11)])
+def test_checkpoint_layout_is_the_reference_state_dict(tag, ns, nc, n_view):
+    """bundlesdf_amd/checkpoint.py against NeRFSmall.state_dict() of the reference (key names, order, shapes, values) and
+    its forward: a 'model' entry written here loads into the reference and vice versa"""
+    from bundlesdf_amd.checkpoint import mlp_flat_from_state, mlp_state_from_flat
+    g = _plugin_golden()
+    desc, dims = lib.make_mlp_desc(ns, nc, 32, n_view, 1)
+    flat = torch.from_numpy(g[f'sd_{tag}_flat'])
+    state = mlp_state_from_flat(flat, dims, ns)
+    assert list(state.keys()) == [str(k) for k in g[f'sd_{tag}_keys']]
+    assert [list(v.shape) + [0] * (2 - v.dim()) for v in state.values()] == g[f'sd_{tag}_shapes'].tolist()
+    assert np.array_equal(torch.cat([v.reshape(-1) for v in state.values()]).numpy(), g[f'sd_{tag}_cat'])
+    assert torch.equal(mlp_flat_from_state(state, dims, ns), flat)
+    # the flat layout is what the oracle (and the kernels' weight packer) consume: same network function as the reference
+    shape = O.FieldShape(input_ch=32, input_ch_views=n_view, num_layers=ns, num_layers_color=nc)
+    params, off = [], 0
+    for o, i in dims:
+        W = flat[off:off + o * i].reshape(o, i); off += o * i
+        b = flat[off:off + o]; off += o
+        params.append((W, b))
+    y = O.mlp_forward(shape, params, torch.from_numpy(g[f'sd_{tag}_x'])).detach().numpy()
+    assert np.abs(y - g[f'sd_{tag}_y']).max() < 1e-6
+    bad = dict(state)
+    bad['sigma_net.0.weight'] = bad['sigma_net.0.weight'][:, :16]
+    with pytest.raises(ValueError):
+        mlp_flat_from_state(bad, dims, ns)
+    bad = dict(state)
+    bad['color_net.9.weight'] = torch.zeros(1)
+    with pytest.raises(ValueError):
+        mlp_flat_from_state(bad, dims, ns)
