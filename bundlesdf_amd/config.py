@@ -48,8 +48,6 @@ def validate_cfg(cfg):
         bad.append("use_viewdirs = 0")
     if float(cfg.get('raw_noise_std', 0)) > 0:
         bad.append("raw_noise_std > 0")
-    if float(cfg.get('pose_reg_weight', 0)) > 0:
-        bad.append("pose_reg_weight > 0")
     if int(cfg.get('feature_grid_dim', 2)) != 2:
         bad.append("feature_grid_dim != 2")
     if bad:

@@ -244,6 +244,35 @@ __global__ void k_feature_reg(const float* __restrict__ data, float* __restrict_
   if (i < n) grad[i] += k * data[i];
 }
 
+// pose_reg = w * || pose_array.data[1:] ||_2  (nerf_runner.py:749-752; frame 0 is the anchor and is excluded):
+// grad += scale * w * x / ||x||  (0 when the norm is 0, like torch), loss_out[0] += w * ||x||
+__global__ __launch_bounds__(256) void k_pose_reg(const float* __restrict__ pose, float* __restrict__ grad, int n, float w,
+                                                   float scale, float* __restrict__ loss_out) {
+  __shared__ float sm[256];
+  float s = 0.0f;
+  for (int i = 6 + threadIdx.x; i < n; i += 256) s += pose[i] * pose[i];
+  sm[threadIdx.x] = s;
+  __syncthreads();
+  for (int k = 128; k > 0; k >>= 1) {
+    if (threadIdx.x < k) sm[threadIdx.x] += sm[threadIdx.x + k];
+    __syncthreads();
+  }
+  const float nrm = sqrtf(sm[0]);
+  if (nrm > 0.0f)
+    for (int i = 6 + threadIdx.x; i < n; i += 256) grad[i] += scale * w * (pose[i] / nrm);
+  if (threadIdx.x == 0 && loss_out) loss_out[0] += w * nrm;
+}
+
+extern "C" int nof_pose_reg(const float* pose_data, float* grad_pose, int32_t F, float pose_reg_weight, float grad_scale,
+                             float* loss_out, void* stream) {
+  if (F <= 1 || pose_reg_weight == 0.0f) return 0;
+  NOF_ARG(pose_data && grad_pose);
+  hipLaunchKernelGGL(k_pose_reg, dim3(1), dim3(256), 0, (hipStream_t)stream, pose_data, grad_pose, (int)F * 6, pose_reg_weight,
+                     grad_scale, loss_out);
+  NOF_LAUNCH_OK();
+  return 0;
+}
+
 extern "C" int nof_small_regs(const float* feat_data, float* grad_feat, int32_t n_feat, float feature_reg_weight,
                                float grad_scale, void* stream) {
   if (n_feat <= 0 || feature_reg_weight == 0.0f) return 0;

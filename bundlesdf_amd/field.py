@@ -278,6 +278,9 @@ class NeuralObjectField:
                        C.c_float(self.max_trans), C.c_float(self.max_rot),
                        self._seg(self.grads, 'pose') if self.optimize_poses else None,
                        self._seg(self.grads, 'feat') if self.ff > 0 else None, None, self.F)
+        if self.optimize_poses and float(cfg.get('pose_reg_weight', 0)) > 0:
+            self._call('nof_pose_reg', self.pose, self._seg(self.grads, 'pose'), self.F, C.c_float(cfg['pose_reg_weight']),
+                       C.c_float(1.0 / self.world_size), self.loss_out)
         if self.ff > 0:
             self._call('nof_small_regs', self.feat, self._seg(self.grads, 'feat'), self.n_feat,
                      C.c_float(cfg['feature_reg_weight']), C.c_float(1.0 / self.world_size))

@@ -249,6 +249,11 @@ int nof_pose_reduce_bwd(const float* pose_data, const float* g_ray, const float*
 int nof_small_regs(const float* feat_data, float* grad_feat, int32_t n_feat, float feature_reg_weight,
                    float grad_scale, void* stream);
 
+/* pose regulariser (nerf_runner.py:749-752): loss += w * ||pose_data[1:]||_2; grad_pose += grad_scale * d/dpose; loss_out[0]
+ * (may be NULL) += the term. */
+int nof_pose_reg(const float* pose_data, float* grad_pose, int32_t F, float pose_reg_weight, float grad_scale,
+                 float* loss_out, void* stream);
+
 /* ---- optimiser ---------------------------------------------------------------------------------- */
 /* torch.optim.Adam(betas, eps=1e-15, weight_decay=0) over the flat buffer; entries [0,n_basic) use lr,
  * [n_basic,n) use lr_pose (param groups nerf_runner.py:498-500).  step is 1-based.  Grads are zeroed. */

@@ -165,3 +165,23 @@ def test_train_step_is_graph_capturable(nof):
     d = (g_replay - g_eager).abs().max().item()
     assert d <= 1e-3 * g_eager.abs().max().item(), d          # atomics: summation order only
     assert torch.isfinite(g_replay).all() and g_replay.abs().sum().item() > 0
+
+
+def test_pose_regulariser_matches_oracle(nof):
+    """pose_reg_weight > 0 (nerf_runner.py:749-752; off in the reference's config.yml): loss and pose gradients"""
+    cfg, fld, orc, batch, rng = _pair(nof, 'fp32', R=128)
+    for c in (cfg, fld.cfg, orc.cfg):
+        c['pose_reg_weight'] = 0.37
+    R = batch.shape[0]
+    Ns, Na = cfg['N_samples'], cfg['N_samples_around_depth']
+    u_occ = rng.random((R, Ns)).astype(np.float32)
+    u_dep = rng.random((R, Na)).astype(np.float32)
+    fld.train_step(U.dev(batch), None, R, U.dev(u_occ), U.dev(u_dep), do_step=False)
+    torch.cuda.synchronize()
+    ref = orc.train_step(batch, u_occ, u_dep, do_step=False)
+    got_loss, want_loss = fld.losses()['loss'], float(ref['losses']['loss'])
+    assert abs(got_loss - want_loss) < 2e-4 * abs(want_loss), (got_loss, want_loss)
+    gp = cpu(fld._seg(fld.grads, 'pose')).reshape(-1, 6)
+    rp = np.asarray(ref['grads'][-1].detach() if hasattr(ref['grads'][-1], 'detach') else ref['grads'][-1]).reshape(-1, 6)
+    assert rel_l2(gp, rp) < 5e-4, rel_l2(gp, rp)
+    assert np.abs(gp[0]).max() == 0                      # the anchor frame takes no part
