@@ -182,7 +182,9 @@ def make_hash_grid(n_levels, level_dim, base_resolution, log2_hashmap_size, desi
     g.L, g.C = n_levels, level_dim
     S = np.float32(np.log2(per_level_scale))
     for l in range(n_levels):
-        scale = np.float32(np.exp2(np.float32(np.float32(l) * S)).astype(np.float32) * np.float32(base_resolution) - np.float32(1.0))
+        # exp2f(level*S) correctly rounded (float64 exp2 then one rounding == glibc exp2f; NumPy's float32 exp2 is 1 ulp off)
+        e = np.float32(np.exp2(np.float64(np.float32(np.float32(l) * S))))
+        scale = np.float32(e * np.float32(base_resolution) - np.float32(1.0))
         res = int(np.ceil(scale)) + 1
         size = offsets[l + 1] - offsets[l]
         stride, d = 1, 0

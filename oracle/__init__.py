@@ -16,8 +16,13 @@ Pinning status (see DESIGN.md "Oracle"):
     ray_box_intersection_batch, get_camera_rays_np, get_truncation and the train_loop
     loss assembly are PINNED against outputs of the reference's own pure-PyTorch code
     executed on CPU (tests/golden/make_golden.py -> tests/golden/*.npz).
-  * the multires hash encoder (CUDA only in the reference), the kaolin octree ray
-    tracer and pytorch3d's se3_exp_map are third-party/CUDA code that cannot run here:
-    for those the oracle is a restatement of the published algorithm and parity is
-    UNPINNED ("parity unpinned": the reference holds no golden vectors for them).
+  * the multires hash encoder (forward, dy_dx, table-gradient scatter, input gradient:
+    gridencoder.cu), the occupied-voxel sampler walk and the ray-trace post-process
+    (common.cu) are PINNED against the reference's own kernels compiled as host C++
+    (oracle/ref_build.py -> oracle/_ref/libnof_ref.so, tests/test_ref_native.py), and the
+    committed train_loop fixture was generated with those compiled kernels under the
+    reference's own grid.py / OctreeManager.ray_trace.
+  * kaolin's octree ray tracer (unbatched_raytrace) and pytorch3d's se3_exp_map are
+    third-party code absent from the reference tree: for those two the oracle is a
+    restatement of the published algorithm and parity is UNPINNED.
 """

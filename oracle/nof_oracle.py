@@ -28,8 +28,9 @@ class HashGeometry:
     Indexing constants follow gridencoder.cu:154-156 (float32):
       S = (float)log2(per_level_scale); scale = exp2f(level*S)*H - 1; resolution = ceil(scale)+1.
     The reference evaluates exp2f on the device; here (and in the HIP product) the
-    per-level (scale, resolution) pairs are evaluated ONCE on the host in float32 and
-    handed to the kernels, so oracle and product share bit-identical level constants.
+    per-level (scale, resolution) pairs are evaluated ONCE on the host with a correctly
+    rounded exp2f and handed to the kernels, so oracle, product and the reference's kernel
+    compiled as host code (oracle/_ref) share bit-identical level constants.
     """
 
     def __init__(self, n_levels=16, level_dim=2, base_resolution=16, log2_hashmap_size=19,
@@ -53,7 +54,10 @@ class HashGeometry:
         S = f32(np.log2(self.per_level_scale))           # grid.py:45 -> `const float S`
         self.S = S
         lv = np.arange(n_levels, dtype=np.uint32).astype(f32)
-        self.scale = (np.exp2((lv * S).astype(f32)).astype(f32) * f32(self.H) - f32(1.0)).astype(f32)
+        # exp2f correctly rounded (float64 exp2, one rounding): bit-equal to glibc's exp2f, i.e. to gridencoder.cu:155
+        # compiled as host code (tests/test_ref_native.py::test_level_constants_bitwise); NumPy's own float32 exp2
+        # is 1 ulp off on some levels
+        self.scale = (np.exp2((lv * S).astype(f32).astype(np.float64)).astype(f32) * f32(self.H) - f32(1.0)).astype(f32)
         self.resolution = (np.ceil(self.scale).astype(np.int64) + 1)
         self.size = (self.offsets[1:] - self.offsets[:-1]).astype(np.int64)
         # dense-vs-hash decision of get_grid_index (gridencoder.cu:67-80)
@@ -379,14 +383,22 @@ def trace_rays(occ_l, rays_o, rays_d, max_hits=None):
     Returns (t_in_out [R,H,2] float32 zero-padded, cell_ids [R,H] int32 (-1 pad), n_hits [R] int32)
     with H = max hits (or max_hits).  cell id = (x*n + y)*n + z.
     """
+    flat_ray, flat_io, flat_cid = trace_rays_flat(occ_l, rays_o, rays_d)
+    R = np.asarray(rays_o).shape[0]
+    return postprocess_hits(flat_ray, flat_io, R, max_hits=max_hits, cell_ids=flat_cid)
+
+
+def trace_rays_flat(occ_l, rays_o, rays_d):
+    """The flat list kaolin's unbatched_raytrace hands back (Utils.py:457), per the geometric definition of trace_rays:
+    ray_index [M] int64 (ascending), depth_in_out [M,2] float32 front-to-back within a ray, cell id [M] int64 --
+    every occupied cell whose slab test passes, BEFORE the filters of common.cu:137-147."""
     o = np.ascontiguousarray(rays_o, dtype=f32)
     d = np.ascontiguousarray(rays_d, dtype=f32)
     R = o.shape[0]
     n = occ_l.shape[0]
     cells = np.argwhere(occ_l)                                     # [M,3] sorted by cell id
     ids = ((cells[:, 0] * n + cells[:, 1]) * n + cells[:, 2]).astype(np.int64)
-    per_ray = []
-    H = 0
+    fr, fio, fc = [], [], []
     for r0 in range(0, R, 256):
         r1 = min(R, r0 + 256)
         sl = [_axis_slabs(o[r0:r1, a], d[r0:r1, a], n) for a in range(3)]
@@ -396,33 +408,58 @@ def trace_rays(occ_l, rays_o, rays_d, max_hits=None):
         hit = tin <= tout
         for r in range(r1 - r0):
             h = np.nonzero(hit[r])[0]
-            order = np.lexsort((ids[h], tout[r, h], tin[r, h]))
-            h = h[order]
-            keep_t, keep_c = [], []
-            for k in h:
-                a, b = tin[r, k], tout[r, k]
-                if a == 0 or b == 0:
-                    break
-                if a > b:
-                    continue
-                if abs(b - a) < MIN_LEN:
-                    continue
-                keep_t.append((a, b))
-                keep_c.append(ids[k])
-            per_ray.append((keep_t, keep_c))
-            H = max(H, len(keep_t))
-    if max_hits is not None:
-        H = max_hits
+            h = h[np.lexsort((ids[h], tout[r, h], tin[r, h]))]
+            fr.append(np.full(len(h), r0 + r, dtype=np.int64))
+            fio.append(np.stack([tin[r, h], tout[r, h]], -1).astype(f32).reshape(-1, 2))
+            fc.append(ids[h])
+    if not fr:
+        return np.zeros(0, np.int64), np.zeros((0, 2), f32), np.zeros(0, np.int64)
+    return np.concatenate(fr), np.concatenate(fio), np.concatenate(fc)
+
+
+def postprocess_hits(ray_index, depth_in_out, N_rays, max_hits=None, cell_ids=None):
+    """Utils.py:466-470 + postprocessOctreeRayTracingKernel (common.cu:129-149): per hit ray copy its run of (in,out)
+    pairs into a zero-padded [N_rays, H, 2] table; stop at the first entry whose in or out is 0, skip in>out and
+    |out-in|<1e-4.  With max_hits=None, H is the reference's max_intersections (longest run BEFORE filtering,
+    Utils.py:467) when cell_ids is None -- the exact shape the reference returns -- or the longest kept run when the
+    caller also wants cell ids (trace_rays).  PINNED against the reference's kernel compiled as host code
+    (tests/test_ref_native.py)."""
+    ray_index = np.asarray(ray_index, np.int64)
+    dio = np.asarray(depth_in_out, f32).reshape(-1, 2)
+    M = ray_index.shape[0]
+    starts = np.flatnonzero(np.concatenate([[True], ray_index[1:] != ray_index[:-1]])) if M else np.zeros(0, np.int64)
+    ends = np.concatenate([starts[1:], [M]]) if M else starts
+    kept = {}
+    H_ref = int((ends - starts).max()) if M else 1
+    H_kept = 0
+    for s0, s1 in zip(starts, ends):
+        r = int(ray_index[s0])
+        keep_t, keep_c = [], []
+        for i in range(s0, s1):
+            a, b = dio[i, 0], dio[i, 1]
+            if a == 0 or b == 0:
+                break
+            if a > b:
+                continue
+            if abs(b - a) < MIN_LEN:
+                continue
+            keep_t.append((a, b))
+            keep_c.append(-1 if cell_ids is None else cell_ids[i])
+        kept[r] = (keep_t, keep_c)           # a ray id that re-appears later overwrites (the kernel would too)
+        H_kept = max(H_kept, len(keep_t))
+    H = max_hits if max_hits is not None else (H_ref if cell_ids is None else H_kept)
     H = max(H, 1)
-    tio = np.zeros((R, H, 2), dtype=f32)
-    cid = -np.ones((R, H), dtype=np.int32)
-    nh = np.zeros(R, dtype=np.int32)
-    for r, (kt, kc) in enumerate(per_ray):
+    tio = np.zeros((N_rays, H, 2), dtype=f32)
+    cid = -np.ones((N_rays, H), dtype=np.int32)
+    nh = np.zeros(N_rays, dtype=np.int32)
+    for r, (kt, kc) in kept.items():
         m = min(len(kt), H)
         nh[r] = m
         if m:
             tio[r, :m] = np.array(kt[:m], dtype=f32)
             cid[r, :m] = np.array(kc[:m], dtype=np.int32)
+    if cell_ids is None:
+        return tio
     return tio, cid, nh
 
 
@@ -454,14 +491,17 @@ def sample_rays_uniform(N, near, far, u):
     return np.clip(z, near, far).astype(f32)
 
 
-def walk_boxes(z_in_out, z_cont):
+def walk_boxes(z_in_out, z_cont, return_spin=False):
     """sample_rays_uniform_occupied_voxels_kernel (common.cu:41-105): map a distance along the
     concatenated occupied length back into the per-voxel intervals.  Where the reference prints
-    an error and spins (:66-72,:87-93) this returns the end of the last valid box (the HIP
-    product raises its error flag in that case)."""
+    an error and spins forever (:66-72,:87-93: the remaining distance exceeds eps=1e-4 past the last
+    box, or the very first box is a terminator) this returns the end of the last valid box and, with
+    return_spin, a [R,N] bool mask of those samples (the HIP product raises its error flag there).
+    PINNED against the reference's kernel compiled as host code (tests/test_ref_native.py)."""
     R, N = z_cont.shape
     Hn = z_in_out.shape[1]
     out = np.zeros((R, N), dtype=f32)
+    spin = np.zeros((R, N), dtype=bool)
     eps = f32(1e-4)
     for r in range(R):
         if z_in_out[r, 0, 0] == 0:
@@ -472,6 +512,7 @@ def walk_boxes(z_in_out, z_cont):
             while True:
                 if ib >= Hn or z_in_out[r, ib, 0] == 0:
                     out[r, s] = z_in_out[r, max(ib - 1, 0), 1]
+                    spin[r, s] = not (zr <= eps and (ib >= Hn or ib >= 1))
                     break
                 bl = f32(z_in_out[r, ib, 1] - z_in_out[r, ib, 0])
                 if zr <= bl:
@@ -479,7 +520,7 @@ def walk_boxes(z_in_out, z_cont):
                     break
                 zr = f32(zr - bl)
                 ib += 1
-    return out
+    return (out, spin) if return_spin else out
 
 
 def sample_occupied(t_in_out, viewdir_cam_z, N, u, depths=None, trunc=None, near_sc=None, far_sc=None):

@@ -5,10 +5,15 @@
 
 The reference modules cannot be imported here (cv2, kaolin, pytorch3d, open3d, mycuda ... are absent), so the source
 text of individual functions / classes / methods is cut out of the read-only mount with `ast` at generation time and
-exec'd -- nothing is copied into this repository.  Only the four native pieces the reference itself delegates to
-CUDA / third parties are injected from oracle/nof_oracle.py (hash-grid encoder, octree ray tracer, the occupied-voxel
-sampler kernel, se3_exp_map); everything else that runs below is reference code:
+exec'd -- nothing is copied into this repository.  The reference's two pybind modules are stood in for by ITS OWN native
+code compiled as host C++ (oracle/_ref, recipe oracle/ref_build.py): `gridencoder.grid_encode_forward/backward` under the
+reference's own grid.py autograd Function and GridEncoder module, `common.sampleRaysUniformOccupiedVoxels` and
+`common.postprocessOctreeRayTracing` under the reference's own OctreeManager.ray_trace.  Only two third-party pieces that
+are absent from the reference tree are injected from oracle/nof_oracle.py: kaolin's `unbatched_raytrace` (the flat
+ray/cell intersection list) and pytorch3d's `se3_exp_map`.  Everything else that runs below is reference code:
 
+  mycuda/         : gridencoder.cu, common.cu (compiled), torch_ngp_grid_encoder/grid.py (_grid_encode, GridEncoder)
+  Utils.py        : OctreeManager.ray_trace
   nerf_helpers.py : SHEncoder, NeRFSmall, get_masks, get_sdf_loss, ray_box_intersection_batch, get_camera_rays_np,
                     PoseArray.get_matrices
   nerf_runner.py  : sample_rays_uniform, compute_near_far_and_filter_rays, DataLoader,
@@ -30,6 +35,7 @@ import torch.nn.functional as F
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from oracle import nof_oracle as O   # noqa: E402
+from oracle import ref_native as RN  # noqa: E402
 
 REF = os.environ.get('BUNDLESDF_REFERENCE', '/root/reference')
 warnings.filterwarnings('ignore')
@@ -68,6 +74,21 @@ def build_namespace():
         exec(s, ns)
     for s in cut('nerf_runner.py', ['sample_rays_uniform', 'compute_near_far_and_filter_rays', 'DataLoader']):
         exec(s, ns)
+    # the reference's own grid.py on top of its own kernels (compiled as host code)
+    gns = dict(np=np, torch=torch, nn=nn, Function=torch.autograd.Function, gridencoder=RN.gridencoder_module(),
+               custom_fwd=torch.cuda.amp.custom_fwd, custom_bwd=torch.cuda.amp.custom_bwd,
+               _gridtype_to_id={'hash': 0, 'tiled': 1}, print=lambda *a, **k: None)
+    for s in cut('mycuda/torch_ngp_grid_encoder/grid.py', ['_grid_encode']):
+        exec(s, gns)
+    gns['grid_encode'] = gns['_grid_encode'].apply
+    for s in cut('mycuda/torch_ngp_grid_encoder/grid.py', ['GridEncoder']):
+        exec(s, gns)
+    ns['GridEncoder'] = gns['GridEncoder']
+    # the reference's own OctreeManager.ray_trace around kaolin's tracer (injected) and its own post-process kernel
+    ons = dict(np=np, torch=torch)
+    exec('class RefOctree:\n' + cut('Utils.py', ['ray_trace'], cls='OctreeManager')[0], ons)
+    ns['RefOctree'] = ons['RefOctree']
+    ns['_octree_ns'] = ons
     methods = cut('nerf_runner.py', ['get_truncation', 'raw2outputs', 'sample_rays_uniform_occupied_voxels', 'render_rays',
                                      'run_network', 'batchify_rays', 'render', 'train_loop', 'schedule_lr'], cls='NerfRunner')
     cls_src = 'class RefRunner:\n' + '\n\n'.join(methods)
@@ -91,32 +112,34 @@ class UniformQueue:
         return t
 
 
-class HashModule(nn.Module):
-    """injected piece 1: GridEncoder (mycuda/torch_ngp_grid_encoder/grid.py:106-172) -> oracle restatement"""
-
-    def __init__(self, geo, table):
-        super().__init__()
-        self.geo = geo
-        self.embeddings = nn.Parameter(table.clone())
-        self.out_dim = geo.out_dim
-
-    def forward(self, inputs, bound=1):
-        return O.hash_encode((inputs + bound) / (2 * bound), self.embeddings, self.geo)
+def make_hash_module(ns, geo_kw, table):
+    """The reference's GridEncoder (grid.py:106-172) with a given table; runs gridencoder.cu compiled as host code."""
+    m = ns['GridEncoder'](input_dim=3, **geo_kw)
+    assert tuple(m.embeddings.shape) == tuple(table.shape)
+    m.embeddings.data = table.clone()
+    return m
 
 
-class OctreeStub:
-    """injected piece 2: OctreeManager.ray_trace (Utils.py:443-475) -> oracle restatement"""
+def make_octree(ns, occ_l):
+    """The reference's OctreeManager.ray_trace (Utils.py:443-475) with kaolin's unbatched_raytrace injected from the
+    oracle's geometric definition (third-party, unpinned) and the reference's own post-process kernel (compiled)."""
+    ons = ns['_octree_ns']
+    holder = {}
 
-    def __init__(self, occ_l):
-        self.occ_l = occ_l
+    def unbatched_raytrace(octree, point_hierarchies, pyramid, exsum, rays_o, rays_d, level, return_depth=True, with_exit=True):
+        fr, fio, fc = O.trace_rays_flat(occ_l, rays_o.detach().numpy(), rays_d.detach().numpy())
+        holder['flat'] = (fr, fio, fc)
+        return torch.from_numpy(fr).int(), torch.from_numpy(fc), torch.from_numpy(fio)
 
-    def ray_trace(self, rays_o, rays_d, level, debug=False):
-        tio, cid, nh = O.trace_rays(self.occ_l, rays_o.detach().numpy(), rays_d.detach().numpy())
-        tio = torch.from_numpy(tio)
-        self.last = (tio.numpy().copy(), cid, nh)
-        far = tio[:, :, 1].max(dim=-1)[0].reshape(-1, 1)
-        near = tio[:, 0, 0].reshape(-1, 1)
-        return near, far, None, tio
+    ons['kaolin'] = types.SimpleNamespace(render=types.SimpleNamespace(spc=types.SimpleNamespace(unbatched_raytrace=unbatched_raytrace)))
+    mycuda = types.ModuleType('mycuda')
+    mycuda.common = RN.common_module()
+    sys.modules['mycuda'] = mycuda                      # `from mycuda import common` inside ray_trace
+    o = ons['RefOctree']()
+    o.octree = o.point_hierarchies = o.exsum = None
+    o.pyramids = [None]
+    o.holder = holder
+    return o
 
 
 def main():
@@ -196,6 +219,8 @@ def main():
                    num_levels=8, log2_hashmap_size=12, finest_res=128, n_step=100, first_frame_weight=10)
         Fn = c2w.shape[0]
         geo = O.HashGeometry(cfg['num_levels'], 2, cfg['base_res'], cfg['log2_hashmap_size'], cfg['finest_res'])
+        geo_kw = dict(n_levels=cfg['num_levels'], level_dim=2, base_resolution=cfg['base_res'],
+                      log2_hashmap_size=cfg['log2_hashmap_size'], desired_resolution=cfg['finest_res'])
         torch.manual_seed(5)
         table = (torch.rand(geo.n_entries, 2) * 2 - 1) * 0.05
         model = ns['NeRFSmall'](num_layers=2, hidden_dim=64, geo_feat_dim=15, num_layers_color=3, hidden_dim_color=64,
@@ -212,17 +237,15 @@ def main():
             def __call__(self, ids):
                 return self.data[ids]
 
-        common = types.SimpleNamespace(sampleRaysUniformOccupiedVoxels=lambda zio, zc, zv: torch.from_numpy(
-            O.walk_boxes(zio.numpy(), zc.numpy())))             # injected piece 3: common.cu:41-125
-        ns['common'] = common
+        ns['common'] = RN.common_module()                       # common.cu:41-125 itself, compiled as host code
         r = ns['RefRunner']()
         r.cfg = cfg
         r.global_step = 1
         r.N_iters = cfg['n_step'] + 1
-        r.models = {'embed_fn': HashModule(geo, table), 'embeddirs_fn': ns['SHEncoder'](degree=3), 'model': model,
+        r.models = {'embed_fn': make_hash_module(ns, geo_kw, table), 'embeddirs_fn': ns['SHEncoder'](degree=3), 'model': model,
                     'model_fine': None, 'feature_array': FeatArr(), 'pose_array': pose}
         r.c2w_array = torch.from_numpy(c2w)
-        r.octree_m = OctreeStub(occ)
+        r.octree_m = make_octree(ns, occ)
         r.ray_dir_slice, r.ray_rgb_slice, r.ray_depth_slice, r.ray_mask_slice = [0, 1, 2], [3, 4, 5], 6, 7
         r.ray_frame_id_slice, r.ray_type_slice, r.ray_near_slice, r.ray_far_slice = 8, 9, 10, 11
         R = batch.shape[0]
