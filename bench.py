@@ -1,12 +1,18 @@
 #!/usr/bin/env python
 """Benchmark of the Neural Object Field hot path on MI355X.
 
-    python bench.py [--gpus N --steps K --warmup W]          (N > 1: launched by torch.distributed.run, one rank per GPU)
+    python bench.py [--gpus N --steps K --warmup W]
+
+N > 1: one rank per GPU over RCCL.  Started plainly (`python bench.py --gpus N`, no WORLD_SIZE in the environment) it
+launches its N ranks itself through torch.distributed.run and fails loudly when fewer than N GPUs are visible; started by
+torch.distributed.run (the driver's way) it is one of the ranks.
 
 A step = one full train_loop iteration (batch draw -> occupancy trace -> z sampling -> hash encode -> SDF/colour MLPs ->
 compositing + losses -> backward -> [RCCL gradient all-reduce] -> Adam) over a synthetic 640x480 RGBD keyframe pool
 resident in HBM.  Workload = BASELINE.json configs[1]: 64 keyframes per GPU, 4096 rays/step, hash L=16 T=2^19 (base 16
--> finest 256), SDF-MLP 3x64 + colour-MLP 2x64, bf16 MFMA, 128+64 samples per ray.  Prints ONE JSON line.
+-> finest 256), SDF-MLP 3x64 + colour-MLP 2x64, 128+64 samples per ray, 16-bit MFMA operands: fp16 (the reference's
+autocast type) with the hi+lo operand split in the forward kernels -- the mode whose SDF/colour outputs are within 1e-3 of
+the fp32 oracle (tests/test_gpu_step.py) -- and a loss-scaled fp16 backward.  Prints ONE JSON line.
 """
 import argparse
 import json
@@ -24,6 +30,10 @@ def log(msg):
     print(f'[bench {time.strftime("%H:%M:%S")}] {msg}', file=sys.stderr, flush=True)
 
 
+PRECISION_NOTE = {
+    'fp16x3': 'fp16 MFMA operands (hi+lo operand split = 3 MFMAs per product in the forward kernels, loss-scaled fp16 backward)',
+    'bf16x3': 'bf16 MFMA operands (hi+lo operand split in the forward kernels, bf16 backward)',
+    'bf16': 'bf16 MFMA', 'fp16': 'fp16 MFMA (loss-scaled backward)', 'fp32': 'exact fp32 MFMA'}
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 MFMA_BF16_PEAK_TF = 2500.0     # dense bf16 MFMA
 
@@ -55,7 +65,8 @@ def build_runner(args, rank, world, device):
         dist.all_gather(cs, c)
         cloud = torch.cat(cs, 0).cpu().numpy()
     sync = None
-    if dist.is_initialized():               # RCCL sum; gradients are pre-scaled by 1/world_size on the device
+    if dist.is_initialized() and world > 1:  # RCCL sum; gradients are pre-scaled by 1/world_size on the device (a sum over one
+                                             # rank is the identity: a world-size-1 launch issues no collective at all)
         from bundlesdf_amd.dist import GradSync
         sync = GradSync()                   # bucketed: the fine hash levels' slice is reduced beside the rest of the backward
         if os.environ.get('NOF_DP_OVERLAP', '1') == '0':
@@ -128,6 +139,25 @@ def cpu_baseline(seconds=20.0, rays_per_step=4096, log2_T=19, mlp='baseline'):
                       f"keyframes 640x480, torch threads={ncores}"}
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks (one per GPU, RCCL) through torch.distributed.run
+    and hand its exit status on.  Rank 0 prints the JSON line on the inherited stdout."""
+    import socket
+    import subprocess
+    n_dev = torch.cuda.device_count()
+    if n_dev < args.gpus:
+        raise SystemExit(f'bench.py: --gpus {args.gpus} but only {n_dev} GPU(s) are visible; refusing to run fewer ranks '
+                         f'than asked for (the result would claim n_gpus={args.gpus})')
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}',
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    log('self-launch: ' + ' '.join(cmd))
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -138,13 +168,15 @@ def main():
     ap.add_argument('--log2_T', type=int, default=19)
     ap.add_argument('--height', type=int, default=480)
     ap.add_argument('--width', type=int, default=640)
-    ap.add_argument('--precision', default='bf16', choices=['bf16', 'fp16', 'fp32'])
+    ap.add_argument('--precision', default='fp16x3', choices=['fp16x3', 'bf16x3', 'bf16', 'fp16', 'fp32'])
     ap.add_argument('--mlp', default='baseline', choices=['baseline', 'reference'],
                     help='baseline: SDF 3x64 + colour 2x64 (BASELINE.json cfg2); reference: NeRFSmall(2,3) nerf_runner.py:221')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-seconds', type=float, default=25.0)
     args = ap.parse_args()
 
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        return self_launch(args)
     import torch.distributed as dist
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
@@ -161,7 +193,8 @@ def main():
             dist.init_process_group('nccl', device_id=device)
         else:
             dist.init_process_group(backend)
-    assert world == args.gpus or world == 1, f'--gpus {args.gpus} but WORLD_SIZE={world}'
+    if world != args.gpus:
+        raise SystemExit(f'bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: the two must agree (n_gpus in the result is WORLD_SIZE)')
 
     log(f'rank {rank}/{world}: building the keyframe pool and ray table')
     runner, cfg = build_runner(args, rank, world, device)
@@ -219,14 +252,18 @@ def main():
         fl_fwd = 2.0 * (n_mlp - sum(o for o, _ in fld.layer_dims))      # 2*MAC per sample
         work = {
             'nof_hash_encode_fwd': ('hbm', B * (16 * 8 * 2 * 4 + 12 + 16 * 2 * 4)),
-            'nof_hash_encode_bwd': ('hbm', B * (16 * 2 * 4 + 2 * 16 * 8 * 2 * 4 + 12 + 16 * 8 * 2 * 4 + 12)),
+            # dfeat read (L*C*4) + atomic read-modify-write of 8 corners x 2 channels per level (2*L*8*2*4) = 2112 B/sample
+            'nof_hash_encode_bwd': ('hbm', B * (16 * 2 * 4 + 2 * 16 * 8 * 2 * 4)),
             'nof_mlp_fwd': ('mfma', B * fl_fwd),
             'nof_mlp_bwd': ('mfma', B * 3.0 * fl_fwd),
             'nof_adam_step': ('hbm', fld.n_total * 32.0),
         }
+        # the entry point also computes dL/dx (k_hash_dx, gridencoder.cu:202-245,340-365) on a side stream: 8 gathers per level
+        # + coordinates in, gradient out = 1048 B/sample more than SURVEY 8d's scatter-only figure
+        extra_bytes = {'nof_hash_encode_bwd': B * (16 * 8 * 2 * 4 + 12 + 12)}
         traffic = None          # HBM bytes per launch from the committed PMC passes (profiles/pmc_traffic.json), same workload only
         try:
-            if args.precision == 'bf16' and args.mlp == 'baseline' and R == 4096 and args.log2_T == 19:
+            if args.mlp == 'baseline' and R == 4096 and args.log2_T == 19:
                 pm = json.load(open(os.path.join(ROOT, 'profiles', 'pmc_traffic.json')))
                 traffic = pm.get(dominant, {}).get('traffic_bytes')
         except Exception:
@@ -237,7 +274,11 @@ def main():
             if kind == 'hbm':
                 ach = amount / (dom_ms * 1e-3) / 1e9
                 roof = {"kernel": dominant, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes": amount, "avg_ms": dom_ms}
+                        "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes": amount, "avg_ms": dom_ms,
+                        "traffic_source": "profiles/pmc_traffic.json (rocprofv3 --pmc passes of this workload, committed; "
+                                          "not re-measured in this run)" if traffic else None}
+                if dominant in extra_bytes:      # the same launch priced with everything it computes (scatter + dL/dx)
+                    roof["frac_incl_input_grad"] = (amount + extra_bytes[dominant]) / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
             else:
                 ach = amount / (dom_ms * 1e-3) / 1e12
                 roof = {"kernel": dominant, "bound": "mfma", "achieved": ach, "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s",
@@ -251,15 +292,16 @@ def main():
         out = {
             "metric": "ray_samples_per_sec", "value": value, "unit": "ray-samples/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": args.precision, "data": "synthetic",
+            "dtype": {'fp16x3': 'fp16', 'bf16x3': 'bf16'}.get(args.precision, args.precision), "data": "synthetic",
             "config": {"workload": f"{cfg_name}: {args.keyframes} synthetic {args.width}x{args.height} RGBD keyframes per GPU, "
                                    f"{R} rays/step x {S} samples, hash L=16 T=2^{args.log2_T} base16->256, "
                                    f"MLP {'SDF 3x64 + colour 2x64' if args.mlp == 'baseline' else 'SDF 2x64 + colour 3x64'}, "
-                                   f"{args.precision} MFMA, fp32 table/Adam",
+                                   f"{PRECISION_NOTE[args.precision]}, fp32 table/accumulators/Adam",
                        "rays_per_step": R, "samples_per_ray": S, "keyframes_per_gpu": args.keyframes,
                        "pool_rays": int(runner.rays.shape[0]), "parallelism": f"dp{world}"},
             "train_iters_per_sec": it_s * 1.0,
             "kernel_ms_warmup": {k: round(v, 4) for k, v in sorted(ktimes.items(), key=lambda kv: -kv[1])},
+            "valid_sample_fraction": losses['n_valid_samples'] / B,     # samples inside [-1,1]^3 (the rest still run the MLPs)
             "loss": losses['loss'], "flags": flags, "dp_param_checksum_spread": dp_spread, "param_checksum": checksum,
             "roofline": roof,
         }

@@ -7,9 +7,12 @@ The reference saves one state_dict per module:
     'pose_array'     PoseArray: data [F, 6];   'feature_array'  FeatureArray: data [F, ff]
     'optimizer', 'octree' (kaolin bytes), 'global_step'
 Here all parameters live in one flat buffer [table | MLP in PyTorch parameter order | features | poses]; these helpers
-convert between the two so that a field trained by either implementation can be loaded by the other.  The optimiser state
-and the kaolin octree bytes are not convertible (different optimiser object / no kaolin): the octree is rebuilt from the
-point cloud, Adam's moments restart.  Pure tensor shuffling, no GPU needed.
+convert between the two so that a field trained by either implementation can be loaded by the other -- including the
+'optimizer' entry, which the reference's load_weights reads unconditionally (nerf_runner.py:544): it is written as the
+state_dict of a torch.optim.Adam built like create_optimizer does (nerf_runner.py:492-504: group 'basic' = embeddings, NeRFSmall
+parameters, feature array in that order; group 'pose_array'), with step / exp_avg / exp_avg_sq taken from the flat moment
+buffers, and read back the same way.  The kaolin octree bytes are not convertible (no kaolin): the octree is rebuilt from
+the point cloud.  Pure tensor shuffling, no GPU needed.
 """
 import numpy as np
 import torch
@@ -48,13 +51,74 @@ def mlp_flat_from_state(state, layer_dims, n_sigma):
     return torch.cat(parts)
 
 
+def _param_shapes(field):
+    """[(segment, offset in the segment, shape)] in the reference optimiser's parameter order, and the index of the first
+    parameter of the 'pose_array' group (None without pose optimisation)."""
+    out = [('table', 0, (field.n_entries, 2))]
+    off = 0
+    for o, i in field.layer_dims:
+        out.append(('mlp', off, (o, i)))
+        off += o * i
+        out.append(('mlp', off, (o,)))
+        off += o
+    if field.ff > 0:
+        out.append(('feat', 0, (field.F, field.ff)))
+    n_basic = len(out)
+    if field.optimize_poses:
+        out.append(('pose', 0, (field.F, 6)))
+    return out, (n_basic if field.optimize_poses else None)
+
+
+def optimizer_state_dict(field, lrs=None):
+    """state_dict of the torch.optim.Adam the reference builds in create_optimizer (nerf_runner.py:492-504), filled from the
+    field's flat Adam moments: what its load_weights hands to optimizer.load_state_dict (nerf_runner.py:544)."""
+    shapes, pose_at = _param_shapes(field)
+    lr, lr_pose = lrs if lrs is not None else field.learning_rates()
+    params = [torch.nn.Parameter(torch.zeros(shape)) for _, _, shape in shapes]
+    n_basic = pose_at if pose_at is not None else len(params)
+    groups = [{'name': 'basic', 'params': params[:n_basic], 'lr': lr}]
+    if pose_at is not None:
+        groups.append({'name': 'pose_array', 'params': params[n_basic:], 'lr': lr_pose})
+    opt = torch.optim.Adam(groups, betas=(0.9, 0.999), weight_decay=0, eps=1e-15)
+    if field.global_step > 0:
+        for p, (seg, off, shape) in zip(params, shapes):
+            n = int(np.prod(shape))
+            m = field._seg(field.exp_avg, seg)[off:off + n].detach().cpu().reshape(shape).clone()
+            v = field._seg(field.exp_avg_sq, seg)[off:off + n].detach().cpu().reshape(shape).clone()
+            opt.state[p] = {'step': torch.tensor(float(field.global_step)), 'exp_avg': m, 'exp_avg_sq': v}
+    return opt.state_dict()
+
+
+def load_optimizer_state_dict(field, sd):
+    """inverse of optimizer_state_dict: Adam moments (and the step count) of a reference checkpoint -> the flat buffers.
+    Returns the step count, or None when the checkpoint's optimiser had not stepped yet."""
+    shapes, _ = _param_shapes(field)
+    ids = [i for g in sd['param_groups'] for i in g['params']]
+    if len(ids) != len(shapes):
+        raise ValueError(f"optimizer state has {len(ids)} parameters, this field has {len(shapes)}")
+    step = None
+    for pid, (seg, off, shape) in zip(ids, shapes):
+        st = sd['state'].get(pid)
+        if st is None:
+            continue
+        n = int(np.prod(shape))
+        for key, buf in (('exp_avg', field.exp_avg), ('exp_avg_sq', field.exp_avg_sq)):
+            t = torch.as_tensor(st[key], dtype=torch.float32)
+            if tuple(t.shape) != tuple(shape):
+                raise ValueError(f"optimizer state {key} of parameter {pid} is {tuple(t.shape)}, expected {tuple(shape)}")
+            field._seg(buf, seg)[off:off + n].copy_(t.reshape(-1).to(buf.device))
+        step = int(float(st['step']))
+    return step
+
+
 def to_reference_checkpoint(field, global_step=0):
     """dict in the reference's layout (CPU tensors) from a NeuralObjectField"""
     ck = {'global_step': int(global_step),
           'model': mlp_state_from_flat(field.mlp, field.layer_dims, field.n_sigma),
           'embed_fn': {'embeddings': field.table.detach().cpu().reshape(-1, 2).clone(),
                        'offsets': torch.as_tensor(np.asarray(field.offsets), dtype=torch.int32)},
-          'embeddirs_fn': {}}
+          'embeddirs_fn': {},
+          'optimizer': optimizer_state_dict(field)}
     if field.optimize_poses:
         ck['pose_array'] = {'data': field.pose.detach().cpu().reshape(field.F, 6).clone()}
     if field.ff > 0:
@@ -84,4 +148,9 @@ def load_reference_checkpoint(field, ck):
     field.load_parameters(table=emb, mlp=mlp_flat_from_state(ck['model'], field.layer_dims, field.n_sigma), feat=feat, pose=pose)
     field.exp_avg.zero_()
     field.exp_avg_sq.zero_()
+    field.grads.zero_()
+    if 'optimizer' in ck:
+        step = load_optimizer_state_dict(field, ck['optimizer'])
+        if step is not None:
+            field.global_step = step
     return int(ck.get('global_step', 0))

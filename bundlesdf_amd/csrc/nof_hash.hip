@@ -367,6 +367,12 @@ static int side_stream(SideStream** out) {
   int dev = 0;
   NOF_HIP(hipGetDevice(&dev));
   if (g_side.stream == nullptr || g_side.device != dev) {
+    if (g_side.stream != nullptr) {                                    // device changed: the old stream and events belong to the other device
+      (void)hipEventDestroy(g_side.fork);
+      (void)hipEventDestroy(g_side.join);
+      (void)hipStreamDestroy(g_side.stream);
+      g_side = SideStream();
+    }
     NOF_HIP(hipStreamCreateWithFlags(&g_side.stream, hipStreamNonBlocking));   // (stream priority made no measurable difference)
     NOF_HIP(hipEventCreateWithFlags(&g_side.fork, hipEventDisableTiming));
     NOF_HIP(hipEventCreateWithFlags(&g_side.join, hipEventDisableTiming));

@@ -98,9 +98,12 @@ __device__ __forceinline__ int inmap(const NofMlpDesc& d, int l, int q, int hi, 
 // -- packing inside each workgroup cost ~60 us of dependent global loads per workgroup and dominated the forward).
 //   fw[(pair_base(l) + p*QN + q)][step][lane][t] = W_l[32p + i][inmap(l,q,hi,KR*step+t)]                (lane = hi*32+i)
 //   bw[(pair_base(l) + q*PN + p)][step][lane][t] = W_l[32p + nloc(hi,KR*step+t)][inmap(l,q,hi(i),r(i))]
-//   image = [ fw : npair*1024 elems | bw : npair*1024 elems | bias : nob*32 floats ]
+//   image = [ fw : npair*1024 elems | bw : npair*1024 elems | bias : nob*32 floats | (fw_lo : npair*1024 elems) ]
+// fw_lo (split-forward precisions only) holds the rounding residual of fw: fw_lo = round(W - float(fw)), so that fw + fw_lo
+// carries twice the operand's mantissa (fp16: 22 bits, bf16: 16 bits).
 template <class P>
-__global__ __launch_bounds__(256) void k_mlp_pack(NofMlpDesc d, const float* __restrict__ params, char* __restrict__ image) {
+__global__ __launch_bounds__(256) void k_mlp_pack(NofMlpDesc d, const float* __restrict__ params, char* __restrict__ image,
+                                                  int with_lo) {
   constexpr int KR = P::KR;
   typedef typename P::elem elem;
   const int n_layers = d.n_sigma + d.n_color;
@@ -108,6 +111,7 @@ __global__ __launch_bounds__(256) void k_mlp_pack(NofMlpDesc d, const float* __r
   elem* fw = (elem*)image;
   elem* bw = fw + (size_t)npair * 16 * 64;
   float* bias = (float*)(bw + (size_t)npair * 16 * 64);
+  elem* fw_lo = (elem*)(bias + (size_t)oblk_base(d, n_layers) * 32);
   const int total = npair * 16 * 64;
   for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
     const int lane = e & 63, r = (e >> 6) & 15;
@@ -125,7 +129,9 @@ __global__ __launch_bounds__(256) void k_mlp_pack(NofMlpDesc d, const float* __r
       const int p = pair / qn, q = pair % qn;
       const int row = 32 * p + i, col = inmap(d, l, q, hi, r);
       const float v = (row < out_dim && col >= 0) ? W[row * in_dim + col] : 0.0f;
-      fw[(((size_t)(base + p * qn + q) * (16 / KR) + r / KR) * 64 + lane) * KR + r % KR] = (elem)v;
+      const size_t at = (((size_t)(base + p * qn + q) * (16 / KR) + r / KR) * 64 + lane) * KR + r % KR;
+      fw[at] = (elem)v;
+      if (with_lo) fw_lo[at] = (elem)(v - (float)(elem)v);
     }
     {
       const int q = pair / pn, p = pair % pn;
@@ -168,17 +174,31 @@ struct Shp {                                       // compile-time layer table (
 // ---- one dense layer -------------------------------------------------------------
 // out[p][r] = neuron 32p + nloc(hi,r) of sample j (lane = sample).  `frag_off` / `bias_off` are compile-time byte offsets of the
 // layer's fragments / biases inside the dynamic LDS block, so every ds_read is base-register + immediate.
-template <class P, int QN, int PN>
+// SPLIT (16-bit operand types only): both operands are carried as hi + lo = value rounded to the operand type + the rounded
+// residual, and the product is the three MFMAs hi*hi + hi*lo + lo*hi (the lo*lo term is below fp32 rounding): twice the
+// operand mantissa (fp16: 22 bits), i.e. fp32-class outputs from the 16-bit matrix cores at 3x the (idle) MFMA work.
+// `lo_off` = byte offset of the layer's residual fragments (same layout as the main ones).
+template <class P, int QN, int PN, bool SPLIT = false>
 __device__ __forceinline__ void dense_o1(const char* smem, int frag_off, int bias_off, const float (&in)[QN][16],
-                                         float (&out)[PN][16], int lane) {
+                                         float (&out)[PN][16], int lane, int lo_off = 0) {
   constexpr int KR = P::KR, NSTEP = 16 / KR;
   constexpr int FB = 64 * KR * (int)sizeof(typename P::elem);          // bytes of one fragment (all 64 lanes)
+  static_assert(!SPLIT || KR == 8, "the operand split is for the 16-bit operand types");
   const int hi = lane >> 5;
   typename P::frag bop[QN][NSTEP];
+  typename P::frag blo[SPLIT ? QN : 1][SPLIT ? NSTEP : 1];
 #pragma unroll
   for (int q = 0; q < QN; ++q)
 #pragma unroll
-    for (int s = 0; s < NSTEP; ++s) bop[q][s] = P::pack(&in[q][KR * s]);
+    for (int s = 0; s < NSTEP; ++s) {
+      bop[q][s] = P::pack(&in[q][KR * s]);
+      if constexpr (SPLIT) {
+        float res[KR];
+#pragma unroll
+        for (int t = 0; t < KR; ++t) res[t] = in[q][KR * s + t] - (float)bop[q][s][t];
+        blo[q][s] = P::pack(res);
+      }
+    }
   const char* fl = smem + lane * (KR * (int)sizeof(typename P::elem));
   const char* bl = smem + bias_off + hi * 16;
 #pragma unroll
@@ -194,6 +214,11 @@ __device__ __forceinline__ void dense_o1(const char* smem, int frag_off, int bia
 #pragma unroll
       for (int s = 0; s < NSTEP; ++s) {
         const typename P::frag a = *(const typename P::frag*)(fl + frag_off + ((p * QN + q) * NSTEP + s) * FB);
+        if constexpr (SPLIT) {
+          const typename P::frag al = *(const typename P::frag*)(fl + lo_off + ((p * QN + q) * NSTEP + s) * FB);
+          acc = P::mma(al, bop[q][s], acc);
+          acc = P::mma(a, blo[q][s], acc);
+        }
         acc = P::mma(a, bop[q][s], acc);
       }
 #pragma unroll
@@ -287,11 +312,12 @@ __device__ __forceinline__ void load_sig_o1(const typename P::elem* __restrict__
 #define FW_OFF(l) (SH::pair_base(l) * PAIR_BYTES)
 #define BW_OFF(l) (BW_BASE + SH::pair_base(l) * PAIR_BYTES)
 #define BIAS_OFF(l) (BIAS_BASE + SH::oblk_base(l) * 32 * 4)
+#define LO_OFF(l) (LO_BASE + SH::pair_base(l) * PAIR_BYTES)
 
 // =====================================================================================================
 // forward: raw[b] = (rgb_raw[3], sdf)
 // =====================================================================================================
-template <class P, int NS, int NC, bool SDF_ONLY>
+template <class P, int NS, int NC, bool SDF_ONLY, bool SPLIT>
 __global__ __launch_bounds__(256, 2) void k_mlp_fwd(      // >= 2 waves/SIMD: no AGPRs, so MFMA results land in VGPRs directly
 NofMlpDesc d, const char* __restrict__ image,
                                                   const float2* __restrict__ feat, int L, const float* __restrict__ view,
@@ -300,8 +326,12 @@ NofMlpDesc d, const char* __restrict__ image,
   typedef Shp<NS, NC> SH;
   constexpr int NL = SDF_ONLY ? NS : NS + NC;
   constexpr int BIAS_BASE = SH::pair_base(NL) * PAIR_BYTES;           // this kernel keeps only the first NL layers' fragments
+  constexpr int LO_BASE = BIAS_BASE + SH::oblk_base(NL) * 32 * 4;     // residual fragments of the split forward
   copy16(smem, image, (size_t)BIAS_BASE);
   copy16(smem + BIAS_BASE, image + 2 * (size_t)SH::pair_base(NS + NC) * PAIR_BYTES, (size_t)SH::oblk_base(NL) * 32 * 4);
+  if constexpr (SPLIT)
+    copy16(smem + LO_BASE, image + 2 * (size_t)SH::pair_base(NS + NC) * PAIR_BYTES + (size_t)SH::oblk_base(NS + NC) * 32 * 4,
+           (size_t)BIAS_BASE);
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int hi = lane >> 5, j = lane & 31;
@@ -317,19 +347,19 @@ NofMlpDesc d, const char* __restrict__ image,
     for (int r = 0; r < 16; ++r) x[0][r] = xn[0][r];
     load_feat_o1(feat, L, B, (tile + tstride) * 32 + j, hi, xn);      // out-of-range tiles load nothing (b >= B -> zeros)
     float h[2][16], so[1][16];
-    dense_o1<P, 1, 2>(smem, FW_OFF(0), BIAS_OFF(0), x, h, lane);
+    dense_o1<P, 1, 2, SPLIT>(smem, FW_OFF(0), BIAS_OFF(0), x, h, lane, LO_OFF(0));
     relu_mask<2>(h);
 #pragma unroll
     for (int l = 1; l < NS - 1; ++l) {
       float h2[2][16];
-      dense_o1<P, 2, 2>(smem, FW_OFF(l), BIAS_OFF(l), h, h2, lane);
+      dense_o1<P, 2, 2, SPLIT>(smem, FW_OFF(l), BIAS_OFF(l), h, h2, lane, LO_OFF(l));
       relu_mask<2>(h2);
 #pragma unroll
       for (int p = 0; p < 2; ++p)
 #pragma unroll
         for (int r = 0; r < 16; ++r) h[p][r] = h2[p][r];
     }
-    dense_o1<P, 2, 1>(smem, FW_OFF(NS - 1), BIAS_OFF(NS - 1), h, so, lane);
+    dense_o1<P, 2, 1, SPLIT>(smem, FW_OFF(NS - 1), BIAS_OFF(NS - 1), h, so, lane, LO_OFF(NS - 1));
     if constexpr (SDF_ONLY) {
       if (hi == 0 && b < B) out[b] = so[0][0];
     } else {
@@ -340,12 +370,12 @@ NofMlpDesc d, const char* __restrict__ image,
         if (sig != nullptr) store_sig_o1<P>(sig, B, b, hi, so[0]);     // the colour net's operand, kept for the split backward
       }
       load_view_o1(view, S, B, b, hi, cin[1]);
-      dense_o1<P, 2, 2>(smem, FW_OFF(NS), BIAS_OFF(NS), cin, h, lane);
+      dense_o1<P, 2, 2, SPLIT>(smem, FW_OFF(NS), BIAS_OFF(NS), cin, h, lane, LO_OFF(NS));
       relu_mask<2>(h);
 #pragma unroll
       for (int l = NS + 1; l < NS + NC - 1; ++l) {
         float h2[2][16];
-        dense_o1<P, 2, 2>(smem, FW_OFF(l), BIAS_OFF(l), h, h2, lane);
+        dense_o1<P, 2, 2, SPLIT>(smem, FW_OFF(l), BIAS_OFF(l), h, h2, lane, LO_OFF(l));
         relu_mask<2>(h2);
 #pragma unroll
         for (int p = 0; p < 2; ++p)
@@ -353,7 +383,7 @@ NofMlpDesc d, const char* __restrict__ image,
           for (int r = 0; r < 16; ++r) h[p][r] = h2[p][r];
       }
       float co[1][16];
-      dense_o1<P, 2, 1>(smem, FW_OFF(NS + NC - 1), BIAS_OFF(NS + NC - 1), h, co, lane);
+      dense_o1<P, 2, 1, SPLIT>(smem, FW_OFF(NS + NC - 1), BIAS_OFF(NS + NC - 1), h, co, lane, LO_OFF(NS + NC - 1));
       if (hi == 0 && b < B) ((float4*)out)[b] = make_float4(co[0][0], co[0][1], co[0][2], so[0][0]);
     }
   }
@@ -367,7 +397,7 @@ NofMlpDesc d, const char* __restrict__ image,
 // the B-operand layout of the first layer); occupancy is spatially coherent (level <= 6 cells vs 1/512 voxels), so a
 // wave-uniform skip of all-empty tiles is the whole compaction that is needed.
 // =====================================================================================================
-template <class P, int NS, int NC>
+template <class P, int NS, int NC, bool SPLIT>
 __global__ __launch_bounds__(256, 2) void k_sdf_grid(NofMlpDesc d, const char* __restrict__ image, NofHashGrid g,
                                                       const float2* __restrict__ table, const uint32_t* __restrict__ occ_bits,
                                                       int occ_n, const float* __restrict__ tx, const float* __restrict__ ty,
@@ -376,8 +406,12 @@ __global__ __launch_bounds__(256, 2) void k_sdf_grid(NofMlpDesc d, const char* _
   extern __shared__ __attribute__((aligned(16))) char smem[];
   typedef Shp<NS, NC> SH;
   constexpr int BIAS_BASE = SH::pair_base(NS) * PAIR_BYTES;
+  constexpr int LO_BASE = BIAS_BASE + SH::oblk_base(NS) * 32 * 4;
   copy16(smem, image, (size_t)BIAS_BASE);
   copy16(smem + BIAS_BASE, image + 2 * (size_t)SH::pair_base(NS + NC) * PAIR_BYTES, (size_t)SH::oblk_base(NS) * 32 * 4);
+  if constexpr (SPLIT)
+    copy16(smem + LO_BASE, image + 2 * (size_t)SH::pair_base(NS + NC) * PAIR_BYTES + (size_t)SH::oblk_base(NS + NC) * 32 * 4,
+           (size_t)BIAS_BASE);
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int hi = lane >> 5, j = lane & 31;
@@ -411,19 +445,19 @@ __global__ __launch_bounds__(256, 2) void k_sdf_grid(NofMlpDesc d, const char* _
       x[0][2 * kk + 1] = v.y;
     }
     float h[2][16], so[1][16];
-    dense_o1<P, 1, 2>(smem, FW_OFF(0), BIAS_OFF(0), x, h, lane);
+    dense_o1<P, 1, 2, SPLIT>(smem, FW_OFF(0), BIAS_OFF(0), x, h, lane, LO_OFF(0));
     relu_mask<2>(h);
 #pragma unroll
     for (int l = 1; l < NS - 1; ++l) {
       float h2[2][16];
-      dense_o1<P, 2, 2>(smem, FW_OFF(l), BIAS_OFF(l), h, h2, lane);
+      dense_o1<P, 2, 2, SPLIT>(smem, FW_OFF(l), BIAS_OFF(l), h, h2, lane, LO_OFF(l));
       relu_mask<2>(h2);
 #pragma unroll
       for (int pp = 0; pp < 2; ++pp)
 #pragma unroll
         for (int r = 0; r < 16; ++r) h[pp][r] = h2[pp][r];
     }
-    dense_o1<P, 2, 1>(smem, FW_OFF(NS - 1), BIAS_OFF(NS - 1), h, so, lane);
+    dense_o1<P, 2, 1, SPLIT>(smem, FW_OFF(NS - 1), BIAS_OFF(NS - 1), h, so, lane, LO_OFF(NS - 1));
     if (hi == 0 && in_range) sdf[vox] = inside ? so[0][0] : outside;
   }
 }
@@ -545,7 +579,7 @@ __device__ __forceinline__ void dw_block(float (&dw)[2][16], float* db_lane, con
 // sums the 4 * n_workgroups rows.
 template <class SH, int LA, int LB>
 __device__ __forceinline__ void flush_dw(const NofMlpDesc& d, const float (&dw)[SH::NL][2][2][16], const float* dbw,
-                                         float* __restrict__ partials) {
+                                         float* __restrict__ partials, float unscale) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int hi = lane >> 5, j = lane & 31;
   const int hi_j = (j >> 2) & 1, r_j = (j & 3) + 4 * (j >> 3);      // dW column lane j = input slot (hi_j, r_j)
@@ -564,7 +598,7 @@ __device__ __forceinline__ void flush_dw(const NofMlpDesc& d, const float (&dw)[
             for (int r = 0; r < 16; ++r) {
               if (r < SH::nacc(l)) {
                 const int row = 32 * p + nloc(hi, r);
-                if (col >= 0 && row < out_dim) dst[d.w_off[l] + row * in_dim + col] = dw[l][p][q][r];
+                if (col >= 0 && row < out_dim) dst[d.w_off[l] + row * in_dim + col] = dw[l][p][q][r] * unscale;
               }
             }
           }
@@ -572,7 +606,7 @@ __device__ __forceinline__ void flush_dw(const NofMlpDesc& d, const float (&dw)[
         float v = dbw[(2 * l + p) * 64];                               // lane-private sums of lanes (hi, j): the pair shares row j
         v += __shfl_xor(v, 32, 64);
         const int row = 32 * p + j;
-        if (hi == 0 && row < out_dim) dst[d.b_off[l] + row] = v;
+        if (hi == 0 && row < out_dim) dst[d.b_off[l] + row] = v * unscale;
       }
     }
   }
@@ -607,6 +641,10 @@ __global__ __launch_bounds__(256) void k_mlp_bwd(NofMlpDesc d, const char* __res
   for (int k = 0; k < NSLOT; ++k) dbw[k * 64] = 0.0f;
   Ident<P> I;
   I.init(lane);
+  // loss scaling of the 16-bit backward (the reference's GradScaler, nerf_runner.py:159,758): the loss gradient is multiplied
+  // by a power of two where it enters and every fp32 output is divided by it where it leaves -- exact in fp32, and it keeps
+  // the ~1e-7 gradients of a 1/(R*S)-normalised loss out of binary16's subnormal range inside the MFMA operands
+  const float gscale = d.grad_scale > 0.0f ? d.grad_scale : 1.0f, gunscale = 1.0f / gscale;
 
   float dw[NL][2][2][16];                             // persistent per-wave dW accumulators (only the live entries are touched)
 #pragma unroll
@@ -684,8 +722,8 @@ __global__ __launch_bounds__(256) void k_mlp_bwd(NofMlpDesc d, const char* __res
       for (int r = 0; r < 16; ++r) g1[p][r] = 0.0f;
     if (hi == 0 && b < B) {                           // draw[b] = (d rgb_raw[3], d sdf)
       const float4 t = draw[b];
-      g1[0][0] = t.x; g1[0][1] = t.y; g1[0][2] = t.z;
-      dsdf1 = t.w;
+      g1[0][0] = t.x * gscale; g1[0][1] = t.y * gscale; g1[0][2] = t.z * gscale;
+      dsdf1 = t.w * gscale;
     }
     // ---- colour net: head down to colour layer 1 ----
 #pragma unroll
@@ -733,8 +771,8 @@ __global__ __launch_bounds__(256) void k_mlp_bwd(NofMlpDesc d, const char* __res
         sb += __shfl_xor(sb, 32, 64);
         const int hi_j = (j >> 2) & 1, u = (j & 3) + 4 * (j >> 3);   // lane j holds slot (hi_j, r_j) -> view column 16 hi_j + r_j
         if (hi == 0 && hi_j == 0 && u < d.n_view) {
-          if (sa != 0.0f) atomicAdd(&dview[ray0 * NOF_VIEW_COLS + u], sa);
-          if (sb != 0.0f) atomicAdd(&dview[(ray0 + 1) * NOF_VIEW_COLS + u], sb);
+          if (sa != 0.0f) atomicAdd(&dview[ray0 * NOF_VIEW_COLS + u], sa * gunscale);
+          if (sb != 0.0f) atomicAdd(&dview[(ray0 + 1) * NOF_VIEW_COLS + u], sb * gunscale);
         }
       }
       // gradient of the sigma net output block: geo_feat grads + the loss' own d sdf (output 0 = hi 0, reg 0)
@@ -775,14 +813,14 @@ __global__ __launch_bounds__(256) void k_mlp_bwd(NofMlpDesc d, const char* __res
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
           const int level = 8 * hi + k;
-          if (level < L) dfeat[(int64_t)level * B + b] = make_float2(df1[2 * k], df1[2 * k + 1]);
+          if (level < L) dfeat[(int64_t)level * B + b] = make_float2(df1[2 * k] * gunscale, df1[2 * k + 1] * gunscale);
         }
       }
     }
   }
 
   // ---------------- reduce the workgroup's dW/db and write its row of `partials` ----------------
-  flush_dw<SH, 0, NL>(d, dw, dbw, partials);
+  flush_dw<SH, 0, NL>(d, dw, dbw, partials, gunscale);
 }
 
 // =====================================================================================================
@@ -830,6 +868,10 @@ __global__ __launch_bounds__(256, 2) void k_mlp_bwd_color(NofMlpDesc d, const ch
   float* dbw = dbl - (2 * NS) * 64;                                                 // so that [2 l + p] addresses it (never dereferenced below 2 NS)
   Ident<P> I;
   I.init(lane);
+  // loss scaling of the 16-bit backward (the reference's GradScaler, nerf_runner.py:159,758): the loss gradient is multiplied
+  // by a power of two where it enters and every fp32 output is divided by it where it leaves -- exact in fp32, and it keeps
+  // the ~1e-7 gradients of a 1/(R*S)-normalised loss out of binary16's subnormal range inside the MFMA operands
+  const float gscale = d.grad_scale > 0.0f ? d.grad_scale : 1.0f, gunscale = 1.0f / gscale;
   float dw[NL][2][2][16];
 #pragma unroll
   for (int l = NS; l < NL; ++l)
@@ -880,8 +922,8 @@ __global__ __launch_bounds__(256, 2) void k_mlp_bwd_color(NofMlpDesc d, const ch
       for (int r = 0; r < 16; ++r) g1[p][r] = 0.0f;
     if (hi == 0 && b < B) {                           // draw[b] = (d rgb_raw[3], d sdf)
       const float4 t = draw[b];
-      g1[0][0] = t.x; g1[0][1] = t.y; g1[0][2] = t.z;
-      dsdf1 = t.w;
+      g1[0][0] = t.x * gscale; g1[0][1] = t.y * gscale; g1[0][2] = t.z * gscale;
+      dsdf1 = t.w * gscale;
     }
 #pragma unroll
     for (int l = NL - 1; l > NS; --l) {
@@ -926,15 +968,15 @@ __global__ __launch_bounds__(256, 2) void k_mlp_bwd_color(NofMlpDesc d, const ch
         sb += __shfl_xor(sb, 32, 64);
         const int hi_j = (j >> 2) & 1, u = (j & 3) + 4 * (j >> 3);
         if (hi == 0 && hi_j == 0 && u < d.n_view) {
-          if (sa != 0.0f) atomicAdd(&dview[ray0 * NOF_VIEW_COLS + u], sa);
-          if (sb != 0.0f) atomicAdd(&dview[(ray0 + 1) * NOF_VIEW_COLS + u], sb);
+          if (sa != 0.0f) atomicAdd(&dview[ray0 * NOF_VIEW_COLS + u], sa * gunscale);
+          if (sb != 0.0f) atomicAdd(&dview[(ray0 + 1) * NOF_VIEW_COLS + u], sb * gunscale);
         }
       }
       if (hi == 0) ds1[0] += dsdf1;                    // the loss' own d sdf joins the geo_feat gradients (output 0 = hi 0, reg 0)
       store_sig_o1<P>(dsig, B, b, hi, ds1);
     }
   }
-  flush_dw<SH, NS, NL>(d, dw, dbw, partials);
+  flush_dw<SH, NS, NL>(d, dw, dbw, partials, gunscale);
 #undef CFW
 #undef CBW
 #undef CBIAS
@@ -973,6 +1015,10 @@ __global__ __launch_bounds__(256, 2) void k_mlp_bwd_sigma(NofMlpDesc d, const ch
   for (int k = 0; k < 2 * NS; ++k) dbw[k * 64] = 0.0f;
   Ident<P> I;
   I.init(lane);
+  // loss scaling of the 16-bit backward (the reference's GradScaler, nerf_runner.py:159,758): the loss gradient is multiplied
+  // by a power of two where it enters and every fp32 output is divided by it where it leaves -- exact in fp32, and it keeps
+  // the ~1e-7 gradients of a 1/(R*S)-normalised loss out of binary16's subnormal range inside the MFMA operands
+  const float gscale = d.grad_scale > 0.0f ? d.grad_scale : 1.0f, gunscale = 1.0f / gscale;
   float dw[NL][2][2][16];
 #pragma unroll
   for (int l = 0; l < NS; ++l)
@@ -1047,12 +1093,12 @@ __global__ __launch_bounds__(256, 2) void k_mlp_bwd_sigma(NofMlpDesc d, const ch
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
           const int level = 8 * hi + k;
-          if (level < L) dfeat[(int64_t)level * B + b] = make_float2(df1[2 * k], df1[2 * k + 1]);
+          if (level < L) dfeat[(int64_t)level * B + b] = make_float2(df1[2 * k] * gunscale, df1[2 * k + 1] * gunscale);
         }
       }
     }
   }
-  flush_dw<SH, 0, NS>(d, dw, dbw, partials);
+  flush_dw<SH, 0, NS>(d, dw, dbw, partials, gunscale);
 #undef SFW
 #undef SBW
 #undef SBIAS
@@ -1070,7 +1116,8 @@ static int check_desc(const NofMlpDesc* d) {
   if (d->in_feat < 1 || d->in_feat > 32) return nof_set_error(-1, "mlp: L*C must be <= 32 (got %d)", d->in_feat);
   if (d->n_view < 0 || d->n_view > NOF_VIEW_COLS) return nof_set_error(-1, "mlp: n_view must be <= 16 (got %d)", d->n_view);
   if (d->geo != 15) return nof_set_error(-1, "mlp: geo_feat_dim must be 15 (got %d)", d->geo);
-  if (d->precision < 0 || d->precision > 2) return nof_set_error(-1, "mlp: precision must be 0 (fp32), 1 (bf16) or 2 (fp16)");
+  if (d->precision < 0 || d->precision > 4)
+    return nof_set_error(-1, "mlp: precision must be 0 (fp32), 1 (bf16), 2 (fp16), 3 (fp16, split forward) or 4 (bf16, split forward)");
   const int nl = d->n_sigma + d->n_color;
   for (int l = 0; l < nl; ++l) {
     const int exp_in = l == 0 ? d->in_feat : (l == d->n_sigma ? d->n_view + d->geo : 64);
@@ -1082,6 +1129,8 @@ static int check_desc(const NofMlpDesc* d) {
 }
 
 static size_t elem_size(int precision) { return precision == 0 ? 4 : 2; }
+static bool is_split(int precision) { return precision >= 3; }            // 3-term operand split in the forward kernels
+static bool is_bf16(int precision) { return precision == 1 || precision == 4; }
 static int n_pairs(const NofMlpDesc& d, int nl) { return pair_base(d, nl); }
 static int n_oblk(const NofMlpDesc& d, int nl) { return oblk_base(d, nl); }
 
@@ -1106,21 +1155,30 @@ static int set_smem(K kernel, size_t bytes) {
   else { FN(P, 3, 3, __VA_ARGS__) }
 #define DISPATCH_PREC(FN, ...)                                                                            \
   if (d->precision == 0) { DISPATCH_SHAPE(PrecF32, FN, __VA_ARGS__) }                                     \
-  else if (d->precision == 1) { DISPATCH_SHAPE(PrecBF16, FN, __VA_ARGS__) }                               \
+  else if (is_bf16(d->precision)) { DISPATCH_SHAPE(PrecBF16, FN, __VA_ARGS__) }                           \
   else { DISPATCH_SHAPE(PrecF16, FN, __VA_ARGS__) }
+// forward-type kernels: the 16-bit types also exist with the 3-term operand split
+#define DISPATCH_PREC_FWD(FN)                                                                             \
+  if (d->precision == 0) { DISPATCH_SHAPE(PrecF32, FN, false) }                                           \
+  else if (d->precision == 1) { DISPATCH_SHAPE(PrecBF16, FN, false) }                                     \
+  else if (d->precision == 2) { DISPATCH_SHAPE(PrecF16, FN, false) }                                      \
+  else if (d->precision == 3) { DISPATCH_SHAPE(PrecF16, FN, true) }                                       \
+  else { DISPATCH_SHAPE(PrecBF16, FN, true) }
 
 extern "C" int64_t nof_mlp_packed_bytes(const NofMlpDesc* d) {
   if (check_desc(d)) return -1;
   const int nl = d->n_sigma + d->n_color;
-  return 2 * (int64_t)n_pairs(*d, nl) * 16 * 64 * (int64_t)elem_size(d->precision) + (int64_t)n_oblk(*d, nl) * 32 * 4;
+  return (is_split(d->precision) ? 3 : 2) * (int64_t)n_pairs(*d, nl) * 16 * 64 * (int64_t)elem_size(d->precision) +
+         (int64_t)n_oblk(*d, nl) * 32 * 4;
 }
 
 extern "C" int nof_mlp_pack(const NofMlpDesc* d, const float* mlp_params, void* packed, void* stream) {
   if (int e = check_desc(d)) return e;
   NOF_ARG(mlp_params && packed);
-  if (d->precision == 0) hipLaunchKernelGGL(k_mlp_pack<PrecF32>, dim3(64), dim3(256), 0, (hipStream_t)stream, *d, mlp_params, (char*)packed);
-  else if (d->precision == 1) hipLaunchKernelGGL(k_mlp_pack<PrecBF16>, dim3(64), dim3(256), 0, (hipStream_t)stream, *d, mlp_params, (char*)packed);
-  else hipLaunchKernelGGL(k_mlp_pack<PrecF16>, dim3(64), dim3(256), 0, (hipStream_t)stream, *d, mlp_params, (char*)packed);
+  const int lo = is_split(d->precision) ? 1 : 0;
+  if (d->precision == 0) hipLaunchKernelGGL(k_mlp_pack<PrecF32>, dim3(64), dim3(256), 0, (hipStream_t)stream, *d, mlp_params, (char*)packed, 0);
+  else if (is_bf16(d->precision)) hipLaunchKernelGGL(k_mlp_pack<PrecBF16>, dim3(64), dim3(256), 0, (hipStream_t)stream, *d, mlp_params, (char*)packed, lo);
+  else hipLaunchKernelGGL(k_mlp_pack<PrecF16>, dim3(64), dim3(256), 0, (hipStream_t)stream, *d, mlp_params, (char*)packed, lo);
   NOF_LAUNCH_OK();
   return 0;
 }
@@ -1145,17 +1203,18 @@ extern "C" int nof_mlp_fwd(const NofMlpDesc* d, const void* packed, const float*
   NOF_ARG(packed && feat && view && raw && B >= 0 && S >= 1 && L >= 1 && L * 2 == d->in_feat);
   if (B == 0) return 0;
   const int nl = d->n_sigma + d->n_color;
-  const size_t shm = (size_t)n_pairs(*d, nl) * 16 * 64 * elem_size(d->precision) + (size_t)n_oblk(*d, nl) * 32 * 4;
+  const size_t shm = (is_split(d->precision) ? 2 : 1) * (size_t)n_pairs(*d, nl) * 16 * 64 * elem_size(d->precision) +
+                     (size_t)n_oblk(*d, nl) * 32 * 4;
   const int64_t ntiles = (B + 31) / 32;
   const unsigned blocks = (unsigned)(nof_div_up(ntiles, 4) < 1024 ? nof_div_up(ntiles, 4) : 1024);
-#define LAUNCH_FWD(P, NS_, NC_, dummy)                                                                    \
+#define LAUNCH_FWD(P, NS_, NC_, SPLIT_)                                                                   \
   {                                                                                                       \
-    auto kern = k_mlp_fwd<P, NS_, NC_, false>;                                                            \
+    auto kern = k_mlp_fwd<P, NS_, NC_, false, SPLIT_>;                                                    \
     if (int e = set_smem(kern, shm)) return e;                                                            \
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), shm, (hipStream_t)stream, *d, (const char*)packed,  \
                        (const float2*)feat, (int)L, view, (int)S, raw, (typename P::elem*)sigma_out, B);  \
   }
-  DISPATCH_PREC(LAUNCH_FWD, 0)
+  DISPATCH_PREC_FWD(LAUNCH_FWD)
 #undef LAUNCH_FWD
   NOF_LAUNCH_OK();
   return 0;
@@ -1167,17 +1226,18 @@ extern "C" int nof_mlp_sdf(const NofMlpDesc* d, const void* packed, const float*
   NOF_ARG(packed && feat && sdf && B >= 0 && L >= 1 && L * 2 == d->in_feat);
   if (B == 0) return 0;
   const int nl = d->n_sigma;
-  const size_t shm = (size_t)n_pairs(*d, nl) * 16 * 64 * elem_size(d->precision) + (size_t)n_oblk(*d, nl) * 32 * 4;
+  const size_t shm = (is_split(d->precision) ? 2 : 1) * (size_t)n_pairs(*d, nl) * 16 * 64 * elem_size(d->precision) +
+                     (size_t)n_oblk(*d, nl) * 32 * 4;
   const int64_t ntiles = (B + 31) / 32;
   const unsigned blocks = (unsigned)(nof_div_up(ntiles, 4) < 1024 ? nof_div_up(ntiles, 4) : 1024);
-#define LAUNCH_SDF(P, NS_, NC_, dummy)                                                                    \
+#define LAUNCH_SDF(P, NS_, NC_, SPLIT_)                                                                   \
   {                                                                                                       \
-    auto kern = k_mlp_fwd<P, NS_, NC_, true>;                                                             \
+    auto kern = k_mlp_fwd<P, NS_, NC_, true, SPLIT_>;                                                     \
     if (int e = set_smem(kern, shm)) return e;                                                            \
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), shm, (hipStream_t)stream, *d, (const char*)packed,  \
                        (const float2*)feat, (int)L, (const float*)nullptr, 1, sdf, (typename P::elem*)nullptr, B); \
   }
-  DISPATCH_PREC(LAUNCH_SDF, 0)
+  DISPATCH_PREC_FWD(LAUNCH_SDF)
 #undef LAUNCH_SDF
   NOF_LAUNCH_OK();
   return 0;
@@ -1211,7 +1271,7 @@ extern "C" int nof_mlp_bwd(const NofMlpDesc* d, const void* packed, const float*
                        (const float2*)feat, (int)L, (const typename P::elem*)dsigma_ws, (float2*)dfeat,   \
                        partials, B);                                                                      \
   }
-    if (d->precision == 1) { DISPATCH_SHAPE(PrecBF16, LAUNCH_SPLIT, 0) }
+    if (is_bf16(d->precision)) { DISPATCH_SHAPE(PrecBF16, LAUNCH_SPLIT, 0) }
     else { DISPATCH_SHAPE(PrecF16, LAUNCH_SPLIT, 0) }
 #undef LAUNCH_SPLIT
     NOF_LAUNCH_OK();
@@ -1243,18 +1303,19 @@ extern "C" int nof_sdf_grid_query(const NofHashGrid* g, const NofMlpDesc* d, con
   NOF_ARG(packed && table && tx && ty && tz && sdf && nx >= 0 && ny >= 0 && nz >= 0 && level >= 0 && level <= 8);
   if (nx == 0 || ny == 0 || nz == 0) return 0;
   const int nl = d->n_sigma;
-  const size_t shm = (size_t)n_pairs(*d, nl) * 16 * 64 * elem_size(d->precision) + (size_t)n_oblk(*d, nl) * 32 * 4;
+  const size_t shm = (is_split(d->precision) ? 2 : 1) * (size_t)n_pairs(*d, nl) * 16 * 64 * elem_size(d->precision) +
+                     (size_t)n_oblk(*d, nl) * 32 * 4;
   const int64_t ntiles = (int64_t)nx * ny * ((nz + 31) / 32);
   const unsigned blocks = (unsigned)(nof_div_up(ntiles, 4) < 2048 ? nof_div_up(ntiles, 4) : 2048);
-#define LAUNCH_GRID(P, NS_, NC_, dummy)                                                                   \
+#define LAUNCH_GRID(P, NS_, NC_, SPLIT_)                                                                  \
   {                                                                                                       \
-    auto kern = k_sdf_grid<P, NS_, NC_>;                                                                  \
+    auto kern = k_sdf_grid<P, NS_, NC_, SPLIT_>;                                                          \
     if (int e = set_smem(kern, shm)) return e;                                                            \
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), shm, (hipStream_t)stream, *d, (const char*)packed, *g, \
                        (const float2*)table, occ_bits, 1 << level, tx, ty, tz, (int)nx, (int)ny, (int)nz, \
                        outside_value, sdf);                                                               \
   }
-  DISPATCH_PREC(LAUNCH_GRID, 0)
+  DISPATCH_PREC_FWD(LAUNCH_GRID)
 #undef LAUNCH_GRID
   NOF_LAUNCH_OK();
   return 0;

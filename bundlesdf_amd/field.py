@@ -20,7 +20,11 @@ import torch
 from . import lib
 from .config import validate_cfg
 
-PRECISIONS = {'fp32': 0, 'bf16': 1, 'fp16': 2}
+# MFMA operand types.  'fp16x3' / 'bf16x3': forward kernels carry both operands as hi + lo (three MFMAs per product, fp32-class
+# outputs: the mode that meets north_star's 1e-3 on SDF/colour), backward in the plain 16-bit type like the reference's
+# autocast path -- with a loss scale for fp16 (NofMlpDesc.grad_scale), like its GradScaler.
+PRECISIONS = {'fp32': 0, 'bf16': 1, 'fp16': 2, 'fp16x3': 3, 'bf16x3': 4}
+FP16_MODES = (2, 3)
 
 
 class NeuralObjectField:
@@ -63,7 +67,6 @@ class NeuralObjectField:
         self.occ_bits = None
         self.level = None
         self.global_step = 0
-        self.N_iters = cfg['n_step'] + 1
         self._bufs = {}
         self.nblk = lib.load().nof_mlp_bwd_blocks()
         self.packed = torch.empty(int(lib.load().nof_mlp_packed_bytes(C.byref(self.desc))), dtype=torch.uint8, device=dev)
@@ -175,7 +178,7 @@ class NeuralObjectField:
         with index s uses the rate set at the last such g < s."""
         s = self.global_step
         g = 0 if s <= 10 else ((s - 1) // 10) * 10
-        k = 1.0 if g == 0 else self.cfg['decay_rate'] ** (float(g) / self.N_iters)
+        k = 1.0 if g == 0 else self.cfg['decay_rate'] ** (float(g) / (self.cfg['n_step'] + 1))   # N_iters, nerf_runner.py:160
         return self.cfg['lrate'] * k, self.cfg['lrate_pose'] * k
 
     # ---- buffers --------------------------------------------------------------------------------------
@@ -198,6 +201,14 @@ class NeuralObjectField:
         cfg = self.cfg
         return lib.NofSampleCfg(cfg['N_samples'], cfg['N_samples_around_depth'], cfg['near'] * cfg['sc_factor'],
                                 cfg['far'] * cfg['sc_factor'], self.truncation(), cfg['neg_trunc_ratio'], seed, step)
+
+    def _set_grad_scale(self, B):
+        """fp16 operands only: loss scale of the MLP backward = the power of two nearest below B/16, at most 2^16 (the
+        reference's GradScaler starts at 2^16, nerf_runner.py:159).  Every loss term is a mean over R*S = B samples, so the
+        loss gradient is O(weight / B): the scale brings it to O(weight / 16), far inside binary16's normal range and
+        three orders of magnitude below its maximum.  Applied and removed inside nof_mlp_bwd; exact (power of two)."""
+        if self.desc.precision in FP16_MODES:
+            self.desc.grad_scale = float(2 ** int(min(16, max(0, math.floor(math.log2(max(B, 16) / 16.0))))))
 
     def _loss_cfg(self):
         cfg = self.cfg
@@ -249,6 +260,7 @@ class NeuralObjectField:
         self._call('nof_composite_loss', C.byref(lc), b['raw'], b['z_vals'], b['valid'], b['batch'], R, S, b['rgb_map'],
                  None, b['draw'], b['loss_rows'], self.loss_out)
         b['dview'].zero_()
+        self._set_grad_scale(B)
         self._call('nof_mlp_bwd', C.byref(self.desc), self.packed, b['feat'], self.L, b['view'], S, b['draw'], b['sig'],
                    b['dsig'], b['dfeat'],
                  b['dview'], b['partials'], B)

@@ -50,7 +50,7 @@ class NofMlpDesc(C.Structure):
                 ('n_view', C.c_int32), ('geo', C.c_int32),
                 ('w_off', C.c_int32 * NOF_MAX_LAYERS), ('b_off', C.c_int32 * NOF_MAX_LAYERS),
                 ('out_dim', C.c_int32 * NOF_MAX_LAYERS), ('in_dim', C.c_int32 * NOF_MAX_LAYERS),
-                ('n_params', C.c_int32), ('precision', C.c_int32)]
+                ('n_params', C.c_int32), ('precision', C.c_int32), ('grad_scale', C.c_float)]
 
 
 class NofLossCfg(C.Structure):

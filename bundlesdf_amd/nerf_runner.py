@@ -79,8 +79,9 @@ class NerfRunner:
         self.mesh = None
         self.N_iters = self.cfg['n_step'] + 1
         self.build_octree_pts = np.asarray(build_octree_pcd.points).copy()
-        # amp: true in config.yml selects the 16-bit MFMA path (fp16 = the reference's autocast operand type)
-        self.precision = precision or cfg.get('mfma_precision', 'fp16' if cfg.get('amp', True) else 'fp32')
+        # amp: true in config.yml selects the 16-bit MFMA path: fp16 = the reference's autocast operand type, forward with the
+        # hi/lo operand split (outputs within 1e-3 of fp32), backward plain fp16 with a loss scale like its GradScaler
+        self.precision = precision or cfg.get('mfma_precision', 'fp16x3' if cfg.get('amp', True) else 'fp32')
         self.n_sigma, self.n_color = n_sigma, n_color
         self.world_size, self.rank, self.grad_sync = world_size, rank, grad_sync
         # data parallel: `images/depths/masks` hold this rank's keyframes, which are frames frame_offset.. of `poses`
@@ -131,6 +132,7 @@ class NerfRunner:
         self.field.exp_avg_sq.zero_()
         self.field.grads.zero_()
         self.field.global_step = 0
+        self.field._packed_step = None
 
     # ---- occupancy ---------------------------------------------------------------------------------------
     def build_octree(self):
@@ -173,6 +175,10 @@ class NerfRunner:
 
     # ---- growing the keyframe pool (nerf_runner.py:352-433) ----------------------------------------------
     def add_new_frames(self, images, depths, masks, normal_maps, poses, occ_masks=None, new_pcd=None, reuse_weights=False):
+        if self.world_size > 1:
+            # a rank's local frame i is global frame i + frame_offset; frames appended to one rank's shard would take ids that
+            # belong to the next rank's shard.  Growing a sharded pool needs a per-rank local->global id map: not built.
+            raise NotImplementedError('add_new_frames with world_size > 1 (keyframe-sharded data parallel) is not supported')
         prev = len(self.images)
         r = int(self.cfg['down_scale_ratio'])
         images, depths, masks = images[:, ::r, ::r], depths[:, ::r, ::r], masks[:, ::r, ::r]
@@ -276,13 +282,17 @@ class NerfRunner:
 
     def load_weights(self, ckpt_path):
         """accepts both layouts: this implementation's, and checkpoints written by the reference's save_weights (parameters
-        only: its optimiser state and kaolin octree bytes have no counterpart here)"""
+        and Adam state; its kaolin octree bytes have no counterpart here)"""
         ck = torch.load(ckpt_path)
         f = self.field
         if 'params' not in ck and 'model' in ck:
-            self.global_step = load_reference_checkpoint(f, ck)
-            f.global_step = self.global_step
+            f.global_step = 0
+            self.global_step = load_reference_checkpoint(f, ck)      # sets f.global_step from the optimiser state when present
+            if f.global_step == 0:
+                f.global_step = self.global_step
             return
+        f._packed_step = None                   # the MFMA weight image belongs to the old parameters
+        f.grads.zero_()
         f.params.copy_(ck['params'].to(f.device))
         f.exp_avg.copy_(ck['exp_avg'].to(f.device))
         f.exp_avg_sq.copy_(ck['exp_avg_sq'].to(f.device))

@@ -155,6 +155,9 @@ typedef struct {
   int32_t out_dim[NOF_MAX_LAYERS], in_dim[NOF_MAX_LAYERS];
   int32_t n_params;
   int32_t precision;                      /* 0: fp32 MFMA (exact), 1: bf16 MFMA, 2: fp16 MFMA */
+  float grad_scale;                       /* nof_mlp_bwd only: loss scale (a power of two; 0 = 1).  draw is multiplied by it on
+                                           * entry and dfeat / dview / partials are divided by it on exit, so callers never see
+                                           * it: what the reference's GradScaler does for its fp16 autocast path */
 } NofMlpDesc;
 /* Weights are consumed as an MFMA-fragment image: nof_mlp_pack converts the fp32 PyTorch-layout parameters (once per
  * optimiser step) into `packed` (nof_mlp_packed_bytes() bytes, caller-allocated); fwd / bwd / sdf read only the image. */

@@ -116,6 +116,54 @@ def test_train_step_matches_oracle(nof, precision, ff, ns, nc):
         fld.exp_avg_sq.copy_(torch.cat([o[p]['exp_avg_sq'].reshape(-1) for p in orc.all_params()]).cuda())
 
 
+@pytest.mark.parametrize("ns,nc", [(2, 3), (3, 2)])
+def test_default_precision_meets_1e3_on_outputs(nof, ns, nc):
+    """The precision bench.py and amp=True default to ('fp16x3': fp16 MFMA operands, hi+lo split in the forward kernels,
+    loss-scaled fp16 backward) against the PURE fp32 oracle: SDF and colour within north_star's 1e-3 (max-norm) at the
+    reference's network shape (2,3) and at BASELINE cfg2's (3,2); gradients against the oracle with the backward's fp16
+    operand rounding (= the reference's autocast path)."""
+    from bundlesdf_amd.field import NeuralObjectField
+    cfg, fld, orc, batch, rng = _pair(nof, 'fp32', 0, ns, nc)
+    fld16 = NeuralObjectField(cfg, fld.F, cpu(fld.c2w).reshape(-1, 4, 4), precision='fp16x3', n_sigma=ns, n_color=nc)
+    fld16.params.copy_(fld.params)
+    fld16.occ_bits, fld16.level, fld16.max_level, fld16.max_hits = fld.occ_bits, fld.level, fld.max_level, fld.max_hits
+    orc16 = O.OracleField(cfg, orc.geo, orc.shape, fld.F, cpu(fld.c2w).reshape(-1, 4, 4), orc.occ_l,
+                          table=cpu(fld.table).reshape(-1, 2), mlp=[[W.clone(), b.clone()] for W, b in fld.mlp_state()],
+                          pose=cpu(fld.pose).reshape(-1, 6), operand_dtype=torch.float16)
+    R = batch.shape[0]
+    Ns, Na = cfg['N_samples'], cfg['N_samples_around_depth']
+    S = Ns + Na
+    u_occ = rng.random((R, Ns)).astype(np.float32)
+    u_dep = rng.random((R, Na)).astype(np.float32)
+    b = fld16.train_step(U.dev(batch), None, R, U.dev(u_occ), U.dev(u_dep), do_step=False)
+    torch.cuda.synchronize()
+    assert fld16.desc.grad_scale == 2.0 ** int(np.floor(np.log2(R * S / 16.0)))
+    ref = orc.train_step(batch, u_occ, u_dep, do_step=False)
+    ref16 = orc16.train_step(batch, u_occ, u_dep, do_step=False)
+    v_ref = ref['fwd']['valid_samples'].numpy()
+    both = cpu(b['valid']).reshape(R, S).astype(bool) & v_ref
+    raw_ref = ref['fwd']['raw'].detach().numpy()
+    raw = cpu(b['raw']).reshape(R, S, 4)
+    e_rgb, e_sdf = rel_max(raw[both][:, :3], raw_ref[both][:, :3]), rel_max(raw[both][:, 3], raw_ref[both][:, 3])
+    print(f'fp16x3 ({ns},{nc}) vs fp32 oracle: colour {e_rgb:.2e}, sdf {e_sdf:.2e}')
+    assert e_rgb < 1e-3 and e_sdf < 1e-3                                # north_star
+    assert e_rgb < 2e-4 and e_sdf < 2e-4                                # what the split forward actually delivers
+    assert np.abs(cpu(b['rgb_map']) - ref['fwd']['rgb_map'].detach().numpy()).max() < 2e-4
+    Lo = fld16.losses()
+    for k in ('loss', 'rgb_loss', 'fs_loss', 'sdf_loss'):
+        r = float(ref['losses'][k])
+        assert abs(Lo[k] - r) <= 5e-4 * abs(r) + 1e-7, (k, Lo[k], r)
+    names = ['table'] + [f'mlp{i}' for i in range(2 * (ns + nc))] + ['pose']
+    g16 = dict(zip(names, ref16['grads']))
+    gt = cpu(fld16._seg(fld16.grads, 'table')).reshape(-1, 2)
+    assert rel_l2(gt, g16['table'].numpy()) < 6e-3, rel_l2(gt, g16['table'].numpy())
+    gm = cpu(fld16._seg(fld16.grads, 'mlp'))
+    gm_ref = torch.cat([g.reshape(-1) for n, g in g16.items() if n.startswith('mlp')]).numpy()
+    for l in range(ns + nc):
+        lo, hi = fld16.desc.w_off[l], fld16.desc.b_off[l] + fld16.desc.out_dim[l]
+        assert rel_l2(gm[lo:hi], gm_ref[lo:hi]) < 6e-3, (l, rel_l2(gm[lo:hi], gm_ref[lo:hi]))
+
+
 def test_philox_training_reduces_loss(nof):
     """No injected uniforms (in-kernel Philox), bf16 MFMA, 40 steps on the synthetic scene: the loss must fall."""
     cfg, fld, orc, batch, rng = _pair(nof, 'bf16', R=512)

@@ -256,3 +256,64 @@ def test_checkpoint_layout_is_the_reference_state_dict(tag, ns, nc, n_view):
     bad['color_net.9.weight'] = torch.zeros(1)
     with pytest.raises(ValueError):
         mlp_flat_from_state(bad, dims, ns)
+
+
+def test_reference_checkpoint_carries_a_loadable_adam_state():
+    """to_reference_checkpoint's 'optimizer' entry loads into a torch.optim.Adam built the way the reference's
+    create_optimizer builds it (nerf_runner.py:492-504: embeddings, NeRFSmall parameters, feature array | pose array), which
+    is what its load_weights does unconditionally (nerf_runner.py:544) -- and reads back into the flat moment buffers."""
+    from bundlesdf_amd import checkpoint as ck
+
+    class CpuField:                       # the attributes checkpoint.py uses of a NeuralObjectField, on the CPU
+        def __init__(self):
+            self.n_entries, self.F, self.ff, self.n_sigma = 96, 3, 2, 2
+            self.desc, self.layer_dims = lib.make_mlp_desc(2, 3, 32, 9 + self.ff, 1)
+            self.optimize_poses = True
+            self.offsets = np.array([0, 40, 96])
+            self.n_table, self.n_mlp = 2 * self.n_entries, self.desc.n_params
+            self.n_feat, self.n_pose = self.F * self.ff, self.F * 6
+            self.n_basic = self.n_table + self.n_mlp + self.n_feat
+            n = self.n_basic + self.n_pose
+            g = torch.Generator().manual_seed(0)
+            self.params, self.grads = torch.randn(n, generator=g), torch.zeros(n)
+            self.exp_avg, self.exp_avg_sq = torch.randn(n, generator=g), torch.rand(n, generator=g)
+            self.global_step = 37
+            self._packed_step = 0
+
+        def learning_rates(self):
+            return 0.004, 0.002
+
+        def load_parameters(self, table=None, mlp=None, feat=None, pose=None):
+            for name, val in (('table', table), ('mlp', mlp), ('feat', feat), ('pose', pose)):
+                if val is not None:
+                    self._seg(self.params, name).copy_(torch.as_tensor(val).reshape(-1))
+
+    from bundlesdf_amd.field import NeuralObjectField
+    CpuField._seg = NeuralObjectField._seg
+    for name in ('table', 'mlp', 'feat', 'pose'):
+        setattr(CpuField, name, property(lambda s, n=name: s._seg(s.params, n)))
+    f = CpuField()
+    data = ck.to_reference_checkpoint(f, global_step=37)
+    # what the reference does with it: the same modules' parameters in the same order, then load_state_dict
+    ref_params = [torch.nn.Parameter(torch.zeros(f.n_entries, 2))]
+    for o, i in f.layer_dims:
+        ref_params += [torch.nn.Parameter(torch.zeros(o, i)), torch.nn.Parameter(torch.zeros(o))]
+    ref_params.append(torch.nn.Parameter(torch.zeros(f.F, f.ff)))
+    pose = torch.nn.Parameter(torch.zeros(f.F, 6))
+    opt = torch.optim.Adam([{'name': 'basic', 'params': ref_params, 'lr': 0.01}, {'name': 'pose_array', 'params': [pose], 'lr': 0.01}],
+                           betas=(0.9, 0.999), weight_decay=0, eps=1e-15)
+    opt.load_state_dict(data['optimizer'])
+    assert [g['name'] for g in opt.param_groups] == ['basic', 'pose_array']
+    assert opt.param_groups[0]['lr'] == 0.004 and opt.param_groups[1]['lr'] == 0.002 and opt.param_groups[0]['eps'] == 1e-15
+    assert torch.equal(opt.state[ref_params[0]]['exp_avg'].reshape(-1), f._seg(f.exp_avg, 'table'))
+    assert torch.equal(opt.state[pose]['exp_avg_sq'].reshape(-1), f._seg(f.exp_avg_sq, 'pose'))
+    assert float(opt.state[pose]['step']) == 37.0
+    got = torch.cat([opt.state[p]['exp_avg'].reshape(-1) for p in ref_params + [pose]])
+    assert torch.equal(got, f.exp_avg)                   # every moment, in the flat buffer's own order
+    # ... and back: a fresh field takes parameters, moments and the step count from the reference-format file
+    g = CpuField()
+    g.params.zero_(), g.exp_avg.zero_(), g.exp_avg_sq.zero_()
+    g.global_step = 0
+    assert ck.load_reference_checkpoint(g, data) == 37
+    assert g.global_step == 37
+    assert torch.equal(g.params, f.params) and torch.equal(g.exp_avg, f.exp_avg) and torch.equal(g.exp_avg_sq, f.exp_avg_sq)
