@@ -34,13 +34,15 @@ PRECISION_NOTE = {
     'fp16x3': 'fp16 MFMA operands (hi+lo operand split = 3 MFMAs per product in the forward kernels, loss-scaled fp16 backward)',
     'bf16x3': 'bf16 MFMA operands (hi+lo operand split in the forward kernels, bf16 backward)',
     'bf16': 'bf16 MFMA', 'fp16': 'fp16 MFMA (loss-scaled backward)', 'fp32': 'exact fp32 MFMA'}
+# (num_layers, num_layers_color, hidden): BASELINE cfg2's network, the reference's own (nerf_runner.py:221), BASELINE cfg5's
+MLP_SHAPES = {'baseline': (3, 2, 64), 'reference': (2, 3, 64), 'cfg5': (4, 4, 128)}
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 MFMA_BF16_PEAK_TF = 2500.0     # dense bf16 MFMA
 
 
 def workload_cfg(args):
     from bundlesdf_amd.config import default_cfg
-    return default_cfg(n_step=100000, N_rand=args.rays, num_levels=16, log2_hashmap_size=args.log2_T, finest_res=256,
+    return default_cfg(n_step=100000, N_rand=args.rays, num_levels=16, log2_hashmap_size=args.log2_T, finest_res=args.finest,
                        base_res=16, N_samples=128, N_samples_around_depth=64, far=1.0, frame_features=0,
                        save_octree_clouds=False, i_print=10 ** 9, i_weights=10 ** 9)
 
@@ -71,14 +73,17 @@ def build_runner(args, rank, world, device):
         sync = GradSync()                   # bucketed: the fine hash levels' slice is reduced beside the rest of the backward
         if os.environ.get('NOF_DP_OVERLAP', '1') == '0':
             sync = sync.__call__            # one blocking all-reduce of the whole buffer
-    ns, nc = (3, 2) if args.mlp == 'baseline' else (2, 3)
+    ns, nc, hidden = MLP_SHAPES[args.mlp]
+    precision = args.precision
+    if hidden != 64 or ns > 3 or nc > 3:        # the wide kernels have no operand split: fp16x3 / bf16x3 run as fp16 / bf16 there
+        precision = {'fp16x3': 'fp16', 'bf16x3': 'bf16'}.get(precision, precision)
     runner = NerfRunner(cfg, pool['rgbs'], depths=pool['depths'], masks=pool['masks'], normal_maps=None, poses=poses,
-                        K=pool['K'], build_octree_pcd=synthetic.PointCloud(cloud), precision=args.precision, n_sigma=ns,
-                        n_color=nc, world_size=world, rank=rank, grad_sync=sync, frame_offset=rank * F_local)
+                        K=pool['K'], build_octree_pcd=synthetic.PointCloud(cloud), precision=precision, n_sigma=ns,
+                        n_color=nc, world_size=world, rank=rank, grad_sync=sync, frame_offset=rank * F_local, hidden=hidden)
     return runner, cfg
 
 
-def cpu_baseline(seconds=20.0, rays_per_step=4096, log2_T=19, mlp='baseline'):
+def cpu_baseline(seconds=20.0, rays_per_step=4096, log2_T=19, mlp='baseline', finest=256):
     """The oracle (CPU PyTorch fp32 restatement of nerf_runner's step = "nerf_runner's CPU PyTorch path": the reference itself
     has none) on the SAME step as the GPU workload -- same rays per step, samples per ray, hash grid and MLP shape -- for a
     bounded number of steps on this box's host cores.  The pool holds 4 keyframes instead of 64: the cost of a step does not
@@ -93,7 +98,7 @@ def cpu_baseline(seconds=20.0, rays_per_step=4096, log2_T=19, mlp='baseline'):
     torch.set_num_threads(ncores)
     log(f'cpu_baseline: {ncores} threads of {os.cpu_count()} cores')
     pool = synthetic.make_pool(n_frames=4, H=480, W=640, seed=0, analytic_bounds=True)
-    cfg = default_cfg(n_step=500, N_rand=rays_per_step, num_levels=16, log2_hashmap_size=log2_T, finest_res=256, base_res=16,
+    cfg = default_cfg(n_step=500, N_rand=rays_per_step, num_levels=16, log2_hashmap_size=log2_T, finest_res=finest, base_res=16,
                       N_samples=128, N_samples_around_depth=64, far=1.0, sc_factor=pool['sc_factor'],
                       translation=pool['translation'], use_octree=1)
     occ, occ_l, max_level, level = O.build_occupancy(pool['pcd_normalized'], cfg)
@@ -111,9 +116,10 @@ def cpu_baseline(seconds=20.0, rays_per_step=4096, log2_T=19, mlp='baseline'):
         rows.append(r[trace_fn(o, d)])
     rays = np.concatenate(rows, 0).astype(np.float32)
     torch.manual_seed(0)
-    geo = O.HashGeometry(16, 2, 16, log2_T, 256)
-    ns, nc = (3, 2) if mlp == 'baseline' else (2, 3)
-    field = O.OracleField(cfg, geo, O.FieldShape(num_layers=ns, num_layers_color=nc), 4, pool['poses'], occ_l)
+    geo = O.HashGeometry(16, 2, 16, log2_T, finest)
+    ns, nc, hidden = MLP_SHAPES[mlp]
+    field = O.OracleField(cfg, geo, O.FieldShape(num_layers=ns, num_layers_color=nc, hidden_dim=hidden, hidden_dim_color=hidden),
+                          4, pool['poses'], occ_l)
     rng = np.random.default_rng(0)
     R, S = rays_per_step, 192
     times = []
@@ -135,7 +141,7 @@ def cpu_baseline(seconds=20.0, rays_per_step=4096, log2_T=19, mlp='baseline'):
     return {"value": R * S / med, "unit": "ray-samples/s", "cores": ncores, "kind": "port",
             "iters_per_s": 1.0 / med,
             "sample": f"{len(times)} timed steps (1 warm-up) of oracle/nof_oracle.py OracleField.train_step on the workload's own "
-                      f"step: {R} rays x {S} samples, L=16 T=2^{log2_T}, MLP SDF {ns}x64 + colour {nc}x64, fp32, rays of 4 "
+                      f"step: {R} rays x {S} samples, L=16 T=2^{log2_T}, MLP SDF {ns}x{hidden} + colour {nc}x{hidden}, fp32, rays of 4 "
                       f"keyframes 640x480, torch threads={ncores}"}
 
 
@@ -169,8 +175,11 @@ def main():
     ap.add_argument('--height', type=int, default=480)
     ap.add_argument('--width', type=int, default=640)
     ap.add_argument('--precision', default='fp16x3', choices=['fp16x3', 'bf16x3', 'bf16', 'fp16', 'fp32'])
-    ap.add_argument('--mlp', default='baseline', choices=['baseline', 'reference'],
-                    help='baseline: SDF 3x64 + colour 2x64 (BASELINE.json cfg2); reference: NeRFSmall(2,3) nerf_runner.py:221')
+    ap.add_argument('--mlp', default='baseline', choices=['baseline', 'reference', 'cfg5'],
+                    help='baseline: SDF 3x64 + colour 2x64 (BASELINE.json cfg2); reference: NeRFSmall(2,3) nerf_runner.py:221; '
+                         'cfg5: SDF 4x128 + colour 4x128 (BASELINE.json cfg5, with --rays 16384 --log2_T 22 --width 1280 --height 720 '
+                         '--precision fp16)')
+    ap.add_argument('--finest', type=int, default=256, help='finest hash resolution (256: cfg1-3; 512: cfg4/5)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-seconds', type=float, default=25.0)
     args = ap.parse_args()
@@ -256,6 +265,8 @@ def main():
             'nof_hash_encode_bwd': ('hbm', B * (16 * 2 * 4 + 2 * 16 * 8 * 2 * 4)),
             'nof_mlp_fwd': ('mfma', B * fl_fwd),
             'nof_mlp_bwd': ('mfma', B * 3.0 * fl_fwd),
+            'nof_mlp_wide_fwd': ('mfma', B * fl_fwd),
+            'nof_mlp_wide_bwd': ('mfma', B * 2.0 * fl_fwd),           # no recompute on the wide path: data + weight gradients
             'nof_adam_step': ('hbm', fld.n_total * 32.0),
         }
         # the entry point also computes dL/dx (k_hash_dx, gridencoder.cu:202-245,340-365) on a side stream: 8 gathers per level
@@ -288,15 +299,17 @@ def main():
                     "traffic": None, "avg_ms": dom_ms}
         shape_key = (args.keyframes, R, args.log2_T, args.mlp, args.width, args.height)
         cfg_name = {(64, 4096, 19, 'baseline', 640, 480): 'cfg2' if world == 1 else 'cfg3',
-                    (4, 1024, 14, 'reference', 640, 480): 'cfg1 shapes'}.get(shape_key, 'custom')
+                    (4, 1024, 14, 'reference', 640, 480): 'cfg1 shapes',
+                    (64, 16384, 22, 'cfg5', 1280, 720): 'cfg5 (per GPU)'}.get(shape_key, 'custom')
         out = {
             "metric": "ray_samples_per_sec", "value": value, "unit": "ray-samples/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": {'fp16x3': 'fp16', 'bf16x3': 'bf16'}.get(args.precision, args.precision), "data": "synthetic",
+            "dtype": {'fp16x3': 'fp16', 'bf16x3': 'bf16'}.get(runner.precision, runner.precision), "data": "synthetic",
             "config": {"workload": f"{cfg_name}: {args.keyframes} synthetic {args.width}x{args.height} RGBD keyframes per GPU, "
-                                   f"{R} rays/step x {S} samples, hash L=16 T=2^{args.log2_T} base16->256, "
-                                   f"MLP {'SDF 3x64 + colour 2x64' if args.mlp == 'baseline' else 'SDF 2x64 + colour 3x64'}, "
-                                   f"{PRECISION_NOTE[args.precision]}, fp32 table/accumulators/Adam",
+                                   f"{R} rays/step x {S} samples, hash L=16 T=2^{args.log2_T} base16->{args.finest}, "
+                                   f"MLP SDF {MLP_SHAPES[args.mlp][0]}x{MLP_SHAPES[args.mlp][2]} + colour "
+                                   f"{MLP_SHAPES[args.mlp][1]}x{MLP_SHAPES[args.mlp][2]}, "
+                                   f"{PRECISION_NOTE[runner.precision]}, fp32 table/accumulators/Adam",
                        "rays_per_step": R, "samples_per_ray": S, "keyframes_per_gpu": args.keyframes,
                        "pool_rays": int(runner.rays.shape[0]), "parallelism": f"dp{world}"},
             "train_iters_per_sec": it_s * 1.0,
@@ -306,7 +319,7 @@ def main():
             "roofline": roof,
         }
         if not args.no_cpu_baseline and world == 1:          # the CPU leg is timed on rank 0 at N = 1 only
-            out["cpu_baseline"] = cpu_baseline(args.cpu_seconds, R, args.log2_T, args.mlp)
+            out["cpu_baseline"] = cpu_baseline(args.cpu_seconds, R, args.log2_T, args.mlp, args.finest)
         print(json.dumps(out), flush=True)
     if dist.is_initialized():
         dist.barrier()

@@ -63,11 +63,13 @@ struct PrecF16 {
 __host__ __device__ __forceinline__ constexpr int nloc(int hi, int r) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
 
 // ---- layer bookkeeping (runtime, from the descriptor) -------------------------------------------
-__host__ __device__ __forceinline__ int lay_qn(int l) { return l == 0 ? 1 : 2; }
-__host__ __device__ __forceinline__ int lay_pn(const NofMlpDesc& d, int l) { return d.out_dim[l] > 32 ? 2 : 1; }
+// input blocks: hash features fit one block; colour layer 0 reads [sigma-out block | view block]; every other layer reads the
+// hidden/32 blocks of the previous hidden layer.  output blocks: ceil(out/32).  (hidden = 64: qn = 2, pn in {1,2} as before.)
+__host__ __device__ __forceinline__ int lay_qn(const NofMlpDesc& d, int l) { return l == 0 ? 1 : (l == d.n_sigma ? 2 : d.hidden / 32); }
+__host__ __device__ __forceinline__ int lay_pn(const NofMlpDesc& d, int l) { return (d.out_dim[l] + 31) / 32; }
 __host__ __device__ inline int pair_base(const NofMlpDesc& d, int l) {
   int s = 0;
-  for (int k = 0; k < l; ++k) s += lay_pn(d, k) * lay_qn(k);
+  for (int k = 0; k < l; ++k) s += lay_pn(d, k) * lay_qn(d, k);
   return s;
 }
 __host__ __device__ inline int oblk_base(const NofMlpDesc& d, int l) {
@@ -117,11 +119,11 @@ __global__ __launch_bounds__(256) void k_mlp_pack(NofMlpDesc d, const float* __r
     const int lane = e & 63, r = (e >> 6) & 15;
     int pair = e >> 10, l = 0;
     for (;; ++l) {
-      const int cnt = lay_pn(d, l) * lay_qn(l);
+      const int cnt = lay_pn(d, l) * lay_qn(d, l);
       if (pair < cnt) break;
       pair -= cnt;
     }
-    const int qn = lay_qn(l), pn = lay_pn(d, l), base = pair_base(d, l);
+    const int qn = lay_qn(d, l), pn = lay_pn(d, l), base = pair_base(d, l);
     const int hi = lane >> 5, i = lane & 31;
     const float* W = params + d.w_off[l];
     const int in_dim = d.in_dim[l], out_dim = d.out_dim[l];
@@ -1109,9 +1111,9 @@ __global__ __launch_bounds__(256, 2) void k_mlp_bwd_sigma(NofMlpDesc d, const ch
 // =====================================================================================================
 static int check_desc(const NofMlpDesc* d) {
   if (!d) return nof_set_error(-1, "mlp descriptor is NULL");
-  if (d->hidden != 64) return nof_set_error(-1, "mlp: hidden width must be 64 (got %d)", d->hidden);
-  if (d->n_sigma < 2 || d->n_sigma > 3 || d->n_color < 2 || d->n_color > 3)
-    return nof_set_error(-1, "mlp: supported depths are num_layers in {2,3}, num_layers_color in {2,3} (got %d,%d)",
+  if (d->hidden != 64 && d->hidden != 128) return nof_set_error(-1, "mlp: hidden width must be 64 or 128 (got %d)", d->hidden);
+  if (d->n_sigma < 2 || d->n_sigma > 4 || d->n_color < 2 || d->n_color > 4)
+    return nof_set_error(-1, "mlp: supported depths are num_layers in {2,3,4}, num_layers_color in {2,3,4} (got %d,%d)",
                          d->n_sigma, d->n_color);
   if (d->in_feat < 1 || d->in_feat > 32) return nof_set_error(-1, "mlp: L*C must be <= 32 (got %d)", d->in_feat);
   if (d->n_view < 0 || d->n_view > NOF_VIEW_COLS) return nof_set_error(-1, "mlp: n_view must be <= 16 (got %d)", d->n_view);
@@ -1120,14 +1122,24 @@ static int check_desc(const NofMlpDesc* d) {
     return nof_set_error(-1, "mlp: precision must be 0 (fp32), 1 (bf16), 2 (fp16), 3 (fp16, split forward) or 4 (bf16, split forward)");
   const int nl = d->n_sigma + d->n_color;
   for (int l = 0; l < nl; ++l) {
-    const int exp_in = l == 0 ? d->in_feat : (l == d->n_sigma ? d->n_view + d->geo : 64);
-    const int exp_out = l == d->n_sigma - 1 ? 1 + d->geo : (l == nl - 1 ? 3 : 64);
+    const int exp_in = l == 0 ? d->in_feat : (l == d->n_sigma ? d->n_view + d->geo : d->hidden);
+    const int exp_out = l == d->n_sigma - 1 ? 1 + d->geo : (l == nl - 1 ? 3 : d->hidden);
     if (d->in_dim[l] != exp_in || d->out_dim[l] != exp_out)
       return nof_set_error(-1, "mlp: layer %d is %dx%d, expected %dx%d", l, d->out_dim[l], d->in_dim[l], exp_out, exp_in);
   }
   return 0;
 }
 
+// Networks the register-resident kernels above are instantiated for: hidden 64, depths {2,3}.  Everything else (hidden 128,
+// depth 4: BASELINE cfg5's 4x128 + 4x128) runs through the per-network kernels of nof_mlp_wide.h (nof_mlp_wide_* entry points).
+static bool is_wide(const NofMlpDesc* d) { return d->hidden != 64 || d->n_sigma > 3 || d->n_color > 3; }
+static int check_narrow(const NofMlpDesc* d) {
+  if (int e = check_desc(d)) return e;
+  if (is_wide(d))
+    return nof_set_error(-1, "mlp: hidden %d / depths (%d,%d) run through nof_mlp_wide_fwd / nof_mlp_wide_bwd / nof_mlp_wide_sdf",
+                         d->hidden, d->n_sigma, d->n_color);
+  return 0;
+}
 static size_t elem_size(int precision) { return precision == 0 ? 4 : 2; }
 static bool is_split(int precision) { return precision >= 3; }            // 3-term operand split in the forward kernels
 static bool is_bf16(int precision) { return precision == 1 || precision == 4; }
@@ -1176,9 +1188,10 @@ extern "C" int nof_mlp_pack(const NofMlpDesc* d, const float* mlp_params, void* 
   if (int e = check_desc(d)) return e;
   NOF_ARG(mlp_params && packed);
   const int lo = is_split(d->precision) ? 1 : 0;
-  if (d->precision == 0) hipLaunchKernelGGL(k_mlp_pack<PrecF32>, dim3(64), dim3(256), 0, (hipStream_t)stream, *d, mlp_params, (char*)packed, 0);
-  else if (is_bf16(d->precision)) hipLaunchKernelGGL(k_mlp_pack<PrecBF16>, dim3(64), dim3(256), 0, (hipStream_t)stream, *d, mlp_params, (char*)packed, lo);
-  else hipLaunchKernelGGL(k_mlp_pack<PrecF16>, dim3(64), dim3(256), 0, (hipStream_t)stream, *d, mlp_params, (char*)packed, lo);
+  const unsigned pack_blocks = (unsigned)nof_div_up((int64_t)n_pairs(*d, d->n_sigma + d->n_color) * 1024, 256);   // one element per thread
+  if (d->precision == 0) hipLaunchKernelGGL(k_mlp_pack<PrecF32>, dim3(pack_blocks), dim3(256), 0, (hipStream_t)stream, *d, mlp_params, (char*)packed, 0);
+  else if (is_bf16(d->precision)) hipLaunchKernelGGL(k_mlp_pack<PrecBF16>, dim3(pack_blocks), dim3(256), 0, (hipStream_t)stream, *d, mlp_params, (char*)packed, lo);
+  else hipLaunchKernelGGL(k_mlp_pack<PrecF16>, dim3(pack_blocks), dim3(256), 0, (hipStream_t)stream, *d, mlp_params, (char*)packed, lo);
   NOF_LAUNCH_OK();
   return 0;
 }
@@ -1199,7 +1212,7 @@ extern "C" int nof_mlp_bwd_blocks(void) {
 
 extern "C" int nof_mlp_fwd(const NofMlpDesc* d, const void* packed, const float* feat, int32_t L, const float* view,
                             int32_t S, float* raw, void* sigma_out, int64_t B, void* stream) {
-  if (int e = check_desc(d)) return e;
+  if (int e = check_narrow(d)) return e;
   NOF_ARG(packed && feat && view && raw && B >= 0 && S >= 1 && L >= 1 && L * 2 == d->in_feat);
   if (B == 0) return 0;
   const int nl = d->n_sigma + d->n_color;
@@ -1222,7 +1235,7 @@ extern "C" int nof_mlp_fwd(const NofMlpDesc* d, const void* packed, const float*
 
 extern "C" int nof_mlp_sdf(const NofMlpDesc* d, const void* packed, const float* feat, int32_t L, float* sdf,
                             int64_t B, void* stream) {
-  if (int e = check_desc(d)) return e;
+  if (int e = check_narrow(d)) return e;
   NOF_ARG(packed && feat && sdf && B >= 0 && L >= 1 && L * 2 == d->in_feat);
   if (B == 0) return 0;
   const int nl = d->n_sigma;
@@ -1246,7 +1259,7 @@ extern "C" int nof_mlp_sdf(const NofMlpDesc* d, const void* packed, const float*
 extern "C" int nof_mlp_bwd(const NofMlpDesc* d, const void* packed, const float* feat, int32_t L, const float* view,
                             int32_t S, const float* draw, const void* sigma_out, void* dsigma_ws, float* dfeat, float* dview,
                             float* partials, int64_t B, void* stream) {
-  if (int e = check_desc(d)) return e;
+  if (int e = check_narrow(d)) return e;
   NOF_ARG(packed && feat && view && draw && dfeat && dview && partials && B >= 0 && S >= 32 && L * 2 == d->in_feat);
   const int nl = d->n_sigma + d->n_color, ns = d->n_sigma;
   const size_t es = elem_size(d->precision), pair_bytes = 16 * 64 * es;
@@ -1298,7 +1311,7 @@ extern "C" int nof_mlp_bwd(const NofMlpDesc* d, const void* packed, const float*
 extern "C" int nof_sdf_grid_query(const NofHashGrid* g, const NofMlpDesc* d, const void* packed, const float* table,
                                    const uint32_t* occ_bits, int32_t level, const float* tx, const float* ty, const float* tz,
                                    int32_t nx, int32_t ny, int32_t nz, float outside_value, float* sdf, void* stream) {
-  if (int e = check_desc(d)) return e;
+  if (int e = check_narrow(d)) return e;
   NOF_ARG(g && g->C == 2 && g->L >= 1 && g->L <= NOF_MAX_LEVELS && g->L * 2 == d->in_feat);
   NOF_ARG(packed && table && tx && ty && tz && sdf && nx >= 0 && ny >= 0 && nz >= 0 && level >= 0 && level <= 8);
   if (nx == 0 || ny == 0 || nz == 0) return 0;
@@ -1356,3 +1369,5 @@ extern "C" int nof_mfma_probe(int32_t precision, const float* A, const float* Bm
   NOF_LAUNCH_OK();
   return 0;
 }
+
+#include "nof_mlp_wide.h"

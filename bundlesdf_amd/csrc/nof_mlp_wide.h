@@ -1,0 +1,570 @@
+// Wide / deep NeRFSmall shapes (hidden 128 and/or 4 layers per network: BASELINE.json cfg5's "MLP 4x128", nerf_helpers.py:243-294
+// is parameterised in hidden_dim / num_layers) on the gfx950 matrix cores.  Included at the end of nof_mlp.hip: it reuses
+// that file's operand layouts, fragment image (k_mlp_pack), dense_o1 / bwd_data / transpose32 primitives and host helpers.
+//
+// Why a second set of kernels: the register-resident design of nof_mlp.hip keeps every weight fragment of both orientations
+// in LDS and every dW accumulator in registers.  A 128x128 layer is 32 KB of fragments per orientation and 256 accumulator
+// registers per wave; 4+4 such layers are 168 KB per orientation.  So here
+//   * each network (sigma, colour) and each direction is its own kernel with ONE orientation of ONE network resident in LDS
+//     (<= 88 KB for 4x128, 16-bit operands), shared by a 512-thread workgroup (8 waves, 2 per SIMD);
+//   * the forward kernels store the hidden activations (post-ReLU, operand precision, [layer][B][H] sample-major) instead of the
+//     backward recomputing them, and the backward-data kernels store the pre-activation gradients the same way;
+//   * the weight gradients are a separate split-K pass per layer (k_wide_dw): a wave owns ONE 32-neuron output block (16 * QN
+//     accumulator registers), transposes its 32-sample tile of gradients / inputs on the matrix core (transpose32) and
+//     accumulates across its share of the batch; per-wave partial rows are summed by nof_reduce_partials like the narrow path.
+// Algorithmic HBM traffic of the staging per hidden layer and sample: H*2 B written + read twice for the activations, H*2 B
+// written + read for the gradients (~1.3 KB at H = 128): this path is HBM-bound by construction (DESIGN.md "wide network").
+// 16-bit operand types only (fp32 fragments of a 128-wide network do not fit LDS); precisions 3 / 4 run as 2 / 1 here (no
+// operand split: the residual fragments would double the LDS image).
+#pragma once
+
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+template <class P> struct Vec4;
+template <> struct Vec4<PrecF16> { typedef f16x4 type; };
+template <> struct Vec4<PrecBF16> { typedef bf16x4 type; };
+
+// ---- rows of the staging buffers: [B][H] elements, neuron n of block p at column 32 p + n ------------------------------------
+// lane (sample j, hi) holds neurons 32p + 8g + 4hi + {0..3} of block p in registers 4g..4g+3: one 8-byte access per (p, g)
+template <class P>
+__device__ __forceinline__ void store_blk(typename P::elem* __restrict__ row, int p, int hi, const float (&v)[16]) {
+  typedef typename Vec4<P>::type v4;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    v4 t;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) t[k] = (typename P::elem)v[4 * g + k];
+    *reinterpret_cast<v4*>(row + 32 * p + 8 * g + 4 * hi) = t;
+  }
+}
+template <class P>
+__device__ __forceinline__ void load_blk(const typename P::elem* __restrict__ row, int p, int hi, bool ok, float (&v)[16]) {
+  typedef typename Vec4<P>::type v4;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    v4 t;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) t[k] = (typename P::elem)0.0f;
+    if (ok) t = *reinterpret_cast<const v4*>(row + 32 * p + 8 * g + 4 * hi);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[4 * g + k] = (float)t[k];
+  }
+}
+
+template <int PN>
+__device__ __forceinline__ void relu_inplace(float (&h)[PN][16]) {
+#pragma unroll
+  for (int p = 0; p < PN; ++p)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) h[p][r] = fmaxf(h[p][r], 0.0f);
+}
+
+#define WPAIR ((int)(16 * 64 * sizeof(typename P::elem)))
+
+// =====================================================================================================
+// forward, sigma net: features -> hidden layers (stored) -> head: sdf -> raw[b].w (or sdf[b]), sig[b] = 16 head outputs
+// =====================================================================================================
+template <class P, int HB>
+__global__ __launch_bounds__(512) void k_wide_fwd_sigma(NofMlpDesc d, const char* __restrict__ image,
+                                                         const float2* __restrict__ feat, int L,
+                                                         typename P::elem* __restrict__ hid, int64_t hid_stride,
+                                                         float* __restrict__ out, int out_stride, int out_off,
+                                                         typename P::elem* __restrict__ sig, int64_t B) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int NS = d.n_sigma, NL = d.n_sigma + d.n_color;
+  const int bias_base = pair_base(d, NS) * WPAIR;
+  copy16(smem, image, (size_t)bias_base);
+  copy16(smem + bias_base, image + 2 * (size_t)pair_base(d, NL) * WPAIR, (size_t)oblk_base(d, NS) * 128);
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  const int hi = lane >> 5, j = lane & 31;
+  const int H = 32 * HB;
+  const int64_t ntiles = (B + 31) / 32;
+  for (int64_t tile = (int64_t)blockIdx.x * nw + wave; tile < ntiles; tile += (int64_t)gridDim.x * nw) {
+    asm volatile("" ::: "memory");
+    const int64_t b = tile * 32 + j;
+    const bool ok = b < B;
+    float x[1][16], h[HB][16], so[1][16];
+    load_feat_o1(feat, L, B, b, hi, x);
+    dense_o1<P, 1, HB>(smem, 0, bias_base, x, h, lane);
+    relu_inplace<HB>(h);
+    int foff = HB * WPAIR, boff = bias_base + HB * 128;
+    for (int l = 1; l < NS - 1; ++l) {
+      if (hid != nullptr && ok) {
+#pragma unroll
+        for (int p = 0; p < HB; ++p) store_blk<P>(hid + (int64_t)(l - 1) * hid_stride + b * H, p, hi, h[p]);
+      }
+      float h2[HB][16];
+      dense_o1<P, HB, HB>(smem, foff, boff, h, h2, lane);
+      relu_inplace<HB>(h2);
+#pragma unroll
+      for (int p = 0; p < HB; ++p)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) h[p][r] = h2[p][r];
+      foff += HB * HB * WPAIR;
+      boff += HB * 128;
+    }
+    if (hid != nullptr && ok) {
+#pragma unroll
+      for (int p = 0; p < HB; ++p) store_blk<P>(hid + (int64_t)(NS - 2) * hid_stride + b * H, p, hi, h[p]);
+    }
+    dense_o1<P, HB, 1>(smem, foff, boff, h, so, lane);
+    if (sig != nullptr) store_sig_o1<P>(sig, B, b, hi, so[0]);
+    if (hi == 0 && ok) out[b * out_stride + out_off] = so[0][0];
+  }
+}
+
+// =====================================================================================================
+// forward, colour net: [sig | view] -> hidden layers (stored) -> rgb_raw -> raw[b].xyz
+// =====================================================================================================
+template <class P, int HB>
+__global__ __launch_bounds__(512) void k_wide_fwd_color(NofMlpDesc d, const char* __restrict__ image,
+                                                         const typename P::elem* __restrict__ sig,
+                                                         const float* __restrict__ view, int S,
+                                                         typename P::elem* __restrict__ hid, int64_t hid_stride,
+                                                         float* __restrict__ raw, int64_t B) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int NS = d.n_sigma, NC = d.n_color, NL = NS + NC;
+  const int PA = pair_base(d, NS), PB = pair_base(d, NL), OA = oblk_base(d, NS), OB = oblk_base(d, NL);
+  const int bias_base = (PB - PA) * WPAIR;
+  copy16(smem, image + (size_t)PA * WPAIR, (size_t)bias_base);
+  copy16(smem + bias_base, image + 2 * (size_t)PB * WPAIR + OA * 128, (size_t)(OB - OA) * 128);
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  const int hi = lane >> 5, j = lane & 31;
+  const int H = 32 * HB;
+  const int64_t ntiles = (B + 31) / 32;
+  for (int64_t tile = (int64_t)blockIdx.x * nw + wave; tile < ntiles; tile += (int64_t)gridDim.x * nw) {
+    asm volatile("" ::: "memory");
+    const int64_t b = tile * 32 + j;
+    const bool ok = b < B;
+    float cin[2][16], h[HB][16], co[1][16];
+    load_sig_o1<P>(sig, B, b, hi, cin[0]);
+    load_view_o1(view, S, B, b, hi, cin[1]);
+    dense_o1<P, 2, HB>(smem, 0, bias_base, cin, h, lane);
+    relu_inplace<HB>(h);
+    int foff = 2 * HB * WPAIR, boff = bias_base + HB * 128;
+    for (int l = 1; l < NC - 1; ++l) {
+      if (hid != nullptr && ok) {
+#pragma unroll
+        for (int p = 0; p < HB; ++p) store_blk<P>(hid + (int64_t)(NS - 1 + l - 1) * hid_stride + b * H, p, hi, h[p]);
+      }
+      float h2[HB][16];
+      dense_o1<P, HB, HB>(smem, foff, boff, h, h2, lane);
+      relu_inplace<HB>(h2);
+#pragma unroll
+      for (int p = 0; p < HB; ++p)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) h[p][r] = h2[p][r];
+      foff += HB * HB * WPAIR;
+      boff += HB * 128;
+    }
+    if (hid != nullptr && ok) {
+#pragma unroll
+      for (int p = 0; p < HB; ++p) store_blk<P>(hid + (int64_t)(NS - 1 + NC - 2) * hid_stride + b * H, p, hi, h[p]);
+    }
+    dense_o1<P, HB, 1>(smem, foff, boff, h, co, lane);
+    if (hi == 0 && ok) { raw[b * 4] = co[0][0]; raw[b * 4 + 1] = co[0][1]; raw[b * 4 + 2] = co[0][2]; }
+  }
+}
+
+// mask a sample-per-lane gradient block by the stored post-ReLU activation of the same units (on <=> activation > 0)
+template <class P>
+__device__ __forceinline__ void mask_by_row(const typename P::elem* __restrict__ row, int p, int hi, bool ok, float (&g)[16]) {
+  float a[16];
+  load_blk<P>(row, p, hi, ok, a);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) g[r] = a[r] > 0.0f ? g[r] : 0.0f;
+}
+
+// =====================================================================================================
+// backward (data path), colour net: draw -> pre-activation gradients of every colour layer (stored), dsig, dview
+// gbuf[l] rows are [B][H]; a head's gradient occupies block 0 of its row.
+// =====================================================================================================
+template <class P, int HB>
+__global__ __launch_bounds__(512) void k_wide_bwd_color(NofMlpDesc d, const char* __restrict__ image,
+                                                         const typename P::elem* __restrict__ hid, int64_t hid_stride,
+                                                         int S, const float4* __restrict__ draw,
+                                                         typename P::elem* __restrict__ gbuf, int64_t g_stride,
+                                                         typename P::elem* __restrict__ dsig, float* __restrict__ dview,
+                                                         int64_t B) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int NS = d.n_sigma, NC = d.n_color, NL = NS + NC;
+  const int PA = pair_base(d, NS), PB = pair_base(d, NL);
+  copy16(smem, image + (size_t)(PB + PA) * WPAIR, (size_t)(PB - PA) * WPAIR);       // the bw orientation of the colour layers
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  const int hi = lane >> 5, j = lane & 31;
+  const int H = 32 * HB;
+  Ident<P> I;
+  I.init(lane);
+  const float gscale = d.grad_scale > 0.0f ? d.grad_scale : 1.0f, gunscale = 1.0f / gscale;
+  const int64_t ntiles = (B + 31) / 32;
+  for (int64_t tile = (int64_t)blockIdx.x * nw + wave; tile < ntiles; tile += (int64_t)gridDim.x * nw) {
+    asm volatile("" ::: "memory");
+    const int64_t t0 = tile * 32, b = t0 + j;
+    const bool ok = b < B;
+    float gh[1][16], g[HB][16];
+    float dsdf1 = 0.0f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) gh[0][r] = 0.0f;
+    if (hi == 0 && ok) {
+      const float4 t = draw[b];
+      gh[0][0] = t.x * gscale; gh[0][1] = t.y * gscale; gh[0][2] = t.z * gscale;
+      dsdf1 = t.w * gscale;
+    }
+    if (ok) store_blk<P>(gbuf + (int64_t)(NL - 1) * g_stride + b * H, 0, hi, gh[0]);
+    // head -> last hidden colour layer
+    int woff = (pair_base(d, NL - 1) - PA) * WPAIR;
+    {
+      const typename P::elem* arow = hid + (int64_t)(NS - 1 + NC - 2) * hid_stride + b * H;
+#pragma unroll
+      for (int q = 0; q < HB; ++q) {
+        bwd_data<P, 1>(smem, woff, q, gh, g[q], lane);
+        mask_by_row<P>(arow, q, hi, ok, g[q]);
+      }
+    }
+    for (int l = NL - 2; l > NS; --l) {                               // hidden colour layers above layer 0
+      if (ok) {
+#pragma unroll
+        for (int p = 0; p < HB; ++p) store_blk<P>(gbuf + (int64_t)l * g_stride + b * H, p, hi, g[p]);
+      }
+      woff = (pair_base(d, l) - PA) * WPAIR;
+      const typename P::elem* arow = hid + (int64_t)(NS - 1 + (l - 1 - NS)) * hid_stride + b * H;
+      float g2[HB][16];
+#pragma unroll
+      for (int q = 0; q < HB; ++q) {
+        bwd_data<P, HB>(smem, woff, q, g, g2[q], lane);
+        mask_by_row<P>(arow, q, hi, ok, g2[q]);
+      }
+#pragma unroll
+      for (int p = 0; p < HB; ++p)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) g[p][r] = g2[p][r];
+    }
+    // colour layer 0: inputs [sigma-out block | view block]
+    if (ok) {
+#pragma unroll
+      for (int p = 0; p < HB; ++p) store_blk<P>(gbuf + (int64_t)NS * g_stride + b * H, p, hi, g[p]);
+    }
+    float ds1[16], dv1[16], dv2[16];
+    bwd_data<P, HB>(smem, 0, 0, g, ds1, lane);
+    bwd_data<P, HB>(smem, 0, 1, g, dv1, lane);
+    transpose32<P>(I, dv1, dv2);
+    {
+      const int64_t ray0 = t0 / S;
+      const int64_t end0 = (ray0 + 1) * S, endB = end0 < B ? end0 : B;
+      float sa = 0.0f, sb = 0.0f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int64_t bs = t0 + nloc(hi, r);
+        if (bs < endB) sa += dv2[r];
+        else if (bs < B) sb += dv2[r];
+      }
+      sa += __shfl_xor(sa, 32, 64);
+      sb += __shfl_xor(sb, 32, 64);
+      const int hi_j = (j >> 2) & 1, u = (j & 3) + 4 * (j >> 3);
+      if (hi == 0 && hi_j == 0 && u < d.n_view) {
+        if (sa != 0.0f) atomicAdd(&dview[ray0 * NOF_VIEW_COLS + u], sa * gunscale);
+        if (sb != 0.0f) atomicAdd(&dview[(ray0 + 1) * NOF_VIEW_COLS + u], sb * gunscale);
+      }
+    }
+    if (hi == 0) ds1[0] += dsdf1;
+    store_sig_o1<P>(dsig, B, b, hi, ds1);
+  }
+}
+
+// =====================================================================================================
+// backward (data path), sigma net: dsig -> pre-activation gradients of every sigma layer (stored), dfeat
+// =====================================================================================================
+template <class P, int HB>
+__global__ __launch_bounds__(512) void k_wide_bwd_sigma(NofMlpDesc d, const char* __restrict__ image,
+                                                         const typename P::elem* __restrict__ hid, int64_t hid_stride,
+                                                         const typename P::elem* __restrict__ dsig,
+                                                         typename P::elem* __restrict__ gbuf, int64_t g_stride,
+                                                         float2* __restrict__ dfeat, int L, int64_t B) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int NS = d.n_sigma, NL = d.n_sigma + d.n_color;
+  const int PB = pair_base(d, NL), PS = pair_base(d, NS);
+  copy16(smem, image + (size_t)PB * WPAIR, (size_t)PS * WPAIR);                       // the bw orientation of the sigma layers
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  const int hi = lane >> 5, j = lane & 31;
+  const int H = 32 * HB;
+  const float gunscale = d.grad_scale > 0.0f ? 1.0f / d.grad_scale : 1.0f;
+  const int64_t ntiles = (B + 31) / 32;
+  for (int64_t tile = (int64_t)blockIdx.x * nw + wave; tile < ntiles; tile += (int64_t)gridDim.x * nw) {
+    asm volatile("" ::: "memory");
+    const int64_t b = tile * 32 + j;
+    const bool ok = b < B;
+    float gh[1][16], g[HB][16];
+    load_sig_o1<P>(dsig, B, b, hi, gh[0]);
+    if (ok) store_blk<P>(gbuf + (int64_t)(NS - 1) * g_stride + b * H, 0, hi, gh[0]);
+    int woff = pair_base(d, NS - 1) * WPAIR;
+    {
+      const typename P::elem* arow = hid + (int64_t)(NS - 2) * hid_stride + b * H;
+#pragma unroll
+      for (int q = 0; q < HB; ++q) {
+        bwd_data<P, 1>(smem, woff, q, gh, g[q], lane);
+        mask_by_row<P>(arow, q, hi, ok, g[q]);
+      }
+    }
+    for (int l = NS - 2; l >= 1; --l) {
+      if (ok) {
+#pragma unroll
+        for (int p = 0; p < HB; ++p) store_blk<P>(gbuf + (int64_t)l * g_stride + b * H, p, hi, g[p]);
+      }
+      woff = pair_base(d, l) * WPAIR;
+      const typename P::elem* arow = hid + (int64_t)(l - 1) * hid_stride + b * H;
+      float g2[HB][16];
+#pragma unroll
+      for (int q = 0; q < HB; ++q) {
+        bwd_data<P, HB>(smem, woff, q, g, g2[q], lane);
+        mask_by_row<P>(arow, q, hi, ok, g2[q]);
+      }
+#pragma unroll
+      for (int p = 0; p < HB; ++p)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) g[p][r] = g2[p][r];
+    }
+    if (ok) {
+#pragma unroll
+      for (int p = 0; p < HB; ++p) store_blk<P>(gbuf + b * H, p, hi, g[p]);
+    }
+    float df1[16];
+    bwd_data<P, HB>(smem, 0, 0, g, df1, lane);
+    if (ok) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int level = 8 * hi + k;
+        if (level < L) dfeat[(int64_t)level * B + b] = make_float2(df1[2 * k] * gunscale, df1[2 * k + 1] * gunscale);
+      }
+    }
+  }
+}
+
+// =====================================================================================================
+// weight gradients of ONE layer: dW[32p + n][k] = sum_b G[b][32p + n] X[b][k], db likewise.  The four waves of a workgroup
+// split into PN output blocks x 4/PN tile streams: wave w owns block p = w % PN of the tiles of partial row
+// blockIdx.x * (4/PN) + w / PN, so the PN waves that need the same X rows (and the four quarters of the same G row) sit on
+// one CU and share them through its L1.  `partials` is [rows][n_params]: every (layer, block) writes its own entries of every
+// row, so after all layers each row is completely defined.
+// KIND: 0 = hash features (QN = 1), 1 = a stored hidden activation row (QN = H/32), 2 = colour layer 0's [sig | view] (QN = 2)
+// =====================================================================================================
+template <class P, int QN, int KIND>
+__global__ __launch_bounds__(256) void k_wide_dw(NofMlpDesc d, int l, int PN, const typename P::elem* __restrict__ grow,
+                                                  int H, const float2* __restrict__ feat, int L,
+                                                  const typename P::elem* __restrict__ xrow,
+                                                  const typename P::elem* __restrict__ sig, const float* __restrict__ view,
+                                                  int S, float* __restrict__ partials, int rows, int64_t B) {
+  constexpr int KR = P::KR, NSTEP = 16 / KR;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int hi = lane >> 5, j = lane & 31;
+  const int p = wave % PN;
+  const int row = blockIdx.x * (4 / PN) + wave / PN;
+  Ident<P> I;
+  I.init(lane);
+  const float gunscale = d.grad_scale > 0.0f ? 1.0f / d.grad_scale : 1.0f;
+  f32x16 acc[QN];
+#pragma unroll
+  for (int q = 0; q < QN; ++q)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[q][r] = 0.0f;
+  float db = 0.0f;
+  const int64_t ntiles = (B + 31) / 32;
+  for (int64_t tile = row; tile < ntiles; tile += rows) {
+    const int64_t b = tile * 32 + j;
+    const bool ok = b < B;
+    float g1[16], g2[16];
+    load_blk<P>(grow + b * H, p, hi, ok, g1);
+    transpose32<P>(I, g1, g2);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) db += g2[r];
+    typename P::frag ga[NSTEP];
+#pragma unroll
+    for (int s = 0; s < NSTEP; ++s) ga[s] = P::pack(&g2[KR * s]);
+#pragma unroll
+    for (int q = 0; q < QN; ++q) {
+      float x1[16], x2[16];
+      if constexpr (KIND == 0) {
+        float xf[1][16];
+        load_feat_o1(feat, L, B, b, hi, xf);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) x1[r] = xf[0][r];
+      } else if constexpr (KIND == 1) {
+        load_blk<P>(xrow + b * H, q, hi, ok, x1);
+      } else {
+        if (q == 0) load_sig_o1<P>(sig, B, b, hi, x1);
+        else load_view_o1(view, S, B, b, hi, x1);
+      }
+      transpose32<P>(I, x1, x2);
+#pragma unroll
+      for (int s = 0; s < NSTEP; ++s) acc[q] = P::mma(ga[s], P::pack(&x2[KR * s]), acc[q]);
+    }
+  }
+  // flush: lane j = input slot (hi_j, r_j) of block q, register r = neuron 32p + nloc(hi, r)
+  const int hi_j = (j >> 2) & 1, r_j = (j & 3) + 4 * (j >> 3);
+  float* __restrict__ dst = partials + (size_t)row * d.n_params;
+  const int in_dim = d.in_dim[l], out_dim = d.out_dim[l];
+#pragma unroll
+  for (int q = 0; q < QN; ++q) {
+    const int col = inmap(d, l, q, hi_j, r_j);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int orow = 32 * p + nloc(hi, r);
+      if (col >= 0 && orow < out_dim) dst[d.w_off[l] + orow * in_dim + col] = acc[q][r] * gunscale;
+    }
+  }
+  db += __shfl_xor(db, 32, 64);
+  if (hi == 0 && 32 * p + j < out_dim) dst[d.b_off[l] + 32 * p + j] = db * gunscale;
+}
+
+// =====================================================================================================
+// host side
+// =====================================================================================================
+static int check_wide(const NofMlpDesc* d) {
+  if (int e = check_desc(d)) return e;
+  if (d->precision == 0)
+    return nof_set_error(-1, "mlp (wide path, hidden %d depths %d,%d): 16-bit operand types only (fp32 fragments do not fit LDS)",
+                         d->hidden, d->n_sigma, d->n_color);
+  return 0;
+}
+static int64_t wide_hid_layers(const NofMlpDesc* d) { return (d->n_sigma - 1) + (d->n_color - 1); }
+static const int kWideRows = 512;                                         // wave-rows of `partials` (128 workgroups per output block)
+
+// workspace layout (bytes, 256-aligned): [hid : n_hid * B * H elems][gbuf : NL * B * H elems][sig : B * 16 elems][dsig : B * 16 elems]
+struct WideWs { char *hid, *gbuf, *sig, *dsig; int64_t total; };
+static WideWs wide_ws(const NofMlpDesc* d, void* base, int64_t B) {
+  auto up = [](int64_t x) { return (x + 255) / 256 * 256; };
+  const int64_t row = (int64_t)d->hidden * 2, nl = d->n_sigma + d->n_color;
+  WideWs w;
+  int64_t off = 0;
+  w.hid = (char*)base + off; off += up(wide_hid_layers(d) * B * row);
+  w.gbuf = (char*)base + off; off += up(nl * B * row);
+  w.sig = (char*)base + off; off += up(B * 32);
+  w.dsig = (char*)base + off; off += up(B * 32);
+  w.total = off;
+  return w;
+}
+extern "C" int64_t nof_mlp_wide_workspace_bytes(const NofMlpDesc* d, int64_t B) {
+  if (check_wide(d) || B < 0) return -1;
+  return wide_ws(d, nullptr, B).total;
+}
+extern "C" int nof_mlp_wide_partial_rows(void) { return kWideRows; }
+
+template <class P, int HB>
+static int wide_fwd_launch(const NofMlpDesc* d, const void* packed, const float* feat, int32_t L, const float* view, int32_t S,
+                           float* out, int out_stride, int out_off, const WideWs* ws, bool store_hidden, bool sdf_only,
+                           int64_t B, hipStream_t st) {
+  const int ns = d->n_sigma, nl = d->n_sigma + d->n_color;
+  const size_t pair_bytes = 16 * 64 * 2;
+  const size_t shm_s = (size_t)pair_base(*d, ns) * pair_bytes + (size_t)oblk_base(*d, ns) * 128;
+  const size_t shm_c = (size_t)(pair_base(*d, nl) - pair_base(*d, ns)) * pair_bytes + (size_t)(oblk_base(*d, nl) - oblk_base(*d, ns)) * 128;
+  const int64_t ntiles = (B + 31) / 32;
+  const unsigned blocks = (unsigned)(nof_div_up(ntiles, 8) < (int64_t)nof_cu_count() ? nof_div_up(ntiles, 8) : nof_cu_count());
+  typedef typename P::elem elem;
+  const int64_t hs = B * (int64_t)d->hidden;
+  auto ks = k_wide_fwd_sigma<P, HB>;
+  if (int e = set_smem(ks, shm_s)) return e;
+  hipLaunchKernelGGL(ks, dim3(blocks), dim3(512), shm_s, st, *d, (const char*)packed, (const float2*)feat, (int)L,
+                     store_hidden ? (elem*)ws->hid : (elem*)nullptr, hs, out, out_stride, out_off,
+                     sdf_only ? (elem*)nullptr : (elem*)ws->sig, B);
+  if (!sdf_only) {
+    auto kc = k_wide_fwd_color<P, HB>;
+    if (int e = set_smem(kc, shm_c)) return e;
+    hipLaunchKernelGGL(kc, dim3(blocks), dim3(512), shm_c, st, *d, (const char*)packed, (const elem*)ws->sig, view, (int)S,
+                       store_hidden ? (elem*)ws->hid : (elem*)nullptr, hs, out, B);
+  }
+  return 0;
+}
+
+#define WIDE_DISPATCH(FN, ...)                                                                            \
+  if (is_bf16(d->precision)) {                                                                            \
+    if (d->hidden == 128) { if (int e = FN<PrecBF16, 4>(__VA_ARGS__)) return e; }                         \
+    else { if (int e = FN<PrecBF16, 2>(__VA_ARGS__)) return e; }                                          \
+  } else {                                                                                                \
+    if (d->hidden == 128) { if (int e = FN<PrecF16, 4>(__VA_ARGS__)) return e; }                          \
+    else { if (int e = FN<PrecF16, 2>(__VA_ARGS__)) return e; }                                           \
+  }
+
+/* feat [L,B,2], view [R,16] -> raw [B,4]; the hidden activations and the sigma head's output stay in `workspace` for
+ * nof_mlp_wide_bwd (workspace: nof_mlp_wide_workspace_bytes(desc, B) bytes, caller-allocated). */
+extern "C" int nof_mlp_wide_fwd(const NofMlpDesc* d, const void* packed, const float* feat, int32_t L, const float* view,
+                                 int32_t S, float* raw, void* workspace, int64_t B, void* stream) {
+  if (int e = check_wide(d)) return e;
+  NOF_ARG(packed && feat && view && raw && workspace && B >= 0 && S >= 1 && L >= 1 && L * 2 == d->in_feat);
+  if (B == 0) return 0;
+  const WideWs ws = wide_ws(d, workspace, B);
+  WIDE_DISPATCH(wide_fwd_launch, d, packed, feat, L, view, S, raw, 4, 3, &ws, true, false, B, (hipStream_t)stream)
+  NOF_LAUNCH_OK();
+  return 0;
+}
+
+/* sigma net only: feat [L,B,2] -> sdf [B] (NeRFSmall.forward_sdf); needs no workspace */
+extern "C" int nof_mlp_wide_sdf(const NofMlpDesc* d, const void* packed, const float* feat, int32_t L, float* sdf, int64_t B,
+                                 void* stream) {
+  if (int e = check_wide(d)) return e;
+  NOF_ARG(packed && feat && sdf && B >= 0 && L >= 1 && L * 2 == d->in_feat);
+  if (B == 0) return 0;
+  WIDE_DISPATCH(wide_fwd_launch, d, packed, feat, L, (const float*)nullptr, 1, sdf, 1, 0, (const WideWs*)nullptr, false, true, B,
+                (hipStream_t)stream)
+  NOF_LAUNCH_OK();
+  return 0;
+}
+
+template <class P, int HB>
+static int wide_bwd_launch(const NofMlpDesc* d, const void* packed, const float* feat, int32_t L, const float* view, int32_t S,
+                           const float* draw, const WideWs* ws, float* dfeat, float* dview, float* partials, int64_t B,
+                           hipStream_t st) {
+  typedef typename P::elem elem;
+  const int ns = d->n_sigma, nc = d->n_color, nl = ns + nc, H = d->hidden;
+  const size_t pair_bytes = 16 * 64 * 2;
+  const size_t shm_s = (size_t)pair_base(*d, ns) * pair_bytes;
+  const size_t shm_c = (size_t)(pair_base(*d, nl) - pair_base(*d, ns)) * pair_bytes;
+  const int64_t ntiles = (B + 31) / 32;
+  const unsigned blocks = (unsigned)(nof_div_up(ntiles, 8) < (int64_t)nof_cu_count() ? nof_div_up(ntiles, 8) : nof_cu_count());
+  const int64_t hs = B * (int64_t)H;
+  elem *hid = (elem*)ws->hid, *gbuf = (elem*)ws->gbuf, *sig = (elem*)ws->sig, *dsig = (elem*)ws->dsig;
+  auto kc = k_wide_bwd_color<P, HB>;
+  auto ks = k_wide_bwd_sigma<P, HB>;
+  if (int e = set_smem(kc, shm_c)) return e;
+  if (int e = set_smem(ks, shm_s)) return e;
+  hipLaunchKernelGGL(kc, dim3(blocks), dim3(512), shm_c, st, *d, (const char*)packed, (const elem*)hid, hs, (int)S,
+                     (const float4*)draw, gbuf, hs, dsig, dview, B);
+  hipLaunchKernelGGL(ks, dim3(blocks), dim3(512), shm_s, st, *d, (const char*)packed, (const elem*)hid, hs, (const elem*)dsig, gbuf,
+                     hs, (float2*)dfeat, (int)L, B);
+  // weight gradients, layer by layer
+  for (int l = 0; l < nl; ++l) {
+    const int PN = lay_pn(*d, l);
+    const unsigned grid = (unsigned)(kWideRows * PN / 4);              // PN in {1, 2, 4}: 4 / PN tile streams per workgroup
+    const elem* grow = gbuf + (int64_t)l * hs;
+    if (l == 0) {
+      hipLaunchKernelGGL((k_wide_dw<P, 1, 0>), dim3(grid), dim3(256), 0, st, *d, l, PN, grow, H, (const float2*)feat, (int)L,
+                         (const elem*)nullptr, (const elem*)nullptr, (const float*)nullptr, (int)S, partials, kWideRows, B);
+    } else if (l == ns) {
+      hipLaunchKernelGGL((k_wide_dw<P, 2, 2>), dim3(grid), dim3(256), 0, st, *d, l, PN, grow, H, (const float2*)nullptr, (int)L,
+                         (const elem*)nullptr, (const elem*)sig, view, (int)S, partials, kWideRows, B);
+    } else {
+      const int hidx = l < ns ? l - 1 : (ns - 1) + (l - 1 - ns);       // the stored activation that is this layer's input
+      hipLaunchKernelGGL((k_wide_dw<P, HB, 1>), dim3(grid), dim3(256), 0, st, *d, l, PN, grow, H, (const float2*)nullptr, (int)L,
+                         (const elem*)(hid + (int64_t)hidx * hs), (const elem*)nullptr, (const float*)nullptr, (int)S, partials,
+                         kWideRows, B);
+    }
+  }
+  return 0;
+}
+
+/* draw [B,4] -> dfeat [L,B,2] (overwritten), dview [R,16] ACCUMULATED, partials [nof_mlp_wide_partial_rows(), n_params]
+ * overwritten (sum the rows with nof_reduce_partials).  `workspace` as left by nof_mlp_wide_fwd of the same batch. */
+extern "C" int nof_mlp_wide_bwd(const NofMlpDesc* d, const void* packed, const float* feat, int32_t L, const float* view,
+                                 int32_t S, const float* draw, void* workspace, float* dfeat, float* dview, float* partials,
+                                 int64_t B, void* stream) {
+  if (int e = check_wide(d)) return e;
+  NOF_ARG(packed && feat && view && draw && workspace && dfeat && dview && partials && B >= 0 && S >= 32 && L * 2 == d->in_feat);
+  if (B == 0) return 0;
+  const WideWs ws = wide_ws(d, workspace, B);
+  WIDE_DISPATCH(wide_bwd_launch, d, packed, feat, L, view, S, draw, &ws, dfeat, dview, partials, B, (hipStream_t)stream)
+  NOF_LAUNCH_OK();
+  return 0;
+}
+#undef WPAIR

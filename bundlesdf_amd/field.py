@@ -29,7 +29,7 @@ FP16_MODES = (2, 3)
 
 class NeuralObjectField:
     def __init__(self, cfg, n_frames, c2w, device='cuda', precision='bf16', n_sigma=2, n_color=3, seed_init=True,
-                 world_size=1, rank=0):
+                 world_size=1, rank=0, hidden=64):
         lib.load()
         self.cfg = cfg
         self.device = torch.device(device)
@@ -43,8 +43,11 @@ class NeuralObjectField:
             cfg['num_levels'], cfg['feature_grid_dim'], cfg['base_res'], cfg['log2_hashmap_size'], cfg['finest_res'])
         self.L = int(cfg['num_levels'])
         self.desc, self.layer_dims = lib.make_mlp_desc(n_sigma, n_color, 2 * self.L, self.n_view,
-                                                       PRECISIONS[precision] if isinstance(precision, str) else precision)
-        self.n_sigma, self.n_color = n_sigma, n_color
+                                                       PRECISIONS[precision] if isinstance(precision, str) else precision,
+                                                       hidden=hidden)
+        self.n_sigma, self.n_color, self.hidden = n_sigma, n_color, int(hidden)
+        # hidden 128 / 4 layers per network (BASELINE cfg5) run through the nof_mlp_wide_* kernels (staged activations)
+        self.wide = hidden != 64 or n_sigma > 3 or n_color > 3
         self.optimize_poses = bool(cfg.get('optimize_poses', 1))
         self.n_table = self.n_entries * 2
         self.n_mlp = self.desc.n_params
@@ -68,7 +71,7 @@ class NeuralObjectField:
         self.level = None
         self.global_step = 0
         self._bufs = {}
-        self.nblk = lib.load().nof_mlp_bwd_blocks()
+        self.nblk = lib.load().nof_mlp_wide_partial_rows() if self.wide else lib.load().nof_mlp_bwd_blocks()
         self.packed = torch.empty(int(lib.load().nof_mlp_packed_bytes(C.byref(self.desc))), dtype=torch.uint8, device=dev)
         self._packed_step = None     # optimiser step the fragment image was built for
         self.profile = None          # dict name -> [(start_event, end_event)] when per-kernel timing is on (bench.py)
@@ -193,8 +196,9 @@ class NeuralObjectField:
                 feat=e(self.L, B, 2), raw=e(B, 4), draw=e(B, 4), dfeat=e(self.L, B, 2), dview=e(R, 16), dpts=e(B, 3),
                 rgb_map=e(R, 3), partials=e(self.nblk, self.n_mlp), loss_rows=e(R, 8), g_ray=e(R, 12),
                 # sigma-head output / its gradient in MFMA operand precision: the hand-off of the split MLP backward
-                sig=e(B, 16, dt=torch.int16) if self.desc.precision != 0 else None,
-                dsig=e(B, 16, dt=torch.int16) if self.desc.precision != 0 else None)
+                sig=e(B, 16, dt=torch.int16) if self.desc.precision != 0 and not self.wide else None,
+                dsig=e(B, 16, dt=torch.int16) if self.desc.precision != 0 and not self.wide else None,
+                wide_ws=e(int(lib.load().nof_mlp_wide_workspace_bytes(C.byref(self.desc), B)), dt=torch.uint8) if self.wide else None)
         return self._bufs[key]
 
     def _sample_cfg(self, seed, step):
@@ -245,7 +249,10 @@ class NeuralObjectField:
                    self.flags)
         B = R * S
         self._call('nof_hash_encode_fwd', C.byref(self.grid), b['pts_w'], self.table, b['feat'], B)
-        self._call('nof_mlp_fwd', C.byref(self.desc), self.packed, b['feat'], self.L, b['view'], S, b['raw'], b['sig'], B)
+        if self.wide:
+            self._call('nof_mlp_wide_fwd', C.byref(self.desc), self.packed, b['feat'], self.L, b['view'], S, b['raw'], b['wide_ws'], B)
+        else:
+            self._call('nof_mlp_fwd', C.byref(self.desc), self.packed, b['feat'], self.L, b['view'], S, b['raw'], b['sig'], B)
         return b, S
 
     def train_step(self, pool, ids, R, u_occ=None, u_dep=None, seed=0, do_step=True, want_cells=False,
@@ -261,9 +268,12 @@ class NeuralObjectField:
                  None, b['draw'], b['loss_rows'], self.loss_out)
         b['dview'].zero_()
         self._set_grad_scale(B)
-        self._call('nof_mlp_bwd', C.byref(self.desc), self.packed, b['feat'], self.L, b['view'], S, b['draw'], b['sig'],
-                   b['dsig'], b['dfeat'],
-                 b['dview'], b['partials'], B)
+        if self.wide:
+            self._call('nof_mlp_wide_bwd', C.byref(self.desc), self.packed, b['feat'], self.L, b['view'], S, b['draw'],
+                       b['wide_ws'], b['dfeat'], b['dview'], b['partials'], B)
+        else:
+            self._call('nof_mlp_bwd', C.byref(self.desc), self.packed, b['feat'], self.L, b['view'], S, b['draw'], b['sig'],
+                       b['dsig'], b['dfeat'], b['dview'], b['partials'], B)
         self._call('nof_reduce_partials', b['partials'], self.nblk, self.n_mlp, self._seg(self.grads, 'mlp'))
         dpts = b['dpts'] if self.optimize_poses else None
         gtab = self._seg(self.grads, 'table')
@@ -325,7 +335,7 @@ class NeuralObjectField:
             feat = torch.empty(self.L, n, 2, device=self.device)
             p = pts[i:i + n].contiguous()
             lib.call('nof_hash_encode_fwd', C.byref(self.grid), p, self.table, feat, n)
-            lib.call('nof_mlp_sdf', C.byref(self.desc), self.packed, feat, self.L, out[i:i + n], n)
+            lib.call('nof_mlp_wide_sdf' if self.wide else 'nof_mlp_sdf', C.byref(self.desc), self.packed, feat, self.L, out[i:i + n], n)
         return out
 
     def query_sdf_grid(self, tx, ty, tz, outside_value=1.0, use_octree=True):
@@ -336,6 +346,22 @@ class NeuralObjectField:
         nx, ny, nz = (int(a.numel()) for a in ax)
         out = torch.empty(nx, ny, nz, device=self.device)
         occ = self.occ_bits if use_octree else None
+        if self.wide:
+            # no fused grid kernel for the wide networks: x-slabs of voxel centres -> octree mask (nof_occgrid_query) -> hash
+            # encode + sigma net of the voxels inside (query_sdf), all on the device
+            out.fill_(outside_value)
+            yz = torch.stack(torch.meshgrid(ax[1], ax[2], indexing='ij'), -1).reshape(-1, 2)
+            for i in range(nx):
+                pts = torch.cat([ax[0][i].expand(yz.shape[0], 1), yz], -1).contiguous()
+                if occ is not None:
+                    inside = torch.empty(pts.shape[0], dtype=torch.uint8, device=self.device)
+                    lib.call('nof_occgrid_query', occ, self.level, pts, inside, pts.shape[0])
+                    sel = inside.bool()
+                else:
+                    sel = torch.ones(pts.shape[0], dtype=torch.bool, device=self.device)
+                if sel.any():
+                    out[i].view(-1)[sel] = self.query_sdf(pts[sel])
+            return out
         lib.call('nof_sdf_grid_query', C.byref(self.grid), C.byref(self.desc), self.packed, self.table, occ, self.level,
                  ax[0], ax[1], ax[2], nx, ny, nz, C.c_float(outside_value), out)
         return out

@@ -101,6 +101,11 @@ _SIGNATURES = {
     'nof_cloud_filter': ([_P, _I64, _P, _P, _P, _I64, C.c_double, C.c_double, _P], C.c_int),
     'nof_compact_rows': ([_P, _P, _P, _I64, _P, _P], C.c_int),
     'nof_bary_uv': ([_P, _P, _P, _P, _P, _I64, _P, _P], C.c_int),
+    'nof_mlp_wide_workspace_bytes': ([C.POINTER(NofMlpDesc), _I64], C.c_int64),
+    'nof_mlp_wide_partial_rows': ([], C.c_int),
+    'nof_mlp_wide_fwd': ([C.POINTER(NofMlpDesc), _P, _P, _I32, _P, _I32, _P, _P, _I64, _P], C.c_int),
+    'nof_mlp_wide_sdf': ([C.POINTER(NofMlpDesc), _P, _P, _I32, _P, _I64, _P], C.c_int),
+    'nof_mlp_wide_bwd': ([C.POINTER(NofMlpDesc), _P, _P, _I32, _P, _I32, _P, _P, _P, _P, _P, _I64, _P], C.c_int),
     'nof_mfma_probe': ([_I32, _P, _P, _P, _I32, _P], C.c_int),
     'nof_atomic_probe': ([_I32, _P, _P, _I64, _P], C.c_int),
 }

@@ -63,7 +63,7 @@ class PoseArrayView:
 class NerfRunner:
     def __init__(self, cfg, images, depths, masks, normal_maps, poses, K, _run=None, occ_masks=None,
                  build_octree_pcd=None, precision=None, n_sigma=2, n_color=3, world_size=1, rank=0, grad_sync=None,
-                 frame_offset=0):
+                 frame_offset=0, hidden=64):
         if not torch.cuda.is_available():
             raise lib.NofError('NerfRunner needs an MI355X: there is no CPU path for the Neural Object Field')
         lib.load()
@@ -82,7 +82,7 @@ class NerfRunner:
         # amp: true in config.yml selects the 16-bit MFMA path: fp16 = the reference's autocast operand type, forward with the
         # hi/lo operand split (outputs within 1e-3 of fp32), backward plain fp16 with a loss scale like its GradScaler
         self.precision = precision or cfg.get('mfma_precision', 'fp16x3' if cfg.get('amp', True) else 'fp32')
-        self.n_sigma, self.n_color = n_sigma, n_color
+        self.n_sigma, self.n_color, self.hidden = n_sigma, n_color, hidden
         self.world_size, self.rank, self.grad_sync = world_size, rank, grad_sync
         # data parallel: `images/depths/masks` hold this rank's keyframes, which are frames frame_offset.. of `poses`
         self.frame_offset = int(frame_offset)
@@ -120,7 +120,7 @@ class NerfRunner:
         old = self.field
         self.field = NeuralObjectField(self.cfg, len(self.poses), self.poses, precision=self.precision,
                                        n_sigma=self.n_sigma, n_color=self.n_color, world_size=self.world_size,
-                                       rank=self.rank)
+                                       rank=self.rank, hidden=self.hidden)
         if old is not None and old.occ_bits is not None:
             self.field.occ_bits, self.field.level, self.field.max_level = old.occ_bits, old.level, old.max_level
             self.field.max_hits = old.max_hits

@@ -184,6 +184,22 @@ int nof_reduce_partials(const float* partials, int32_t n_rows, int32_t n_cols, f
 int nof_mlp_sdf(const NofMlpDesc* h_desc, const void* packed, const float* feat, int32_t L,
                 float* sdf, int64_t B, void* stream);
 
+/* ---- wide / deep networks: hidden 128 and/or 4 layers per network (BASELINE cfg5: SDF 4x128 + colour 4x128; NeRFSmall is
+ * parameterised in hidden_dim / num_layers, nerf_helpers.py:243-294).  nof_mlp_fwd / _bwd / _sdf / nof_sdf_grid_query accept
+ * hidden 64 with depths {2,3} and reject everything else with a message naming these entry points.  16-bit operand types only.
+ * One network and one fragment orientation per kernel is resident in LDS; hidden activations and pre-activation gradients are
+ * staged in `workspace` (nof_mlp_wide_workspace_bytes(desc, B) bytes, caller-allocated, must survive from the forward to the
+ * backward call of the same batch).  Same tensors as the narrow entry points otherwise; `partials` is
+ * [nof_mlp_wide_partial_rows(), n_params] floats, overwritten, to be summed with nof_reduce_partials. */
+int64_t nof_mlp_wide_workspace_bytes(const NofMlpDesc* h_desc, int64_t B);
+int nof_mlp_wide_partial_rows(void);
+int nof_mlp_wide_fwd(const NofMlpDesc* h_desc, const void* packed, const float* feat, int32_t L, const float* view, int32_t S,
+                     float* raw, void* workspace, int64_t B, void* stream);
+int nof_mlp_wide_sdf(const NofMlpDesc* h_desc, const void* packed, const float* feat, int32_t L, float* sdf, int64_t B,
+                     void* stream);
+int nof_mlp_wide_bwd(const NofMlpDesc* h_desc, const void* packed, const float* feat, int32_t L, const float* view, int32_t S,
+                     const float* draw, void* workspace, float* dfeat, float* dview, float* partials, int64_t B, void* stream);
+
 /* bytes of the `partials` workspace of nof_mlp_bwd (= nof_mlp_bwd_blocks() * n_params * 4); -1 on a bad descriptor */
 int64_t nof_mlp_bwd_workspace_bytes(const NofMlpDesc* h_desc);
 

@@ -269,10 +269,22 @@ def _linear(h, W, b, operand_dtype):
     return Fnn.linear(_round_ste(h, operand_dtype), _round_ste(W, operand_dtype), b)
 
 
-def mlp_forward(shape, params, x, operand_dtype=None):
+def mlp_forward(shape, params, x, operand_dtype=None, split_forward=False):
     """NeRFSmall.forward (nerf_helpers.py:305-321). x = [hash(input_ch) | views(input_ch_views)];
     returns [rgb_raw(3), sdf(1)].  operand_dtype=torch.float16/bfloat16 restates the autocast path the reference
-    trains with (nerf_runner.py:1289-1294: 16-bit GEMM operands, fp32 accumulate, fp32 bias)."""
+    trains with (nerf_runner.py:1289-1294: 16-bit GEMM operands, fp32 accumulate, fp32 bias).
+
+    split_forward (with an operand_dtype): the model of the product's 'fp16x3' / 'bf16x3' modes -- VALUES of the outputs and
+    of the sigma head's hand-off to the colour net are the fp32 ones (the forward kernels carry operands as hi + lo), while
+    the GRADIENT flows through the 16-bit-rounded network (the backward kernels recompute with plain 16-bit operands)."""
+    if split_forward and operand_dtype is not None:
+        with torch.no_grad():
+            exact = mlp_forward(shape, params, x, None)
+            h32 = x[:, :shape.input_ch]
+            for l in range(shape.num_layers):
+                h32 = _linear(h32, params[l][0], params[l][1], None)
+                if l != shape.num_layers - 1:
+                    h32 = torch.relu(h32)
     ns, nc = shape.num_layers, shape.num_layers_color
     h = x[:, :shape.input_ch]
     views = x[:, shape.input_ch:]
@@ -281,6 +293,8 @@ def mlp_forward(shape, params, x, operand_dtype=None):
         h = _linear(h, W, b, operand_dtype)
         if l != ns - 1:
             h = torch.relu(h)
+    if split_forward and operand_dtype is not None:
+        h = h + (h32 - h).detach()                       # the hand-off carries the exact head output (then rounded as an operand)
     sigma, geo = h[:, 0], h[:, 1:]
     h = torch.cat([views, geo], dim=-1)
     for l in range(nc):
@@ -288,7 +302,10 @@ def mlp_forward(shape, params, x, operand_dtype=None):
         h = _linear(h, W, b, operand_dtype)
         if l != nc - 1:
             h = torch.relu(h)
-    return torch.cat([h, sigma[:, None]], dim=-1)
+    out = torch.cat([h, sigma[:, None]], dim=-1)
+    if split_forward and operand_dtype is not None:
+        out = out + (exact - out).detach()
+    return out
 
 
 def mlp_forward_sdf(shape, params, feat, operand_dtype=None):
@@ -636,9 +653,10 @@ def losses(rgb_map, raw, z_vals, valid_samples, batch, cfg, truncation, first_fr
 # --------------------------------------------------------------------------------------
 class OracleField:
     def __init__(self, cfg, geo, shape, n_frames, c2w, occ_l, table=None, mlp=None, pose=None, feat=None,
-                 operand_dtype=None):
+                 operand_dtype=None, split_forward=False):
         self.cfg, self.geo, self.shape, self.F = cfg, geo, shape, n_frames
         self.operand_dtype = operand_dtype
+        self.split_forward = split_forward
         self.c2w = torch.as_tensor(c2w, dtype=torch.float32)
         self.occ_l = occ_l
         ff = cfg.get('frame_features', 0)
@@ -713,7 +731,7 @@ class OracleField:
         dirs_w = (tf[:, :3, :3] @ viewdirs[:, :, None])[:, :, 0]
         sh = sh_encode(dirs_w, cfg['multires_views'])
         parts.append(sh[:, None].expand(-1, S, -1).reshape(R * S, -1))
-        raw = mlp_forward(self.shape, self.mlp, torch.cat(parts, -1), self.operand_dtype).reshape(R, S, 4)
+        raw = mlp_forward(self.shape, self.mlp, torch.cat(parts, -1), self.operand_dtype, self.split_forward).reshape(R, S, 4)
         valid = valid.view(R, S)
         trunc = get_truncation(cfg, self.global_step)
         rgb_map, w = raw2outputs(raw, z_vals, batch[:, 6], valid, cfg, trunc)

@@ -44,7 +44,7 @@ def test_argument_errors_are_reported_not_crashing():
     rc = so.nof_hash_encode_fwd(ctypes.byref(g), None, None, None, 0, None)
     assert rc < 0 and b'C == 2' in so.nof_last_error()
     d, _ = lib.make_mlp_desc(2, 3, 32, 9)
-    d.hidden = 128
+    d.hidden = 96                                        # 64 and 128 are the supported widths
     rc = so.nof_mlp_fwd(ctypes.byref(d), None, None, 16, None, 192, None, None, 0, None)
     assert rc < 0 and b'hidden' in so.nof_last_error()
     assert so.nof_version() >= 100

@@ -338,7 +338,7 @@ def test_mlp_backward(nof, ns, nc, ff, L, precision, split):
     view_t = torch.randn(R, 9 + ff).requires_grad_(True)
     ps = [[W.clone().requires_grad_(True), b.clone().requires_grad_(True)] for W, b in params]
     x = torch.cat([feat, view_t.repeat_interleave(S, 0)], -1)
-    out = O.mlp_forward(shape, ps, x, ODT[precision])
+    out = O.mlp_forward(shape, ps, x, ODT[precision], split_forward=precision >= 3)
     draw = torch.randn(B, 4)
     (out * draw).sum().backward()
     view = torch.zeros(R, 16)
@@ -378,6 +378,71 @@ def test_mlp_backward(nof, ns, nc, ff, L, precision, split):
     assert (cpu(dview)[:, 9 + ff:] == 0).all()
     for k, (l2, mx) in report.items():
         assert l2 < TOL_L2[precision] and mx < TOL_MAX[precision], (k, l2, mx)
+
+
+@pytest.mark.parametrize("ns,nc,hidden,ff,L", [(4, 4, 128, 0, 16), (2, 3, 128, 2, 16), (4, 4, 64, 0, 16), (3, 4, 128, 2, 4)])
+@pytest.mark.parametrize("precision", [1, 2])
+def test_mlp_wide_forward_backward(nof, ns, nc, hidden, ff, L, precision):
+    """The wide / deep shapes (BASELINE cfg5: SDF 4x128 + colour 4x128, fp16) through nof_mlp_wide_fwd / _sdf / _bwd: outputs,
+    dfeat, dview and every layer's dW / db against the oracle with the same 16-bit operand rounding."""
+    torch.manual_seed(3)
+    n_view = 9 + ff
+    shape = O.FieldShape(input_ch=2 * L, input_ch_views=n_view, num_layers=ns, hidden_dim=hidden, num_layers_color=nc,
+                         hidden_dim_color=hidden)
+    params = O.init_mlp_params(shape)
+    for W, b in params:
+        b.add_(torch.randn_like(b) * 0.1)
+    desc, dims = nof.make_mlp_desc(ns, nc, 2 * L, n_view, precision, hidden=hidden)
+    flat = torch.cat([torch.cat([W.reshape(-1), b.reshape(-1)]) for W, b in params])
+    assert flat.numel() == desc.n_params == shape.n_params()
+    R, S = 23, 48                                        # B not a multiple of 32, S not a multiple of 32
+    B = R * S
+    feat = (torch.randn(B, 2 * L) * 0.5).requires_grad_(True)
+    view_t = torch.randn(R, n_view).requires_grad_(True)
+    ps = [[W.clone().requires_grad_(True), b.clone().requires_grad_(True)] for W, b in params]
+    x = torch.cat([feat, view_t.repeat_interleave(S, 0)], -1)
+    ref32 = O.mlp_forward(shape, params, x.detach()).detach().numpy()
+    out = O.mlp_forward(shape, ps, x, ODT[precision])
+    draw = torch.randn(B, 4)
+    (out * draw).sum().backward()
+    ref_m = out.detach().numpy()
+    view = torch.zeros(R, 16)
+    view[:, :n_view] = view_t.detach()
+    d_feat = feat.detach().reshape(B, L, 2).permute(1, 0, 2).contiguous().cuda()
+    packed = _pack(nof, desc, flat)
+    ws = torch.zeros(int(nof.load().nof_mlp_wide_workspace_bytes(C.byref(desc), B)), dtype=torch.uint8, device='cuda')
+    raw = torch.zeros(B, 4, device='cuda')
+    nof.call('nof_mlp_wide_fwd', C.byref(desc), packed, d_feat, L, view.cuda(), S, raw, ws, B)
+    sdf = torch.zeros(B, device='cuda')
+    nof.call('nof_mlp_wide_sdf', C.byref(desc), packed, d_feat, L, sdf, B)
+    with pytest.raises(nof.NofError):                    # the narrow entry points name the wide ones instead of mis-computing
+        nof.call('nof_mlp_fwd', C.byref(desc), packed, d_feat, L, view.cuda(), S, raw, None, B)
+    rows = nof.load().nof_mlp_wide_partial_rows()
+    dfeat = torch.full((L, B, 2), 3.0, device='cuda')
+    dview = torch.zeros(R, 16, device='cuda')
+    partials = torch.full((rows, desc.n_params), 5.0, device='cuda')
+    nof.call('nof_mlp_wide_bwd', C.byref(desc), packed, d_feat, L, view.cuda(), S, draw.cuda(), ws, dfeat, dview, partials, B)
+    gflat = torch.zeros(desc.n_params, device='cuda')
+    nof.call('nof_reduce_partials', partials, rows, desc.n_params, gflat)
+    torch.cuda.synchronize()
+    scale = np.abs(ref32).max()
+    e32, em = np.abs(cpu(raw) - ref32).max() / scale, np.abs(cpu(raw) - ref_m).max() / scale
+    print(f'wide ({ns},{nc},{hidden}) precision {precision}: forward vs fp32 {e32:.2e}, vs same rounding {em:.2e}')
+    assert e32 < TOL[precision] and em < {1: 6e-3, 2: 8e-4}[precision]
+    assert np.abs(cpu(sdf) - ref32[:, 3]).max() / scale < TOL[precision]
+    ref_df, ref_dv = feat.grad.numpy(), view_t.grad.numpy()
+    got_df = cpu(dfeat).transpose(1, 0, 2).reshape(B, 2 * L)
+    ref_g = torch.cat([torch.cat([W.grad.reshape(-1), b.grad.reshape(-1)]) for W, b in ps]).numpy()
+    got_g = cpu(gflat)
+    report = {'dfeat': (rel_l2(got_df, ref_df), rel_max(got_df, ref_df)),
+              'dview': (rel_l2(cpu(dview)[:, :n_view], ref_dv), rel_max(cpu(dview)[:, :n_view], ref_dv))}
+    for l in range(ns + nc):
+        lo, hi = desc.w_off[l], desc.b_off[l] + desc.out_dim[l]
+        report[f'layer{l}'] = (rel_l2(got_g[lo:hi], ref_g[lo:hi]), rel_max(got_g[lo:hi], ref_g[lo:hi]))
+    print('wide bwd', {k: (f'{a:.2e}', f'{b:.2e}') for k, (a, b) in report.items()})
+    assert (cpu(dview)[:, n_view:] == 0).all()
+    for k, (l2, mx) in report.items():
+        assert l2 < 1.5 * TOL_L2[precision] and mx < 1.5 * TOL_MAX[precision], (k, l2, mx)
 
 
 def test_mlp_backward_fp16_loss_scale(nof):

@@ -123,8 +123,8 @@ def test_checkpoint_roundtrip(nof, tmp_path):
 
 def test_reference_format_checkpoint_roundtrip(nof, tmp_path):
     """save_weights(reference_format=True) writes the reference's layout ('model' / 'embed_fn' / 'pose_array' /
-    'feature_array' state_dicts, nerf_runner.py:546-566); load_weights reads it back into a fresh field: same parameters,
-    same rendered raw outputs."""
+    'feature_array' / 'optimizer' state_dicts, nerf_runner.py:546-566); load_weights reads it back into a fresh field: same
+    parameters, same Adam moments and step count."""
     from tests.test_gpu_step import _pair
     from tests import util as U
     from bundlesdf_amd.checkpoint import to_reference_checkpoint, load_reference_checkpoint
@@ -136,14 +136,15 @@ def test_reference_format_checkpoint_roundtrip(nof, tmp_path):
     p = str(tmp_path / 'ref_format.pth')
     torch.save(ck, p)
     ck2 = torch.load(p)
-    assert set(ck2) >= {'global_step', 'model', 'embed_fn', 'pose_array', 'feature_array'}
+    assert set(ck2) >= {'global_step', 'model', 'embed_fn', 'pose_array', 'feature_array', 'optimizer'}
     assert ck2['embed_fn']['embeddings'].shape == (fld.n_entries, 2) and ck2['pose_array']['data'].shape == (fld.F, 6)
-    before = fld.params.clone()
+    before, m, v = fld.params.clone(), fld.exp_avg.clone(), fld.exp_avg_sq.clone()
     fld.params.zero_()
+    fld.global_step = 0
     assert load_reference_checkpoint(fld, ck2) == 3
     torch.cuda.synchronize()
     assert torch.equal(fld.params, before)
-    assert float(fld.exp_avg.abs().sum()) == 0.0
+    assert torch.equal(fld.exp_avg, m) and torch.equal(fld.exp_avg_sq, v) and fld.global_step == 3 and float(m.abs().sum()) > 0
     ck2['embed_fn']['embeddings'] = ck2['embed_fn']['embeddings'][:-8]
     with pytest.raises(ValueError):
         load_reference_checkpoint(fld, ck2)

@@ -17,21 +17,22 @@ def cpu(t):
     return t.detach().cpu().numpy()
 
 
-def _pair(nof, precision, ff=0, ns=2, nc=3, L=16, R=256, seed=0):
+def _pair(nof, precision, ff=0, ns=2, nc=3, L=16, R=256, seed=0, hidden=64):
     from bundlesdf_amd.field import NeuralObjectField
     level = 4
     cfg, occ, c2w, batch = _scene(nof, R=R, level=level, seed=seed)
     cfg.update(frame_features=ff, num_levels=L, n_step=20)
     F = c2w.shape[0]
     torch.manual_seed(seed)
-    fld = NeuralObjectField(cfg, F, c2w, precision=precision, n_sigma=ns, n_color=nc)
+    fld = NeuralObjectField(cfg, F, c2w, precision=precision, n_sigma=ns, n_color=nc, hidden=hidden)
     rng = np.random.default_rng(seed + 10)
     pose0 = (rng.normal(size=(F, 6)) * 0.2).astype(np.float32)
     table0 = (rng.uniform(-1, 1, size=(fld.n_entries, 2)) * 0.05).astype(np.float32)   # lively features (default init is 1e-4)
     fld.load_parameters(table=table0, pose=pose0)
     fld.set_occupancy(U.occ_to_coords(occ), level, level)
     geo = O.HashGeometry(L, 2, cfg['base_res'], cfg['log2_hashmap_size'], cfg['finest_res'])
-    shape = O.FieldShape(input_ch=2 * L, input_ch_views=9 + ff, num_layers=ns, num_layers_color=nc)
+    shape = O.FieldShape(input_ch=2 * L, input_ch_views=9 + ff, num_layers=ns, num_layers_color=nc, hidden_dim=hidden,
+                         hidden_dim_color=hidden)
     mlp = [[W.clone(), b.clone()] for W, b in fld.mlp_state()]
     feat0 = cpu(fld.feat).reshape(F, ff) if ff else None
     orc = O.OracleField(cfg, geo, shape, F, c2w, occ, table=table0, mlp=mlp, pose=pose0, feat=feat0,
@@ -121,7 +122,7 @@ def test_default_precision_meets_1e3_on_outputs(nof, ns, nc):
     """The precision bench.py and amp=True default to ('fp16x3': fp16 MFMA operands, hi+lo split in the forward kernels,
     loss-scaled fp16 backward) against the PURE fp32 oracle: SDF and colour within north_star's 1e-3 (max-norm) at the
     reference's network shape (2,3) and at BASELINE cfg2's (3,2); gradients against the oracle with the backward's fp16
-    operand rounding (= the reference's autocast path)."""
+    operand rounding (= the reference's autocast path) evaluated at the exact forward values (oracle split_forward)."""
     from bundlesdf_amd.field import NeuralObjectField
     cfg, fld, orc, batch, rng = _pair(nof, 'fp32', 0, ns, nc)
     fld16 = NeuralObjectField(cfg, fld.F, cpu(fld.c2w).reshape(-1, 4, 4), precision='fp16x3', n_sigma=ns, n_color=nc)
@@ -129,7 +130,7 @@ def test_default_precision_meets_1e3_on_outputs(nof, ns, nc):
     fld16.occ_bits, fld16.level, fld16.max_level, fld16.max_hits = fld.occ_bits, fld.level, fld.max_level, fld.max_hits
     orc16 = O.OracleField(cfg, orc.geo, orc.shape, fld.F, cpu(fld.c2w).reshape(-1, 4, 4), orc.occ_l,
                           table=cpu(fld.table).reshape(-1, 2), mlp=[[W.clone(), b.clone()] for W, b in fld.mlp_state()],
-                          pose=cpu(fld.pose).reshape(-1, 6), operand_dtype=torch.float16)
+                          pose=cpu(fld.pose).reshape(-1, 6), operand_dtype=torch.float16, split_forward=True)
     R = batch.shape[0]
     Ns, Na = cfg['N_samples'], cfg['N_samples_around_depth']
     S = Ns + Na
@@ -162,6 +163,53 @@ def test_default_precision_meets_1e3_on_outputs(nof, ns, nc):
     for l in range(ns + nc):
         lo, hi = fld16.desc.w_off[l], fld16.desc.b_off[l] + fld16.desc.out_dim[l]
         assert rel_l2(gm[lo:hi], gm_ref[lo:hi]) < 6e-3, (l, rel_l2(gm[lo:hi], gm_ref[lo:hi]))
+
+
+def test_wide_network_step_matches_oracle(nof):
+    """BASELINE cfg5's network (SDF 4x128 + colour 4x128, fp16 MFMA) through a whole step: outputs, losses and every gradient
+    group against the oracle with fp16 operand rounding; then 30 Philox steps reduce the loss."""
+    ns = nc = 4
+    cfg, fld, orc, batch, rng = _pair(nof, 'fp16', 0, ns, nc, hidden=128)
+    assert fld.wide
+    R = batch.shape[0]
+    Ns, Na = cfg['N_samples'], cfg['N_samples_around_depth']
+    S = Ns + Na
+    u_occ = rng.random((R, Ns)).astype(np.float32)
+    u_dep = rng.random((R, Na)).astype(np.float32)
+    b = fld.train_step(U.dev(batch), None, R, U.dev(u_occ), U.dev(u_dep), do_step=False)
+    torch.cuda.synchronize()
+    ref = orc.train_step(batch, u_occ, u_dep, do_step=False)
+    both = cpu(b['valid']).reshape(R, S).astype(bool) & ref['fwd']['valid_samples'].numpy()
+    raw_ref = ref['fwd']['raw'].detach().numpy()
+    raw = cpu(b['raw']).reshape(R, S, 4)
+    e = rel_max(raw[both], raw_ref[both])
+    print(f'wide 4x128 fp16 step: raw rel-max {e:.2e}')
+    assert e < 3e-3
+    Lo = fld.losses()
+    for k in ('loss', 'rgb_loss', 'fs_loss', 'sdf_loss'):
+        r = float(ref['losses'][k])
+        assert abs(Lo[k] - r) <= 5e-3 * abs(r) + 1e-7, (k, Lo[k], r)
+    names = ['table'] + [f'mlp{i}' for i in range(2 * (ns + nc))] + ['pose']
+    g_ref = dict(zip(names, ref['grads']))
+    gt = cpu(fld._seg(fld.grads, 'table')).reshape(-1, 2)
+    assert rel_l2(gt, g_ref['table'].numpy()) < 6e-3, rel_l2(gt, g_ref['table'].numpy())
+    gm = cpu(fld._seg(fld.grads, 'mlp'))
+    gm_ref = torch.cat([g.reshape(-1) for n, g in g_ref.items() if n.startswith('mlp')]).numpy()
+    for l in range(ns + nc):
+        lo, hi = fld.desc.w_off[l], fld.desc.b_off[l] + fld.desc.out_dim[l]
+        assert rel_l2(gm[lo:hi], gm_ref[lo:hi]) < 6e-3, (l, rel_l2(gm[lo:hi], gm_ref[lo:hi]))
+    gp = cpu(fld._seg(fld.grads, 'pose')).reshape(-1, 6)
+    assert rel_l2(gp, g_ref['pose'].numpy()) < 3e-2
+    fld.grads.zero_()
+    first = None
+    for it in range(30):
+        fld.train_step(U.dev(batch), None, R, seed=5)
+        if it == 0:
+            first = fld.losses()['loss']
+    last = fld.losses()['loss']
+    assert np.isfinite(last) and last < 0.8 * first, (first, last)
+    sdf = fld.query_sdf(b['pts_w'][:1000])
+    assert torch.isfinite(sdf).all()
 
 
 def test_philox_training_reduces_loss(nof):
