@@ -14,7 +14,7 @@ CSRC = os.path.join(HERE, 'csrc')
 OBJ = os.path.join(CSRC, 'build')
 LIB = os.path.join(HERE, 'libnof_hip.so')
 SOURCES = ['nof_capi.hip', 'nof_hash.hip', 'nof_trace.hip', 'nof_loss.hip', 'nof_pose.hip', 'nof_mlp.hip', 'nof_mesh.hip']
-HEADERS = [os.path.join(CSRC, 'nof_common.h'), os.path.join(CSRC, 'nof_hash_dev.h'), os.path.join(HERE, '..', 'include', 'nof_hip.h')]
+HEADERS = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith('.h')) + [os.path.join(HERE, '..', 'include', 'nof_hip.h')]
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=off', '-munsafe-fp-atomics',
          '-Wno-unused-result', '-Wno-pass-failed']
 # NOTE: `-mllvm -amdgpu-mfma-vgpr-form` (keeps MFMA results in VGPRs: -23 % instructions in k_mlp_bwd) MISCOMPILES

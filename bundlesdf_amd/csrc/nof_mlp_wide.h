@@ -6,7 +6,8 @@
 // in LDS and every dW accumulator in registers.  A 128x128 layer is 32 KB of fragments per orientation and 256 accumulator
 // registers per wave; 4+4 such layers are 168 KB per orientation.  So here
 //   * each network (sigma, colour) and each direction is its own kernel with ONE orientation of ONE network resident in LDS
-//     (<= 88 KB for 4x128, 16-bit operands), shared by a 512-thread workgroup (8 waves, 2 per SIMD);
+//     (<= 88 KB for 4x128, 16-bit operands), shared by a 768-thread workgroup (12 waves, 3 per SIMD, <= 168 VGPRs: these
+//     kernels wait on every staged row they load, so occupancy is what hides the latency: 512 threads were 1.6x slower);
 //   * the forward kernels store the hidden activations (post-ReLU, operand precision, [layer][B][H] sample-major) instead of the
 //     backward recomputing them, and the backward-data kernels store the pre-activation gradients the same way;
 //   * the weight gradients are a separate split-K pass per layer (k_wide_dw): a wave owns ONE 32-neuron output block (16 * QN
@@ -18,37 +19,28 @@
 // operand split: the residual fragments would double the LDS image).
 #pragma once
 
-typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-template <class P> struct Vec4;
-template <> struct Vec4<PrecF16> { typedef f16x4 type; };
-template <> struct Vec4<PrecBF16> { typedef bf16x4 type; };
-
-// ---- rows of the staging buffers: [B][H] elements, neuron n of block p at column 32 p + n ------------------------------------
-// lane (sample j, hi) holds neurons 32p + 8g + 4hi + {0..3} of block p in registers 4g..4g+3: one 8-byte access per (p, g)
+// ---- rows of the staging buffers: [B][H] elements in REGISTER order -------------------------------------------------------
+// The buffers are private to these kernels, so a row is laid out the way a lane holds it: the 16 values of block p that lane
+// (sample j, hi) keeps in registers r = 0..15 (neurons 32p + nloc(hi, r)) are contiguous at element 32p + 16hi + r: two
+// 16-byte accesses per block instead of four 8-byte ones (these kernels are bound by the number of lane-addresses, not bytes).
 template <class P>
 __device__ __forceinline__ void store_blk(typename P::elem* __restrict__ row, int p, int hi, const float (&v)[16]) {
-  typedef typename Vec4<P>::type v4;
-#pragma unroll
-  for (int g = 0; g < 4; ++g) {
-    v4 t;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) t[k] = (typename P::elem)v[4 * g + k];
-    *reinterpret_cast<v4*>(row + 32 * p + 8 * g + 4 * hi) = t;
-  }
+  typename P::frag* dst = reinterpret_cast<typename P::frag*>(row + 32 * p + 16 * hi);
+  dst[0] = P::pack(&v[0]);
+  dst[1] = P::pack(&v[8]);
 }
 template <class P>
 __device__ __forceinline__ void load_blk(const typename P::elem* __restrict__ row, int p, int hi, bool ok, float (&v)[16]) {
-  typedef typename Vec4<P>::type v4;
+  typename P::frag a, b;
 #pragma unroll
-  for (int g = 0; g < 4; ++g) {
-    v4 t;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) t[k] = (typename P::elem)0.0f;
-    if (ok) t = *reinterpret_cast<const v4*>(row + 32 * p + 8 * g + 4 * hi);
-#pragma unroll
-    for (int k = 0; k < 4; ++k) v[4 * g + k] = (float)t[k];
+  for (int k = 0; k < 8; ++k) { a[k] = (typename P::elem)0.0f; b[k] = (typename P::elem)0.0f; }
+  if (ok) {
+    const typename P::frag* src = reinterpret_cast<const typename P::frag*>(row + 32 * p + 16 * hi);
+    a = src[0];
+    b = src[1];
   }
+#pragma unroll
+  for (int k = 0; k < 8; ++k) { v[k] = (float)a[k]; v[8 + k] = (float)b[k]; }
 }
 
 template <int PN>
@@ -65,7 +57,7 @@ __device__ __forceinline__ void relu_inplace(float (&h)[PN][16]) {
 // forward, sigma net: features -> hidden layers (stored) -> head: sdf -> raw[b].w (or sdf[b]), sig[b] = 16 head outputs
 // =====================================================================================================
 template <class P, int HB>
-__global__ __launch_bounds__(512) void k_wide_fwd_sigma(NofMlpDesc d, const char* __restrict__ image,
+__global__ __launch_bounds__(768) void k_wide_fwd_sigma(NofMlpDesc d, const char* __restrict__ image,
                                                          const float2* __restrict__ feat, int L,
                                                          typename P::elem* __restrict__ hid, int64_t hid_stride,
                                                          float* __restrict__ out, int out_stride, int out_off,
@@ -118,7 +110,7 @@ __global__ __launch_bounds__(512) void k_wide_fwd_sigma(NofMlpDesc d, const char
 // forward, colour net: [sig | view] -> hidden layers (stored) -> rgb_raw -> raw[b].xyz
 // =====================================================================================================
 template <class P, int HB>
-__global__ __launch_bounds__(512) void k_wide_fwd_color(NofMlpDesc d, const char* __restrict__ image,
+__global__ __launch_bounds__(768) void k_wide_fwd_color(NofMlpDesc d, const char* __restrict__ image,
                                                          const typename P::elem* __restrict__ sig,
                                                          const float* __restrict__ view, int S,
                                                          typename P::elem* __restrict__ hid, int64_t hid_stride,
@@ -182,7 +174,7 @@ __device__ __forceinline__ void mask_by_row(const typename P::elem* __restrict__
 // gbuf[l] rows are [B][H]; a head's gradient occupies block 0 of its row.
 // =====================================================================================================
 template <class P, int HB>
-__global__ __launch_bounds__(512) void k_wide_bwd_color(NofMlpDesc d, const char* __restrict__ image,
+__global__ __launch_bounds__(768) void k_wide_bwd_color(NofMlpDesc d, const char* __restrict__ image,
                                                          const typename P::elem* __restrict__ hid, int64_t hid_stride,
                                                          int S, const float4* __restrict__ draw,
                                                          typename P::elem* __restrict__ gbuf, int64_t g_stride,
@@ -278,7 +270,7 @@ __global__ __launch_bounds__(512) void k_wide_bwd_color(NofMlpDesc d, const char
 // backward (data path), sigma net: dsig -> pre-activation gradients of every sigma layer (stored), dfeat
 // =====================================================================================================
 template <class P, int HB>
-__global__ __launch_bounds__(512) void k_wide_bwd_sigma(NofMlpDesc d, const char* __restrict__ image,
+__global__ __launch_bounds__(768) void k_wide_bwd_sigma(NofMlpDesc d, const char* __restrict__ image,
                                                          const typename P::elem* __restrict__ hid, int64_t hid_stride,
                                                          const typename P::elem* __restrict__ dsig,
                                                          typename P::elem* __restrict__ gbuf, int64_t g_stride,
@@ -345,23 +337,26 @@ __global__ __launch_bounds__(512) void k_wide_bwd_sigma(NofMlpDesc d, const char
 
 // =====================================================================================================
 // weight gradients of ONE layer: dW[32p + n][k] = sum_b G[b][32p + n] X[b][k], db likewise.  The four waves of a workgroup
-// split into PN output blocks x 4/PN tile streams: wave w owns block p = w % PN of the tiles of partial row
-// blockIdx.x * (4/PN) + w / PN, so the PN waves that need the same X rows (and the four quarters of the same G row) sit on
-// one CU and share them through its L1.  `partials` is [rows][n_params]: every (layer, block) writes its own entries of every
-// row, so after all layers each row is completely defined.
+// split into PN output blocks x NST = 4/PN tile streams: wave w owns output block p = w % PN of the tiles of partial row
+// blockIdx.x * NST + w / PN.  The PN waves of a stream need the same QN input blocks of the same tile, so each of them loads
+// and transposes (on the matrix core) only the blocks q = p, p + PN, ... and they exchange the transposed operand fragments
+// through LDS (double-buffered, one workgroup barrier per tile): 2 + 2 QN/PN sixteen-byte loads per lane and tile instead of
+// 2 + 2 QN.  `partials` is [rows][n_params]: every (layer, block) writes its own entries of every row, so after all layers
+// each row is completely defined.
 // KIND: 0 = hash features (QN = 1), 1 = a stored hidden activation row (QN = H/32), 2 = colour layer 0's [sig | view] (QN = 2)
 // =====================================================================================================
-template <class P, int QN, int KIND>
-__global__ __launch_bounds__(256) void k_wide_dw(NofMlpDesc d, int l, int PN, const typename P::elem* __restrict__ grow,
+template <class P, int QN, int KIND, int PN>
+__global__ __launch_bounds__(256) void k_wide_dw(NofMlpDesc d, int l, const typename P::elem* __restrict__ grow,
                                                   int H, const float2* __restrict__ feat, int L,
                                                   const typename P::elem* __restrict__ xrow,
                                                   const typename P::elem* __restrict__ sig, const float* __restrict__ view,
                                                   int S, float* __restrict__ partials, int rows, int64_t B) {
-  constexpr int KR = P::KR, NSTEP = 16 / KR;
+  constexpr int KR = P::KR, NSTEP = 16 / KR, NST = 4 / PN, MAXQ = (QN + PN - 1) / PN;
+  __shared__ typename P::frag xs[2][NST][QN][NSTEP][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int hi = lane >> 5, j = lane & 31;
-  const int p = wave % PN;
-  const int row = blockIdx.x * (4 / PN) + wave / PN;
+  const int p = wave % PN, stream = wave / PN;
+  const int row = blockIdx.x * NST + stream;
   Ident<P> I;
   I.init(lane);
   const float gunscale = d.grad_scale > 0.0f ? 1.0f / d.grad_scale : 1.0f;
@@ -372,35 +367,65 @@ __global__ __launch_bounds__(256) void k_wide_dw(NofMlpDesc d, int l, int PN, co
     for (int r = 0; r < 16; ++r) acc[q][r] = 0.0f;
   float db = 0.0f;
   const int64_t ntiles = (B + 31) / 32;
-  for (int64_t tile = row; tile < ntiles; tile += rows) {
+  const int n_it = (int)((ntiles + rows - 1) / rows);                  // the same trip count for every wave (barrier inside)
+  // the NEXT tile's gradient block and this wave's share of the input blocks are loaded while the current tile is computed
+  float g1[16], xn[MAXQ][16];
+  auto fetch = [&](int64_t tile) {
     const int64_t b = tile * 32 + j;
-    const bool ok = b < B;
-    float g1[16], g2[16];
+    const bool ok = tile < ntiles && b < B;
     load_blk<P>(grow + b * H, p, hi, ok, g1);
-    transpose32<P>(I, g1, g2);
+#pragma unroll
+    for (int m = 0; m < MAXQ; ++m) {
+      const int q = p + m * PN;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) xn[m][r] = 0.0f;
+      if (q < QN) {
+        if constexpr (KIND == 0) {
+          float xf[1][16];
+          load_feat_o1(feat, L, ok ? B : 0, b, hi, xf);
+#pragma unroll
+          for (int r = 0; r < 16; ++r) xn[m][r] = xf[0][r];
+        } else if constexpr (KIND == 1) {
+          load_blk<P>(xrow + b * H, q, hi, ok, xn[m]);
+        } else {
+          if (q == 0) load_sig_o1<P>(sig, ok ? B : 0, b, hi, xn[m]);
+          else load_view_o1(view, S, ok ? B : 0, b, hi, xn[m]);
+        }
+      }
+    }
+  };
+  fetch(row);
+  for (int it = 0; it < n_it; ++it) {
+    float g0[16], x1[MAXQ][16], g2[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) g0[r] = g1[r];
+#pragma unroll
+    for (int m = 0; m < MAXQ; ++m)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) x1[m][r] = xn[m][r];
+    fetch((int64_t)row + (int64_t)(it + 1) * rows);
+    const int buf = it & 1;
+#pragma unroll
+    for (int m = 0; m < MAXQ; ++m) {
+      const int q = p + m * PN;
+      if (q < QN) {
+        float x2[16];
+        transpose32<P>(I, x1[m], x2);
+#pragma unroll
+        for (int s = 0; s < NSTEP; ++s) xs[buf][stream][q][s][lane] = P::pack(&x2[KR * s]);
+      }
+    }
+    transpose32<P>(I, g0, g2);
 #pragma unroll
     for (int r = 0; r < 16; ++r) db += g2[r];
     typename P::frag ga[NSTEP];
 #pragma unroll
     for (int s = 0; s < NSTEP; ++s) ga[s] = P::pack(&g2[KR * s]);
+    __syncthreads();
 #pragma unroll
-    for (int q = 0; q < QN; ++q) {
-      float x1[16], x2[16];
-      if constexpr (KIND == 0) {
-        float xf[1][16];
-        load_feat_o1(feat, L, B, b, hi, xf);
+    for (int q = 0; q < QN; ++q)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) x1[r] = xf[0][r];
-      } else if constexpr (KIND == 1) {
-        load_blk<P>(xrow + b * H, q, hi, ok, x1);
-      } else {
-        if (q == 0) load_sig_o1<P>(sig, B, b, hi, x1);
-        else load_view_o1(view, S, B, b, hi, x1);
-      }
-      transpose32<P>(I, x1, x2);
-#pragma unroll
-      for (int s = 0; s < NSTEP; ++s) acc[q] = P::mma(ga[s], P::pack(&x2[KR * s]), acc[q]);
-    }
+      for (int s = 0; s < NSTEP; ++s) acc[q] = P::mma(ga[s], xs[buf][stream][q][s][lane], acc[q]);
   }
   // flush: lane j = input slot (hi_j, r_j) of block q, register r = neuron 32p + nloc(hi, r)
   const int hi_j = (j >> 2) & 1, r_j = (j & 3) + 4 * (j >> 3);
@@ -430,7 +455,7 @@ static int check_wide(const NofMlpDesc* d) {
   return 0;
 }
 static int64_t wide_hid_layers(const NofMlpDesc* d) { return (d->n_sigma - 1) + (d->n_color - 1); }
-static const int kWideRows = 512;                                         // wave-rows of `partials` (128 workgroups per output block)
+static const int kWideRows = 1024;                                        // wave-rows of `partials`: 4 waves per SIMD of the weight-gradient pass
 
 // workspace layout (bytes, 256-aligned): [hid : n_hid * B * H elems][gbuf : NL * B * H elems][sig : B * 16 elems][dsig : B * 16 elems]
 struct WideWs { char *hid, *gbuf, *sig, *dsig; int64_t total; };
@@ -461,18 +486,18 @@ static int wide_fwd_launch(const NofMlpDesc* d, const void* packed, const float*
   const size_t shm_s = (size_t)pair_base(*d, ns) * pair_bytes + (size_t)oblk_base(*d, ns) * 128;
   const size_t shm_c = (size_t)(pair_base(*d, nl) - pair_base(*d, ns)) * pair_bytes + (size_t)(oblk_base(*d, nl) - oblk_base(*d, ns)) * 128;
   const int64_t ntiles = (B + 31) / 32;
-  const unsigned blocks = (unsigned)(nof_div_up(ntiles, 8) < (int64_t)nof_cu_count() ? nof_div_up(ntiles, 8) : nof_cu_count());
+  const unsigned blocks = (unsigned)(nof_div_up(ntiles, 12) < (int64_t)nof_cu_count() ? nof_div_up(ntiles, 12) : nof_cu_count());
   typedef typename P::elem elem;
   const int64_t hs = B * (int64_t)d->hidden;
   auto ks = k_wide_fwd_sigma<P, HB>;
   if (int e = set_smem(ks, shm_s)) return e;
-  hipLaunchKernelGGL(ks, dim3(blocks), dim3(512), shm_s, st, *d, (const char*)packed, (const float2*)feat, (int)L,
+  hipLaunchKernelGGL(ks, dim3(blocks), dim3(768), shm_s, st, *d, (const char*)packed, (const float2*)feat, (int)L,
                      store_hidden ? (elem*)ws->hid : (elem*)nullptr, hs, out, out_stride, out_off,
                      sdf_only ? (elem*)nullptr : (elem*)ws->sig, B);
   if (!sdf_only) {
     auto kc = k_wide_fwd_color<P, HB>;
     if (int e = set_smem(kc, shm_c)) return e;
-    hipLaunchKernelGGL(kc, dim3(blocks), dim3(512), shm_c, st, *d, (const char*)packed, (const elem*)ws->sig, view, (int)S,
+    hipLaunchKernelGGL(kc, dim3(blocks), dim3(768), shm_c, st, *d, (const char*)packed, (const elem*)ws->sig, view, (int)S,
                        store_hidden ? (elem*)ws->hid : (elem*)nullptr, hs, out, B);
   }
   return 0;
@@ -522,34 +547,32 @@ static int wide_bwd_launch(const NofMlpDesc* d, const void* packed, const float*
   const size_t shm_s = (size_t)pair_base(*d, ns) * pair_bytes;
   const size_t shm_c = (size_t)(pair_base(*d, nl) - pair_base(*d, ns)) * pair_bytes;
   const int64_t ntiles = (B + 31) / 32;
-  const unsigned blocks = (unsigned)(nof_div_up(ntiles, 8) < (int64_t)nof_cu_count() ? nof_div_up(ntiles, 8) : nof_cu_count());
+  const unsigned blocks = (unsigned)(nof_div_up(ntiles, 12) < (int64_t)nof_cu_count() ? nof_div_up(ntiles, 12) : nof_cu_count());
   const int64_t hs = B * (int64_t)H;
   elem *hid = (elem*)ws->hid, *gbuf = (elem*)ws->gbuf, *sig = (elem*)ws->sig, *dsig = (elem*)ws->dsig;
   auto kc = k_wide_bwd_color<P, HB>;
   auto ks = k_wide_bwd_sigma<P, HB>;
   if (int e = set_smem(kc, shm_c)) return e;
   if (int e = set_smem(ks, shm_s)) return e;
-  hipLaunchKernelGGL(kc, dim3(blocks), dim3(512), shm_c, st, *d, (const char*)packed, (const elem*)hid, hs, (int)S,
+  hipLaunchKernelGGL(kc, dim3(blocks), dim3(768), shm_c, st, *d, (const char*)packed, (const elem*)hid, hs, (int)S,
                      (const float4*)draw, gbuf, hs, dsig, dview, B);
-  hipLaunchKernelGGL(ks, dim3(blocks), dim3(512), shm_s, st, *d, (const char*)packed, (const elem*)hid, hs, (const elem*)dsig, gbuf,
+  hipLaunchKernelGGL(ks, dim3(blocks), dim3(768), shm_s, st, *d, (const char*)packed, (const elem*)hid, hs, (const elem*)dsig, gbuf,
                      hs, (float2*)dfeat, (int)L, B);
-  // weight gradients, layer by layer
+  // weight gradients, layer by layer (PN = output blocks of the layer: HB for the hidden layers, 1 for the two heads)
   for (int l = 0; l < nl; ++l) {
     const int PN = lay_pn(*d, l);
-    const unsigned grid = (unsigned)(kWideRows * PN / 4);              // PN in {1, 2, 4}: 4 / PN tile streams per workgroup
+    const unsigned grid = (unsigned)(kWideRows * PN / 4);              // 4 / PN tile streams per workgroup
     const elem* grow = gbuf + (int64_t)l * hs;
-    if (l == 0) {
-      hipLaunchKernelGGL((k_wide_dw<P, 1, 0>), dim3(grid), dim3(256), 0, st, *d, l, PN, grow, H, (const float2*)feat, (int)L,
-                         (const elem*)nullptr, (const elem*)nullptr, (const float*)nullptr, (int)S, partials, kWideRows, B);
-    } else if (l == ns) {
-      hipLaunchKernelGGL((k_wide_dw<P, 2, 2>), dim3(grid), dim3(256), 0, st, *d, l, PN, grow, H, (const float2*)nullptr, (int)L,
-                         (const elem*)nullptr, (const elem*)sig, view, (int)S, partials, kWideRows, B);
-    } else {
-      const int hidx = l < ns ? l - 1 : (ns - 1) + (l - 1 - ns);       // the stored activation that is this layer's input
-      hipLaunchKernelGGL((k_wide_dw<P, HB, 1>), dim3(grid), dim3(256), 0, st, *d, l, PN, grow, H, (const float2*)nullptr, (int)L,
-                         (const elem*)(hid + (int64_t)hidx * hs), (const elem*)nullptr, (const float*)nullptr, (int)S, partials,
-                         kWideRows, B);
-    }
+    const int hidx = l < ns ? l - 1 : (ns - 1) + (l - 1 - ns);         // the stored activation that is a hidden layer's input
+    const elem* xin = (l == 0 || l == ns) ? (const elem*)nullptr : (const elem*)(hid + (int64_t)hidx * hs);
+#define WIDE_DW(QN_, KIND_, PN_)                                                                          \
+    hipLaunchKernelGGL((k_wide_dw<P, QN_, KIND_, PN_>), dim3(grid), dim3(256), 0, st, *d, l, grow, H, (const float2*)feat, \
+                       (int)L, xin, (const elem*)sig, view, (int)S, partials, kWideRows, B)
+    if (l == 0) { WIDE_DW(1, 0, HB); }
+    else if (l == ns) { WIDE_DW(2, 2, HB); }
+    else if (PN == 1) { WIDE_DW(HB, 1, 1); }
+    else { WIDE_DW(HB, 1, HB); }
+#undef WIDE_DW
   }
   return 0;
 }
