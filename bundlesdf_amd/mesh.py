@@ -83,9 +83,11 @@ class Mesh:
     (Utils.py:512-513, bundlesdf.py:748-766): .vertices (assignable), .faces, apply_transform, merge_vertices,
     remove_duplicate_faces, export('*.obj'|'*.ply'), copy."""
 
-    def __init__(self, vertices, faces, process=False):
+    def __init__(self, vertices, faces, process=False, uv=None, texture=None):
         self.vertices = np.asarray(vertices, dtype=np.float64)
         self.faces = np.asarray(faces, dtype=np.int64)
+        self.uv = None if uv is None else np.asarray(uv, dtype=np.float64)      # per-vertex texture coordinates in [0,1]
+        self.texture = texture                                                   # [H,W,3] uint8, row 0 = top (image order)
 
     def apply_transform(self, T):
         T = np.asarray(T, dtype=np.float64)
@@ -101,7 +103,29 @@ class Mesh:
         self.faces = self.faces[np.sort(idx)]
 
     def copy(self):
-        return Mesh(self.vertices.copy(), self.faces.copy())
+        return Mesh(self.vertices.copy(), self.faces.copy(), uv=None if self.uv is None else self.uv.copy(), texture=self.texture)
+
+    def unwrap(self, tex_res=1024):
+        """A UV parameterisation (what trimesh's mesh.unwrap() = xatlas gives the reference, nerf_runner.py:1484): here a
+        per-triangle atlas -- every triangle gets its own half of a square cell of the texture, vertices are duplicated per
+        face (3F vertices), cells are inset by one texel so that neighbouring triangles never share texels."""
+        F = len(self.faces)
+        n = int(np.ceil(np.sqrt((F + 1) // 2))) or 1
+        cell = (tex_res - 1) / n                                   # texels per cell side
+        if cell < 4:
+            raise ValueError(f'{F} triangles do not fit a {tex_res}^2 texture (cell {cell:.2f} texels): raise tex_res or simplify')
+        k = np.arange(F)
+        c, upper = k // 2, (k % 2).astype(bool)
+        cx, cy = (c % n) * cell, (c // n) * cell
+        m = 1.0                                                    # inset (texels)
+        lo = np.stack([np.stack([cx + m, cy + m], -1), np.stack([cx + cell - 2.5 * m, cy + m], -1),
+                       np.stack([cx + m, cy + cell - 2.5 * m], -1)], 1)
+        up = np.stack([np.stack([cx + cell - m, cy + cell - m], -1), np.stack([cx + 2.5 * m, cy + cell - m], -1),
+                       np.stack([cx + cell - m, cy + 2.5 * m], -1)], 1)
+        uv_tex = np.where(upper[:, None, None], up, lo)            # [F,3,2] texel coordinates
+        verts = self.vertices[self.faces].reshape(-1, 3)
+        faces = np.arange(3 * F, dtype=np.int64).reshape(F, 3)
+        return Mesh(verts, faces, uv=uv_tex.reshape(-1, 2) / (tex_res - 1))
 
     @property
     def face_normals(self):
@@ -127,6 +151,20 @@ class Mesh:
                         f'property float z\nelement face {len(self.faces)}\nproperty list uchar int vertex_indices\nend_header\n')
                 np.savetxt(f, self.vertices, fmt='%.7f')
                 np.savetxt(f, np.concatenate([np.full((len(self.faces), 1), 3), self.faces], 1), fmt='%d')
+        elif self.uv is not None:                                 # textured OBJ: .obj + .mtl + .png, like trimesh's exporter
+            base = path[:-4]
+            name = base.split('/')[-1]
+            with open(path, 'w') as f:
+                f.write(f'mtllib {name}.mtl\nusemtl material_0\n')
+                np.savetxt(f, self.vertices, fmt='v %.7f %.7f %.7f')
+                np.savetxt(f, self.uv, fmt='vt %.7f %.7f')
+                fi = self.faces + 1
+                np.savetxt(f, np.stack([fi[:, 0], fi[:, 0], fi[:, 1], fi[:, 1], fi[:, 2], fi[:, 2]], 1), fmt='f %d/%d %d/%d %d/%d')
+            with open(base + '.mtl', 'w') as f:
+                f.write(f'newmtl material_0\nKa 1 1 1\nKd 1 1 1\nKs 0 0 0\nmap_Kd {name}.png\n')
+            if self.texture is not None:
+                from PIL import Image
+                Image.fromarray(np.asarray(self.texture, np.uint8)).save(base + '.png')
         else:
             with open(path, 'w') as f:
                 np.savetxt(f, self.vertices, fmt='v %.7f %.7f %.7f')

@@ -231,6 +231,16 @@ int nof_mt_vertices(const float* vol, int32_t nx, int32_t ny, int32_t nz, float 
  * uvs_tex [nv,2] f32 per-vertex texture coordinates -> uvs [n,2]: barycentric blend of the hit triangle's uvs. */
 int nof_bary_uv(const int64_t* faces, const float* verts, const float* hit_locations, const int64_t* hit_face_ids,
                 const float* uvs_tex, int64_t n_hits, float* uvs, void* stream);
+/* ---- texture bake, one keyframe (NerfRunner.mesh_texture_from_train_images, nerf_runner.py:1499-1535) ------------------
+ * Replaces, per frame: the pyrender depth render + trimesh.proximity.closest_point (visible surface point and triangle of
+ * every pixel: z-buffer rasteriser), common.rayColorToTextureImageCUDA (barycentric UV) and the one-colour-per-texel-and-frame
+ * accumulation.  ob_in_cam (HOST, 12 floats: rows of the 3x4 normalised-object -> OpenCV-camera transform), K4 (HOST: fx, fy, cx,
+ * cy); verts [nv,3] f32, faces [nf,3] i64, uvs_tex [nv,2] f32 in texel units (uv * (tex_res-1)), mask [H,W] u8, rgb [H,W,3]
+ * f32 raw colours; pixels whose rendered depth is below min_depth are skipped; zbuf [H*W] u64 and owner [tex_res^2] i32 are
+ * scratch; tex [tex_res,tex_res,3] / wtex [tex_res,tex_res] f32 are ACCUMULATED (divide at the end). */
+int nof_texture_bake_frame(const float* h_ob_in_cam, const float* h_K4, int32_t H, int32_t W, const float* verts,
+                           const int64_t* faces, int64_t n_faces, const float* uvs_tex, const uint8_t* mask, const float* rgb,
+                           float min_depth, int32_t tex_res, uint64_t* zbuf, int32_t* owner, float* tex, float* wtex, void* stream);
 
 /* ---- compositing + losses + dL/draw (raw2outputs, train_loop, get_sdf_loss) ---------------------- */
 typedef struct {
