@@ -1,4 +1,5 @@
 """CPU tests of the iso-surface extraction used by NerfRunner.extract_mesh (bundlesdf_amd/mesh.py)."""
+import pytest
 import numpy as np
 
 from bundlesdf_amd.mesh import Mesh, largest_component, make_mesh, marching_tetrahedra
@@ -59,3 +60,47 @@ def test_largest_component_and_mesh_container(tmp_path):
     txt = open(out).read().splitlines()
     assert sum(l.startswith('v ') for l in txt) == len(big.vertices) and sum(l.startswith('f ') for l in txt) == len(big.faces)
     assert make_mesh(v, f) is not None
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# marching tetrahedra (the product's extractor) against marching cubes (what the reference calls, nerf_runner.py:1388-1394)
+def _noisy_sdf(n, seed, noise):
+    from scipy.ndimage import gaussian_filter
+    rng = np.random.default_rng(seed)
+    g = np.stack(np.meshgrid(*[np.arange(n, dtype=np.float64)] * 3, indexing='ij'), -1)
+    c = n / 2 + rng.uniform(-0.5, 0.5, 3)
+    ax = np.array([0.33, 0.25, 0.4]) * n
+    sdf = (np.linalg.norm((g - c) / ax, axis=-1) - 1.0) * ax.min()          # ellipsoid, roughly in voxel units
+    sdf += gaussian_filter(rng.normal(size=(n, n, n)), 1.5) * noise * 6.0     # smooth perturbation of ~noise voxels
+    return np.clip(sdf / 3.0, -1, 1).astype(np.float32)                      # truncated like the field's output
+
+
+@pytest.mark.parametrize("seed,noise", [(0, 0.0), (1, 0.3), (2, 0.6), (3, 1.0)])
+def test_marching_tetrahedra_is_within_half_a_voxel_of_marching_cubes(seed, noise):
+    """The reference extracts with skimage's marching cubes; the product with marching tetrahedra.  Both put vertices on
+    sign-changing grid edges by linear interpolation (MT adds the face / body diagonals of its six tetrahedra), so the surfaces
+    can differ only inside a cell: symmetric Hausdorff distance < 0.5 voxel, mean distance < 0.1 voxel, on noisy SDFs."""
+    from oracle import marching_cubes as MC
+    vol = _noisy_sdf(48, seed, noise)
+    v_mc, f_mc = MC.marching_cubes(vol, 0.0)
+    v_mt, f_mt = marching_tetrahedra(vol, 0.0)
+    # marching cubes' vertex set is a subset of marching tetrahedra's (the grid-edge crossings; MT adds diagonal crossings)
+    key = lambda v: set(map(tuple, np.round(v, 6)))
+    assert key(v_mc) <= key(v_mt)
+    e = np.sort(np.concatenate([f_mc[:, [0, 1]], f_mc[:, [1, 2]], f_mc[:, [2, 0]]]), 1)
+    _, cnt = np.unique(e, axis=0, return_counts=True)
+    assert (cnt == 2).all()                                                   # the restated marching cubes is watertight
+    hd, mean = MC.hausdorff(v_mc, f_mc, v_mt, f_mt)
+    print(f'MT vs MC (noise {noise}): Hausdorff {hd:.3f} voxel, mean {mean:.3f} voxel, V {len(v_mc)} / {len(v_mt)}')
+    assert hd < 0.5 and mean < 0.1
+
+
+def test_marching_cubes_table_is_complete_and_symmetric():
+    from oracle import marching_cubes as MC
+    assert len(MC._TABLE) == 256 and len(MC._TABLE[0]) == 0 and len(MC._TABLE[255]) == 0
+    assert all(len(MC._TABLE[c]) >= 1 for c in range(1, 255))
+    assert max(len(t) for t in MC._TABLE) <= 6
+    for c in (1, 2, 4, 8, 16, 32, 64, 128):                                    # one corner inside: one triangle on its three edges
+        tri = MC._TABLE[c]
+        corner = int(np.log2(c))
+        assert len(tri) == 1 and all(corner in MC._EDGES[e] for e in tri[0])
