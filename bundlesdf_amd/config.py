@@ -34,10 +34,10 @@ def load_yaml(path, **over):
 
 def validate_cfg(cfg):
     """Options of the reference's config the MI355X path does not implement are rejected loudly, never ignored.
-    (All of them are 0 / off in the reference's own config.yml; two are dead code there)"""
+    (All of them are 0 / off in the reference's own config.yml; two are dead code there)
+    eikonal_weight > 0 IS implemented (nof_eikonal): the reference's train_loop path for it is dead code (nerf_runner.py:686,
+    1297-1302), so the term uses the one meaningful normal of the reference, d sdf / d x of run_network_density (:1342-1345)."""
     bad = []
-    if float(cfg.get('eikonal_weight', 0)) > 0:
-        bad.append("eikonal_weight > 0 (dead code in the reference: train_loop renders with get_normals=False, nerf_runner.py:686,734-738)")
     if float(cfg.get('depth_weight', 0)) > 0:
         bad.append("depth_weight > 0 (references an undefined name in the reference, nerf_runner.py:718)")
     if int(cfg.get('N_importance', 0)) > 0:

@@ -43,8 +43,14 @@ struct Scatter {
   uint32_t key;                                                    // cell id (10 bits per axis) or ~0 when out of range
 };
 
+// Eikonal option (nerf_runner.py:734-738 with the normal of run_network_density, :1342-1345): the normal n = d sdf / d x is
+// 0.5 * sum_levels sum_c g[l,c] * dy_dx[l,d,c] with g = d sdf / d feature (`geik`, level-major like dfeat) and dy_dx the finite
+// differences of kernel_grid (gridencoder.cu:202-245), which are LINEAR in the table: corner k of level l receives
+// g[l,c] * 0.5 * scale * sum_d dE/dn_d * (+-1 by bit d of k) * w'_{k,d} on top of the ordinary w_k * dfeat.  `dedn` [B,3] is
+// dE/dn per sample (already carrying the loss weight); both pointers NULL = no eikonal term.
 __device__ __forceinline__ Scatter make_scatter(const HashLevel& lv, const float* __restrict__ pts_w,
-                                                const float2* __restrict__ dfeat, int level, int64_t b, int64_t B) {
+                                                const float2* __restrict__ dfeat, int level, int64_t b, int64_t B,
+                                                const float2* __restrict__ geik = nullptr, const float* __restrict__ dedn = nullptr) {
   Scatter sc;
   sc.key = 0xFFFFFFFFu;
 #pragma unroll
@@ -66,6 +72,25 @@ __device__ __forceinline__ Scatter make_scatter(const HashLevel& lv, const float
     sc.idx[k] = grid_index(lv, p[0], p[1], p[2]);
     sc.vx[k] = wk * gr.x;
     sc.vy[k] = wk * gr.y;
+  }
+  if (geik != nullptr) {
+    const float2 ge = geik[(int64_t)level * B + b];
+    const float dn[3] = {dedn[b * 3], dedn[b * 3 + 1], dedn[b * 3 + 2]};
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      float ce = 0.0f;
+#pragma unroll
+      for (int d = 0; d < 3; ++d) {
+        float wp = 1.0f;                                               // w'_{k,d}: the weights of the other two dimensions
+#pragma unroll
+        for (int e = 0; e < 3; ++e)
+          if (e != d) wp *= (k & (1 << e)) ? c.f[e] : 1.0f - c.f[e];
+        ce += ((k & (1 << d)) ? dn[d] : -dn[d]) * wp;
+      }
+      ce *= 0.5f * lv.scale;
+      sc.vx[k] += ce * ge.x;
+      sc.vy[k] += ce * ge.y;
+    }
   }
   return sc;
 }
@@ -148,7 +173,7 @@ __device__ __forceinline__ void wave_lds_sync() {
 
 __global__ __launch_bounds__(256) void k_hash_bwd_agg(NofHashGrid g, LevelList ll, const float* __restrict__ pts_w,
                                                        const float2* __restrict__ dfeat, float* __restrict__ grad_table,
-                                                       int64_t B) {
+                                                       int64_t B, const float2* __restrict__ geik, const float* __restrict__ dedn) {
   __shared__ __attribute__((aligned(16))) AggStage st;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int64_t n_tiles = ((B + 63) / 64) * ll.n;                     // (64 samples, level) tiles, level fastest
@@ -157,7 +182,7 @@ __global__ __launch_bounds__(256) void k_hash_bwd_agg(NofHashGrid g, LevelList l
   const int level = ll.level[tile % ll.n];
   const int64_t b = (tile / ll.n) * 64 + lane;
   const HashLevel lv = load_level(g, level);
-  const Scatter sc = make_scatter(lv, pts_w, dfeat, level, b, B);
+  const Scatter sc = make_scatter(lv, pts_w, dfeat, level, b, B, geik, dedn);
   const bool valid = sc.key != 0xFFFFFFFFu;
   const uint32_t prev = __shfl_up(sc.key, 1, 64);
   const bool head = valid && (lane == 0 || prev != sc.key);           // lanes are consecutive samples of one ray
@@ -222,7 +247,7 @@ __global__ __launch_bounds__(256) void k_hash_bwd_agg(NofHashGrid g, LevelList l
 // levels whose slice fits LDS: accumulate privately, flush once
 __global__ __launch_bounds__(1024) void k_hash_bwd_lds(NofHashGrid g, LevelList ll, int chunks, const float* __restrict__ pts_w,
                                                         const float2* __restrict__ dfeat, float* __restrict__ grad_table,
-                                                        int64_t B) {
+                                                        int64_t B, const float2* __restrict__ geik, const float* __restrict__ dedn) {
   extern __shared__ __attribute__((aligned(16))) float acc[];
   const int level = ll.level[blockIdx.x % ll.n];
   const int chunk = blockIdx.x / ll.n;
@@ -235,7 +260,7 @@ __global__ __launch_bounds__(1024) void k_hash_bwd_lds(NofHashGrid g, LevelList 
   const int64_t hi = lo + per < B ? lo + per : B;
   for (int64_t base = lo; base < hi; base += blockDim.x) {
     const int64_t b = base + threadIdx.x;
-    Scatter sc = make_scatter(lv, pts_w, dfeat, level, b < hi ? b : B, B);
+    Scatter sc = make_scatter(lv, pts_w, dfeat, level, b < hi ? b : B, B, geik, dedn);
     if (wave_merge_runs(sc)) {
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
@@ -255,10 +280,16 @@ __global__ __launch_bounds__(1024) void k_hash_bwd_lds(NofHashGrid g, LevelList 
 // dL/dpts_w per sample: gathers only (kernel_input_backward + the dy_dx part of kernel_grid, gridencoder.cu:202-245,340-365)
 __global__ __launch_bounds__(256) void k_hash_dx(NofHashGrid g, const float* __restrict__ pts_w,
                                                   const float2* __restrict__ table, const float2* __restrict__ dfeat,
-                                                  float* __restrict__ dpts, int64_t B) {
+                                                  float* __restrict__ dpts, int64_t B, const float2* __restrict__ geik,
+                                                  const float* __restrict__ dedn) {
   const int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (b >= B) return;
   float dx[3] = {0.f, 0.f, 0.f};
+  // eikonal option: dE/dx through the normal's own dependence on x -- the mixed second derivatives of the trilinear blend
+  // (d n_d / d x_e = 0.25 * scale^2 * sum_t w_t (F[d1,e1,t] - F[d1,e0,t] - F[d0,e1,t] + F[d0,e0,t]), F = g . corner features)
+  float dxe[3] = {0.f, 0.f, 0.f};
+  float dn[3] = {0.f, 0.f, 0.f};
+  if (geik != nullptr) { dn[0] = dedn[b * 3]; dn[1] = dedn[b * 3 + 1]; dn[2] = dedn[b * 3 + 2]; }
   for (int level = 0; level < g.L; ++level) {
     const HashLevel lv = load_level(g, level);
     const CellPos c = locate(pts_w, b, lv.scale);
@@ -289,9 +320,30 @@ __global__ __launch_bounds__(256) void k_hash_dx(NofHashGrid g, const float* __r
       }
       dx[gd] += s;
     }
+    if (geik != nullptr) {
+      const float2 ge = geik[(int64_t)level * B + b];
+      float Fk[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) Fk[k] = ge.x * v[k].x + ge.y * v[k].y;
+#pragma unroll
+      for (int e = 0; e < 3; ++e)
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+          if (d == e) continue;
+          const int t = 3 - d - e;                                     // the third dimension
+          float m = 0.0f;
+#pragma unroll
+          for (int bt = 0; bt < 2; ++bt) {
+            const int base = bt << t;
+            const float wt = bt ? c.f[t] : 1.0f - c.f[t];
+            m += wt * (((Fk[base | (1 << d) | (1 << e)] - Fk[base | (1 << d)]) - Fk[base | (1 << e)]) + Fk[base]);
+          }
+          dxe[e] += dn[d] * 0.25f * lv.scale * lv.scale * m;
+        }
+    }
   }
 #pragma unroll
-  for (int gd = 0; gd < 3; ++gd) dpts[b * 3 + gd] = dx[gd] * 0.5f;    // d x01 / d x = 1/2 (grid.py:160)
+  for (int gd = 0; gd < 3; ++gd) dpts[b * 3 + gd] = dx[gd] * 0.5f + dxe[gd];    // d x01 / d x = 1/2 (grid.py:160)
 }
 
 __global__ __launch_bounds__(256) void k_hash_indices(NofHashGrid g, const float* __restrict__ pts_w,
@@ -394,8 +446,19 @@ extern "C" int nof_hash_encode_bwd(const NofHashGrid* g, const float* pts_w, con
 extern "C" int nof_hash_encode_bwd_levels(const NofHashGrid* g, const float* pts_w, const float* table, const float* dfeat,
                                            float* grad_table, float* dpts, int32_t level_lo, int32_t level_hi, int64_t B,
                                            void* stream) {
+  return nof_hash_encode_bwd_eik(g, pts_w, table, dfeat, nullptr, nullptr, grad_table, dpts, level_lo, level_hi, B, stream);
+}
+
+// The same with the eikonal term's contributions (geik [L,B,2] = d sdf / d feature, dedn [B,3] = dE/dn, both from nof_eikonal;
+// both NULL = plain backward): table gradient through the finite differences, input gradient through the mixed second
+// derivatives.  One scatter pass serves both terms.
+extern "C" int nof_hash_encode_bwd_eik(const NofHashGrid* g, const float* pts_w, const float* table, const float* dfeat,
+                                        const float* geik_, const float* dedn, float* grad_table, float* dpts, int32_t level_lo,
+                                        int32_t level_hi, int64_t B, void* stream) {
   if (int e = check_grid(g)) return e;
   NOF_ARG(pts_w && table && dfeat && grad_table && B >= 0 && level_lo >= 0 && level_lo <= level_hi && level_hi <= g->L);
+  NOF_ARG((geik_ == nullptr) == (dedn == nullptr));
+  const float2* geik = (const float2*)geik_;
   if (B == 0) return 0;
   hipStream_t st = (hipStream_t)stream;
   // split the levels: slices of <= 48 KiB are accumulated in LDS (their few hundred rows would be hot lines for global
@@ -426,12 +489,12 @@ extern "C" int nof_hash_encode_bwd_levels(const NofHashGrid* g, const float* pts
     const int64_t cap = 4ll * nof_cu_count();
     if (blocks > cap) blocks = cap;
     hipLaunchKernelGGL(k_hash_bwd_agg, dim3((unsigned)blocks), dim3(256), 0, st, *g, big, pts_w, (const float2*)dfeat,
-                       grad_table, B);
+                       grad_table, B, geik, dedn);
     NOF_LAUNCH_OK();
   }
   if (dpts) {
     hipLaunchKernelGGL(k_hash_dx, dim3((unsigned)nof_div_up(B, 256)), dim3(256), 0, s2, *g, pts_w, (const float2*)table,
-                       (const float2*)dfeat, dpts, B);
+                       (const float2*)dfeat, dpts, B, geik, dedn);
     NOF_LAUNCH_OK();
   }
   if (small.n > 0) {
@@ -439,7 +502,7 @@ extern "C" int nof_hash_encode_bwd_levels(const NofHashGrid* g, const float* pts
     if (lds_need > 64 * 1024)
       NOF_HIP(hipFuncSetAttribute((const void*)k_hash_bwd_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_need));
     hipLaunchKernelGGL(k_hash_bwd_lds, dim3((unsigned)(chunks * small.n)), dim3(1024), lds_need, s2, *g, small, chunks, pts_w,
-                       (const float2*)dfeat, grad_table, B);
+                       (const float2*)dfeat, grad_table, B, geik, dedn);
     NOF_LAUNCH_OK();
   }
   if (fork) {

@@ -1107,6 +1107,222 @@ __global__ __launch_bounds__(256, 2) void k_mlp_bwd_sigma(NofMlpDesc d, const ch
 }
 
 // =====================================================================================================
+// Eikonal option (cfg eikonal_weight > 0): E = w * mean over {sdf < 1} of (|n| - 1)^2 with n = d sdf / d x (nerf_runner.py:
+// 734-738; the normal as run_network_density defines it, :1342-1345 -- train_loop's own normal path is dead code).
+// One fused pass per 32-sample tile, exact-fp32 MFMA, everything the second-order term needs in registers:
+//   a. hash gathers of the lane's 8 levels: features and dy_dx (gridencoder.cu:160-245);
+//   b. sigma net forward (ReLU masks);
+//   c. its backward with a unit gradient on the sdf output: delta_l per layer and g = d sdf / d feature;
+//   d. n = 0.5 * sum g . dy_dx, dE/dn, the loss; g and dE/dn are stored for the table / input gradients, which ride in the
+//      hash backward (nof_hash_encode_bwd_eik);
+//   e. the weight gradient: with q_0 = dE/dg and the tangents q_{l+1} = relu'(z_l) . (W_l q_l), dE/dW_l = delta_l (x) q_l
+//      (forward-over-reverse); the sample contraction runs on the matrix core exactly like dW of the ordinary backward.
+// `selected` / `n_sel`: s_b = sdf_b < 1 is re-derived from this kernel's own sdf; n_sel[0] = their number (device scalar,
+// computed by the caller from the forward's raw output) normalises the mean.
+// =====================================================================================================
+template <int NS, int NC>
+__global__ __launch_bounds__(256) void k_eikonal(NofMlpDesc d, const char* __restrict__ image, NofHashGrid g,
+                                                  const float2* __restrict__ table, const float* __restrict__ pts_w,
+                                                  const uint8_t* __restrict__ valid, const float* __restrict__ n_sel,
+                                                  float weight, float gscale, float2* __restrict__ geik, float* __restrict__ dedn,
+                                                  float* __restrict__ partials, float* __restrict__ loss_out, int64_t B) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  typedef PrecF32 P;
+  typedef Shp<NS, NC> SH;
+  constexpr int NL = NS + NC;
+  constexpr int NPS = SH::pair_base(NS);                               // the sigma layers' fragment pairs
+  constexpr int BW_BASE = NPS * PAIR_BYTES;
+  constexpr int BIAS_BASE = 2 * NPS * PAIR_BYTES;
+  constexpr int ZB_BASE = BIAS_BASE + SH::oblk_base(NS) * 128;         // a zero "bias" for the tangent pass
+  constexpr int DB_BASE = ZB_BASE + 2 * 128;
+  copy16(smem, image, (size_t)NPS * PAIR_BYTES);
+  copy16(smem + BW_BASE, image + (size_t)SH::pair_base(NL) * PAIR_BYTES, (size_t)NPS * PAIR_BYTES);
+  copy16(smem + BIAS_BASE, image + 2 * (size_t)SH::pair_base(NL) * PAIR_BYTES, (size_t)SH::oblk_base(NS) * 128);
+  for (int e = threadIdx.x; e < 64; e += blockDim.x) ((float*)(smem + ZB_BASE))[e] = 0.0f;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int hi = lane >> 5, j = lane & 31;
+  float* dbz = (float*)(smem + DB_BASE) + wave * (2 * NS + 1) * 64 + lane;      // [2 l + p][lane] zeros (no bias gradient) + 1 dummy
+#pragma unroll
+  for (int k = 0; k < 2 * NS + 1; ++k) dbz[k * 64] = 0.0f;
+  float* dummy = dbz + 2 * NS * 64;
+  __syncthreads();
+  Ident<P> I;
+  I.init(lane);
+  typedef In2Store<P, 2, false> Store;
+  float dw[NL][2][2][16];
+#pragma unroll
+  for (int l = 0; l < NS; ++l)
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+      for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (p < SH::pn(l) && q < SH::qn(l) && r < SH::nacc(l)) dw[l][p][q][r] = 0.0f;
+  float loss_acc = 0.0f;
+  const float nsel = n_sel[0];
+  const float ke = nsel > 0.0f ? gscale * weight / nsel : 0.0f;      // gradients carry the data-parallel 1/world, the loss value does not
+  const int64_t ntiles = (B + 31) / 32;
+  for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < ntiles; tile += (int64_t)gridDim.x * 4) {
+    asm volatile("" ::: "memory");
+    const int64_t b = tile * 32 + j;
+    const bool ok = b < B;
+    // ---- a. features and dy_dx of this lane's 8 levels ----
+    float x[1][16], dy[8][3][2];
+    {
+      float pt[3] = {0.f, 0.f, 0.f};
+      const bool in = ok && valid[b] != 0;                             // outside [-1,1]^3: zero features, zero normal (nerf_runner.py:1245-1266)
+      if (ok) { pt[0] = pts_w[b * 3]; pt[1] = pts_w[b * 3 + 1]; pt[2] = pts_w[b * 3 + 2]; }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int level = 8 * hi + k;
+        float2 f = make_float2(0.f, 0.f);
+#pragma unroll
+        for (int dd = 0; dd < 3; ++dd) { dy[k][dd][0] = 0.f; dy[k][dd][1] = 0.f; }
+        if (in && level < g.L) {
+          const HashLevel lv = load_level(g, level);
+          const CellPos c = locate3(pt, lv.scale);
+          if (!c.oob) {
+            const float2* __restrict__ tl = table + lv.offset;
+            float2 v[8];
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk)
+              v[kk] = tl[grid_index(lv, c.g[0] + (kk & 1), c.g[1] + ((kk >> 1) & 1), c.g[2] + ((kk >> 2) & 1))];
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk) {
+              float w = 1.0f;
+#pragma unroll
+              for (int dd = 0; dd < 3; ++dd) w *= (kk & (1 << dd)) ? c.f[dd] : 1.0f - c.f[dd];
+              f.x += w * v[kk].x; f.y += w * v[kk].y;
+            }
+#pragma unroll
+            for (int gd = 0; gd < 3; ++gd)
+#pragma unroll
+              for (int kk = 0; kk < 8; ++kk) {
+                if (kk & (1 << gd)) continue;
+                float w = lv.scale;
+#pragma unroll
+                for (int dd = 0; dd < 3; ++dd)
+                  if (dd != gd) w *= (kk & (1 << dd)) ? c.f[dd] : 1.0f - c.f[dd];
+                dy[k][gd][0] += w * (v[kk | (1 << gd)].x - v[kk].x);
+                dy[k][gd][1] += w * (v[kk | (1 << gd)].y - v[kk].y);
+              }
+          }
+        }
+        x[0][2 * k] = f.x; x[0][2 * k + 1] = f.y;
+      }
+    }
+    // ---- b. forward ----
+    uint32_t m1[NS];
+    float h[2][16], so[1][16];
+    dense_o1<P, 1, 2>(smem, FW_OFF(0), BIAS_OFF(0), x, h, lane);
+    m1[0] = relu_mask<2>(h);
+#pragma unroll
+    for (int l = 1; l < NS - 1; ++l) {
+      float hn[2][16];
+      dense_o1<P, 2, 2>(smem, FW_OFF(l), BIAS_OFF(l), h, hn, lane);
+      m1[l] = relu_mask<2>(hn);
+#pragma unroll
+      for (int p = 0; p < 2; ++p)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) h[p][r] = hn[p][r];
+    }
+    dense_o1<P, 2, 1>(smem, FW_OFF(NS - 1), BIAS_OFF(NS - 1), h, so, lane);
+    // ---- c. backward with d sdf = 1: delta_l (gradient at the pre-activation of layer l) and g ----
+    float delta[NS][2][16];
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) delta[NS - 1][p][r] = 0.0f;
+    if (hi == 0 && ok) delta[NS - 1][0][0] = 1.0f;
+#pragma unroll
+    for (int l = NS - 1; l >= 1; --l) {
+      if (l == NS - 1) {
+        float ga[1][16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ga[0][r] = delta[l][0][r];
+        bwd_data<P, 1>(smem, BW_OFF(l), 0, ga, delta[l - 1][0], lane);
+        bwd_data<P, 1>(smem, BW_OFF(l), 1, ga, delta[l - 1][1], lane);
+      } else {
+        bwd_data<P, 2>(smem, BW_OFF(l), 0, delta[l], delta[l - 1][0], lane);
+        bwd_data<P, 2>(smem, BW_OFF(l), 1, delta[l], delta[l - 1][1], lane);
+      }
+      apply_mask<2>(delta[l - 1], m1[l - 1]);
+    }
+    float gf[16];
+    bwd_data<P, 2>(smem, BW_OFF(0), 0, delta[0], gf, lane);
+    // ---- d. normal, loss, dE/dn, q_0 ----
+    float n[3];
+#pragma unroll
+    for (int dd = 0; dd < 3; ++dd) {
+      float a = 0.0f;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) a += gf[2 * k] * dy[k][dd][0] + gf[2 * k + 1] * dy[k][dd][1];
+      a += __shfl_xor(a, 32, 64);
+      n[dd] = 0.5f * a;                                                 // d x01 / d x = 1/2 (grid.py:160)
+    }
+    const float sdf = __shfl(so[0][0], j, 64);                          // lane (j, hi = 0) holds the sdf of sample j
+    const float nrm = sqrtf((n[0] * n[0] + n[1] * n[1]) + n[2] * n[2]);
+    const bool sel = ok && sdf < 1.0f;
+    float dn[3];
+#pragma unroll
+    for (int dd = 0; dd < 3; ++dd) dn[dd] = (sel && nrm > 0.0f) ? ke * 2.0f * (nrm - 1.0f) * n[dd] / nrm : 0.0f;
+    if (sel && hi == 0) loss_acc += (nrm - 1.0f) * (nrm - 1.0f);
+    if (ok) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int level = 8 * hi + k;
+        if (level < g.L) geik[(int64_t)level * B + b] = make_float2(gf[2 * k], gf[2 * k + 1]);
+      }
+      if (hi == 0) { dedn[b * 3] = dn[0]; dedn[b * 3 + 1] = dn[1]; dedn[b * 3 + 2] = dn[2]; }
+    }
+    float q0[1][16];
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+#pragma unroll
+      for (int c2 = 0; c2 < 2; ++c2)
+        q0[0][2 * k + c2] = 0.5f * ((dn[0] * dy[k][0][c2] + dn[1] * dy[k][1][c2]) + dn[2] * dy[k][2][c2]);
+    // ---- e. tangent pass: dW_l += delta_l (x) q_l, q_{l+1} = relu'(z_l) . (W_l q_l) ----
+    Store st;
+    {
+      park_o2<P>(st, I, 0, q0[0]);
+      dw_block<P, 1, 16>(dw[0][0], dummy, I, delta[0][0], st, 0);
+      dw_block<P, 1, 16>(dw[0][1], dummy, I, delta[0][1], st, 0);
+    }
+    float q[2][16];
+    dense_o1<P, 1, 2>(smem, FW_OFF(0), ZB_BASE, q0, q, lane);
+    apply_mask<2>(q, m1[0]);
+#pragma unroll
+    for (int l = 1; l < NS; ++l) {
+      park_o2<P>(st, I, 0, q[0]);
+      park_o2<P>(st, I, 1, q[1]);
+      if (l == NS - 1) {
+        dw_block<P, 2, 8>(dw[l][0], dummy, I, delta[l][0], st, 0);
+      } else {
+        dw_block<P, 2, 16>(dw[l][0], dummy, I, delta[l][0], st, 0);
+        dw_block<P, 2, 16>(dw[l][1], dummy, I, delta[l][1], st, 0);
+        float qn[2][16];
+        dense_o1<P, 2, 2>(smem, FW_OFF(l), ZB_BASE, q, qn, lane);
+        apply_mask<2>(qn, m1[l]);
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) q[p][r] = qn[p][r];
+      }
+    }
+  }
+  flush_dw<SH, 0, NS>(d, dw, dbz, partials, 1.0f);
+  // loss: one atomic pair per wave
+  loss_acc += __shfl_xor(loss_acc, 1, 64);  loss_acc += __shfl_xor(loss_acc, 2, 64);  loss_acc += __shfl_xor(loss_acc, 4, 64);
+  loss_acc += __shfl_xor(loss_acc, 8, 64);  loss_acc += __shfl_xor(loss_acc, 16, 64); loss_acc += __shfl_xor(loss_acc, 32, 64);
+  if (lane == 0 && loss_acc != 0.0f && nsel > 0.0f) {
+    const float e = weight * loss_acc / nsel;
+    atomicAdd(&loss_out[0], e);
+    atomicAdd(&loss_out[7], e);
+  }
+}
+
+// =====================================================================================================
 // host side
 // =====================================================================================================
 static int check_desc(const NofMlpDesc* d) {
@@ -1366,6 +1582,35 @@ extern "C" int nof_mfma_probe(int32_t precision, const float* A, const float* Bm
   if (precision == 0) hipLaunchKernelGGL(k_mfma_probe<PrecF32>, dim3(1), dim3(64), 0, (hipStream_t)stream, A, Bm, D, K);
   else if (precision == 1) hipLaunchKernelGGL(k_mfma_probe<PrecBF16>, dim3(1), dim3(64), 0, (hipStream_t)stream, A, Bm, D, K);
   else hipLaunchKernelGGL(k_mfma_probe<PrecF16>, dim3(1), dim3(64), 0, (hipStream_t)stream, A, Bm, D, K);
+  NOF_LAUNCH_OK();
+  return 0;
+}
+
+/* Eikonal term (cfg eikonal_weight > 0; nerf_runner.py:734-738 with the normal of run_network_density, :1342-1345).
+ * `desc32` / `packed32`: the SAME network packed with precision 0 (the term is evaluated with the exact-fp32 MFMA whatever the
+ * training precision).  pts_w [B,3], valid [B] u8, n_sel: device scalar = number of samples with sdf < 1 (from the forward's raw),
+ * weight = eikonal_weight, grad_scale = 1/world_size (gradients only).  Writes geik [L,B,2] and dedn [B,3] (consumed by nof_hash_encode_bwd_eik), the sigma
+ * layers' weight gradient as per-wave rows of partials_e [nof_mlp_bwd_blocks(), n_params] (other entries untouched: zero them
+ * once), and ADDS the term to loss_out[0] and loss_out[7]. */
+extern "C" int nof_eikonal(const NofMlpDesc* d, const void* packed32, const NofHashGrid* g, const float* table, const float* pts_w,
+                            const uint8_t* valid, const float* n_sel, float weight, float grad_scale, float* geik, float* dedn,
+                            float* partials_e, float* loss_out, int64_t B, void* stream) {
+  if (int e = check_narrow(d)) return e;
+  NOF_ARG(d->precision == 0 && g && g->C == 2 && g->L * 2 == d->in_feat);
+  NOF_ARG(packed32 && table && pts_w && valid && n_sel && geik && dedn && partials_e && loss_out && B >= 0);
+  if (B == 0) return 0;
+  const int ns = d->n_sigma;
+  const size_t shm = 2 * (size_t)n_pairs(*d, ns) * 16 * 64 * 4 + (size_t)n_oblk(*d, ns) * 128 + 2 * 128 + (size_t)4 * (2 * ns + 1) * 64 * 4;
+  const unsigned blocks = (unsigned)nof_mlp_bwd_blocks() / 4;
+#define LAUNCH_EIK(P_, NS_, NC_, dummy)                                                                   \
+  {                                                                                                       \
+    auto kern = k_eikonal<NS_, NC_>;                                                                      \
+    if (int e = set_smem(kern, shm)) return e;                                                            \
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), shm, (hipStream_t)stream, *d, (const char*)packed32, *g, \
+                       (const float2*)table, pts_w, valid, n_sel, weight, grad_scale, (float2*)geik, dedn, partials_e, loss_out, B); \
+  }
+  DISPATCH_SHAPE(PrecF32, LAUNCH_EIK, 0)
+#undef LAUNCH_EIK
   NOF_LAUNCH_OK();
   return 0;
 }

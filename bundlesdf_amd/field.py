@@ -48,6 +48,12 @@ class NeuralObjectField:
         self.n_sigma, self.n_color, self.hidden = n_sigma, n_color, int(hidden)
         # hidden 128 / 4 layers per network (BASELINE cfg5) run through the nof_mlp_wide_* kernels (staged activations)
         self.wide = hidden != 64 or n_sigma > 3 or n_color > 3
+        self.eikonal = float(cfg.get('eikonal_weight', 0)) > 0
+        if self.eikonal:
+            if self.wide:
+                raise NotImplementedError('eikonal_weight > 0 with the wide networks (hidden 128 / 4 layers) is not implemented')
+            # the second-order term is evaluated with the exact-fp32 MFMA whatever the training precision: its own fragment image
+            self.desc32, _ = lib.make_mlp_desc(n_sigma, n_color, 2 * self.L, self.n_view, 0, hidden=hidden)
         self.optimize_poses = bool(cfg.get('optimize_poses', 1))
         self.n_table = self.n_entries * 2
         self.n_mlp = self.desc.n_params
@@ -73,6 +79,8 @@ class NeuralObjectField:
         self._bufs = {}
         self.nblk = lib.load().nof_mlp_wide_partial_rows() if self.wide else lib.load().nof_mlp_bwd_blocks()
         self.packed = torch.empty(int(lib.load().nof_mlp_packed_bytes(C.byref(self.desc))), dtype=torch.uint8, device=dev)
+        if self.eikonal:
+            self.packed32 = torch.empty(int(lib.load().nof_mlp_packed_bytes(C.byref(self.desc32))), dtype=torch.uint8, device=dev)
         self._packed_step = None     # optimiser step the fragment image was built for
         self.profile = None          # dict name -> [(start_event, end_event)] when per-kernel timing is on (bench.py)
         self.profile_only = None
@@ -198,7 +206,10 @@ class NeuralObjectField:
                 # sigma-head output / its gradient in MFMA operand precision: the hand-off of the split MLP backward
                 sig=e(B, 16, dt=torch.int16) if self.desc.precision != 0 and not self.wide else None,
                 dsig=e(B, 16, dt=torch.int16) if self.desc.precision != 0 and not self.wide else None,
-                wide_ws=e(int(lib.load().nof_mlp_wide_workspace_bytes(C.byref(self.desc), B)), dt=torch.uint8) if self.wide else None)
+                wide_ws=e(int(lib.load().nof_mlp_wide_workspace_bytes(C.byref(self.desc), B)), dt=torch.uint8) if self.wide else None,
+                # eikonal option: d sdf / d feature, dE/dn, and the sigma layers' weight-gradient rows (colour entries stay zero)
+                geik=e(self.L, B, 2) if self.eikonal else None, dedn=e(B, 3) if self.eikonal else None,
+                partials_e=torch.zeros(self.nblk, self.n_mlp, device=d) if self.eikonal else None)
         return self._bufs[key]
 
     def _sample_cfg(self, seed, step):
@@ -226,6 +237,8 @@ class NeuralObjectField:
         """fp32 PyTorch-layout MLP parameters -> MFMA fragment image (once per optimiser step)."""
         if force or self._packed_step != self.global_step:
             self._call('nof_mlp_pack', C.byref(self.desc), self.mlp, self.packed)
+            if self.eikonal:
+                self._call('nof_mlp_pack', C.byref(self.desc32), self.mlp, self.packed32)
             self._packed_step = self.global_step
 
     def update_poses(self):
@@ -275,6 +288,15 @@ class NeuralObjectField:
             self._call('nof_mlp_bwd', C.byref(self.desc), self.packed, b['feat'], self.L, b['view'], S, b['draw'], b['sig'],
                        b['dsig'], b['dfeat'], b['dview'], b['partials'], B)
         self._call('nof_reduce_partials', b['partials'], self.nblk, self.n_mlp, self._seg(self.grads, 'mlp'))
+        geik = dedn = None
+        if self.eikonal:
+            # nerf_runner.py:734-738: mean over the samples with sdf < 1 (their number stays on the device)
+            n_sel = (b['raw'][:, 3] < 1).sum().float().reshape(1)
+            self._call('nof_eikonal', C.byref(self.desc32), self.packed32, C.byref(self.grid), self.table, b['pts_w'], b['valid'],
+                       n_sel, C.c_float(cfg['eikonal_weight']), C.c_float(1.0 / self.world_size), b['geik'], b['dedn'],
+                       b['partials_e'], self.loss_out, B)
+            self._call('nof_reduce_partials', b['partials_e'], self.nblk, self.n_mlp, self._seg(self.grads, 'mlp'))
+            geik, dedn = b['geik'], b['dedn']
         dpts = b['dpts'] if self.optimize_poses else None
         gtab = self._seg(self.grads, 'table')
         hashed = [l for l in range(self.L) if self.grid.hashed[l]]
@@ -284,11 +306,14 @@ class NeuralObjectField:
             # data parallel: the fine (hashed) levels first; their slice [rows of level `split` .., MLP] of the flat gradient
             # buffer (80 % of its bytes at cfg2) is all-reduced while the coarse levels, dL/dx and the pose kernels still run
             a = 2 * int(self.offsets[split])
-            self._call('nof_hash_encode_bwd_levels', C.byref(self.grid), b['pts_w'], self.table, b['dfeat'], gtab, None,
+            self._call('nof_hash_encode_bwd_eik', C.byref(self.grid), b['pts_w'], self.table, b['dfeat'], geik, dedn, gtab, None,
                        split, self.L, B)
             grad_sync.start(self.grads[a:self.n_table + self.n_mlp])
-            self._call('nof_hash_encode_bwd_levels', C.byref(self.grid), b['pts_w'], self.table, b['dfeat'], gtab, dpts,
+            self._call('nof_hash_encode_bwd_eik', C.byref(self.grid), b['pts_w'], self.table, b['dfeat'], geik, dedn, gtab, dpts,
                        0, split, B)
+        elif self.eikonal:
+            self._call('nof_hash_encode_bwd_eik', C.byref(self.grid), b['pts_w'], self.table, b['dfeat'], geik, dedn, gtab, dpts,
+                       0, self.L, B)
         else:
             self._call('nof_hash_encode_bwd', C.byref(self.grid), b['pts_w'], self.table, b['dfeat'], gtab, dpts, B)
         if self.optimize_poses or self.ff > 0:
@@ -370,4 +395,4 @@ class NeuralObjectField:
         """dict of the last step's loss terms (one host sync)."""
         v = self.loss_out.cpu().numpy()
         return dict(loss=float(v[0]), rgb_loss=float(v[1]), fs_loss=float(v[2]), sdf_loss=float(v[3]),
-                    fs_rgb_loss=float(v[4]), n_valid_samples=float(v[5]), n_valid_rays=float(v[6]))
+                    fs_rgb_loss=float(v[4]), n_valid_samples=float(v[5]), n_valid_rays=float(v[6]), eikonal_loss=float(v[7]))

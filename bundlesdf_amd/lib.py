@@ -101,6 +101,8 @@ _SIGNATURES = {
     'nof_cloud_filter': ([_P, _I64, _P, _P, _P, _I64, C.c_double, C.c_double, _P], C.c_int),
     'nof_compact_rows': ([_P, _P, _P, _I64, _P, _P], C.c_int),
     'nof_bary_uv': ([_P, _P, _P, _P, _P, _I64, _P, _P], C.c_int),
+    'nof_hash_encode_bwd_eik': ([C.POINTER(NofHashGrid), _P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I64, _P], C.c_int),
+    'nof_eikonal': ([C.POINTER(NofMlpDesc), _P, C.POINTER(NofHashGrid), _P, _P, _P, _P, _F, _F, _P, _P, _P, _P, _I64, _P], C.c_int),
     'nof_mlp_wide_workspace_bytes': ([C.POINTER(NofMlpDesc), _I64], C.c_int64),
     'nof_mlp_wide_partial_rows': ([], C.c_int),
     'nof_mlp_wide_fwd': ([C.POINTER(NofMlpDesc), _P, _P, _I32, _P, _I32, _P, _P, _I64, _P], C.c_int),

@@ -57,6 +57,13 @@ int nof_hash_encode_bwd(const NofHashGrid* h_grid, const float* pts_w, const flo
 /* Same, restricted to the table rows of levels [level_lo, level_hi); dpts (if given) still covers all levels. */
 int nof_hash_encode_bwd_levels(const NofHashGrid* h_grid, const float* pts_w, const float* table, const float* dfeat,
                                float* grad_table, float* dpts, int32_t level_lo, int32_t level_hi, int64_t B, void* stream);
+/* The same with the eikonal term (cfg eikonal_weight > 0; nerf_runner.py:734-738 with the normal of run_network_density,
+ * :1342-1345): geik [L,B,2] = d sdf / d feature and dedn [B,3] = dE/dn as written by nof_eikonal (both NULL = plain backward).
+ * The normal is linear in the table (finite differences, gridencoder.cu:202-245), so its table gradient rides in the same
+ * scatter; its input gradient (mixed second derivatives of the trilinear blend) is added to dpts. */
+int nof_hash_encode_bwd_eik(const NofHashGrid* h_grid, const float* pts_w, const float* table, const float* dfeat,
+                            const float* geik, const float* dedn, float* grad_table, float* dpts, int32_t level_lo,
+                            int32_t level_hi, int64_t B, void* stream);
 int nof_hash_corner_indices(const NofHashGrid* h_grid, const float* pts_w, int32_t* idx, int64_t B, void* stream);
 
 /* ---- pose corrections (replaces PoseArray.get_matrices + pytorch3d se3_exp_map) ---------------- */
@@ -199,6 +206,16 @@ int nof_mlp_wide_sdf(const NofMlpDesc* h_desc, const void* packed, const float* 
                      void* stream);
 int nof_mlp_wide_bwd(const NofMlpDesc* h_desc, const void* packed, const float* feat, int32_t L, const float* view, int32_t S,
                      const float* draw, void* workspace, float* dfeat, float* dview, float* partials, int64_t B, void* stream);
+
+/* ---- eikonal option (cfg eikonal_weight > 0; nerf_runner.py:734-738 with the normal of run_network_density, :1342-1345):
+ * E = w * mean over {sdf < 1} of (|d sdf / d x| - 1)^2, evaluated with the exact-fp32 MFMA.  h_desc32 / packed32: the network
+ * packed with precision 0.  pts_w [B,3], valid [B] u8, n_sel: DEVICE scalar (float) = number of samples with sdf < 1, weight =
+ * eikonal_weight, grad_scale = 1/world_size (applied to the gradients only).  Writes geik [L,B,2] (d sdf / d feature) and dedn [B,3] (dE/dn) for nof_hash_encode_bwd_eik,
+ * the sigma layers' weight gradient as per-wave rows of partials_e [nof_mlp_bwd_blocks(), n_params] (the colour layers'
+ * entries are never written: zero the buffer once), and ADDS the term to loss_out[0] and loss_out[7]. */
+int nof_eikonal(const NofMlpDesc* h_desc32, const void* packed32, const NofHashGrid* h_grid, const float* table,
+                const float* pts_w, const uint8_t* valid, const float* n_sel, float weight, float grad_scale, float* geik,
+                float* dedn, float* partials_e, float* loss_out, int64_t B, void* stream);
 
 /* bytes of the `partials` workspace of nof_mlp_bwd (= nof_mlp_bwd_blocks() * n_params * 4); -1 on a bad descriptor */
 int64_t nof_mlp_bwd_workspace_bytes(const NofMlpDesc* h_desc);

@@ -721,6 +721,9 @@ class OracleField:
         pts = rays_d[:, None, :] * z_vals[:, :, None]
         pts_w = (tf[:, None, :3, :3] @ pts[..., None])[..., 0] + tf[:, None, :3, 3]
         flat = pts_w.reshape(-1, 3)
+        eik = float(cfg.get('eikonal_weight', 0)) > 0
+        if eik and not flat.requires_grad:
+            flat = flat.detach().requires_grad_(True)
         valid = (torch.abs(flat) <= 1).all(dim=-1)
         emb = torch.zeros(flat.shape[0], self.geo.out_dim)
         x01 = (flat[valid] + 1) / 2
@@ -732,10 +735,17 @@ class OracleField:
         sh = sh_encode(dirs_w, cfg['multires_views'])
         parts.append(sh[:, None].expand(-1, S, -1).reshape(R * S, -1))
         raw = mlp_forward(self.shape, self.mlp, torch.cat(parts, -1), self.operand_dtype, self.split_forward).reshape(R, S, 4)
+        normals = None
+        if eik:
+            # the field's normal = d sdf / d x_world with grad_outputs = 1: the only meaningful normal path of the reference
+            # (run_network_density, nerf_runner.py:1342-1345; train_loop's own is dead code: :686, :1297-1302 give zeros).
+            # create_graph: the eikonal term is differentiated again (table, sigma net, poses).
+            (normals,) = torch.autograd.grad(raw[..., 3].sum(), flat, create_graph=True, allow_unused=True)
+            normals = torch.zeros_like(flat) if normals is None else normals
         valid = valid.view(R, S)
         trunc = get_truncation(cfg, self.global_step)
         rgb_map, w = raw2outputs(raw, z_vals, batch[:, 6], valid, cfg, trunc)
-        return dict(raw=raw, rgb_map=rgb_map, weights=w, valid_samples=valid, pts_w=pts_w)
+        return dict(raw=raw, rgb_map=rgb_map, weights=w, valid_samples=valid, pts_w=pts_w, normals=normals)
 
     def loss(self, batch, z_vals, fwd):
         cfg = self.cfg
@@ -746,6 +756,11 @@ class OracleField:
             loss = loss + cfg['feature_reg_weight'] * (self.feat ** 2).mean()       # nerf_runner.py:745-747
         if self.pose is not None and cfg.get('pose_reg_weight', 0) > 0:
             loss = loss + cfg['pose_reg_weight'] * self.pose[1:].norm()             # :749-752
+        if float(cfg.get('eikonal_weight', 0)) > 0:                                 # :734-738
+            sdf = fwd['raw'][..., 3].reshape(-1)
+            eikonal = ((torch.norm(fwd['normals'][sdf < 1], dim=-1) - 1) ** 2).mean() * cfg['eikonal_weight']
+            out['eikonal_loss'] = eikonal
+            loss = loss + eikonal
         out['loss'] = loss
         return out
 

@@ -263,6 +263,64 @@ def test_train_step_is_graph_capturable(nof):
     assert torch.isfinite(g_replay).all() and g_replay.abs().sum().item() > 0
 
 
+@pytest.mark.parametrize("ns,nc", [(3, 2), (2, 3)])
+def test_eikonal_matches_oracle(nof, ns, nc):
+    """eikonal_weight > 0 (nerf_runner.py:734-738 with the normal of run_network_density, :1342-1345; off in the reference's
+    config.yml): the term itself and EVERY gradient group (hash table through the finite differences, sigma-net weights through
+    the forward-over-reverse pass, poses through the mixed second derivatives) against the oracle's double backward, fp32 mode."""
+    from bundlesdf_amd.field import NeuralObjectField
+    cfg, fld0, orc0, batch, rng = _pair(nof, 'fp32', 0, ns, nc, R=192)
+    cfg['eikonal_weight'] = 0.3
+    F = fld0.F
+    c2w = cpu(fld0.c2w).reshape(-1, 4, 4)
+    fld = NeuralObjectField(cfg, F, c2w, precision='fp32', n_sigma=ns, n_color=nc)
+    fld.params.copy_(fld0.params)
+    fld.occ_bits, fld.level, fld.max_level, fld.max_hits = fld0.occ_bits, fld0.level, fld0.max_level, fld0.max_hits
+    orc = O.OracleField(cfg, orc0.geo, orc0.shape, F, c2w, orc0.occ_l, table=cpu(fld.table).reshape(-1, 2),
+                        mlp=[[W.clone(), b.clone()] for W, b in fld.mlp_state()], pose=cpu(fld.pose).reshape(-1, 6))
+    R = batch.shape[0]
+    Ns, Na = cfg['N_samples'], cfg['N_samples_around_depth']
+    u_occ = rng.random((R, Ns)).astype(np.float32)
+    u_dep = rng.random((R, Na)).astype(np.float32)
+    fld.train_step(U.dev(batch), None, R, U.dev(u_occ), U.dev(u_dep), do_step=False)
+    torch.cuda.synchronize()
+    ref = orc.train_step(batch, u_occ, u_dep, do_step=False)
+    # the same step without the term: the difference of the two IS the eikonal gradient (checked on its own below)
+    cfg0 = dict(cfg, eikonal_weight=0.0)
+    orc_plain = O.OracleField(cfg0, orc0.geo, orc0.shape, F, c2w, orc0.occ_l, table=cpu(fld.table).reshape(-1, 2),
+                              mlp=[[W.clone(), b.clone()] for W, b in fld.mlp_state()], pose=cpu(fld.pose).reshape(-1, 6))
+    ref0 = orc_plain.train_step(batch, u_occ, u_dep, do_step=False)
+    fld0.params.copy_(fld.params)
+    fld0.grads.zero_()
+    fld0.train_step(U.dev(batch), None, R, U.dev(u_occ), U.dev(u_dep), do_step=False)
+    torch.cuda.synchronize()
+    Lo = fld.losses()
+    e_ref = float(ref['losses']['eikonal_loss'].detach())
+    print(f'eikonal ({ns},{nc}): term {Lo["eikonal_loss"]:.6f} (oracle {e_ref:.6f}), total {Lo["loss"]:.5f} (oracle {float(ref["losses"]["loss"].detach()):.5f})')
+    assert e_ref > 1e-3 and abs(Lo['eikonal_loss'] - e_ref) < 2e-4 * e_ref
+    assert abs(Lo['loss'] - float(ref['losses']['loss'].detach())) < 2e-4 * abs(float(ref['losses']['loss'].detach()))
+    names = ['table'] + [f'mlp{i}' for i in range(2 * (ns + nc))] + ['pose']
+    g_ref, g_ref0 = dict(zip(names, ref['grads'])), dict(zip(names, ref0['grads']))
+    segs = {'table': (fld._seg(fld.grads, 'table'), fld0._seg(fld0.grads, 'table')),
+            'mlp': (fld._seg(fld.grads, 'mlp'), fld0._seg(fld0.grads, 'mlp')),
+            'pose': (fld._seg(fld.grads, 'pose'), fld0._seg(fld0.grads, 'pose'))}
+    refs = {'table': (g_ref['table'].reshape(-1), g_ref0['table'].reshape(-1)),
+            'mlp': (torch.cat([g.reshape(-1) for n, g in g_ref.items() if n.startswith('mlp')]),
+                    torch.cat([g.reshape(-1) for n, g in g_ref0.items() if n.startswith('mlp')])),
+            'pose': (g_ref['pose'].reshape(-1), g_ref0['pose'].reshape(-1))}
+    for k in ('table', 'mlp', 'pose'):
+        got, got0 = cpu(segs[k][0]), cpu(segs[k][1])
+        want, want0 = refs[k][0].numpy(), refs[k][1].numpy()
+        whole = rel_l2(got, want)
+        eik_only = rel_l2(got - got0, want - want0)                 # the term's own gradient
+        share = np.linalg.norm(want - want0) / np.linalg.norm(want)
+        print(f'  {k}: whole gradient rel-L2 {whole:.2e}; eikonal part rel-L2 {eik_only:.2e} (it is {share:.2%} of the gradient)')
+        assert whole < (4e-3 if k == 'pose' else 5e-4), (k, whole)
+        assert eik_only < (2e-2 if k == 'pose' else 5e-3), (k, eik_only)
+    lo, hi = fld.desc.w_off[ns], fld.n_mlp                           # the colour net is untouched by the term
+    assert np.abs(cpu(segs['mlp'][0])[lo:hi] - cpu(segs['mlp'][1])[lo:hi]).max() < 1e-6 * np.abs(cpu(segs['mlp'][1])[lo:hi]).max() + 1e-9
+
+
 def test_pose_regulariser_matches_oracle(nof):
     """pose_reg_weight > 0 (nerf_runner.py:749-752; off in the reference's config.yml): loss and pose gradients"""
     cfg, fld, orc, batch, rng = _pair(nof, 'fp32', R=128)

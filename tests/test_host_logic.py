@@ -52,7 +52,8 @@ def test_mlp_descriptor_is_pytorch_parameter_order(ns, nc, ff):
 
 def test_unsupported_configuration_is_rejected_loudly():
     validate_cfg(default_cfg())
-    for key, val in (('eikonal_weight', 0.1), ('depth_weight', 1.0), ('N_importance', 64), ('N_samples_around_depth', 0),
+    validate_cfg(default_cfg(eikonal_weight=0.1))            # implemented (nof_eikonal)
+    for key, val in (('depth_weight', 1.0), ('N_importance', 64), ('N_samples_around_depth', 0),
                      ('use_viewdirs', 0), ('raw_noise_std', 1.0), ('feature_grid_dim', 4)):
         with pytest.raises(NotImplementedError, match=key.split('_')[0]):
             validate_cfg(default_cfg(**{key: val}))
