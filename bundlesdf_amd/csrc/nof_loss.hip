@@ -185,6 +185,60 @@ __global__ __launch_bounds__(256) void k_adam(float* __restrict__ p, float* __re
   }
 }
 
+// ---- the same with the per-step scalars in device memory (replayable captured step) ----------------------------------
+__global__ void k_step_advance(NofStepState* st, float lrate, float lrate_pose, float decay_rate, int n_iters, float b1, float b2,
+                               int set_step) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const uint32_t s = set_step < 0 ? st->step + 1u : (uint32_t)set_step;
+  st->step = s;
+  // the optimiser step with index s uses the rate set at the last g <= s - 1 with g % 10 == 0, g > 0 (nerf_runner.py:762-763)
+  const uint32_t g = s <= 10u ? 0u : ((s - 1u) / 10u) * 10u;
+  const double k = g == 0u ? 1.0 : pow((double)decay_rate, (double)g / (double)n_iters);
+  const double t = (double)s + 1.0;
+  const double bc1 = 1.0 - pow((double)b1, t), bc2 = 1.0 - pow((double)b2, t);
+  st->step_basic = (float)((double)lrate * k / bc1);
+  st->step_pose = (float)((double)lrate_pose * k / bc1);
+  st->inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
+}
+
+__global__ __launch_bounds__(256) void k_adam_dyn(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
+                                                   float* __restrict__ v, int64_t n, int64_t n_basic,
+                                                   const NofStepState* __restrict__ st, float b1, float b2, float eps) {
+  const float step_basic = st->step_basic, step_pose = st->step_pose, inv_sqrt_bc2 = st->inv_sqrt_bc2;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const float gi = g[i];
+    const float mi = b1 * m[i] + (1.0f - b1) * gi;
+    const float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
+    const float denom = sqrtf(vi) * inv_sqrt_bc2 + eps;
+    const float ss = (i < n_basic) ? step_basic : step_pose;
+    p[i] = p[i] - ss * (mi / denom);
+    m[i] = mi;
+    v[i] = vi;
+    g[i] = 0.0f;
+  }
+}
+
+extern "C" int nof_step_state_advance(NofStepState* d_state, float lrate, float lrate_pose, float decay_rate, int32_t n_iters,
+                                       float beta1, float beta2, int32_t set_step, void* stream) {
+  NOF_ARG(d_state && n_iters > 0);
+  hipLaunchKernelGGL(k_step_advance, dim3(1), dim3(64), 0, (hipStream_t)stream, d_state, lrate, lrate_pose, decay_rate, (int)n_iters,
+                     beta1, beta2, (int)set_step);
+  NOF_LAUNCH_OK();
+  return 0;
+}
+
+extern "C" int nof_adam_step_dyn(float* params, float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, int64_t n_basic,
+                                  const NofStepState* d_state, float beta1, float beta2, float eps, void* stream) {
+  NOF_ARG(params && grads && exp_avg && exp_avg_sq && d_state && n >= 0 && n_basic >= 0 && n_basic <= n);
+  if (n == 0) return 0;
+  const int64_t blocks = nof_div_up(n, 256) < 4096 ? nof_div_up(n, 256) : 4096;
+  hipLaunchKernelGGL(k_adam_dyn, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, params, grads, exp_avg, exp_avg_sq, n,
+                     n_basic, d_state, beta1, beta2, eps);
+  NOF_LAUNCH_OK();
+  return 0;
+}
+
 extern "C" int nof_adam_step(float* params, float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, int64_t n_basic,
                               float lr, float lr_pose, float beta1, float beta2, float eps, int32_t step, void* stream) {
   NOF_ARG(params && grads && exp_avg && exp_avg_sq && n >= 0 && n_basic >= 0 && n_basic <= n && step >= 1);

@@ -344,11 +344,11 @@ __global__ void k_sample_points(NofSampleCfg cfg, const float* __restrict__ batc
   float u;
   if (s < cfg.n_samples) {
     occupied_mode = true; N = cfg.n_samples; i = s;
-    u = u_occ ? u_occ[r * cfg.n_samples + i] : philox_uniform(cfg.seed, (uint32_t)r, (uint32_t)s, cfg.step, 0u);
+    u = u_occ ? u_occ[r * cfg.n_samples + i] : philox_uniform(cfg.seed, (uint32_t)r, (uint32_t)s, cfg.d_step ? *cfg.d_step : cfg.step, 0u);
   } else {
     N = cfg.n_around; i = s - cfg.n_samples;
     occupied_mode = !valid_depth;                                       // nerf_runner.py:1072-1076
-    u = u_dep ? u_dep[r * cfg.n_around + i] : philox_uniform(cfg.seed, (uint32_t)r, (uint32_t)s, cfg.step, 0u);
+    u = u_dep ? u_dep[r * cfg.n_around + i] : philox_uniform(cfg.seed, (uint32_t)r, (uint32_t)s, cfg.d_step ? *cfg.d_step : cfg.step, 0u);
   }
   if (!occupied_mode) {
     const float nd = depth - cfg.trunc;                                  // nerf_runner.py:1067-1071

@@ -84,6 +84,7 @@ class NeuralObjectField:
         self._packed_step = None     # optimiser step the fragment image was built for
         self.profile = None          # dict name -> [(start_event, end_event)] when per-kernel timing is on (bench.py)
         self.profile_only = None
+        self._state = None           # NofStepState on the device (captured-step mode): see sync_step_state / GraphedStep
         if seed_init:
             self.init_parameters()
 
@@ -212,10 +213,20 @@ class NeuralObjectField:
                 partials_e=torch.zeros(self.nblk, self.n_mlp, device=d) if self.eikonal else None)
         return self._bufs[key]
 
-    def _sample_cfg(self, seed, step):
+    def _sample_cfg(self, seed, step, dyn=False):
         cfg = self.cfg
         return lib.NofSampleCfg(cfg['N_samples'], cfg['N_samples_around_depth'], cfg['near'] * cfg['sc_factor'],
-                                cfg['far'] * cfg['sc_factor'], self.truncation(), cfg['neg_trunc_ratio'], seed, step)
+                                cfg['far'] * cfg['sc_factor'], self.truncation(), cfg['neg_trunc_ratio'], seed, step,
+                                self._state.data_ptr() if dyn else None)
+
+    # ---- device-resident step state (NofStepState): what makes a captured step replayable ----------------------
+    def sync_step_state(self):
+        """device state := this field's global_step (and the Adam / schedule constants of the next optimiser step)"""
+        if self._state is None:
+            self._state = torch.zeros(4, dtype=torch.int32, device=self.device)
+        cfg = self.cfg
+        lib.call('nof_step_state_advance', self._state, C.c_float(cfg['lrate']), C.c_float(cfg['lrate_pose']),
+                 C.c_float(cfg['decay_rate']), int(cfg['n_step']) + 1, C.c_float(0.9), C.c_float(0.999), int(self.global_step))
 
     def _set_grad_scale(self, B):
         """fp16 operands only: loss scale of the MLP backward = the power of two nearest below B/16, at most 2^16 (the
@@ -234,6 +245,7 @@ class NeuralObjectField:
 
     # ---- forward pieces -----------------------------------------------------------------------------------
     def pack_weights(self, force=False):
+        force = force or getattr(self, '_dyn', False)      # a captured step must contain the launch whatever the host-side cache says
         """fp32 PyTorch-layout MLP parameters -> MFMA fragment image (once per optimiser step)."""
         if force or self._packed_step != self.global_step:
             self._call('nof_mlp_pack', C.byref(self.desc), self.mlp, self.packed)
@@ -245,7 +257,7 @@ class NeuralObjectField:
         self._call('nof_pose_fwd', self.pose if self.optimize_poses else None, self.c2w, C.c_float(self.max_trans),
                  C.c_float(self.max_rot), self.tf, self.F)
 
-    def forward_batch(self, pool, ids, R, u_occ=None, u_dep=None, seed=0, want_cells=False):
+    def forward_batch(self, pool, ids, R, u_occ=None, u_dep=None, seed=0, want_cells=False, dyn=False):
         """render_rays up to raw (nerf_runner.py:1044-1088); returns the buffer dict."""
         cfg = self.cfg
         S = cfg['N_samples'] + cfg['N_samples_around_depth']
@@ -255,7 +267,7 @@ class NeuralObjectField:
         cid = None
         if want_cells:
             cid = b.setdefault('cell_ids', torch.empty(R, self.max_hits, dtype=torch.int32, device=self.device))
-        sc = self._sample_cfg(seed, self.global_step)
+        sc = self._sample_cfg(seed, self.global_step, dyn)
         self._call('nof_raymarch_sample', C.byref(sc), pool, ids, self.tf, self.feat if self.ff > 0 else None, self.ff,
                    self.sh_degree, self.occ_bits, self.level, R, self.max_hits, u_occ, u_dep, b['batch'], b['rays_o_w'],
                    b['viewdirs_w'], b['view'], b['t_in_out'], cid, b['n_hits'], b['z_vals'], b['pts_w'], b['valid'],
@@ -269,11 +281,14 @@ class NeuralObjectField:
         return b, S
 
     def train_step(self, pool, ids, R, u_occ=None, u_dep=None, seed=0, do_step=True, want_cells=False,
-                   grad_sync=None):
+                   grad_sync=None, dyn=False):
         """One train_loop iteration (nerf_runner.py:679-763).  `grad_sync(flat_grads)` is the data-parallel hook
-        (RCCL all-reduce); gradients are already scaled by 1/world_size."""
+        (RCCL all-reduce); gradients are already scaled by 1/world_size.  dyn=True: the per-step scalars (Philox step, Adam
+        step sizes) are read from the device-resident NofStepState instead of being passed by value, and the state is advanced
+        by the step's last launch -- the form GraphedStep captures."""
         cfg = self.cfg
-        b, S = self.forward_batch(pool, ids, R, u_occ, u_dep, seed, want_cells)
+        self._dyn = dyn
+        b, S = self.forward_batch(pool, ids, R, u_occ, u_dep, seed, want_cells, dyn)
         B = R * S
         lc = self._loss_cfg()
         self.loss_out.zero_()
@@ -338,10 +353,19 @@ class NeuralObjectField:
         elif grad_sync is not None:
             grad_sync(self.grads)
         if do_step:
-            self.adam_step()
+            self.adam_step(dyn)
+        self._dyn = False
         return b
 
-    def adam_step(self):
+    def adam_step(self, dyn=False):
+        if dyn:
+            cfg = self.cfg
+            self._call('nof_adam_step_dyn', self.params, self.grads, self.exp_avg, self.exp_avg_sq, self.n_total, self.n_basic,
+                       self._state, C.c_float(0.9), C.c_float(0.999), C.c_float(1e-15))
+            self._call('nof_step_state_advance', self._state, C.c_float(cfg['lrate']), C.c_float(cfg['lrate_pose']),
+                       C.c_float(cfg['decay_rate']), int(cfg['n_step']) + 1, C.c_float(0.9), C.c_float(0.999), -1)
+            self.global_step += 1
+            return
         lr, lr_pose = self.learning_rates()
         self._call('nof_adam_step', self.params, self.grads, self.exp_avg, self.exp_avg_sq, self.n_total, self.n_basic,
                  C.c_float(lr), C.c_float(lr_pose), C.c_float(0.9), C.c_float(0.999), C.c_float(1e-15),
@@ -396,3 +420,38 @@ class NeuralObjectField:
         v = self.loss_out.cpu().numpy()
         return dict(loss=float(v[0]), rgb_loss=float(v[1]), fs_loss=float(v[2]), sdf_loss=float(v[3]),
                     fs_rgb_loss=float(v[4]), n_valid_samples=float(v[5]), n_valid_rays=float(v[6]), eikonal_loss=float(v[7]))
+
+
+class GraphedStep:
+    """One optimisation step captured into a HIP graph and replayed: 20-odd launches, two fills and the side-stream fork/join
+    of the hash backward become one graph launch.  What changes from step to step lives in device memory: the batch ids in a
+    static buffer (copied in before each replay), the Philox step / Adam step sizes / scheduled learning rates in the field's
+    NofStepState (advanced by the last launch of the captured step).  Not used with a data-parallel gradient sync, with
+    per-kernel event timing, or with a truncation schedule (the truncation is baked into the captured launches)."""
+
+    def __init__(self, field, pool, R, seed):
+        self.field, self.R = field, R
+        self.ids = torch.zeros(R, dtype=torch.int64, device=field.device)
+        field.sync_step_state()
+        step0 = field.global_step
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            with torch.cuda.graph(self.graph, stream=s):
+                field.train_step(pool, self.ids, R, seed=seed, dyn=True)
+        torch.cuda.current_stream().wait_stream(s)
+        field.global_step = step0              # capturing executes nothing: only the host-side counter moved
+        field._packed_step = None
+        self.trunc = field.truncation()
+
+    def usable(self):
+        f = self.field
+        return f.profile is None and f.truncation() == self.trunc
+
+    def __call__(self, ids):
+        self.ids.copy_(ids)
+        self.graph.replay()
+        self.field.global_step += 1
+        self.field._packed_step = None         # the fragment image inside the graph belongs to the parameters before this step

@@ -22,7 +22,7 @@ import torch
 
 from . import lib
 from .checkpoint import load_reference_checkpoint, to_reference_checkpoint
-from .field import NeuralObjectField
+from .field import GraphedStep, NeuralObjectField
 from .mesh_gpu import marching_tetrahedra_gpu
 from .mesh import make_mesh, marching_tetrahedra
 from .nerf_helpers import *          # noqa: F401,F403  (re-exported on purpose, like the reference module does)
@@ -211,8 +211,24 @@ class NerfRunner:
         rows are gathered on the device from the resident pool)."""
         if ids is None:
             ids = self.data_loader.next_ids()
-        self.field.train_step(self.rays, ids, ids.shape[0], seed=self.cfg.get('seed', 0) + 7919 * self.rank,
-                              grad_sync=self.grad_sync)
+        seed = self.cfg.get('seed', 0) + 7919 * self.rank
+        f = self.field
+        # captured-step mode (cfg hip_graph, default on): after a few eager steps (module load, buffers, the hash backward's side
+        # stream) the whole step is replayed as one HIP graph; eager otherwise (data parallel, per-kernel timing, truncation decay)
+        graph_ok = (self.cfg.get('hip_graph', True) and self.grad_sync is None and f.profile is None
+                    and not self.cfg.get('trunc_decay_type', ''))
+        g = getattr(self, '_graph', None)
+        if g is not None and (g.field is not f or g.R != ids.shape[0] or not g.usable() or not graph_ok):
+            g = self._graph = None
+        if graph_ok and g is None and getattr(self, '_eager_steps', 0) >= 3 and getattr(self, '_graph_field', None) is f:
+            g = self._graph = GraphedStep(f, self.rays, ids.shape[0], seed)
+        if g is not None:
+            g(ids)
+        else:
+            if getattr(self, '_graph_field', None) is not f:
+                self._graph_field, self._eager_steps = f, 0
+            self._eager_steps += 1
+            f.train_step(self.rays, ids, ids.shape[0], seed=seed, grad_sync=self.grad_sync)
         if self.global_step % self.cfg['i_print'] == 0 and self.global_step > 0:
             m = self.field.losses()
             logging.info(f"Iter: {self.global_step}, " + ", ".join(f"{k}: {v:.7f}" for k, v in m.items()))

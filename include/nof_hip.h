@@ -133,6 +133,8 @@ typedef struct {
   float    neg_trunc_ratio;
   uint64_t seed;                          /* Philox key when u_occ/u_dep are NULL */
   uint32_t step;                          /* Philox counter word 2 */
+  const uint32_t* d_step;                 /* DEVICE pointer (or NULL): when set, the Philox step is read from it at run time
+                                           * instead of `step` -- what lets a captured step be replayed (NofStepState.step) */
 } NofSampleCfg;
 /* z sampling + point generation (nerf_runner.py:979-1011,1063-1083,1242-1245; common.cu:41-105).
  * u_occ [R,n_samples], u_dep [R,n_around] injected uniforms or NULL (Philox4x32-10).
@@ -149,6 +151,24 @@ int nof_raymarch_sample(const NofSampleCfg* h_cfg, const float* pool, const int6
                         float* batch, float* rays_o_w, float* viewdirs_w, float* view, float* t_in_out,
                         int32_t* cell_ids, int32_t* n_hits, float* z_vals, float* pts_w, uint8_t* valid,
                         int32_t* flags, void* stream);
+
+/* ---- device-resident step state: the per-step scalars of a captured (hipGraph) step --------------------------------------
+ * A captured step bakes every by-value argument into its launches.  The three that change every step -- the Philox step of the
+ * sampler, Adam's step count and the scheduled learning rates -- therefore live in this 16-byte device struct: the sampler reads
+ * `step` through NofSampleCfg.d_step, nof_adam_step_dyn reads the step sizes, and nof_step_state_advance (the last launch of the
+ * captured step) increments `step` and recomputes the rest for the next replay (schedule_lr, nerf_runner.py:579-583: the rate
+ * changes after steps g with g % 10 == 0, g > 0: lr = lrate * decay_rate^(g / n_iters)). */
+typedef struct {
+  uint32_t step;                          /* optimiser steps taken so far (= global_step) */
+  float step_basic, step_pose;            /* lr / (1 - beta1^t), t = step + 1, for the two param groups */
+  float inv_sqrt_bc2;                     /* 1 / sqrt(1 - beta2^t) */
+} NofStepState;
+/* set_step < 0: step += 1; otherwise step = set_step.  Then the Adam constants of the NEXT optimiser step are recomputed. */
+int nof_step_state_advance(NofStepState* d_state, float lrate, float lrate_pose, float decay_rate, int32_t n_iters, float beta1,
+                           float beta2, int32_t set_step, void* stream);
+/* nof_adam_step with lr / step taken from the device state */
+int nof_adam_step_dyn(float* params, float* grads, float* exp_avg, float* exp_avg_sq, int64_t n_total, int64_t n_basic,
+                      const NofStepState* d_state, float beta1, float beta2, float eps, void* stream);
 
 /* ---- SDF + colour tiny-MLPs on MFMA (replaces NeRFSmall's cuBLAS GEMMs) ------------------------ */
 typedef struct {

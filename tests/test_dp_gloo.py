@@ -103,3 +103,25 @@ def test_single_process_helpers_are_identity():
     assert torch.equal(D.all_gather_cat(t), t)
     assert D.make_grad_sync() is None
     assert D.shard_frames(512, 3, 8) == (192, 256)
+
+
+def test_bench_refuses_to_run_fewer_ranks_than_asked():
+    """`python bench.py --gpus N` without a launcher starts its N ranks itself -- and exits loudly, before any measurement, when
+    fewer than N GPUs are visible (here: none), instead of silently benchmarking a smaller world and reporting n_gpus = N; under a
+    launcher a WORLD_SIZE that disagrees with --gpus is an error too."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if torch.cuda.is_available() and torch.cuda.device_count() >= 2:
+        pytest.skip('two GPUs are visible')
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_PORT')}
+    p = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '0'],
+                       capture_output=True, text=True, env=env, timeout=300)
+    assert p.returncode != 0 and 'GPU(s) are visible' in p.stderr and '--gpus 2' in p.stderr, p.stderr[-500:]
+    assert p.stdout.strip() == ''                                     # no result line
+    if not torch.cuda.is_available():
+        return
+    env2 = dict(env, WORLD_SIZE='1', RANK='0', LOCAL_RANK='0')
+    p = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '0'],
+                       capture_output=True, text=True, env=env2, timeout=300)
+    assert p.returncode != 0 and 'WORLD_SIZE=1' in p.stderr

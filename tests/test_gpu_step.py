@@ -36,7 +36,8 @@ def _pair(nof, precision, ff=0, ns=2, nc=3, L=16, R=256, seed=0, hidden=64):
     mlp = [[W.clone(), b.clone()] for W, b in fld.mlp_state()]
     feat0 = cpu(fld.feat).reshape(F, ff) if ff else None
     orc = O.OracleField(cfg, geo, shape, F, c2w, occ, table=table0, mlp=mlp, pose=pose0, feat=feat0,
-                        operand_dtype=ODT[{'fp32': 0, 'bf16': 1, 'fp16': 2}[precision]])
+                        operand_dtype=ODT[{'fp32': 0, 'bf16': 1, 'fp16': 2, 'fp16x3': 3, 'bf16x3': 4}[precision]],
+                        split_forward=precision.endswith('x3'))
     return cfg, fld, orc, batch, rng
 
 
@@ -319,6 +320,51 @@ def test_eikonal_matches_oracle(nof, ns, nc):
         assert eik_only < (2e-2 if k == 'pose' else 5e-3), (k, eik_only)
     lo, hi = fld.desc.w_off[ns], fld.n_mlp                           # the colour net is untouched by the term
     assert np.abs(cpu(segs['mlp'][0])[lo:hi] - cpu(segs['mlp'][1])[lo:hi]).max() < 1e-6 * np.abs(cpu(segs['mlp'][1])[lo:hi]).max() + 1e-9
+
+
+def test_graphed_step_equals_eager_steps(nof):
+    """The product's captured-step mode (GraphedStep: the step as one HIP graph, Philox step / Adam step sizes / learning-rate
+    schedule in the device-resident NofStepState) against eager launches with the scalars passed by value, over 14 steps
+    (the schedule changes the rate after step 10): same batches, same Philox streams -> same parameters up to the
+    summation order of the atomics, and the device state counts the steps."""
+    from bundlesdf_amd.field import GraphedStep, NeuralObjectField
+    cfg, fld, orc, batch, rng = _pair(nof, 'fp16x3', R=256)
+    cfg['n_step'] = 40                                   # a visible decay: lr * 0.1^(g/41)
+    c2w = cpu(fld.c2w).reshape(-1, 4, 4)
+    twin = NeuralObjectField(cfg, fld.F, c2w, precision='fp16x3')
+    twin.params.copy_(fld.params)
+    twin.occ_bits, twin.level, twin.max_level, twin.max_hits = fld.occ_bits, fld.level, fld.max_level, fld.max_hits
+    pool = U.dev(batch)
+    R = batch.shape[0]
+    gen = torch.Generator(device='cuda').manual_seed(0)
+    N = 14
+    id_list = [torch.randperm(R, device='cuda', generator=gen) for _ in range(N)]
+    for i in range(3):                                   # eager warm-up on both (what the runner does before capturing)
+        fld.train_step(pool, id_list[i], R, seed=11)
+        twin.train_step(pool, id_list[i], R, seed=11)
+    g = GraphedStep(twin, pool, R, seed=11)
+    assert twin.global_step == 3
+    z_seen = []
+    for i in range(3, N):
+        fld.train_step(pool, id_list[i], R, seed=11)
+        g(id_list[i])
+        z_seen.append(twin._buffers(R, cfg['N_samples'] + cfg['N_samples_around_depth'])['z_vals'][0, :4].clone())
+    torch.cuda.synchronize()
+    assert fld.global_step == twin.global_step == N
+    state = twin._state.cpu().numpy()
+    assert int(state[0]) == N                            # the device-side step counter
+    lr, _ = twin.learning_rates()                        # host schedule for the NEXT step (index 14: the rate set after step 10)
+    assert lr < cfg['lrate']
+    bc1 = 1.0 - 0.9 ** (N + 1)
+    assert abs(state[1:2].view(np.float32)[0] - lr / bc1) < 1e-6 * lr / bc1
+    assert not torch.equal(z_seen[0], z_seen[1])         # the Philox step really advances between replays
+    d = (fld.params - twin.params).abs()
+    print(f'graph vs eager after {N} steps: max |dp| {d.max().item():.2e}, fraction > 1e-4: {(d > 1e-4).float().mean().item():.2e}, '
+          f'loss {fld.losses()["loss"]:.5f} / {twin.losses()["loss"]:.5f}')
+    # Adam (eps 1e-15) moves a parameter by ~lr per step whatever its gradient's size, so entries whose gradient is summation
+    # noise can drift by a few lr between two runs of the SAME eager code as well: bound the fraction, and the loss
+    assert d.max().item() < 2.0 * N * cfg['lrate'] and (d > 1e-3).float().mean().item() < 2e-2
+    assert abs(fld.losses()['loss'] - twin.losses()['loss']) < 5e-2 * abs(fld.losses()['loss'])
 
 
 def test_pose_regulariser_matches_oracle(nof):
