@@ -37,22 +37,26 @@ def transform_pts(pts, tf):
 
 
 def preprocess_data(rgbs, depths, masks, normal_maps, poses, sc_factor, translation):
-    """nerf_helpers.py:218-240.  In place like the reference: depth < 0.1 m or outside the mask becomes BAD_DEPTH,
-    background colour BAD_COLOR, colours /255, depths and pose translations move to the normalised object space."""
-    depths[depths < 0.1] = BAD_DEPTH
+    """What nerf_helpers.py:218-240 does to the keyframes before they reach NerfRunner, in place on the arrays it is given:
+    invalid depth (< 0.1 m, or outside the mask) -> BAD_DEPTH, background colour -> BAD_COLOR, colours to [0,1] float32,
+    metric depths and camera positions into the normalised object space p_n = (p + translation) * sc_factor, normals to the
+    OpenGL camera frame.  Returns (rgbs, depths [..,1], masks [..,1], normal_maps, poses)."""
+    too_close = depths < 0.1
+    depths[too_close] = BAD_DEPTH
     if masks is not None:
-        rgbs[masks == 0] = BAD_COLOR
-        depths[masks == 0] = BAD_DEPTH
+        background = masks == 0
+        rgbs[background] = BAD_COLOR
+        depths[background] = BAD_DEPTH
         if normal_maps is not None:
-            normal_maps[..., [1, 2]] *= -1
-            normal_maps[masks == 0] = 0
+            normal_maps[..., [1, 2]] *= -1                       # OpenCV -> OpenGL camera axes
+            normal_maps[background] = 0
         masks = masks[..., None]
     rgbs = (rgbs / 255.0).astype(np.float32)
     depths *= sc_factor
-    depths = depths[..., None]
-    poses[:, :3, 3] += translation
-    poses[:, :3, 3] *= sc_factor
-    return rgbs, depths, masks, normal_maps, poses
+    cam_centres = poses[:, :3, 3]                                # a view: the poses are normalised in place
+    cam_centres += translation
+    cam_centres *= sc_factor
+    return rgbs, depths[..., None], masks, normal_maps, poses
 
 
 def get_camera_rays_np(H, W, K):
@@ -94,24 +98,31 @@ def ray_box_intersection_batch(origins, dirs, bounds):
     return torch.where(ishit, tmin, minus), torch.where(ishit, tmax, minus)
 
 
+def _to_metric(T, sc_factor, translation):
+    """camera positions of normalised poses [n,4,4] back to metres, in place: p = p_n / sc_factor - translation"""
+    T[:, :3, 3] /= sc_factor
+    T[:, :3, 3] -= translation
+    return T
+
+
 def get_optimized_poses_in_real_world(poses_normalized, pose_array, sc_factor, translation):
-    """Utils.py:479-505: apply the learnt corrections, undo the normalisation, re-anchor on frame 0 and return
-    OpenCV cam-in-object poses plus the frame-0 offset."""
-    original = poses_normalized.copy()
-    original[:, :3, 3] /= sc_factor
-    original[:, :3, 3] -= translation
-    tf = pose_array.get_matrices(np.arange(len(poses_normalized))).reshape(-1, 4, 4).data.cpu().numpy()
-    optimized = np.array(tf @ poses_normalized).astype(np.float32)
-    optimized[:, :3, 3] /= sc_factor
-    optimized[:, :3, 3] -= translation
-    offset = np.linalg.inv(optimized[0].copy()) @ original[0]
-    for i in range(len(optimized)):
-        optimized[i] = (optimized[i] @ offset) @ glcam_in_cvcam
-    return optimized, offset
+    """The pose hand-back of Utils.py:479-505: learnt correction x input pose per keyframe (normalised object space), both
+    sets taken back to metres, every optimised pose re-expressed so that keyframe 0 keeps its input pose (the corrections
+    share a gauge freedom with the object frame), OpenGL -> OpenCV camera.  Returns (cam_in_ob [n,4,4] float32, offset)."""
+    n = len(poses_normalized)
+    before = _to_metric(poses_normalized.copy(), sc_factor, translation)
+    delta = pose_array.get_matrices(np.arange(n)).reshape(-1, 4, 4).data.cpu().numpy()
+    after = _to_metric(np.array(delta @ poses_normalized).astype(np.float32), sc_factor, translation)
+    offset = np.linalg.inv(after[0].copy()) @ before[0]          # what maps the optimised frame 0 onto the input frame 0
+    for i in range(n):
+        after[i] = (after[i] @ offset) @ glcam_in_cvcam
+    return after, offset
 
 
 def mesh_to_real_world(mesh, pose_offset, translation, sc_factor):
-    """Utils.py:508-514."""
-    mesh.vertices = mesh.vertices / sc_factor - np.array(translation).reshape(1, 3)
+    """Utils.py:508-514: vertices from the normalised object space back to metres, then the frame-0 offset of the pose
+    hand-back, so that the mesh and the handed-back poses share one object frame."""
+    metric = mesh.vertices / sc_factor
+    mesh.vertices = metric - np.array(translation).reshape(1, 3)
     mesh.apply_transform(pose_offset)
     return mesh

@@ -30,20 +30,20 @@ def dilate_mask(mask, k):
 
 
 def compute_near_far_and_filter_rays(cam_in_world, rays, cfg):
-    """nerf_runner.py:39-65: world-space slab test of every ray against cfg['bounding_box']; rays that miss are
-    dropped, the others get |z| of the entry/exit point (camera frame) appended as near, far."""
-    D = rays.shape[-1]
-    rays = rays.reshape(-1, D)
-    dirs_unit = rays[:, :3] / np.linalg.norm(rays[:, :3], axis=-1).reshape(-1, 1)
-    dirs = (cam_in_world[:3, :3] @ rays[:, :3].T).T
-    origins = (cam_in_world @ to_homo(np.zeros(dirs.shape)).T).T[:, :3]
-    bounds = np.array(cfg['bounding_box']).reshape(2, 3)
-    tmin, tmax = ray_box_intersection_batch(origins, dirs, bounds)
-    tmin, tmax = tmin.numpy(), tmax.numpy()
-    ishit = tmin >= 0
-    near = np.abs((dirs_unit * tmin.reshape(-1, 1))[:, 2])[ishit]
-    far = np.abs((dirs_unit * tmax.reshape(-1, 1))[:, 2])[ishit]
-    return np.concatenate((rays[ishit], near.reshape(-1, 1), far.reshape(-1, 1)), axis=-1)
+    """nerf_runner.py:39-65: rays of one keyframe against cfg['bounding_box'] in world space.  Rays that miss the box are
+    dropped; the survivors get two more columns, the camera-frame depth |z| at which they enter and leave it (the ray
+    directions are un-normalised with z = -1, so depth = |t * unit_direction_z|)."""
+    rays = rays.reshape(-1, rays.shape[-1])
+    d_cam = rays[:, :3]
+    unit_z = (d_cam / np.linalg.norm(d_cam, axis=-1).reshape(-1, 1))[:, 2]
+    d_world = (cam_in_world[:3, :3] @ d_cam.T).T
+    centre = (cam_in_world @ to_homo(np.zeros(d_world.shape)).T).T[:, :3]        # the camera centre, once per ray
+    box = np.array(cfg['bounding_box']).reshape(2, 3)
+    t_in, t_out = (t.numpy() for t in ray_box_intersection_batch(centre, d_world, box))
+    hit = t_in >= 0                                              # misses come back as -1
+    depth_in = np.abs(unit_z * t_in)[hit].reshape(-1, 1)
+    depth_out = np.abs(unit_z * t_out)[hit].reshape(-1, 1)
+    return np.concatenate((rays[hit], depth_in, depth_out), axis=-1)
 
 
 def make_frame_rays(frame_id, image, depth, mask_in, pose, K, cfg, occ_mask=None, trace_fn=None):

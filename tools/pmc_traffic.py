@@ -13,17 +13,21 @@ def per_kernel(dbdir, counter):
 
 
 fetch, write = per_kernel('pmc_fetch', 'FETCH_SIZE'), per_kernel('pmc_write', 'WRITE_SIZE')
+# kernels of each C-ABI entry point, by name prefix (the template arguments follow the bench's precision / network shape)
 groups = {'nof_hash_encode_bwd': ['k_hash_bwd_agg', 'k_hash_dx', 'k_hash_bwd_lds'], 'nof_hash_encode_fwd': ['k_hash_fwd'],
-          'nof_mlp_bwd': ['k_mlp_bwd_color<PrecBF16, 3, 2>', 'k_mlp_bwd_sigma<PrecBF16, 3, 2>'],
-          'nof_mlp_fwd': ['k_mlp_fwd<PrecBF16, 3, 2, false>'], 'nof_adam_step': ['k_adam']}
+          'nof_mlp_bwd': ['k_mlp_bwd_color<', 'k_mlp_bwd_sigma<'], 'nof_mlp_fwd': ['k_mlp_fwd<'], 'nof_adam_step': ['k_adam']}
+
+
+def total(table, prefixes):
+    return sum(v for k, v in table.items() if any(k.startswith(p) for p in prefixes))
 out = {'_note': 'HBM-side bytes per launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, KiB * 1024), cfg2 batch '
                 '(4096 rays x 192 samples, L=16, T=2^19), summed over the kernels of each C-ABI entry point. RAW counter values: '
                 'on gfx950 FETCH_SIZE under-reports wide coalesced streaming reads by 2x (MI355X_MICROARCH.md, HBM section); for '
                 '8-byte gathers and atomics it is uncalibrated. Source: the pmc_counters file of the same round in profiles/',
-       'workload': 'cfg2-bf16-baseline'}
+       'workload': 'cfg2 batch, bench.py default precision (fp16x3), 16-keyframe pool'}
 for k, names in groups.items():
-    f = sum(fetch.get(n, 0) for n in names) * 1024
-    w = sum(write.get(n, 0) for n in names) * 1024
+    f = total(fetch, names) * 1024
+    w = total(write, names) * 1024
     out[k] = {'fetch_bytes': f, 'write_bytes': w, 'traffic_bytes': f + w}
 json.dump(out, open(out_path, 'w'), indent=1)
 print(json.dumps({k: v['traffic_bytes'] for k, v in out.items() if isinstance(v, dict)}))

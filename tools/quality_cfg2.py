@@ -1,6 +1,7 @@
 """End-to-end quality at the benchmark configuration (BASELINE cfg2: 64 synthetic 640x480 keyframes, 4096 rays x 192
-samples, L=16 T=2^19, SDF 3x64 + colour 2x64, bf16): train, extract the mesh, Chamfer distance to the analytic ellipsoid,
-pose error before / after.  Run on the GPU box."""
+samples, L=16 T=2^19, SDF 3x64 + colour 2x64): train, extract the mesh, Chamfer distance to the analytic ellipsoid, pose error
+before / after -- one JSON line per --precision (same seed, same data: the exact-fp32 MFMA mode beside the 16-bit modes shows what
+the operand precision does to the CONVERGED field).  Run on the GPU box."""
 import sys, os, json, time, argparse
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -15,15 +16,16 @@ ap = argparse.ArgumentParser()
 ap.add_argument('--steps', type=int, default=3000)
 ap.add_argument('--keyframes', type=int, default=64)
 ap.add_argument('--voxel', type=float, default=0.002)
+ap.add_argument('--precision', default='fp16x3')
 a = ap.parse_args()
-args = argparse.Namespace(keyframes=a.keyframes, height=480, width=640, rays=4096, log2_T=19, mlp='baseline', precision='bf16')
+args = argparse.Namespace(keyframes=a.keyframes, height=480, width=640, rays=4096, log2_T=19, mlp='baseline', precision=a.precision,
+                          finest=256)
 torch.cuda.set_device(0)
 t0 = time.time()
 runner, cfg = bench.build_runner(args, 0, 1, torch.device('cuda', 0))
 cfg['n_step'] = a.steps
 runner.cfg['n_step'] = a.steps
 runner.N_iters = a.steps + 1
-runner.field.N_iters = a.steps + 1
 t1 = time.time()
 runner.train_loop(); first = runner.field.losses(); runner.global_step += 1
 torch.cuda.synchronize(); t2 = time.time()
@@ -50,7 +52,7 @@ r1, r2 = np.sqrt(rng.random(40000)), rng.random(40000)
 ms = (1 - r1)[:, None] * aa[idx] + (r1 * (1 - r2))[:, None] * bb[idx] + (r1 * r2)[:, None] * cc[idx]
 p = rng.normal(size=(40000, 3)); p /= np.linalg.norm(p, axis=1, keepdims=True); gs = p * pool['semi_axes']
 d1, _ = cKDTree(ms).query(gs); d2, _ = cKDTree(gs).query(ms)
-print(json.dumps(dict(steps=a.steps, keyframes=a.keyframes, setup_s=round(t1 - t0, 2), train_s=round(t3 - t2, 3),
+print(json.dumps(dict(precision=a.precision, steps=a.steps, keyframes=a.keyframes, setup_s=round(t1 - t0, 2), train_s=round(t3 - t2, 3),
                       ms_per_step=round((t3 - t2) / (a.steps - 1) * 1e3, 4), loss_first=first['loss'], loss_last=last['loss'],
                       sdf_loss_last=last['sdf_loss'], pose_err_before_mm=round(e0 * 1e3, 3), pose_err_after_mm=round(e1 * 1e3, 3),
                       extract_s=round(t5 - t4, 3), voxel_mm=a.voxel * 1e3, V=len(v), F=len(f),
