@@ -164,6 +164,28 @@ def self_launch(args):
     raise SystemExit(subprocess.call(cmd, env=env))
 
 
+ATOMIC_PEAK_G = 20.8        # G line requests/s: tools/atomic_probe.py on MI355X (profiles/r02_d_atomic_probe.txt)
+
+
+def atomic_roofline(fld, runner, R, S, dom_ms):
+    """Atomic line requests of the last batch's table scatter (tools/scatter_requests.py on its sample points) / launch time."""
+    sys.path.insert(0, os.path.join(ROOT, 'tools'))
+    import scatter_requests as SR
+    b = fld._buffers(R, S)
+    n_rays = min(R, 1024)
+    pts = b['pts_w'][:n_rays * S].cpu().numpy()
+    g = fld.grid
+    lds = [l for l in range(fld.L) if int(g.size[l]) * 8 <= 48 * 1024]            # accumulated in LDS, flushed once (nof_hash.hip)
+    levels = [l for l in range(fld.L) if l not in lds]
+    per = SR.count_requests(pts, list(g.scale), list(g.resolution), list(g.offset), list(g.size), list(g.hashed), levels)
+    req = sum(per.values()) * (R / n_rays)
+    req += sum(64 * min(int(g.size[l]) // 8, 1 << 30) for l in lds)                 # upper bound of the LDS levels' flush
+    ach = req / (dom_ms * 1e-3) / 1e9
+    return {"line_requests": int(req), "achieved": ach, "peak": ATOMIC_PEAK_G, "unit": "G line-requests/s",
+            "frac": ach / ATOMIC_PEAK_G, "sample": f"counted on {n_rays} of the {R} rays of the last batch, scaled",
+            "floor_ms": req / (ATOMIC_PEAK_G * 1e9) * 1e3}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -307,6 +329,14 @@ def main():
                                           "not re-measured in this run)" if traffic else None}
                 if dominant in extra_bytes:      # the same launch priced with everything it computes (scatter + dL/dx)
                     roof["frac_incl_input_grad"] = (amount + extra_bytes[dominant]) / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+                if dominant == 'nof_hash_encode_bwd':
+                    # what actually bounds the scatter: the memory side retires ~20.8 G atomic LINE REQUESTS per second
+                    # (tools/atomic_probe.py; same for every scope, cache flag and data type), and the launch needs one request per
+                    # 64-byte line per atomic instruction.  The requests of THIS batch are counted from its own sample points.
+                    try:
+                        roof["atomic"] = atomic_roofline(fld, runner, R, S, dom_ms)
+                    except Exception as ex:          # measurement aid only
+                        roof["atomic"] = {"error": repr(ex)}
             else:
                 ach = amount / (dom_ms * 1e-3) / 1e12
                 roof = {"kernel": dominant, "bound": "mfma", "achieved": ach, "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s",

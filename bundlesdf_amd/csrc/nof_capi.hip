@@ -53,6 +53,36 @@ __global__ __launch_bounds__(256) void k_atomic_probe(int variant, const uint32_
     if (i < n) table[2 * (size_t)idx[i]] = 1.0f;
     return;
   }
+  if (variant >= 22) {                      // other atomic types on random entries (one 8-byte slot per entry): 22 u32, 23 u64, 24 f64, 25 pk f16
+    if (i >= n) return;
+    void* a = &table[2 * (size_t)idx[i]];
+    if (variant == 22) atomicAdd((unsigned int*)a, 1u);
+    if (variant == 23) atomicAdd((unsigned long long*)a, 1ull);
+    if (variant == 24) atomicAdd((double*)a, 1.0);
+    if (variant == 25) { const uint32_t one2 = 0x3C003C00u; asm volatile("global_atomic_pk_add_f16 %0, %1, off" ::"v"(a), "v"(one2) : "memory"); }
+    return;
+  }
+  if (variant >= 10) {
+    // 10..13: x only, random entries; 14..17: the same with every entry folded into the eighth of the table that belongs to the
+    // XCD the wave runs on (hardware XCC_ID), i.e. no line is touched by two XCDs; 18..21: the same with blockIdx % 8 instead
+    // of XCC_ID.  Instruction flags: +0 none, +1 nt, +2 sc1, +3 sc0 (returns the old value)
+    if (i >= n) return;
+    const int flag = (variant - 10) & 3, part = (variant - 10) >> 2;
+    uint32_t e = idx[i];
+    if (part) {
+      int xcc;
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+      const uint32_t own = part == 1 ? (uint32_t)(xcc & 7) : (blockIdx.x & 7u);
+      e = (e & 0xFFFFu) | (own << 16);
+    }
+    float* a = &table[2 * (size_t)e];
+    const float one = 1.0f;
+    if (flag == 0) asm volatile("global_atomic_add_f32 %0, %1, off" ::"v"(a), "v"(one) : "memory");
+    if (flag == 1) asm volatile("global_atomic_add_f32 %0, %1, off nt" ::"v"(a), "v"(one) : "memory");
+    if (flag == 2) asm volatile("global_atomic_add_f32 %0, %1, off sc1" ::"v"(a), "v"(one) : "memory");
+    if (flag == 3) { float r; asm volatile("global_atomic_add_f32 %0, %1, %2, off sc0\n\ts_waitcnt vmcnt(0)" : "=v"(r) : "v"(a), "v"(one) : "memory"); if (r == -1.0f) table[0] = r; }
+    return;
+  }
   if (i >= n) return;
   const size_t e = (variant == 2) ? (size_t)(i & 0x7FFFF) : (size_t)idx[i];
   atomicAdd(&table[2 * e], 1.0f);
@@ -60,7 +90,7 @@ __global__ __launch_bounds__(256) void k_atomic_probe(int variant, const uint32_
 }
 
 extern "C" int nof_atomic_probe(int32_t variant, const uint32_t* idx, float* table, int64_t n, void* stream) {
-  NOF_ARG(idx && table && n > 0 && variant >= 0 && variant <= 9);
+  NOF_ARG(idx && table && n > 0 && variant >= 0 && variant <= 25);
   const int64_t threads = variant == 1 ? 2 * n : n;
   hipLaunchKernelGGL(k_atomic_probe, dim3((unsigned)nof_div_up(threads, 256)), dim3(256), 0, (hipStream_t)stream, variant, idx,
                      table, n);

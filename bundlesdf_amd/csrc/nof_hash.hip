@@ -51,31 +51,52 @@ struct Scatter {
 __device__ __forceinline__ Scatter make_scatter(const HashLevel& lv, const float* __restrict__ pts_w,
                                                 const float2* __restrict__ dfeat, int level, int64_t b, int64_t B,
                                                 const float2* __restrict__ geik = nullptr, const float* __restrict__ dedn = nullptr) {
+  // straight-line code: a lane past the end or out of range (gridencoder.cu:276-281) reads sample B-1 / keeps its cell but
+  // contributes exact zeros (gradient and fractions zeroed, so nothing non-finite can leak into the wave-level sums)
   Scatter sc;
-  sc.key = 0xFFFFFFFFu;
-#pragma unroll
-  for (int k = 0; k < 8; ++k) { sc.idx[k] = 0; sc.vx[k] = 0.f; sc.vy[k] = 0.f; }
-  if (b >= B) return sc;
-  const CellPos c = locate(pts_w, b, lv.scale);
-  if (c.oob) return sc;                                              // gridencoder.cu:276-281
-  const float2 gr = dfeat[(int64_t)level * B + b];
-  sc.key = c.g[0] | (c.g[1] << 10) | (c.g[2] << 20);
+  const int64_t bb = b < B ? b : B - 1;
+  CellPos c = locate(pts_w, bb, lv.scale);
+  const bool ok = b < B && !c.oob;
+  float2 gr = dfeat[(int64_t)level * B + bb];
+  if (!ok) { gr = make_float2(0.f, 0.f); c.f[0] = c.f[1] = c.f[2] = 0.f; }
+  sc.key = ok ? (c.g[0] | (c.g[1] << 10) | (c.g[2] << 20)) : 0xFFFFFFFFu;
+  // weights: ((1 * a_x) * a_y) * a_z like the reference's loop over d (gridencoder.cu:302-312), shared partial products
+  const float ax[2] = {1.0f - c.f[0], c.f[0]}, ay[2] = {1.0f - c.f[1], c.f[1]}, az[2] = {1.0f - c.f[2], c.f[2]};
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
-    float wk = 1.0f;
-    uint32_t p[3];
-#pragma unroll
-    for (int d = 0; d < 3; ++d) {
-      if (k & (1 << d)) { wk *= c.f[d]; p[d] = c.g[d] + 1u; }
-      else              { wk *= 1.0f - c.f[d]; p[d] = c.g[d]; }
-    }
-    sc.idx[k] = grid_index(lv, p[0], p[1], p[2]);
+    const float wk = (ax[k & 1] * ay[(k >> 1) & 1]) * az[k >> 2];
     sc.vx[k] = wk * gr.x;
     sc.vy[k] = wk * gr.y;
   }
+  // rows: the same values as grid_index() per corner, with the shared terms computed once and ONE wrap test per lane
+  if (lv.hashed) {
+    const uint32_t hy0 = c.g[1] * 2654435761u, hy1 = hy0 + 2654435761u, hz0 = c.g[2] * 805459861u, hz1 = hz0 + 805459861u;
+    const uint32_t yz[4] = {hy0 ^ hz0, hy1 ^ hz0, hy0 ^ hz1, hy1 ^ hz1};
+#pragma unroll
+    for (int k = 0; k < 8; ++k) sc.idx[k] = (c.g[0] + (k & 1)) ^ yz[k >> 1];
+    if ((lv.size & (lv.size - 1u)) == 0u) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) sc.idx[k] &= lv.size - 1u;
+    } else {
+      asm volatile("" ::: "memory");                                   // a real branch: do not compute eight divisions to discard them
+#pragma unroll
+      for (int k = 0; k < 8; ++k) sc.idx[k] %= lv.size;
+    }
+  } else {
+    const uint32_t r1 = lv.res + 1u, r2 = r1 * r1;
+    const uint32_t base = c.g[0] + c.g[1] * r1 + c.g[2] * r2;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) sc.idx[k] = base + (k & 1) + ((k >> 1) & 1) * r1 + (k >> 2) * r2;
+    if (sc.idx[7] >= lv.size) {                                        // the float32 resolution quirk of exact-power levels only
+      asm volatile("" ::: "memory");
+#pragma unroll
+      for (int k = 0; k < 8; ++k) sc.idx[k] %= lv.size;
+    }
+  }
   if (geik != nullptr) {
-    const float2 ge = geik[(int64_t)level * B + b];
-    const float dn[3] = {dedn[b * 3], dedn[b * 3 + 1], dedn[b * 3 + 2]};
+    float2 ge = geik[(int64_t)level * B + bb];
+    if (!ok) ge = make_float2(0.f, 0.f);
+    const float dn[3] = {dedn[bb * 3], dedn[bb * 3 + 1], dedn[bb * 3 + 2]};
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
       float ce = 0.0f;
@@ -121,126 +142,175 @@ __device__ __forceinline__ bool wave_merge_runs(Scatter& sc) {
 
 // Merge + emission for the levels that do not fit LDS.  Measured on MI355X (tools/atomic_probe.py): fp32 atomics retire at
 // ~20.8 G line-requests/s chip-wide, lanes of ONE instruction that fall into the same 64-byte line merge into one request
-// (x/y pair in adjacent lanes: 2x; consecutive entries: 8x) and a hot line serialises (3.8 G/s).  Two consequences:
-//   * runs of adjacent lanes in the same cell are merged before anything leaves the CU.  Two merges were measured and
-//     dropped: a segmented shuffle scan (16 values x 6 steps of ds_bpermute + select + add: ~45% of the kernel's
-//     instructions and all of its LDS round-trip latency) and ds_add_f32 into one LDS slot per run (LDS float atomics
-//     retire ~1 lane per 4.5 cycles on gfx950, 92 us per level regardless of the run structure).  Instead every lane parks
-//     its 16 products in LDS with plain 16-byte stores and the run is summed by the lanes that emit it;
-//   * a run is emitted by 16 ADJACENT lanes -- [corner k][channel] with k's bit 0 = the x neighbour, whose row is
-//     idx+1 for dense levels and for even x of hashed levels (prime 1) -- i.e. 4..8 line requests per cell instead of 16
-//     (different words of one line merge into one request from anywhere in the instruction, variants 7/8 of the probe).
-//     Lane (q, e) of a wave walks the runs q, q+4, ... and adds up element e of their lanes in lane order (deterministic).
-#define AGG_STRIDE 20                                                  // floats per lane slot: 16-byte aligned, conflict-free b128
-#define AGG_ROWS 12                                                    // words per run in the row list (8 used), same reason
-struct AggStage {
-  float val[4][64 * AGG_STRIDE];                                      // [wave][lane * 20 + corner * 2 + channel]
-  uint32_t row[4][64 * AGG_ROWS];                                     // [wave][run * 12 + corner]
-  uint32_t span[4][64];                                               // [wave][run] = first lane | (length << 8)
-};
-
-struct Rows8 {
-  uint32_t r[8];
-};
-__device__ __forceinline__ Rows8 load_rows(const uint32_t* p) {
-  const uint4 a = *reinterpret_cast<const uint4*>(p), b = *reinterpret_cast<const uint4*>(p + 4);
-  Rows8 o;
-  o.r[0] = a.x; o.r[1] = a.y; o.r[2] = a.z; o.r[3] = a.w; o.r[4] = b.x; o.r[5] = b.y; o.r[6] = b.z; o.r[7] = b.w;
-  return o;
-}
-__device__ __forceinline__ uint32_t match_mask(const Rows8& rs, uint32_t row) {
-  uint32_t m = 0;
-#pragma unroll
-  for (int k = 0; k < 8; ++k) m |= (rs.r[k] == row ? 1u : 0u) << k;
-  return m;
-}
-
-// A third measured fact shapes the last step: lanes of one instruction that hit the SAME ADDRESS are not merged (4 lanes on
-// one word cost 4 requests, tools/atomic_probe.py variant 6), and consecutive cells along a ray share a face, i.e. 4 of
-// their 8 table rows.  So rows are de-duplicated across the runs of a wave before emission: the first run of a chain of
-// consecutive runs containing a row owns it and adds up the chain's contributions (exact for any collision pattern: a
-// run that also lists the row earlier in itself, or whose predecessor lists it, is not an owner).
+// (x/y pair in adjacent lanes: 2x; consecutive entries: 8x), lanes that hit the SAME word do not merge, and a hot line
+// serialises (3.8 G/s).  The kernel therefore cuts the number of requests on the CU before anything leaves it:
+//   1. lanes of a wave are consecutive samples of ONE ray, so lanes in the same cell form contiguous RUNS (cfg2: 3..15
+//      samples per run at the hashed levels).  The 16 products of a lane are summed over its run by a segmented inclusive
+//      scan in REGISTERS: DPP row shifts (1, 2, 4, 8) inside the 16-lane rows, then row_bcast:15 / row_bcast:31 across rows,
+//      one v_fmac per value and step with a 0/1 lane mask (`distance to the run's first lane >= reach of the step`).  The
+//      last lane of a run ends up with the run's totals; the summation tree depends on lane positions only (deterministic).
+//      Rounds 1-2 parked all 64 lanes' products in LDS and summed them there: that, not the atomics, was what the kernel
+//      waited for;
+//   2. only those last lanes write to LDS: 16 totals, 8 table rows and the cell id per run;
+//   3. a run is emitted by 16 ADJACENT lanes -- [corner k][channel], k's bit 0 = the x neighbour, whose row is idx+1 for
+//      dense levels and for even x of hashed levels (prime 1) -- i.e. 4..5 line requests per cell instead of 16;
+//   4. consecutive cells along a ray share a face (4 of their 8 grid vertices), and same-word lanes do not merge, so a
+//      vertex is emitted once per CHAIN of consecutive runs whose cells contain it: corner (m, k) hands its total on when the
+//      vertex also belongs to the cell of run m+1, otherwise it collects runs m-1, m-2, ... while their cells contain the
+//      vertex, and emits.  The test is geometric (cell ids), not a comparison of table rows: any partition of the
+//      contributions into atomics is exact, so hash collisions need no special case -- they are simply separate atomics.
 // Every LDS region of the stage is private to one wave and a wave's LDS instructions execute in order, so the phases are
 // separated by compiler-only fences (no workgroup barrier), and the kernel is PERSISTENT per wave: a wave that has issued
-// the atomics of one (64 samples, level) tile goes straight on to the next tile while the memory side retires them.  With
-// one tile per workgroup the waves piled up in the emission phase holding their LDS (4 workgroups/CU), compute and atomics
-// ran back to back (575 us = 256 us with plain stores + ~330 us of atomic time) instead of overlapped.
+// the atomics of one (64 samples, level) tile goes straight on to the next tile while the memory side retires them.
+#define AGG_RUNS 32                                                    // runs per emission window (a tile has up to 64: two windows)
+#define AGG_STRIDE 20                                                  // floats per run slot: 16-byte aligned, conflict-free b128
+#define AGG_NONE 0xFFFFFFFFu
+struct AggStage {
+  float val[4][AGG_RUNS * AGG_STRIDE];                                // [wave][run * 20 + corner * 2 + channel]
+  uint32_t row[4][AGG_RUNS * 8];                                      // [wave][run * 8 + corner]
+  uint2 link[4][AGG_RUNS];                                            // [wave][run]: how the run's corners chain to its neighbours
+  uint32_t key[4][AGG_RUNS];                                          // [wave][run]: cell id (only read by chains of >= 4 cells)
+};
+
+// One step of the scan: v += take * v[lane the DPP control points at], for the 16 values of a lane.  v_fmac_f32 takes its
+// first factor through DPP; lanes without a source lane (row edge, rows outside row_mask) are not written, i.e. add nothing.
+// Written as assembly because the compiler does not fold update_dpp into v_fmac (it emits v_mov_dpp + v_fmac, twice the
+// instructions).  s_nop 4 covers the VALU-write -> DPP-read (2 wait states) and EXEC-write -> DPP (5) hazards the
+// assembler cannot see across the statement boundary; inside the block every instruction reads a register written >= 16
+// instructions earlier.
+#define AGG_F(i, ctrl) "v_fmac_f32_dpp %" #i ", %" #i ", %16 " ctrl "\n\t"
+#define AGG_SCAN_STEP(sc, take, ctrl)                                                                                    \
+  asm volatile("s_nop 4\n\t" AGG_F(0, ctrl) AGG_F(1, ctrl) AGG_F(2, ctrl) AGG_F(3, ctrl) AGG_F(4, ctrl) AGG_F(5, ctrl)     \
+               AGG_F(6, ctrl) AGG_F(7, ctrl) AGG_F(8, ctrl) AGG_F(9, ctrl) AGG_F(10, ctrl) AGG_F(11, ctrl) AGG_F(12, ctrl) \
+               AGG_F(13, ctrl) AGG_F(14, ctrl) AGG_F(15, ctrl)                                                            \
+               : "+v"(sc.vx[0]), "+v"(sc.vy[0]), "+v"(sc.vx[1]), "+v"(sc.vy[1]), "+v"(sc.vx[2]), "+v"(sc.vy[2]),          \
+                 "+v"(sc.vx[3]), "+v"(sc.vy[3]), "+v"(sc.vx[4]), "+v"(sc.vy[4]), "+v"(sc.vx[5]), "+v"(sc.vy[5]),          \
+                 "+v"(sc.vx[6]), "+v"(sc.vy[6]), "+v"(sc.vx[7]), "+v"(sc.vy[7])                                            \
+               : "v"(take))
+
+// Which of the 8 corners of cell `key` are also vertices of cell `other`, and by how much their corner number shifts there
+// (corner k of `key` is corner k - shift of `other`).  Per axis the cells differ by delta: 0 -> every corner, +1 -> the
+// corners with that axis bit set, -1 -> those with it clear, anything else -> none.
+__device__ __forceinline__ uint32_t shared_corners(uint32_t key, uint32_t other, int& shift) {
+  const uint32_t dx = (other & 1023u) - (key & 1023u) + 1u, dy = ((other >> 10) & 1023u) - ((key >> 10) & 1023u) + 1u,
+                 dz = ((other >> 20) & 1023u) - ((key >> 20) & 1023u) + 1u;   // delta + 1 in 0..2 when the cells touch
+  shift = (int)(dx + 2u * dy + 4u * dz) - 7;
+  const uint32_t m = (0xAAFF55u >> (8u * dx)) & (0xCCFF33u >> (8u * dy)) & (0xF0FF0Fu >> (8u * dz)) & 0xFFu;
+  return (other != AGG_NONE && max(dx, max(dy, dz)) < 3u) ? m : 0u;
+}
+
+// does the cell `key` contain grid vertex (vx, vy, vz)?  kk = the vertex's corner number in that cell
+__device__ __forceinline__ bool cell_has(uint32_t key, uint32_t vx, uint32_t vy, uint32_t vz, int& kk) {
+  const uint32_t dx = vx - (key & 1023u), dy = vy - ((key >> 10) & 1023u), dz = vz - ((key >> 20) & 1023u);
+  kk = (int)(dx | (dy << 1) | (dz << 2));
+  return key != AGG_NONE && (dx | dy | dz) < 2u;
+}
+
 __device__ __forceinline__ void wave_lds_sync() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+template <bool EIK>
 __global__ __launch_bounds__(256) void k_hash_bwd_agg(NofHashGrid g, LevelList ll, const float* __restrict__ pts_w,
                                                        const float2* __restrict__ dfeat, float* __restrict__ grad_table,
                                                        int64_t B, const float2* __restrict__ geik, const float* __restrict__ dedn) {
   __shared__ __attribute__((aligned(16))) AggStage st;
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int64_t n_tiles = ((B + 63) / 64) * ll.n;                     // (64 samples, level) tiles, level fastest
-  const int64_t n_waves = (int64_t)gridDim.x * 4;
-  for (int64_t tile = (int64_t)blockIdx.x * 4 + w; tile < n_tiles; tile += n_waves) {
-  const int level = ll.level[tile % ll.n];
-  const int64_t b = (tile / ll.n) * 64 + lane;
-  const HashLevel lv = load_level(g, level);
-  const Scatter sc = make_scatter(lv, pts_w, dfeat, level, b, B, geik, dedn);
-  const bool valid = sc.key != 0xFFFFFFFFu;
-  const uint32_t prev = __shfl_up(sc.key, 1, 64);
-  const bool head = valid && (lane == 0 || prev != sc.key);           // lanes are consecutive samples of one ray
-  const unsigned long long heads = __ballot(head);
-  const unsigned long long breaks = heads | ~__ballot(valid);         // a run ends before the next head or invalid lane
-  const int nl = __popcll(heads);
+  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   float* val = st.val[w];
   uint32_t* row = st.row[w];
-  float4* v4 = reinterpret_cast<float4*>(&val[lane * AGG_STRIDE]);
-#pragma unroll
-  for (int k = 0; k < 4; ++k) v4[k] = make_float4(sc.vx[2 * k], sc.vy[2 * k], sc.vx[2 * k + 1], sc.vy[2 * k + 1]);
-  if (head) {
-    const int slot = __popcll(heads & ((1ull << lane) - 1ull));
-    const unsigned long long after = lane == 63 ? 0ull : (breaks >> (lane + 1));
-    const int len = after ? __builtin_ctzll(after) + 1 : 64 - lane;
-    st.span[w][slot] = (uint32_t)lane | ((uint32_t)len << 8);
-    uint4* r4 = reinterpret_cast<uint4*>(&row[slot * AGG_ROWS]);
-    r4[0] = make_uint4(sc.idx[0], sc.idx[1], sc.idx[2], sc.idx[3]);
-    r4[1] = make_uint4(sc.idx[4], sc.idx[5], sc.idx[6], sc.idx[7]);
-  }
-  wave_lds_sync();
-  // phase 1: lane (q, e) sums element e over the lanes of runs q, q+4, ... (lane order); the total replaces the head's slot
-  const int e = lane & 15, q = lane >> 4;
-  for (int m = q; m < nl; m += 4) {
-    const uint32_t sp = st.span[w][m];
-    float* src = &val[(sp & 0xFF) * AGG_STRIDE + e];
-    const int len = (int)(sp >> 8);
-    float acc = src[0];
-    for (int i = 1; i < len; ++i) acc += src[i * AGG_STRIDE];
-    if (len > 1) src[0] = acc;
-  }
-  wave_lds_sync();
-  // phase 2: row owners collect their chain and emit
-  float* __restrict__ gt = grad_table + 2 * (size_t)lv.offset;
-  const int k = e >> 1, ch = e & 1;
-  for (int m = q; m < nl; m += 4) {
-    const Rows8 mine = load_rows(&row[m * AGG_ROWS]);
-    const uint32_t r = row[m * AGG_ROWS + k];
-    uint32_t mm = match_mask(mine, r);
-    bool owner = (mm & ((1u << k) - 1u)) == 0u;                       // no earlier corner of this run has the same row
-    if (m > 0 && match_mask(load_rows(&row[(m - 1) * AGG_ROWS]), r) != 0u) owner = false;
-    if (!owner) continue;
-    float acc = 0.0f;
-    int j = m;
-    while (true) {
-      const float* sv = &val[(st.span[w][j] & 0xFF) * AGG_STRIDE + ch];
-      while (mm) {
-        const int kk = __builtin_ctz(mm);
-        mm &= mm - 1u;
-        acc += sv[2 * kk];
-      }
-      if (++j >= nl) break;
-      mm = match_mask(load_rows(&row[j * AGG_ROWS]), r);
-      if (mm == 0u) break;
+  uint2* link = st.link[w];
+  uint32_t* keys = st.key[w];
+  const int e = lane & 15, q = lane >> 4, k = e >> 1, ch = e & 1;
+  const unsigned long long le = (2ull << lane) - 1ull;                // lanes 0..lane
+  // (64 samples, level) tiles, level fastest; tile = block * 4 + wave, then + gridDim * 4 per round -- kept as (sample block,
+  // level slot) with a carry instead of dividing every round
+  const uint32_t n_lv = (uint32_t)ll.n, n_sb = (uint32_t)((B + 63) / 64), n_waves = gridDim.x * 4u;
+  const uint32_t t0 = blockIdx.x * 4u + (uint32_t)w, dq = n_waves / n_lv, dr = n_waves % n_lv;
+  uint32_t sb = t0 / n_lv, slot_l = t0 % n_lv;
+  for (; sb < n_sb; sb += dq, slot_l += dr, sb += slot_l >= n_lv ? 1u : 0u, slot_l -= slot_l >= n_lv ? n_lv : 0u) {
+    const int level = ll.level[slot_l];
+    const int64_t b = (int64_t)sb * 64 + lane;
+    const HashLevel lv = load_level(g, level);
+    Scatter sc = make_scatter(lv, pts_w, dfeat, level, b, B, EIK ? geik : nullptr, EIK ? dedn : nullptr);
+    const bool valid = sc.key != AGG_NONE;
+    // neighbours' cells through ds_bpermute (the DPP wavefront shifts do not cross the 16-lane rows on gfx950)
+    const uint32_t kpv = (uint32_t)__builtin_amdgcn_ds_bpermute((lane - 1) << 2, (int)sc.key);
+    const uint32_t knx = (uint32_t)__builtin_amdgcn_ds_bpermute((lane + 1) << 2, (int)sc.key);
+    const uint32_t kprev = lane > 0 ? kpv : AGG_NONE, knext = lane < 63 ? knx : AGG_NONE;
+    const bool head = valid && kprev != sc.key;                       // lanes are consecutive samples of one ray
+    const bool tail = valid && knext != sc.key;
+    const unsigned long long heads = __ballot(head);
+    const int nl = __popcll(heads);
+    if (nl == 0) continue;
+    // 1. run totals in registers
+    const int dist = lane - (63 - __builtin_clzll((heads & le) | 1ull));   // distance to the run's first lane (valid lanes)
+    const float t1 = dist >= 1 ? 1.0f : 0.0f, t2 = dist >= 2 ? 1.0f : 0.0f, t4 = dist >= 4 ? 1.0f : 0.0f,
+                t8 = dist >= 8 ? 1.0f : 0.0f, t15 = dist > (lane & 15) ? 1.0f : 0.0f, t31 = dist >= lane - 31 ? 1.0f : 0.0f;
+    AGG_SCAN_STEP(sc, t1, "row_shr:1 row_mask:0xf bank_mask:0xf");
+    AGG_SCAN_STEP(sc, t2, "row_shr:2 row_mask:0xf bank_mask:0xf");
+    if (__ballot(valid && dist >= 4)) {
+      AGG_SCAN_STEP(sc, t4, "row_shr:4 row_mask:0xf bank_mask:0xf");
+      if (__ballot(valid && dist >= 8)) AGG_SCAN_STEP(sc, t8, "row_shr:8 row_mask:0xf bank_mask:0xf");
     }
-    atomicAdd(&gt[2 * (size_t)r + ch], acc);                          // gridencoder.cu:317-333 (fp32 atomics)
-  }
-  wave_lds_sync();                                                    // the next tile overwrites the stage
+    AGG_SCAN_STEP(sc, t15, "row_bcast:15 row_mask:0xa bank_mask:0xf");   // lane 15 / 47 into rows 1 / 3
+    AGG_SCAN_STEP(sc, t31, "row_bcast:31 row_mask:0xc bank_mask:0xf");   // lane 31 into rows 2, 3
+    // 2. how a run chains to the runs next to it (lane-adjacent runs only: an out-of-range sample breaks the chain).  The
+    //    cell before the run's first lane and the one before that come through ds_bpermute.
+    const int hd = lane - dist;                                       // first lane of this lane's run
+    const uint32_t pk = (uint32_t)__builtin_amdgcn_ds_bpermute((hd - 1) << 2, (int)(sc.key));
+    const int pd = __builtin_amdgcn_ds_bpermute((hd - 1) << 2, dist);
+    const uint32_t kp1 = hd > 0 ? pk : AGG_NONE;
+    const int hd1 = hd - 1 - pd;                                      // first lane of the previous run
+    const uint32_t ppk = (uint32_t)__builtin_amdgcn_ds_bpermute((hd1 - 1) << 2, (int)(sc.key));
+    const uint32_t kp2 = (kp1 != AGG_NONE && hd1 > 0) ? ppk : AGG_NONE;
+    int sh0, sh1, sh2;
+    uint32_t hand_on = shared_corners(sc.key, knext, sh0);            // corners the next run's chain takes
+    uint32_t take1 = shared_corners(sc.key, kp1, sh1);                // corners that collect the previous run ...
+    uint32_t take2 = take1 & shared_corners(sc.key, kp2, sh2);        // ... and the one before it
+    const int slot = __popcll(heads & le) - 1;
+    float* __restrict__ gt = grad_table + 2 * (size_t)lv.offset;
+    for (int base = 0; base < nl; base += AGG_RUNS) {
+      const int cnt = nl - base < AGG_RUNS ? nl - base : AGG_RUNS;
+      // 3. the runs of this window (a window edge breaks the chains, too)
+      if (tail && slot >= base && slot < base + AGG_RUNS) {
+        const int s = slot - base;
+        float4* v4 = reinterpret_cast<float4*>(&val[s * AGG_STRIDE]);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) v4[c] = make_float4(sc.vx[2 * c], sc.vy[2 * c], sc.vx[2 * c + 1], sc.vy[2 * c + 1]);
+        uint4* r4 = reinterpret_cast<uint4*>(&row[s * 8]);
+        r4[0] = make_uint4(sc.idx[0], sc.idx[1], sc.idx[2], sc.idx[3]);
+        r4[1] = make_uint4(sc.idx[4], sc.idx[5], sc.idx[6], sc.idx[7]);
+        const uint32_t ho = s == cnt - 1 ? 0u : hand_on, c1 = s == 0 ? 0u : take1, c2 = s <= 1 ? 0u : take2;
+        link[s] = make_uint2(ho | (c1 << 8) | (c2 << 16), (uint32_t)(sh1 + 16) | ((uint32_t)(sh2 + 16) << 8));
+        keys[s] = sc.key;
+      }
+      wave_lds_sync();
+      // 4. lane (q, e) emits element e = (corner, channel) of runs q, q+4, ...; 16 adjacent lanes = one run
+      for (int m = q; m < cnt; m += 4) {
+        const uint2 lk = link[m];
+        const uint32_t r = row[m * 8 + k];
+        float acc = val[m * AGG_STRIDE + e];
+        if ((lk.x >> k) & 1u) continue;                               // the next run's chain takes it
+        if ((lk.x >> (8 + k)) & 1u) {
+          acc += val[(m - 1) * AGG_STRIDE + 2 * (k - (int)(lk.y & 255u) + 16) + ch];
+          if ((lk.x >> (16 + k)) & 1u) {
+            acc += val[(m - 2) * AGG_STRIDE + 2 * (k - (int)(lk.y >> 8) + 16) + ch];
+            const uint32_t km = keys[m];                              // four or more cells around one vertex: rare
+            const uint32_t vx = (km & 1023u) + (k & 1), vy = ((km >> 10) & 1023u) + ((k >> 1) & 1), vz = ((km >> 20) & 1023u) + (k >> 2);
+            for (int j = m - 3; j >= 0; --j) {
+              int kk;
+              if (!cell_has(keys[j], vx, vy, vz, kk)) break;
+              if (!((link[j].x >> kk) & 1u)) break;                   // (j, kk) did not hand on: it emitted by itself
+              acc += val[j * AGG_STRIDE + 2 * kk + ch];
+            }
+          }
+        }
+        atomicAdd(&gt[2 * (size_t)r + ch], acc);                      // gridencoder.cu:317-333 (fp32 atomics)
+      }
+      wave_lds_sync();                                                // the next window / tile overwrites the stage
+    }
   }
 }
 
@@ -485,11 +555,23 @@ extern "C" int nof_hash_encode_bwd_eik(const NofHashGrid* g, const float* pts_w,
     NOF_HIP(hipStreamWaitEvent(s2, side->fork, 0));
   }
   if (big.n > 0) {
-    int64_t blocks = nof_div_up(nof_div_up(B, 64) * big.n, 4);        // persistent: at most 4 workgroups per CU (LDS)
-    const int64_t cap = 4ll * nof_cu_count();
+    // persistent waves, 2 workgroups per CU: the kernel is bound by the atomic rate of the memory side, which a
+    // few waves per CU saturate; more of them only take L2 bandwidth and CU slots from k_hash_dx / k_hash_bwd_lds running
+    // beside it (cfg2, whole call: 1 -> 646 us, 2 -> 439, 3 -> 474, 4 -> 525, 8 -> 537).  NOF_SCATTER_WGS_PER_CU overrides.
+    int64_t blocks = nof_div_up(nof_div_up(B, 64) * big.n, 4);
+    static const int wgs_per_cu = [] {
+      const char* e = getenv("NOF_SCATTER_WGS_PER_CU");
+      const int v = e ? atoi(e) : 2;
+      return v >= 1 && v <= 10 ? v : 2;
+    }();
+    const int64_t cap = (int64_t)wgs_per_cu * nof_cu_count();
     if (blocks > cap) blocks = cap;
-    hipLaunchKernelGGL(k_hash_bwd_agg, dim3((unsigned)blocks), dim3(256), 0, st, *g, big, pts_w, (const float2*)dfeat,
-                       grad_table, B, geik, dedn);
+    if (geik != nullptr)
+      hipLaunchKernelGGL(k_hash_bwd_agg<true>, dim3((unsigned)blocks), dim3(256), 0, st, *g, big, pts_w, (const float2*)dfeat,
+                         grad_table, B, geik, dedn);
+    else
+      hipLaunchKernelGGL(k_hash_bwd_agg<false>, dim3((unsigned)blocks), dim3(256), 0, st, *g, big, pts_w, (const float2*)dfeat,
+                         grad_table, B, geik, dedn);
     NOF_LAUNCH_OK();
   }
   if (dpts) {

@@ -38,3 +38,17 @@ run1('6 same ADDRESS, lanes 16 apart, 16 lines/instr', 6, idx_rand)
 run1('7 same line diff words, lanes 16 apart, 16 lines/instr', 7, idx_rand)
 run1('8 same line diff words, adjacent lanes, 16 lines/instr', 8, idx_rand)
 run1('9 plain 4-byte stores, random entries (64 lines/instr)', 9, idx_rand)
+
+# round 2: does the place where the atomic executes depend on instruction flags / on keeping a line inside one XCD?
+def run2(name, variant):
+    for rep in range(3):
+        table.zero_()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(); lib.call('nof_atomic_probe', variant, idx_rand, table, n); b.record(); torch.cuda.synchronize()
+    ms = a.elapsed_time(b)
+    print(f'{name:62s} {ms:8.3f} ms  {n / ms / 1e6:8.1f} G line-requests/s  sum={table.sum().item():.0f}')
+for part, pn in enumerate(['random entries over the whole table', 'entries folded into the XCD-owned eighth (XCC_ID)', 'entries folded by blockIdx % 8']):
+    for flag, fn in enumerate(['plain', 'nt', 'sc1', 'sc0 (returning)']):
+        run2(f'{10 + 4 * part + flag} x only, {pn}, {fn}', 10 + 4 * part + flag)
+for v, nm in ((22, 'u32 add'), (23, 'u64 add'), (24, 'f64 add'), (25, 'packed f16 add')):
+    run2(f'{v} random entries, {nm}', v)
