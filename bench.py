@@ -308,9 +308,8 @@ def main():
             'nof_mlp_wide_bwd': ('mfma', B * 2.0 * fl_fwd),           # no recompute on the wide path: data + weight gradients
             'nof_adam_step': ('hbm', fld.n_total * 32.0),
         }
-        # the entry point also computes dL/dx (k_hash_dx, gridencoder.cu:202-245,340-365) on a side stream: 8 gathers per level
-        # + coordinates in, gradient out = 1048 B/sample more than SURVEY 8d's scatter-only figure
-        extra_bytes = {'nof_hash_encode_bwd': B * (16 * 8 * 2 * 4 + 12 + 12)}
+        # (dL/dx -- k_hash_dx, 1048 B/sample -- is its own launch on the step's second stream and is not part of this figure)
+        extra_bytes = {}
         traffic = None          # HBM bytes per launch from the committed PMC passes (profiles/pmc_traffic.json), same workload only
         try:
             if args.mlp == 'baseline' and R == 4096 and args.log2_T == 19:

@@ -202,7 +202,7 @@ class NeuralObjectField:
             self._bufs[key] = dict(
                 batch=e(R, 12), rays_o_w=e(R, 3), viewdirs_w=e(R, 3), view=e(R, 16), t_in_out=e(R, self.max_hits, 2),
                 n_hits=e(R, dt=torch.int32), z_vals=e(R, S), pts_w=e(B, 3), valid=e(B, dt=torch.uint8),
-                feat=e(self.L, B, 2), raw=e(B, 4), draw=e(B, 4), dfeat=e(self.L, B, 2), dview=e(R, 16), dpts=e(B, 3),
+                feat=e(self.L, B, 2), raw=e(B, 4), draw=e(B, 4), dfeat=e(self.L, B, 2), dview=torch.zeros(R, 16, device=d), dpts=e(B, 3),
                 rgb_map=e(R, 3), partials=e(self.nblk, self.n_mlp), loss_rows=e(R, 8), g_ray=e(R, 12),
                 # sigma-head output / its gradient in MFMA operand precision: the hand-off of the split MLP backward
                 sig=e(B, 16, dt=torch.int16) if self.desc.precision != 0 and not self.wide else None,
@@ -212,6 +212,11 @@ class NeuralObjectField:
                 geik=e(self.L, B, 2) if self.eikonal else None, dedn=e(B, 3) if self.eikonal else None,
                 partials_e=torch.zeros(self.nblk, self.n_mlp, device=d) if self.eikonal else None)
         return self._bufs[key]
+
+    def _side_stream(self):
+        if getattr(self, '_side', None) is None:
+            self._side = torch.cuda.Stream(device=self.device)
+        return self._side
 
     def _sample_cfg(self, seed, step, dyn=False):
         cfg = self.cfg
@@ -294,15 +299,13 @@ class NeuralObjectField:
         self.loss_out.zero_()
         self._call('nof_composite_loss', C.byref(lc), b['raw'], b['z_vals'], b['valid'], b['batch'], R, S, b['rgb_map'],
                  None, b['draw'], b['loss_rows'], self.loss_out)
-        b['dview'].zero_()
-        self._set_grad_scale(B)
+        self._set_grad_scale(B)                    # (dview is zero: allocated so, and re-zeroed after its last use in every step)
         if self.wide:
             self._call('nof_mlp_wide_bwd', C.byref(self.desc), self.packed, b['feat'], self.L, b['view'], S, b['draw'],
                        b['wide_ws'], b['dfeat'], b['dview'], b['partials'], B)
         else:
             self._call('nof_mlp_bwd', C.byref(self.desc), self.packed, b['feat'], self.L, b['view'], S, b['draw'], b['sig'],
                        b['dsig'], b['dfeat'], b['dview'], b['partials'], B)
-        self._call('nof_reduce_partials', b['partials'], self.nblk, self.n_mlp, self._seg(self.grads, 'mlp'))
         geik = dedn = None
         if self.eikonal:
             # nerf_runner.py:734-738: mean over the samples with sdf < 1 (their number stays on the device)
@@ -310,36 +313,68 @@ class NeuralObjectField:
             self._call('nof_eikonal', C.byref(self.desc32), self.packed32, C.byref(self.grid), self.table, b['pts_w'], b['valid'],
                        n_sel, C.c_float(cfg['eikonal_weight']), C.c_float(1.0 / self.world_size), b['geik'], b['dedn'],
                        b['partials_e'], self.loss_out, B)
-            self._call('nof_reduce_partials', b['partials_e'], self.nblk, self.n_mlp, self._seg(self.grads, 'mlp'))
             geik, dedn = b['geik'], b['dedn']
         dpts = b['dpts'] if self.optimize_poses else None
         gtab = self._seg(self.grads, 'table')
         hashed = [l for l in range(self.L) if self.grid.hashed[l]]
         split = hashed[0] if hashed and 0 < hashed[0] < self.L else None
         bucketed = grad_sync is not None and hasattr(grad_sync, 'start') and split is not None
+
+        def reduce_mlp():
+            self._call('nof_reduce_partials', b['partials'], self.nblk, self.n_mlp, self._seg(self.grads, 'mlp'))
+            if self.eikonal:
+                self._call('nof_reduce_partials', b['partials_e'], self.nblk, self.n_mlp, self._seg(self.grads, 'mlp'))
+
+        def scatter(dx, lo, hi):
+            """table gradient of levels [lo, hi) (+ dL/dx over all levels on the call's internal stream when dx is given)"""
+            if self.eikonal:
+                self._call('nof_hash_encode_bwd_eik', C.byref(self.grid), b['pts_w'], self.table, b['dfeat'], geik, dedn, gtab, dx,
+                           lo, hi, B)
+            elif (lo, hi) == (0, self.L):
+                self._call('nof_hash_encode_bwd', C.byref(self.grid), b['pts_w'], self.table, b['dfeat'], gtab, dx, B)
+            else:
+                self._call('nof_hash_encode_bwd_levels', C.byref(self.grid), b['pts_w'], self.table, b['dfeat'], gtab, dx, lo, hi, B)
+
+        def pose_kernels():
+            if self.optimize_poses or self.ff > 0:
+                if self.optimize_poses:
+                    self._call('nof_pose_grad_accum', b['dpts'], b['dview'], b['batch'], b['z_vals'], self.c2w, self.tf, self.ff,
+                               self.sh_degree, R, S, b['g_ray'])
+                self._call('nof_pose_reduce_bwd', self.pose if self.optimize_poses else None,
+                           b['g_ray'] if self.optimize_poses else None, b['dview'], b['batch'], R, self.ff,
+                           C.c_float(self.max_trans), C.c_float(self.max_rot),
+                           self._seg(self.grads, 'pose') if self.optimize_poses else None,
+                           self._seg(self.grads, 'feat') if self.ff > 0 else None, None, self.F)
+            b['dview'].zero_()                       # for the next step's atomics
+
         if bucketed:
             # data parallel: the fine (hashed) levels first; their slice [rows of level `split` .., MLP] of the flat gradient
             # buffer (80 % of its bytes at cfg2) is all-reduced while the coarse levels, dL/dx and the pose kernels still run
+            reduce_mlp()
             a = 2 * int(self.offsets[split])
-            self._call('nof_hash_encode_bwd_eik', C.byref(self.grid), b['pts_w'], self.table, b['dfeat'], geik, dedn, gtab, None,
-                       split, self.L, B)
+            scatter(None, split, self.L)
             grad_sync.start(self.grads[a:self.n_table + self.n_mlp])
-            self._call('nof_hash_encode_bwd_eik', C.byref(self.grid), b['pts_w'], self.table, b['dfeat'], geik, dedn, gtab, dpts,
-                       0, split, B)
-        elif self.eikonal:
-            self._call('nof_hash_encode_bwd_eik', C.byref(self.grid), b['pts_w'], self.table, b['dfeat'], geik, dedn, gtab, dpts,
-                       0, self.L, B)
+            scatter(dpts, 0, split)
+            pose_kernels()
+        elif dyn:
+            # captured step: one chain (a second branch in the HIP graph costs more than the overlap returns)
+            reduce_mlp()
+            scatter(dpts, 0, self.L)
+            pose_kernels()
         else:
-            self._call('nof_hash_encode_bwd', C.byref(self.grid), b['pts_w'], self.table, b['dfeat'], gtab, dpts, B)
-        if self.optimize_poses or self.ff > 0:
-            if self.optimize_poses:
-                self._call('nof_pose_grad_accum', b['dpts'], b['dview'], b['batch'], b['z_vals'], self.c2w, self.tf, self.ff,
-                           self.sh_degree, R, S, b['g_ray'])
-            self._call('nof_pose_reduce_bwd', self.pose if self.optimize_poses else None,
-                       b['g_ray'] if self.optimize_poses else None, b['dview'], b['batch'], R, self.ff,
-                       C.c_float(self.max_trans), C.c_float(self.max_rot),
-                       self._seg(self.grads, 'pose') if self.optimize_poses else None,
-                       self._seg(self.grads, 'feat') if self.ff > 0 else None, None, self.F)
+            # The table scatter is bound by the atomic rate of the memory side and is the longest launch of the step; the MLP
+            # partial-row reduction, dL/dx (an empty level range: k_hash_dx only) and the pose / frame-feature gradients that hang
+            # off it are independent of it and run beside it on a second stream (fork / join by events).
+            main = torch.cuda.current_stream()
+            side = self._side_stream()
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                reduce_mlp()
+                if dpts is not None:
+                    scatter(dpts, 0, 0)
+                pose_kernels()
+            scatter(None, 0, self.L)
+            main.wait_stream(side)
         if self.optimize_poses and float(cfg.get('pose_reg_weight', 0)) > 0:
             self._call('nof_pose_reg', self.pose, self._seg(self.grads, 'pose'), self.F, C.c_float(cfg['pose_reg_weight']),
                        C.c_float(1.0 / self.world_size), self.loss_out)
