@@ -228,14 +228,16 @@ __device__ __forceinline__ void dense_o1(const char* smem, int frag_off, int bia
   }
 }
 
-// ReLU in place + the derivative mask for the backward, without compares: bit (16 p + r) of the result is the SIGN bit of the
-// pre-activation (1 = the unit is off).  Per element: one shift, one shift-or, one max -- and no SGPR lane masks (32 v_cmp
-// results per block spilled the scalar file in the backward kernels).  A pre-activation of exactly +0.0 counts as on (its
-// output is 0 either way; PyTorch's relu'(0) = 0 differs only there, a measure-zero event for trained units).
-// NOTE on the inline asm: hipcc's hazard recogniser does not know an asm statement is a VALU instruction, so an asm must never
-// be the FIRST reader of an MFMA result (the required wait states would be missing: measured as 30 % wrong dfeat in one
-// instance).  The asm statements below only read values produced by ordinary VALU instructions; what touches h / g directly
-// is plain C++.  The asm is there because the compiler rewrites the C++ form of the bit tricks back into v_cmp + v_cndmask.
+// ReLU in place + the derivative mask for the backward, without compares and without SGPR lane masks (32 v_cmp results per
+// block spilled the scalar file in the backward kernels).  Per element two instructions: v_alignbit shifts the SIGN bit of the
+// pre-activation into the mask ({mask, h} >> 31 = mask << 1 | sign), and the ReLU itself is a signed-INTEGER max with 0 on the
+// float's bits (negative floats are negative integers; -0.0 -> +0.0; no canonicalising second v_max as fmaxf needs on an MFMA
+// result).  Element i = 16 p + r of n = 16 PN therefore sits at bit n-1-i; the mask is returned inverted (1 = the unit is ON).
+// A pre-activation of exactly +0.0 counts as on (its output is 0 either way; PyTorch's relu'(0) = 0 differs only there, a
+// measure-zero event for trained units).
+// NOTE on inline asm: hipcc's hazard recogniser does not know an asm statement is a VALU instruction, so an asm must never be
+// the FIRST reader of an MFMA result (the required wait states would be missing: measured as 30 % wrong dfeat in one
+// instance).  Everything that touches h / g directly is a builtin or plain C++; the asm in apply_mask only reads the mask.
 template <int PN>
 __device__ __forceinline__ uint32_t relu_mask(float (&h)[PN][16]) {
   uint32_t off = 0;
@@ -243,21 +245,22 @@ __device__ __forceinline__ uint32_t relu_mask(float (&h)[PN][16]) {
   for (int p = 0; p < PN; ++p)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const uint32_t t = __float_as_uint(h[p][r]) >> 31;
-      asm("v_lshl_or_b32 %0, %1, %2, %0" : "+v"(off) : "v"(t), "n"(p * 16 + r));
-      h[p][r] = fmaxf(h[p][r], 0.0f);
+      const int bits = __float_as_int(h[p][r]);
+      const uint32_t t = (uint32_t)bits >> 31;
+      asm("v_lshl_or_b32 %0, %1, %2, %0" : "+v"(off) : "v"(t), "n"(16 * PN - 1 - (p * 16 + r)));
+      h[p][r] = __int_as_float(bits > 0 ? bits : 0);
     }
-  return off;
+  return ~off;
 }
-// g = unit off ? 0 : g   (sign-extended bit field = all-ones where off, then and-not)
+// g = unit on ? g : 0   (sign-extended one-bit field = all-ones where on, then and)
 template <int PN>
-__device__ __forceinline__ void apply_mask(float (&g)[PN][16], uint32_t off) {
+__device__ __forceinline__ void apply_mask(float (&g)[PN][16], uint32_t on) {
 #pragma unroll
   for (int p = 0; p < PN; ++p)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       uint32_t keep;                                                  // all-ones where the unit is on
-      asm("v_bfe_i32 %0, %1, %2, 1\n\tv_not_b32 %0, %0" : "=v"(keep) : "v"(off), "n"(p * 16 + r));
+      asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(keep) : "v"(on), "n"(16 * PN - 1 - (p * 16 + r)));
       g[p][r] = __uint_as_float(__float_as_uint(g[p][r]) & keep);
     }
 }

@@ -318,3 +318,108 @@ def test_reference_checkpoint_carries_a_loadable_adam_state():
     assert ck.load_reference_checkpoint(g, data) == 37
     assert g.global_step == 37
     assert torch.equal(g.params, f.params) and torch.equal(g.exp_avg, f.exp_avg) and torch.equal(g.exp_avg_sq, f.exp_avg_sq)
+
+
+# ------------------------------------------------------------------------------------------------
+def test_scatter_chain_rules_partition_exactly():
+    """The table-gradient scatter (k_hash_bwd_agg, nof_hash.hip) emits a grid vertex once per CHAIN of consecutive runs whose
+    cells contain it: corner (m, k) hands its run total on when the vertex also belongs to the next run's cell, otherwise it
+    collects runs m-1, m-2, ... while their cells contain the vertex and they handed it on.  Restated here with the same
+    masks / corner shifts (tools/scatter_requests.shared_corners) and checked against a direct per-vertex sum on tiles with
+    face-, edge- and corner-adjacent cells, revisited cells, out-of-range lanes and 32-run window edges: every contribution
+    must be emitted exactly once, whatever the adjacency pattern."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools'))
+    import scatter_requests as SR
+    NONE = int(SR.NONE)
+
+    def shared(key, other):
+        m = int(SR.shared_corners(np.array([key], np.int64), np.array([other], np.int64))[0])
+        d = [((other >> (10 * a)) & 1023) - ((key >> (10 * a)) & 1023) for a in range(3)]
+        return m, d[0] + 2 * d[1] + 4 * d[2]                          # corner k of `key` is corner k - shift of `other`
+
+    def corner_vertex(key, k):
+        return ((key & 1023) + (k & 1), ((key >> 10) & 1023) + ((k >> 1) & 1), ((key >> 20) & 1023) + (k >> 2))
+
+    def kernel_rules(keys, vals, window=32):
+        out = {}
+        runs = []                                                     # (first lane, last lane)
+        for i in range(64):
+            if keys[i] != NONE and (i == 0 or keys[i - 1] != keys[i]):
+                j = i
+                while j < 63 and keys[j + 1] == keys[i]:
+                    j += 1
+                runs.append((i, j))
+        info = []
+        for m, (h, t) in enumerate(runs):
+            key = keys[h]
+            knext = keys[t + 1] if t < 63 else NONE
+            kp1 = keys[h - 1] if h > 0 else NONE
+            kp2 = NONE
+            if kp1 != NONE:
+                h1 = runs[m - 1][0]
+                kp2 = keys[h1 - 1] if h1 > 0 else NONE
+            ho, _ = shared(key, knext) if knext != NONE else (0, 0)
+            t1, s1 = shared(key, kp1) if kp1 != NONE else (0, 0)
+            t2, s2 = shared(key, kp2) if kp2 != NONE else (0, 0)
+            info.append([key, ho, t1, t1 & t2, s1, s2, vals[h:t + 1].sum(0)])
+        for base in range(0, len(info), window):
+            W = [list(x) for x in info[base:base + window]]
+            W[-1][1] = 0                                              # a window edge breaks the chains
+            W[0][2] = W[0][3] = 0
+            if len(W) > 1:
+                W[1][3] = 0
+            for m, (key, ho, t1, t2, s1, s2, tot) in enumerate(W):
+                for k in range(8):
+                    if (ho >> k) & 1:
+                        continue
+                    acc = tot[k]
+                    if (t1 >> k) & 1:
+                        acc += W[m - 1][6][k - s1]
+                        if (t2 >> k) & 1:
+                            acc += W[m - 2][6][k - s2]
+                            v = corner_vertex(key, k)
+                            for j in range(m - 3, -1, -1):
+                                c = corner_vertex(W[j][0], 0)
+                                d = [v[a] - c[a] for a in range(3)]
+                                if not all(0 <= x < 2 for x in d):
+                                    break
+                                kk = d[0] | d[1] << 1 | d[2] << 2
+                                if not (W[j][1] >> kk) & 1:
+                                    break
+                                acc += W[j][6][kk]
+                    v = corner_vertex(key, k)
+                    out[v] = out.get(v, 0.0) + acc
+        return out
+
+    def direct(keys, vals):
+        out = {}
+        for i in range(64):
+            if keys[i] != NONE:
+                for k in range(8):
+                    v = corner_vertex(keys[i], k)
+                    out[v] = out.get(v, 0.0) + vals[i, k]
+        return out
+
+    rng = np.random.default_rng(5)
+    for trial in range(60):
+        # a walk through cells: stay, step to a face / edge / corner neighbour, jump, or leave the box for a lane
+        c = rng.integers(2, 60, 3)
+        keys = []
+        p_stay = [0.0, 0.5, 0.8][trial % 3]                           # runs of 1 (two windows), ~2 and ~5 lanes
+        for lane in range(64):
+            u = rng.random()
+            if u < 0.04:
+                keys.append(NONE)
+                continue
+            if u > p_stay + 0.04:
+                if rng.random() < 0.1:
+                    c = rng.integers(2, 60, 3)
+                else:
+                    c = c + rng.integers(-1, 2, 3)
+            keys.append(int(c[0]) | int(c[1]) << 10 | int(c[2]) << 20)
+        vals = rng.normal(size=(64, 8))
+        a, b = kernel_rules(keys, vals), direct(keys, vals)
+        assert set(a) == set(b)
+        assert max(abs(a[v] - b[v]) for v in b) < 1e-9
