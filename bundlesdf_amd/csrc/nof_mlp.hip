@@ -302,6 +302,21 @@ __device__ __forceinline__ void store_sig_o1(typename P::elem* __restrict__ sig,
   if (b < B) *reinterpret_cast<typename P::frag*>(sig + (b * 2 + hi) * 8) = P::pack(&x[0]);
 }
 template <class P>
+__device__ __forceinline__ typename P::frag load_sig_raw(const typename P::elem* __restrict__ sig, int64_t B, int64_t b, int hi) {
+  typename P::frag f;
+#pragma unroll
+  for (int t = 0; t < 8; ++t) f[t] = (typename P::elem)0.0f;
+  if (b < B) f = *reinterpret_cast<const typename P::frag*>(sig + (b * 2 + hi) * 8);
+  return f;
+}
+template <class P>
+__device__ __forceinline__ void sig_to_o1(const typename P::frag& f, float (&x)[16]) {
+#pragma unroll
+  for (int t = 0; t < 8; ++t) x[t] = (float)f[t];
+#pragma unroll
+  for (int r = 8; r < 16; ++r) x[r] = 0.0f;
+}
+template <class P>
 __device__ __forceinline__ void load_sig_o1(const typename P::elem* __restrict__ sig, int64_t B, int64_t b, int hi, float (&x)[16]) {
 #pragma unroll
   for (int r = 0; r < 16; ++r) x[r] = 0.0f;
@@ -889,7 +904,16 @@ __global__ __launch_bounds__(256, 2) void k_mlp_bwd_color(NofMlpDesc d, const ch
           if (p < SH::pn(l) && q < SH::qn(l) && r < SH::nacc(l)) dw[l][p][q][r] = 0.0f;
 
   const int64_t ntiles = (B + 31) / 32;
-  for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < ntiles; tile += (int64_t)gridDim.x * 4) {
+  const int64_t tstride = (int64_t)gridDim.x * 4;
+  // NC == 2: the NEXT tile's inputs are loaded a whole tile ahead (latency hidden behind this tile's MFMA chain).  With three
+  // colour layers the 20 registers do not fit and the kernel spills (44 B of scratch per lane); that build computed dfeat 3 %
+  // wrong on ROCm 7.2 (tests/test_gpu_ops.py::test_mlp_backward caught it), as did the same look-ahead in k_mlp_bwd_sigma
+  // (32 B of scratch) -- so the split kernels stay spill-free: check `.private_segment_fixed_size` after touching them.
+  constexpr bool AHEAD = NC == 2;
+  typename P::frag sign = load_sig_raw<P>(sig, B, AHEAD ? ((int64_t)blockIdx.x * 4 + wave) * 32 + j : B, hi);
+  float viewn[16];
+  load_view_o1(view, S, B, AHEAD ? ((int64_t)blockIdx.x * 4 + wave) * 32 + j : B, hi, viewn);
+  for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < ntiles; tile += tstride) {
     asm volatile("" ::: "memory");
     const int64_t t0 = tile * 32;
     const int64_t b = t0 + j;
@@ -897,8 +921,16 @@ __global__ __launch_bounds__(256, 2) void k_mlp_bwd_color(NofMlpDesc d, const ch
     float h[2][16];
     {
       float cin[2][16];
-      load_sig_o1<P>(sig, B, b, hi, cin[0]);
-      load_view_o1(view, S, B, b, hi, cin[1]);
+      if constexpr (AHEAD) {
+        sig_to_o1<P>(sign, cin[0]);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) cin[1][r] = viewn[r];
+        sign = load_sig_raw<P>(sig, B, (tile + tstride) * 32 + j, hi);
+        load_view_o1(view, S, B, (tile + tstride) * 32 + j, hi, viewn);
+      } else {
+        load_sig_o1<P>(sig, B, b, hi, cin[0]);
+        load_view_o1(view, S, B, b, hi, cin[1]);
+      }
       park_o2<P>(st, I, 0, cin[0]);
       park_o2<P>(st, I, 1, cin[1]);
       dense_o1<P, 2, 2>(smem, CFW(NS), CBIAS(NS), cin, h, lane);
