@@ -235,9 +235,11 @@ __device__ __forceinline__ void dense_o1(const char* smem, int frag_off, int bia
 // result).  Element i = 16 p + r of n = 16 PN therefore sits at bit n-1-i; the mask is returned inverted (1 = the unit is ON).
 // A pre-activation of exactly +0.0 counts as on (its output is 0 either way; PyTorch's relu'(0) = 0 differs only there, a
 // measure-zero event for trained units).
-// NOTE on inline asm: hipcc's hazard recogniser does not know an asm statement is a VALU instruction, so an asm must never be
-// the FIRST reader of an MFMA result (the required wait states would be missing: measured as 30 % wrong dfeat in one
-// instance).  Everything that touches h / g directly is a builtin or plain C++; the asm in apply_mask only reads the mask.
+// NO INLINE ASSEMBLY here (rounds 1-2 had v_lshl_or / v_bfe_i32 as asm statements): hipcc's hazard recogniser does not see an
+// asm statement as a VALU instruction, so the wait states between an in-flight MFMA and a VALU instruction that reads its
+// result or overwrites one of its operands are not inserted.  Whether that bites depends on register allocation: two
+// unrelated changes of the backward kernels (loading the next tile's inputs early) made the 3-layer variants compute dfeat
+// 3-10 % wrong with the asm in place.  Builtins and plain C++ only.
 template <int PN>
 __device__ __forceinline__ uint32_t relu_mask(float (&h)[PN][16]) {
   uint32_t off = 0;
@@ -246,8 +248,7 @@ __device__ __forceinline__ uint32_t relu_mask(float (&h)[PN][16]) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int bits = __float_as_int(h[p][r]);
-      const uint32_t t = (uint32_t)bits >> 31;
-      asm("v_lshl_or_b32 %0, %1, %2, %0" : "+v"(off) : "v"(t), "n"(16 * PN - 1 - (p * 16 + r)));
+      off = __builtin_amdgcn_alignbit(off, (uint32_t)bits, 31);
       h[p][r] = __int_as_float(bits > 0 ? bits : 0);
     }
   return ~off;
@@ -259,8 +260,7 @@ __device__ __forceinline__ void apply_mask(float (&g)[PN][16], uint32_t on) {
   for (int p = 0; p < PN; ++p)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      uint32_t keep;                                                  // all-ones where the unit is on
-      asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(keep) : "v"(on), "n"(16 * PN - 1 - (p * 16 + r)));
+      const uint32_t keep = (uint32_t)__builtin_amdgcn_sbfe((int)on, 16 * PN - 1 - (p * 16 + r), 1);
       g[p][r] = __uint_as_float(__float_as_uint(g[p][r]) & keep);
     }
 }
@@ -1068,14 +1068,23 @@ __global__ __launch_bounds__(256, 2) void k_mlp_bwd_sigma(NofMlpDesc d, const ch
           if (p < SH::pn(l) && q < SH::qn(l) && r < SH::nacc(l)) dw[l][p][q][r] = 0.0f;
 
   const int64_t ntiles = (B + 31) / 32;
-  for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < ntiles; tile += (int64_t)gridDim.x * 4) {
+  const int64_t tstride = (int64_t)gridDim.x * 4;
+  // 64 % of this kernel's wave cycles used to be s_waitcnt on global memory (SQ_WAIT_ANY): the tile's feature loads queued
+  // behind the previous tile's dfeat stores (vmcnt retires in order), and the dsig load was waited for where it was issued.
+  // Now the next tile's features are requested before this tile's last stage (its stores come after them), and dsig at the top.
+  // Holding them for the WHOLE tile does not fit the register file: that build spilled 32 B per lane and computed dfeat wrong.
+  float xn[1][16];
+  load_feat_o1(feat, L, B, ((int64_t)blockIdx.x * 4 + wave) * 32 + j, hi, xn);
+  for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < ntiles; tile += tstride) {
     asm volatile("" ::: "memory");
     const int64_t b = tile * 32 + j;
     uint32_t m1[NS];
     float h[2][16];
+    const typename P::frag dsr = load_sig_raw<P>(dsig, B, b, hi);
     {
       float x[1][16];
-      load_feat_o1(feat, L, B, b, hi, x);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) x[0][r] = xn[0][r];
       park_o2<P>(st, I, 0, x[0]);
       dense_o1<P, 1, 2>(smem, SFW(0), SBIAS(0), x, h, lane);
       m1[0] = relu_mask<2>(h);
@@ -1096,7 +1105,7 @@ __global__ __launch_bounds__(256, 2) void k_mlp_bwd_sigma(NofMlpDesc d, const ch
     park_o2<P>(st, I, 2 * (NS - 1), h[1]);
 
     float g1[2][16];
-    load_sig_o1<P>(dsig, B, b, hi, g1[0]);
+    sig_to_o1<P>(dsr, g1[0]);
 #pragma unroll
     for (int r = 0; r < 16; ++r) g1[1][r] = 0.0f;
 #pragma unroll
@@ -1122,6 +1131,7 @@ __global__ __launch_bounds__(256, 2) void k_mlp_bwd_sigma(NofMlpDesc d, const ch
         for (int r = 0; r < 16; ++r) g1[p][r] = d1[p][r];
     }
     {
+      load_feat_o1(feat, L, B, (tile + tstride) * 32 + j, hi, xn);
       dw_block<P, 1, 16>(dw[0][0], dbw, I, g1[0], st, 0);
       dw_block<P, 1, 16>(dw[0][1], dbw + 64, I, g1[1], st, 0);
       float df1[16];
