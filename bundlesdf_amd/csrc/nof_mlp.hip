@@ -389,7 +389,7 @@ NofMlpDesc d, const char* __restrict__ image,
       if constexpr (P::KR == 8) {
         if (sig != nullptr) store_sig_o1<P>(sig, B, b, hi, so[0]);     // the colour net's operand, kept for the split backward
       }
-      load_view_o1(view, S, B, b, hi, cin[1]);
+      load_view_o1(view, S, B, b, hi, cin[1]);        // (a tile ahead like the features: measured 2 % slower)
       dense_o1<P, 2, 2, SPLIT>(smem, FW_OFF(NS), BIAS_OFF(NS), cin, h, lane, LO_OFF(NS));
       relu_mask<2>(h);
 #pragma unroll
@@ -905,10 +905,8 @@ __global__ __launch_bounds__(256, 2) void k_mlp_bwd_color(NofMlpDesc d, const ch
 
   const int64_t ntiles = (B + 31) / 32;
   const int64_t tstride = (int64_t)gridDim.x * 4;
-  // NC == 2: the NEXT tile's inputs are loaded a whole tile ahead (latency hidden behind this tile's MFMA chain).  With three
-  // colour layers the 20 registers do not fit and the kernel spills (44 B of scratch per lane); that build computed dfeat 3 %
-  // wrong on ROCm 7.2 (tests/test_gpu_ops.py::test_mlp_backward caught it), as did the same look-ahead in k_mlp_bwd_sigma
-  // (32 B of scratch) -- so the split kernels stay spill-free: check `.private_segment_fixed_size` after touching them.
+  // the NEXT tile's inputs are loaded a whole tile ahead (latency hidden behind this tile's MFMA chain) where the 20 registers
+  // cost no heavy spilling (two colour layers; with three: 244 B of scratch per lane), draw at the top of the tile
   constexpr bool AHEAD = NC == 2;
   typename P::frag sign = load_sig_raw<P>(sig, B, AHEAD ? ((int64_t)blockIdx.x * 4 + wave) * 32 + j : B, hi);
   float viewn[16];
@@ -919,6 +917,8 @@ __global__ __launch_bounds__(256, 2) void k_mlp_bwd_color(NofMlpDesc d, const ch
     const int64_t b = t0 + j;
     uint32_t m1[NL];
     float h[2][16];
+    float4 dr = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (hi == 0 && b < B) dr = draw[b];                  // draw[b] = (d rgb_raw[3], d sdf): used after the forward recompute
     {
       float cin[2][16];
       if constexpr (AHEAD) {
@@ -957,10 +957,9 @@ __global__ __launch_bounds__(256, 2) void k_mlp_bwd_color(NofMlpDesc d, const ch
     for (int p = 0; p < 2; ++p)
 #pragma unroll
       for (int r = 0; r < 16; ++r) g1[p][r] = 0.0f;
-    if (hi == 0 && b < B) {                           // draw[b] = (d rgb_raw[3], d sdf)
-      const float4 t = draw[b];
-      g1[0][0] = t.x * gscale; g1[0][1] = t.y * gscale; g1[0][2] = t.z * gscale;
-      dsdf1 = t.w * gscale;
+    if (hi == 0 && b < B) {
+      g1[0][0] = dr.x * gscale; g1[0][1] = dr.y * gscale; g1[0][2] = dr.z * gscale;
+      dsdf1 = dr.w * gscale;
     }
 #pragma unroll
     for (int l = NL - 1; l > NS; --l) {
@@ -1070,9 +1069,8 @@ __global__ __launch_bounds__(256, 2) void k_mlp_bwd_sigma(NofMlpDesc d, const ch
   const int64_t ntiles = (B + 31) / 32;
   const int64_t tstride = (int64_t)gridDim.x * 4;
   // 64 % of this kernel's wave cycles used to be s_waitcnt on global memory (SQ_WAIT_ANY): the tile's feature loads queued
-  // behind the previous tile's dfeat stores (vmcnt retires in order), and the dsig load was waited for where it was issued.
-  // Now the next tile's features are requested before this tile's last stage (its stores come after them), and dsig at the top.
-  // Holding them for the WHOLE tile does not fit the register file: that build spilled 32 B per lane and computed dfeat wrong.
+  // behind the previous tile's dfeat stores (vmcnt retires in order) and were waited for where they were issued, like the dsig
+  // load.  Now the NEXT tile's features are requested a whole tile ahead and dsig at the top of the tile: 111 -> 82 us at cfg2.
   float xn[1][16];
   load_feat_o1(feat, L, B, ((int64_t)blockIdx.x * 4 + wave) * 32 + j, hi, xn);
   for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < ntiles; tile += tstride) {
@@ -1085,6 +1083,7 @@ __global__ __launch_bounds__(256, 2) void k_mlp_bwd_sigma(NofMlpDesc d, const ch
       float x[1][16];
 #pragma unroll
       for (int r = 0; r < 16; ++r) x[0][r] = xn[0][r];
+      load_feat_o1(feat, L, B, (tile + tstride) * 32 + j, hi, xn);
       park_o2<P>(st, I, 0, x[0]);
       dense_o1<P, 1, 2>(smem, SFW(0), SBIAS(0), x, h, lane);
       m1[0] = relu_mask<2>(h);
@@ -1131,7 +1130,6 @@ __global__ __launch_bounds__(256, 2) void k_mlp_bwd_sigma(NofMlpDesc d, const ch
         for (int r = 0; r < 16; ++r) g1[p][r] = d1[p][r];
     }
     {
-      load_feat_o1(feat, L, B, (tile + tstride) * 32 + j, hi, xn);
       dw_block<P, 1, 16>(dw[0][0], dbw, I, g1[0], st, 0);
       dw_block<P, 1, 16>(dw[0][1], dbw + 64, I, g1[1], st, 0);
       float df1[16];
