@@ -266,16 +266,37 @@ __device__ __forceinline__ void apply_mask(float (&g)[PN][16], uint32_t on) {
 }
 
 // ---- tile I/O ------------------------------------------------------------------------------------
-// orientation 1 features: lane (sample j, hi) slot r = feature 16hi + r = (level 8hi + r/2, ch r&1)
+// orientation 1 features: lane (sample j, hi) slot r = feature 16hi + r = (level 8hi + r/2, ch r&1).
+// Addressing: ONE 32-bit byte offset per lane ((8 hi B + b) * 8) + a wave-uniform base per k (feat + k B * 8, in SGPRs), the
+// form global_load takes directly (saddr + voffset); eight per-lane 64-bit addresses cost 16 VGPRs, and in the kernels that run
+// at their register cap those were spilled and reloaded behind s_waitcnt vmcnt(0), one load at a time.  The entry points
+// check that the level-major arrays stay below 4 GiB (L * B * 8 bytes).
+__device__ __forceinline__ uint32_t feat_lane_offset(int64_t B, int64_t b, int hi) {
+  return (uint32_t)(((int64_t)(8 * hi) * B + b) * 8);
+}
 __device__ __forceinline__ void load_feat_o1(const float2* __restrict__ feat, int L, int64_t B, int64_t b, int hi,
                                              float (&x)[1][16]) {
+  const uint32_t voff = feat_lane_offset(B, b, hi);
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
     const int level = 8 * hi + k;
+    const char* base = reinterpret_cast<const char*>(feat) + (size_t)k * (size_t)B * 8;      // wave-uniform
     float2 v = make_float2(0.f, 0.f);
-    if (level < L && b < B) v = feat[(int64_t)level * B + b];
+    if (level < L && b < B) v = *reinterpret_cast<const float2*>(base + voff);
     x[0][2 * k] = v.x;
     x[0][2 * k + 1] = v.y;
+  }
+}
+// dfeat[level 8hi + k][b] = (df[2k], df[2k+1]) * scale, same addressing
+__device__ __forceinline__ void store_dfeat_o1(float2* __restrict__ dfeat, int L, int64_t B, int64_t b, int hi,
+                                               const float (&df)[16], float scale) {
+  if (b >= B) return;
+  const uint32_t voff = feat_lane_offset(B, b, hi);
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int level = 8 * hi + k;
+    char* base = reinterpret_cast<char*>(dfeat) + (size_t)k * (size_t)B * 8;
+    if (level < L) *reinterpret_cast<float2*>(base + voff) = make_float2(df[2 * k] * scale, df[2 * k + 1] * scale);
   }
 }
 __device__ __forceinline__ void load_view_o1(const float* __restrict__ view, int S, int64_t B, int64_t b, int hi,
@@ -300,6 +321,15 @@ __device__ __forceinline__ void load_view_o1(const float* __restrict__ view, int
 template <class P>
 __device__ __forceinline__ void store_sig_o1(typename P::elem* __restrict__ sig, int64_t B, int64_t b, int hi, const float (&x)[16]) {
   if (b < B) *reinterpret_cast<typename P::frag*>(sig + (b * 2 + hi) * 8) = P::pack(&x[0]);
+}
+// "These 16 values are in registers NOW": an empty asm statement that takes them as read-write operands.  Placed between
+// `x = x_next` and the request of the tile after next, it makes the compiler wait for the previous look-ahead loads there (and
+// keep x apart from the registers the new loads land in) instead of right after issuing the new ones, which is what it did in
+// the kernels that run at their register cap (s_waitcnt vmcnt(1) behind the eight new loads: no look-ahead at all).  No
+// instruction is emitted, so there is no MFMA hazard to miss.
+__device__ __forceinline__ void pin16(float (&x)[16]) {
+  asm volatile("" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]), "+v"(x[7]), "+v"(x[8]),
+               "+v"(x[9]), "+v"(x[10]), "+v"(x[11]), "+v"(x[12]), "+v"(x[13]), "+v"(x[14]), "+v"(x[15]));
 }
 template <class P>
 __device__ __forceinline__ typename P::frag load_sig_raw(const typename P::elem* __restrict__ sig, int64_t B, int64_t b, int hi) {
@@ -365,6 +395,7 @@ NofMlpDesc d, const char* __restrict__ image,
     float x[1][16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) x[0][r] = xn[0][r];
+    pin16(x[0]);
     load_feat_o1(feat, L, B, (tile + tstride) * 32 + j, hi, xn);      // out-of-range tiles load nothing (b >= B -> zeros)
     float h[2][16], so[1][16];
     dense_o1<P, 1, 2, SPLIT>(smem, FW_OFF(0), BIAS_OFF(0), x, h, lane, LO_OFF(0));
@@ -829,13 +860,7 @@ __global__ __launch_bounds__(256) void k_mlp_bwd(NofMlpDesc d, const char* __res
       dw_block<P, 1, 16>(dw[0][1], dbw + 64, I, g1[1], st, 0);
       float df1[16];
       bwd_data<P, 2>(smem, BW_OFF(0), 0, g1, df1, lane);
-      if (b < B) {
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-          const int level = 8 * hi + k;
-          if (level < L) dfeat[(int64_t)level * B + b] = make_float2(df1[2 * k] * gunscale, df1[2 * k + 1] * gunscale);
-        }
-      }
+      store_dfeat_o1(dfeat, L, B, b, hi, df1, gunscale);
     }
   }
 
@@ -925,6 +950,8 @@ __global__ __launch_bounds__(256, 2) void k_mlp_bwd_color(NofMlpDesc d, const ch
         sig_to_o1<P>(sign, cin[0]);
 #pragma unroll
         for (int r = 0; r < 16; ++r) cin[1][r] = viewn[r];
+        pin16(cin[0]);
+        pin16(cin[1]);
         sign = load_sig_raw<P>(sig, B, (tile + tstride) * 32 + j, hi);
         load_view_o1(view, S, B, (tile + tstride) * 32 + j, hi, viewn);
       } else {
@@ -1083,6 +1110,7 @@ __global__ __launch_bounds__(256, 2) void k_mlp_bwd_sigma(NofMlpDesc d, const ch
       float x[1][16];
 #pragma unroll
       for (int r = 0; r < 16; ++r) x[0][r] = xn[0][r];
+      pin16(x[0]);
       load_feat_o1(feat, L, B, (tile + tstride) * 32 + j, hi, xn);
       park_o2<P>(st, I, 0, x[0]);
       dense_o1<P, 1, 2>(smem, SFW(0), SBIAS(0), x, h, lane);
@@ -1134,13 +1162,7 @@ __global__ __launch_bounds__(256, 2) void k_mlp_bwd_sigma(NofMlpDesc d, const ch
       dw_block<P, 1, 16>(dw[0][1], dbw + 64, I, g1[1], st, 0);
       float df1[16];
       bwd_data<P, 2>(smem, SBW(0), 0, g1, df1, lane);
-      if (b < B) {
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-          const int level = 8 * hi + k;
-          if (level < L) dfeat[(int64_t)level * B + b] = make_float2(df1[2 * k] * gunscale, df1[2 * k + 1] * gunscale);
-        }
-      }
+      store_dfeat_o1(dfeat, L, B, b, hi, df1, gunscale);
     }
   }
   flush_dw<SH, 0, NS>(d, dw, dbw, partials, gunscale);
@@ -1473,6 +1495,7 @@ extern "C" int nof_mlp_fwd(const NofMlpDesc* d, const void* packed, const float*
                             int32_t S, float* raw, void* sigma_out, int64_t B, void* stream) {
   if (int e = check_narrow(d)) return e;
   NOF_ARG(packed && feat && view && raw && B >= 0 && S >= 1 && L >= 1 && L * 2 == d->in_feat);
+  NOF_ARG((int64_t)L * B * 8 < (1ll << 32));                   // level-major arrays are addressed with 32-bit lane offsets
   if (B == 0) return 0;
   const int nl = d->n_sigma + d->n_color;
   const size_t shm = (is_split(d->precision) ? 2 : 1) * (size_t)n_pairs(*d, nl) * 16 * 64 * elem_size(d->precision) +
@@ -1496,6 +1519,7 @@ extern "C" int nof_mlp_sdf(const NofMlpDesc* d, const void* packed, const float*
                             int64_t B, void* stream) {
   if (int e = check_narrow(d)) return e;
   NOF_ARG(packed && feat && sdf && B >= 0 && L >= 1 && L * 2 == d->in_feat);
+  NOF_ARG((int64_t)L * B * 8 < (1ll << 32));                   // level-major arrays are addressed with 32-bit lane offsets
   if (B == 0) return 0;
   const int nl = d->n_sigma;
   const size_t shm = (is_split(d->precision) ? 2 : 1) * (size_t)n_pairs(*d, nl) * 16 * 64 * elem_size(d->precision) +
@@ -1520,6 +1544,7 @@ extern "C" int nof_mlp_bwd(const NofMlpDesc* d, const void* packed, const float*
                             float* partials, int64_t B, void* stream) {
   if (int e = check_narrow(d)) return e;
   NOF_ARG(packed && feat && view && draw && dfeat && dview && partials && B >= 0 && S >= 32 && L * 2 == d->in_feat);
+  NOF_ARG((int64_t)L * B * 8 < (1ll << 32));                   // level-major arrays are addressed with 32-bit lane offsets
   const int nl = d->n_sigma + d->n_color, ns = d->n_sigma;
   const size_t es = elem_size(d->precision), pair_bytes = 16 * 64 * es;
   const unsigned rows = (unsigned)nof_mlp_bwd_blocks();

@@ -74,13 +74,18 @@ __global__ __launch_bounds__(768) void k_wide_fwd_sigma(NofMlpDesc d, const char
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
   const int hi = lane >> 5, j = lane & 31;
   const int H = 32 * HB;
-  const int64_t ntiles = (B + 31) / 32;
-  for (int64_t tile = (int64_t)blockIdx.x * nw + wave; tile < ntiles; tile += (int64_t)gridDim.x * nw) {
+  const int64_t ntiles = (B + 31) / 32, tstride = (int64_t)gridDim.x * nw;
+  float xn[1][16];                                    // the NEXT tile's features, requested a whole tile ahead
+  load_feat_o1(feat, L, B, ((int64_t)blockIdx.x * nw + wave) * 32 + j, hi, xn);
+  for (int64_t tile = (int64_t)blockIdx.x * nw + wave; tile < ntiles; tile += tstride) {
     asm volatile("" ::: "memory");
     const int64_t b = tile * 32 + j;
     const bool ok = b < B;
     float x[1][16], h[HB][16], so[1][16];
-    load_feat_o1(feat, L, B, b, hi, x);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) x[0][r] = xn[0][r];
+    pin16(x[0]);
+    load_feat_o1(feat, L, B, (tile + tstride) * 32 + j, hi, xn);
     dense_o1<P, 1, HB>(smem, 0, bias_base, x, h, lane);
     relu_inplace<HB>(h);
     int foff = HB * WPAIR, boff = bias_base + HB * 128;
@@ -134,7 +139,7 @@ __global__ __launch_bounds__(768) void k_wide_fwd_color(NofMlpDesc d, const char
     const int64_t b = tile * 32 + j;
     const bool ok = b < B;
     float cin[2][16], h[HB][16], co[1][16];
-    load_sig_o1<P>(sig, B, b, hi, cin[0]);
+    load_sig_o1<P>(sig, B, b, hi, cin[0]);            // (requested a tile ahead: 4-10 % slower at cfg5, measured twice)
     load_view_o1(view, S, B, b, hi, cin[1]);
     dense_o1<P, 2, HB>(smem, 0, bias_base, cin, h, lane);
     relu_inplace<HB>(h);
@@ -287,13 +292,16 @@ __global__ __launch_bounds__(768) void k_wide_bwd_sigma(NofMlpDesc d, const char
   const int hi = lane >> 5, j = lane & 31;
   const int H = 32 * HB;
   const float gunscale = d.grad_scale > 0.0f ? 1.0f / d.grad_scale : 1.0f;
-  const int64_t ntiles = (B + 31) / 32;
-  for (int64_t tile = (int64_t)blockIdx.x * nw + wave; tile < ntiles; tile += (int64_t)gridDim.x * nw) {
+  const int64_t ntiles = (B + 31) / 32, tstride = (int64_t)gridDim.x * nw;
+  typename P::frag dsn = load_sig_raw<P>(dsig, B, ((int64_t)blockIdx.x * nw + wave) * 32 + j, hi);   // a tile ahead
+  for (int64_t tile = (int64_t)blockIdx.x * nw + wave; tile < ntiles; tile += tstride) {
     asm volatile("" ::: "memory");
     const int64_t b = tile * 32 + j;
     const bool ok = b < B;
     float gh[1][16], g[HB][16];
-    load_sig_o1<P>(dsig, B, b, hi, gh[0]);
+    sig_to_o1<P>(dsn, gh[0]);
+    pin16(gh[0]);
+    dsn = load_sig_raw<P>(dsig, B, (tile + tstride) * 32 + j, hi);
     if (ok) store_blk<P>(gbuf + (int64_t)(NS - 1) * g_stride + b * H, 0, hi, gh[0]);
     int woff = pair_base(d, NS - 1) * WPAIR;
     {
@@ -328,13 +336,7 @@ __global__ __launch_bounds__(768) void k_wide_bwd_sigma(NofMlpDesc d, const char
     }
     float df1[16];
     bwd_data<P, HB>(smem, 0, 0, g, df1, lane);
-    if (ok) {
-#pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        const int level = 8 * hi + k;
-        if (level < L) dfeat[(int64_t)level * B + b] = make_float2(df1[2 * k] * gunscale, df1[2 * k + 1] * gunscale);
-      }
-    }
+    store_dfeat_o1(dfeat, L, B, b, hi, df1, gunscale);
   }
 }
 
@@ -521,6 +523,7 @@ extern "C" int nof_mlp_wide_fwd(const NofMlpDesc* d, const void* packed, const f
                                  int32_t S, float* raw, void* workspace, int64_t B, void* stream) {
   if (int e = check_wide(d)) return e;
   NOF_ARG(packed && feat && view && raw && workspace && B >= 0 && S >= 1 && L >= 1 && L * 2 == d->in_feat);
+  NOF_ARG((int64_t)L * B * 8 < (1ll << 32));                   // level-major arrays are addressed with 32-bit lane offsets
   if (B == 0) return 0;
   const WideWs ws = wide_ws(d, workspace, B);
   WIDE_DISPATCH(wide_fwd_launch, d, packed, feat, L, view, S, raw, 4, 3, &ws, true, false, B, (hipStream_t)stream)
@@ -533,6 +536,7 @@ extern "C" int nof_mlp_wide_sdf(const NofMlpDesc* d, const void* packed, const f
                                  void* stream) {
   if (int e = check_wide(d)) return e;
   NOF_ARG(packed && feat && sdf && B >= 0 && L >= 1 && L * 2 == d->in_feat);
+  NOF_ARG((int64_t)L * B * 8 < (1ll << 32));                   // level-major arrays are addressed with 32-bit lane offsets
   if (B == 0) return 0;
   WIDE_DISPATCH(wide_fwd_launch, d, packed, feat, L, (const float*)nullptr, 1, sdf, 1, 0, (const WideWs*)nullptr, false, true, B,
                 (hipStream_t)stream)
@@ -587,6 +591,7 @@ extern "C" int nof_mlp_wide_bwd(const NofMlpDesc* d, const void* packed, const f
                                  int64_t B, void* stream) {
   if (int e = check_wide(d)) return e;
   NOF_ARG(packed && feat && view && draw && workspace && dfeat && dview && partials && B >= 0 && S >= 32 && L * 2 == d->in_feat);
+  NOF_ARG((int64_t)L * B * 8 < (1ll << 32));                   // level-major arrays are addressed with 32-bit lane offsets
   if (B == 0) return 0;
   const WideWs ws = wide_ws(d, workspace, B);
   WIDE_DISPATCH(wide_bwd_launch, d, packed, feat, L, view, S, draw, &ws, dfeat, dview, partials, B, (hipStream_t)stream)

@@ -47,6 +47,11 @@ def test_argument_errors_are_reported_not_crashing():
     d.hidden = 96                                        # 64 and 128 are the supported widths
     rc = so.nof_mlp_fwd(ctypes.byref(d), None, None, 16, None, 192, None, None, 0, None)
     assert rc < 0 and b'hidden' in so.nof_last_error()
+    # the level-major feature arrays are addressed with 32-bit lane offsets: L * B * 8 bytes must stay below 4 GiB
+    d, _ = lib.make_mlp_desc(3, 2, 32, 9)
+    one = ctypes.c_void_p(256)                           # never dereferenced: the size check comes before any launch
+    rc = so.nof_mlp_fwd(ctypes.byref(d), one, one, 16, one, 192, one, None, 1 << 26, None)
+    assert rc < 0 and b'1ll << 32' in so.nof_last_error(), so.nof_last_error()
     assert so.nof_version() >= 100
 
 

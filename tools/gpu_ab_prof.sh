@@ -8,4 +8,4 @@ for v in old new; do
   echo "== $v $(python -c "import json; d=json.loads(open('/tmp/prof_$v.json').read().strip().splitlines()[-1]); print(d['ms_per_step'])")"
   python tools/prof_summary.py $(find /tmp/prof_$v -name "*_results.db" | head -1) | grep "k_mlp\|k_hash" | cut -c1-60,73-110
 done
-timeout 600 python -m pytest tests/test_gpu_ops.py tests/test_gpu_step.py -m gpu -q 2>&1 | tail -1
+
