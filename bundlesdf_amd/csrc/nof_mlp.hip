@@ -211,18 +211,31 @@ __device__ __forceinline__ void dense_o1(const char* smem, int frag_off, int bia
       const float4 bv = *(const float4*)(bl + (32 * p + 8 * g) * 4);
       acc[4 * g] = bv.x; acc[4 * g + 1] = bv.y; acc[4 * g + 2] = bv.z; acc[4 * g + 3] = bv.w;
     }
+    if constexpr (!SPLIT && QN * NSTEP >= 8) {
+      // a long accumulator chain (128-wide layers): all of the block's weight fragments are requested before the chain starts,
+      // so that the MFMAs do not each wait for an LDS read issued just in front of them
+      typename P::frag a[QN * NSTEP];
 #pragma unroll
-    for (int q = 0; q < QN; ++q)
+      for (int t = 0; t < QN * NSTEP; ++t) a[t] = *(const typename P::frag*)(fl + frag_off + (p * QN * NSTEP + t) * FB);
+      asm volatile("" ::: "memory");                                   // keeps the eight reads in front of the chain
 #pragma unroll
-      for (int s = 0; s < NSTEP; ++s) {
-        const typename P::frag a = *(const typename P::frag*)(fl + frag_off + ((p * QN + q) * NSTEP + s) * FB);
-        if constexpr (SPLIT) {
-          const typename P::frag al = *(const typename P::frag*)(fl + lo_off + ((p * QN + q) * NSTEP + s) * FB);
-          acc = P::mma(al, bop[q][s], acc);
-          acc = P::mma(a, blo[q][s], acc);
+      for (int q = 0; q < QN; ++q)
+#pragma unroll
+        for (int s = 0; s < NSTEP; ++s) acc = P::mma(a[q * NSTEP + s], bop[q][s], acc);
+    } else {
+#pragma unroll
+      for (int q = 0; q < QN; ++q)
+#pragma unroll
+        for (int s = 0; s < NSTEP; ++s) {
+          const typename P::frag a = *(const typename P::frag*)(fl + frag_off + ((p * QN + q) * NSTEP + s) * FB);
+          if constexpr (SPLIT) {
+            const typename P::frag al = *(const typename P::frag*)(fl + lo_off + ((p * QN + q) * NSTEP + s) * FB);
+            acc = P::mma(al, bop[q][s], acc);
+            acc = P::mma(a, blo[q][s], acc);
+          }
+          acc = P::mma(a, bop[q][s], acc);
         }
-        acc = P::mma(a, bop[q][s], acc);
-      }
+    }
 #pragma unroll
     for (int r = 0; r < 16; ++r) out[p][r] = acc[r];
   }
@@ -526,13 +539,24 @@ __device__ __forceinline__ void bwd_data(const char* smem, int bw_off, int q, co
   f32x16 a1;
 #pragma unroll
   for (int r = 0; r < 16; ++r) a1[r] = 0.0f;
+  if constexpr (PN * NSTEP >= 8) {                                     // long chain: fragments requested up front (see dense_o1)
+    typename P::frag w[PN * NSTEP];
 #pragma unroll
-  for (int p = 0; p < PN; ++p)
+    for (int t = 0; t < PN * NSTEP; ++t) w[t] = *(const typename P::frag*)(fl + bw_off + (q * PN * NSTEP + t) * FB);
+    asm volatile("" ::: "memory");
 #pragma unroll
-    for (int s = 0; s < NSTEP; ++s) {
-      const typename P::frag w = *(const typename P::frag*)(fl + bw_off + ((q * PN + p) * NSTEP + s) * FB);
-      a1 = P::mma(w, P::pack(&dout1[p][KR * s]), a1);
-    }
+    for (int p = 0; p < PN; ++p)
+#pragma unroll
+      for (int s = 0; s < NSTEP; ++s) a1 = P::mma(w[p * NSTEP + s], P::pack(&dout1[p][KR * s]), a1);
+  } else {
+#pragma unroll
+    for (int p = 0; p < PN; ++p)
+#pragma unroll
+      for (int s = 0; s < NSTEP; ++s) {
+        const typename P::frag w = *(const typename P::frag*)(fl + bw_off + ((q * PN + p) * NSTEP + s) * FB);
+        a1 = P::mma(w, P::pack(&dout1[p][KR * s]), a1);
+      }
+  }
 #pragma unroll
   for (int r = 0; r < 16; ++r) din1[r] = a1[r];
 }
