@@ -55,6 +55,19 @@ def test_argument_errors_are_reported_not_crashing():
     assert so.nof_version() >= 100
 
 
+def test_mlp_kernels_have_no_inline_assembly_instructions():
+    """hipcc's hazard recogniser does not see an `asm` statement as a VALU instruction: next to MFMAs the required wait states
+    are then missing, and whether that corrupts results depends on register allocation (round 2: dfeat 3-10 % wrong in the
+    3-layer backward kernels after an unrelated change).  The matrix-core sources may only contain EMPTY asm statements
+    (scheduling / liveness pins)."""
+    import re
+    src = os.path.join(ROOT, 'bundlesdf_amd', 'csrc')
+    for name in ('nof_mlp.hip', 'nof_mlp_wide.h'):
+        text = open(os.path.join(src, name)).read()
+        for m in re.finditer(r'asm\s*(?:volatile)?\s*\(\s*"([^"]*)"', text):
+            assert m.group(1).strip() == '', (name, m.group(1))
+
+
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     from bundlesdf_amd import lib
     monkeypatch.setattr(lib, '_lib', None)
