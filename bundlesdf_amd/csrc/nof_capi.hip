@@ -53,6 +53,24 @@ __global__ __launch_bounds__(256) void k_atomic_probe(int variant, const uint32_
     if (i < n) table[2 * (size_t)idx[i]] = 1.0f;
     return;
   }
+  if (variant >= 30) {
+    // gather rate of 8-byte table rows (what the hash lookup does): 30 = every lane its own random row, 31 = groups of 8
+    // adjacent lanes read the SAME row (a run of samples in one cell), 32 = one lane of every 8 reads, the others idle.
+    // Each lane does 8 dependent-free gathers; the sum is stored so that nothing is optimised away.
+    if (i >= n) return;
+    const float2* t2 = reinterpret_cast<const float2*>(table);
+    const int64_t base = variant == 30 ? i : (i & ~(int64_t)7);
+    if (variant == 32 && (i & 7) != 0) return;
+    float acc = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const uint32_t e = idx[(base + (int64_t)k * 8191) % n];
+      const float2 v = t2[e];
+      acc += v.x + v.y;
+    }
+    table[2 * (size_t)(1 << 19) + i] = acc;                            // scratch area behind the 2^19 rows (the caller allocates it)
+    return;
+  }
   if (variant >= 22) {                      // other atomic types on random entries (one 8-byte slot per entry): 22 u32, 23 u64, 24 f64, 25 pk f16
     if (i >= n) return;
     void* a = &table[2 * (size_t)idx[i]];
@@ -90,7 +108,7 @@ __global__ __launch_bounds__(256) void k_atomic_probe(int variant, const uint32_
 }
 
 extern "C" int nof_atomic_probe(int32_t variant, const uint32_t* idx, float* table, int64_t n, void* stream) {
-  NOF_ARG(idx && table && n > 0 && variant >= 0 && variant <= 25);
+  NOF_ARG(idx && table && n > 0 && variant >= 0 && variant <= 32);
   const int64_t threads = variant == 1 ? 2 * n : n;
   hipLaunchKernelGGL(k_atomic_probe, dim3((unsigned)nof_div_up(threads, 256)), dim3(256), 0, (hipStream_t)stream, variant, idx,
                      table, n);

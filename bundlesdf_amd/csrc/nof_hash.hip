@@ -367,11 +367,13 @@ __global__ __launch_bounds__(256) void k_hash_dx(NofHashGrid g, const float* __r
     const float2 gr = dfeat[(int64_t)level * B + b];
     const float2* __restrict__ tl = table + lv.offset;
     float2 v[8];
+    uint32_t idx[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
       const uint32_t p0 = c.g[0] + (k & 1), p1 = c.g[1] + ((k >> 1) & 1), p2 = c.g[2] + ((k >> 2) & 1);
-      v[k] = tl[grid_index(lv, p0, p1, p2)];
+      idx[k] = grid_index(lv, p0, p1, p2);
     }
+    gather_corners(lv, tl, idx, v);
     // dy/dx01[gd] = scale * sum_{other two dims} w' * (f_right - f_left)   (gridencoder.cu:202-245)
 #pragma unroll
     for (int gd = 0; gd < 3; ++gd) {

@@ -25,6 +25,8 @@ __device__ __forceinline__ uint32_t grid_index(const HashLevel& lv, uint32_t x, 
   return index;
 }
 
+typedef float RowPair __attribute__((ext_vector_type(4), aligned(8)));   // two consecutive table rows: ONE 16-byte load, 8-byte aligned
+
 struct CellPos {
   uint32_t g[3];
   float f[3];
@@ -51,6 +53,30 @@ __device__ __forceinline__ CellPos locate(const float* __restrict__ pts_w, int64
   return locate3(p, scale);
 }
 
+// The 8 corner rows of a cell.  A gather costs the vector memory pipe per INSTRUCTION (~37 clocks per CU for 64 lanes, whatever
+// the number of active lanes or distinct rows: tools/atomic_probe.py variants 30-32), so the x neighbour comes in the same
+// 16-byte load where it is the next row for the whole wave: dense levels (row = x + y r + z r^2) unless the modulo wrap of an
+// exact-power level hits.  `lv.hashed` is wave-uniform in the caller; the row test is made uniform with a ballot.  Same values
+// as eight separate loads.  Used by k_hash_dx (lane = sample, loop over levels: 247 -> 193 us beside the scatter, 110 -> 91 alone);
+// in k_hash_fwd (lane = (sample, level), 8x the waves) it was 5 % slower and is not used.
+__device__ __forceinline__ void gather_corners(const HashLevel& lv, const float2* __restrict__ tl, const uint32_t (&idx)[8],
+                                               float2 (&v)[8]) {
+  bool pairs = !lv.hashed;
+#pragma unroll
+  for (int k = 0; k < 8; k += 2) pairs = pairs && (idx[k + 1] == idx[k] + 1u);
+  if (__builtin_amdgcn_ballot_w64(!pairs) == 0ull) {
+#pragma unroll
+    for (int k = 0; k < 8; k += 2) {
+      const RowPair t = *reinterpret_cast<const RowPair*>(tl + idx[k]);
+      v[k] = make_float2(t.x, t.y);
+      v[k + 1] = make_float2(t.z, t.w);
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = tl[idx[k]];
+  }
+}
+
 // features of one level at one point: 8 independent 8-byte gathers in flight, then the trilinear blend (gridencoder.cu:174-200)
 __device__ __forceinline__ float2 encode_level(const HashLevel& lv, const float2* __restrict__ table, const CellPos& c) {
   float2 acc = make_float2(0.f, 0.f);
@@ -72,7 +98,7 @@ __device__ __forceinline__ float2 encode_level(const HashLevel& lv, const float2
   }
   float2 v[8];
 #pragma unroll
-  for (int k = 0; k < 8; ++k) v[k] = tl[idx[k]];
+  for (int k = 0; k < 8; ++k) v[k] = tl[idx[k]];                       // (gather_corners' 16-byte pair loads: 5 % slower in k_hash_fwd)
 #pragma unroll
   for (int k = 0; k < 8; ++k) { acc.x += w[k] * v[k].x; acc.y += w[k] * v[k].y; }
   return acc;

@@ -52,3 +52,15 @@ for part, pn in enumerate(['random entries over the whole table', 'entries folde
         run2(f'{10 + 4 * part + flag} x only, {pn}, {fn}', 10 + 4 * part + flag)
 for v, nm in ((22, 'u32 add'), (23, 'u64 add'), (24, 'f64 add'), (25, 'packed f16 add')):
     run2(f'{v} random entries, {nm}', v)
+
+# gather rate of 8-byte rows: does a run of lanes reading the SAME row cost as much as distinct rows?
+tg = torch.zeros((1 << 20) + n, device='cuda')          # 2^19 rows x 2 floats + one result per lane
+def run3(name, variant):
+    for rep in range(3):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(); lib.call('nof_atomic_probe', variant, idx_rand, tg, n); b.record(); torch.cuda.synchronize()
+    ms = a.elapsed_time(b)
+    print(f'{name:62s} {ms:8.3f} ms  {8 * n / ms / 1e6:8.1f} G lane-gathers/s')
+run3('30 8 gathers per lane, every lane its own random row', 30)
+run3('31 8 gathers per lane, 8 adjacent lanes read the same row', 31)
+run3('32 8 gathers, one lane of every 8 active', 32)
