@@ -203,11 +203,7 @@ __device__ __forceinline__ void sh_eval(int degree, float x, float y, float z, f
   }
 }
 
-// 256-thread workgroups, 16 rays per wave (lanes 0-15): the walk is one dependent chain per ray, so a wave lasts as long as
-// its longest ray and 4096 rays are only 64 full waves; four times as many quarter-filled waves finish earlier (max over 16
-// rays instead of 64, 256 waves on 256 CUs) and all four stage the 32 KB bitfield together.
-#define TRACE_RAYS_PER_WAVE 16
-__global__ __launch_bounds__(256) void k_batch_trace(const float* __restrict__ pool, const int64_t* __restrict__ ids,
+__global__ __launch_bounds__(64) void k_batch_trace(const float* __restrict__ pool, const int64_t* __restrict__ ids,
                                                      const float* __restrict__ tf, const float* __restrict__ frame_feat, int ff,
                                                      int sh_degree, const uint32_t* __restrict__ bits, int n, int64_t R,
                                                      int max_hits, float* __restrict__ batch, float* __restrict__ rays_o_w,
@@ -216,9 +212,8 @@ __global__ __launch_bounds__(256) void k_batch_trace(const float* __restrict__ p
                                                      int32_t* __restrict__ n_hits, int32_t* __restrict__ flags) {
   extern __shared__ uint32_t occ_lds[];
   const uint32_t* occ = stage_occ(bits, n, occ_lds);
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int64_t r = ((int64_t)blockIdx.x * 4 + wave) * TRACE_RAYS_PER_WAVE + lane;
-  if (lane >= TRACE_RAYS_PER_WAVE || r >= R) return;
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;      // (16 rays per wave in 4x the waves: 28 -> 33 us, each
+  if (r >= R) return;                                                     //  workgroup stages the 32 KB bitfield)
   const int64_t src = ids ? ids[r] : r;
   float row[NOF_RAY_COLS];
 #pragma unroll
@@ -445,7 +440,7 @@ extern "C" int nof_batch_trace(const float* pool, const int64_t* ids, const floa
   NOF_ARG(ff >= 0 && ff + sh_degree * sh_degree <= NOF_VIEW_COLS && (ff == 0 || frame_feat));
   if (R == 0) return 0;
   NOF_HIP(hipMemsetAsync(t_in_out, 0, (size_t)R * max_hits * 2 * sizeof(float), (hipStream_t)stream));
-  hipLaunchKernelGGL(k_batch_trace, dim3((unsigned)nof_div_up(R, 4 * TRACE_RAYS_PER_WAVE)), dim3(256), occ_lds_bytes(level), (hipStream_t)stream, pool, ids, tf,
+  hipLaunchKernelGGL(k_batch_trace, dim3((unsigned)nof_div_up(R, 64)), dim3(64), occ_lds_bytes(level), (hipStream_t)stream, pool, ids, tf,
                      frame_feat, ff, sh_degree, occ_bits, 1 << level, R, max_hits, batch, rays_o_w, viewdirs_w, view,
                      t_in_out, cell_ids, n_hits, flags);
   NOF_LAUNCH_OK();
