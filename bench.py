@@ -177,12 +177,15 @@ def atomic_roofline(fld, runner, R, S, dom_ms):
     g = fld.grid
     lds = [l for l in range(fld.L) if int(g.size[l]) * 8 <= 48 * 1024]            # accumulated in LDS, flushed once (nof_hash.hip)
     levels = [l for l in range(fld.L) if l not in lds]
-    per = SR.count_requests(pts, list(g.scale), list(g.resolution), list(g.offset), list(g.size), list(g.hashed), levels)
+    nonzero = (b['dfeat'][:, :n_rays * S] != 0).any(-1).cpu().numpy()               # [L, n]: the kernel skips exact zeros
+    per = SR.count_requests(pts, list(g.scale), list(g.resolution), list(g.offset), list(g.size), list(g.hashed), levels,
+                            nonzero=nonzero)
     req = sum(per.values()) * (R / n_rays)
     req += sum(64 * min(int(g.size[l]) // 8, 1 << 30) for l in lds)                 # upper bound of the LDS levels' flush
     ach = req / (dom_ms * 1e-3) / 1e9
     return {"line_requests": int(req), "achieved": ach, "peak": ATOMIC_PEAK_G, "unit": "G line-requests/s",
-            "frac": ach / ATOMIC_PEAK_G, "sample": f"counted on {n_rays} of the {R} rays of the last batch, scaled",
+            "frac": ach / ATOMIC_PEAK_G, "sample": f"counted on {n_rays} of the {R} rays of the last batch, scaled; zero-gradient samples "
+                                                                   f"({1.0 - float(nonzero.any(0).mean()):.2f} of them) emit nothing",
             "floor_ms": req / (ATOMIC_PEAK_G * 1e9) * 1e3}
 
 

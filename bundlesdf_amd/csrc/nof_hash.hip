@@ -233,6 +233,13 @@ __global__ __launch_bounds__(256) void k_hash_bwd_agg(NofHashGrid g, LevelList l
     const int level = ll.level[slot_l];
     const int64_t b = (int64_t)sb * 64 + lane;
     const HashLevel lv = load_level(g, level);
+    // Ray-samples whose loss gradient is EXACTLY zero (background rays, free-space samples whose loss has saturated: two
+    // thirds of a cfg2 batch once the field has settled, tools/zero_grad_probe.py) add nothing to the table: a tile of 64 such
+    // samples is skipped as a whole, and a vertex total of exactly 0 is not emitted -- the same sums, fewer atomics.
+    if constexpr (!EIK) {
+      const float2 g0 = dfeat[(int64_t)level * B + (b < B ? b : B - 1)];
+      if (__ballot(b < B && (g0.x != 0.0f || g0.y != 0.0f)) == 0ull) continue;
+    }
     Scatter sc = make_scatter(lv, pts_w, dfeat, level, b, B, EIK ? geik : nullptr, EIK ? dedn : nullptr);
     const bool valid = sc.key != AGG_NONE;
     // neighbours' cells through ds_bpermute (the DPP wavefront shifts do not cross the 16-lane rows on gfx950)
@@ -307,7 +314,7 @@ __global__ __launch_bounds__(256) void k_hash_bwd_agg(NofHashGrid g, LevelList l
             }
           }
         }
-        atomicAdd(&gt[2 * (size_t)r + ch], acc);                      // gridencoder.cu:317-333 (fp32 atomics)
+        if (acc != 0.0f) atomicAdd(&gt[2 * (size_t)r + ch], acc);    // gridencoder.cu:317-333 (fp32 atomics)
       }
       wave_lds_sync();                                                // the next window / tile overwrites the stage
     }
@@ -330,12 +337,16 @@ __global__ __launch_bounds__(1024) void k_hash_bwd_lds(NofHashGrid g, LevelList 
   const int64_t hi = lo + per < B ? lo + per : B;
   for (int64_t base = lo; base < hi; base += blockDim.x) {
     const int64_t b = base + threadIdx.x;
+    if (geik == nullptr) {                                             // all 64 gradients exactly zero: nothing to add
+      const float2 g0 = dfeat[(int64_t)level * B + (b < hi ? b : hi - 1)];
+      if (__ballot(b < hi && (g0.x != 0.0f || g0.y != 0.0f)) == 0ull) continue;
+    }
     Scatter sc = make_scatter(lv, pts_w, dfeat, level, b < hi ? b : B, B, geik, dedn);
     if (wave_merge_runs(sc)) {
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
-        atomicAdd(&acc[2 * sc.idx[k]], sc.vx[k]);
-        atomicAdd(&acc[2 * sc.idx[k] + 1], sc.vy[k]);
+        if (sc.vx[k] != 0.0f) atomicAdd(&acc[2 * sc.idx[k]], sc.vx[k]);
+        if (sc.vy[k] != 0.0f) atomicAdd(&acc[2 * sc.idx[k] + 1], sc.vy[k]);
       }
     }
   }
@@ -365,6 +376,7 @@ __global__ __launch_bounds__(256) void k_hash_dx(NofHashGrid g, const float* __r
     const CellPos c = locate(pts_w, b, lv.scale);
     if (c.oob) break;                                                  // the point is out of range for every level
     const float2 gr = dfeat[(int64_t)level * B + b];
+    if (geik == nullptr && gr.x == 0.0f && gr.y == 0.0f) continue;     // a zero gradient contributes exactly 0 to dL/dx: no gathers
     const float2* __restrict__ tl = table + lv.offset;
     float2 v[8];
     uint32_t idx[8];

@@ -960,25 +960,40 @@ __global__ __launch_bounds__(256, 2) void k_mlp_bwd_color(NofMlpDesc d, const ch
   typename P::frag sign = load_sig_raw<P>(sig, B, AHEAD ? ((int64_t)blockIdx.x * 4 + wave) * 32 + j : B, hi);
   float viewn[16];
   load_view_o1(view, S, B, AHEAD ? ((int64_t)blockIdx.x * 4 + wave) * 32 + j : B, hi, viewn);
+  // draw[b] = (d rgb_raw[3], d sdf), also a tile ahead: it decides whether the tile has anything to do
+  float4 drn = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (hi == 0 && ((int64_t)blockIdx.x * 4 + wave) * 32 + j < B) drn = draw[((int64_t)blockIdx.x * 4 + wave) * 32 + j];
   for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < ntiles; tile += tstride) {
     asm volatile("" ::: "memory");
     const int64_t t0 = tile * 32;
     const int64_t b = t0 + j;
     uint32_t m1[NL];
     float h[2][16];
-    float4 dr = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (hi == 0 && b < B) dr = draw[b];                  // draw[b] = (d rgb_raw[3], d sdf): used after the forward recompute
-    {
-      float cin[2][16];
-      if constexpr (AHEAD) {
-        sig_to_o1<P>(sign, cin[0]);
+    float4 dr = drn;
+    asm volatile("" : "+v"(dr.x), "+v"(dr.y), "+v"(dr.z), "+v"(dr.w));
+    drn = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (hi == 0 && (tile + tstride) * 32 + j < B) drn = draw[(tile + tstride) * 32 + j];
+    float cin[2][16];
+    if constexpr (AHEAD) {
+      sig_to_o1<P>(sign, cin[0]);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) cin[1][r] = viewn[r];
-        pin16(cin[0]);
-        pin16(cin[1]);
-        sign = load_sig_raw<P>(sig, B, (tile + tstride) * 32 + j, hi);
-        load_view_o1(view, S, B, (tile + tstride) * 32 + j, hi, viewn);
-      } else {
+      for (int r = 0; r < 16; ++r) cin[1][r] = viewn[r];
+      pin16(cin[0]);
+      pin16(cin[1]);
+      sign = load_sig_raw<P>(sig, B, (tile + tstride) * 32 + j, hi);
+      load_view_o1(view, S, B, (tile + tstride) * 32 + j, hi, viewn);
+    }
+    // A tile whose 32 loss gradients are all EXACTLY zero (background rays, free-space samples whose loss has saturated: two
+    // thirds of a cfg2 batch once the field has settled) contributes exactly nothing to dW, db, dview and dsig: skipped, with
+    // dsig = 0 written for the sigma kernel.  Same sums, less work (north_star's per-wavefront compaction, applied where
+    // the zeros are: tools/zero_grad_probe.py).
+    const bool skip = __builtin_amdgcn_ballot_w64(dr.x != 0.0f || dr.y != 0.0f || dr.z != 0.0f || dr.w != 0.0f) == 0ull;
+    float ds1[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) ds1[r] = 0.0f;
+    if (!skip) {
+    {
+      if constexpr (!AHEAD) {
         load_sig_o1<P>(sig, B, b, hi, cin[0]);
         load_view_o1(view, S, B, b, hi, cin[1]);
       }
@@ -1037,7 +1052,7 @@ __global__ __launch_bounds__(256, 2) void k_mlp_bwd_color(NofMlpDesc d, const ch
     {
       dw_block<P, 2, 16>(dw[NS][0], dbw + (2 * NS) * 64, I, g1[0], st, 0);
       dw_block<P, 2, 16>(dw[NS][1], dbw + (2 * NS + 1) * 64, I, g1[1], st, 0);
-      float ds1[16], dv1[16], dv2[16];
+      float dv1[16], dv2[16];
       bwd_data<P, 2>(smem, CBW(NS), 0, g1, ds1, lane);
       bwd_data<P, 2>(smem, CBW(NS), 1, g1, dv1, lane);
       transpose32<P>(I, dv1, dv2);
@@ -1060,8 +1075,9 @@ __global__ __launch_bounds__(256, 2) void k_mlp_bwd_color(NofMlpDesc d, const ch
         }
       }
       if (hi == 0) ds1[0] += dsdf1;                    // the loss' own d sdf joins the geo_feat gradients (output 0 = hi 0, reg 0)
-      store_sig_o1<P>(dsig, B, b, hi, ds1);
     }
+    }                                                    // if (!skip)
+    store_sig_o1<P>(dsig, B, b, hi, ds1);                // zeros for a skipped tile
   }
   flush_dw<SH, NS, NL>(d, dw, dbw, partials, gunscale);
 #undef CFW
@@ -1124,18 +1140,31 @@ __global__ __launch_bounds__(256, 2) void k_mlp_bwd_sigma(NofMlpDesc d, const ch
   // load.  Now the NEXT tile's features are requested a whole tile ahead and dsig at the top of the tile: 111 -> 82 us at cfg2.
   float xn[1][16];
   load_feat_o1(feat, L, B, ((int64_t)blockIdx.x * 4 + wave) * 32 + j, hi, xn);
+  typename P::frag dsn = load_sig_raw<P>(dsig, B, ((int64_t)blockIdx.x * 4 + wave) * 32 + j, hi);
   for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < ntiles; tile += tstride) {
     asm volatile("" ::: "memory");
     const int64_t b = tile * 32 + j;
     uint32_t m1[NS];
     float h[2][16];
-    const typename P::frag dsr = load_sig_raw<P>(dsig, B, b, hi);
-    {
-      float x[1][16];
+    const typename P::frag dsr = dsn;                   // dL/d(sigma out) of this tile, requested a tile ahead like the features
+    dsn = load_sig_raw<P>(dsig, B, (tile + tstride) * 32 + j, hi);
+    float x[1][16];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) x[0][r] = xn[0][r];
-      pin16(x[0]);
-      load_feat_o1(feat, L, B, (tile + tstride) * 32 + j, hi, xn);
+    for (int r = 0; r < 16; ++r) x[0][r] = xn[0][r];
+    pin16(x[0]);
+    load_feat_o1(feat, L, B, (tile + tstride) * 32 + j, hi, xn);
+    bool skip;
+    {
+      // all 32 x 16 gradients exactly zero (the colour kernel skipped the tile, see there): dfeat = 0, nothing else to do
+      typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+      const u32x4 bits = __builtin_bit_cast(u32x4, dsr);
+      skip = __builtin_amdgcn_ballot_w64(((bits.x | bits.y | bits.z | bits.w) & 0x7FFF7FFFu) != 0u) == 0ull;
+    }
+    float df1[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) df1[r] = 0.0f;
+    if (!skip) {
+    {
       park_o2<P>(st, I, 0, x[0]);
       dense_o1<P, 1, 2>(smem, SFW(0), SBIAS(0), x, h, lane);
       m1[0] = relu_mask<2>(h);
@@ -1184,10 +1213,10 @@ __global__ __launch_bounds__(256, 2) void k_mlp_bwd_sigma(NofMlpDesc d, const ch
     {
       dw_block<P, 1, 16>(dw[0][0], dbw, I, g1[0], st, 0);
       dw_block<P, 1, 16>(dw[0][1], dbw + 64, I, g1[1], st, 0);
-      float df1[16];
       bwd_data<P, 2>(smem, SBW(0), 0, g1, df1, lane);
-      store_dfeat_o1(dfeat, L, B, b, hi, df1, gunscale);
     }
+    }                                                                    // if (!skip)
+    store_dfeat_o1(dfeat, L, B, b, hi, df1, gunscale);                   // zeros for a skipped tile
   }
   flush_dw<SH, 0, NS>(d, dw, dbw, partials, gunscale);
 #undef SFW

@@ -36,9 +36,11 @@ def level_rows(vx, vy, vz, res, size, hashed):
     return idx % np.int64(size)
 
 
-def count_requests(pts_w, scale, resolution, offset, size, hashed, levels, window=32):
+def count_requests(pts_w, scale, resolution, offset, size, hashed, levels, window=32, nonzero=None):
     """pts_w [N,3] float32 (N a multiple of 64, consecutive samples of rays); per-level constants as in NofHashGrid.
-    Returns dict(level -> requests) for the given levels."""
+    nonzero: optional [L, N] bool, False where the level's feature gradient of a sample is exactly zero -- the kernel skips tiles
+    without a non-zero gradient and does not emit vertex totals that are exactly zero (taken here as: every run of the vertex's
+    chain, two runs back at most, has only zero gradients).  Returns dict(level -> requests) for the given levels."""
     pts = np.asarray(pts_w, np.float32)
     N = len(pts) // 64 * 64
     pts = pts[:N]
@@ -64,9 +66,26 @@ def count_requests(pts_w, scale, resolution, offset, size, hashed, levels, windo
         hand_on = shared_corners(rk, rnext)
         hand_on[(slot % window == window - 1) | last] = 0
         group = rt * 64 + slot // 4                                      # one atomic instruction = 4 runs of one tile
+        dead = None
+        if nonzero is not None:
+            nz = np.asarray(nonzero[l][:N], bool) & valid
+            hpos, tpos = np.flatnonzero(head), np.flatnonzero(tail)
+            csum = np.concatenate([[0], np.cumsum(nz)])
+            rz = (csum[tpos + 1] - csum[hpos]) == 0                      # run has only zero gradients
+            # the run a corner collects from: lane-adjacent previous run(s) of the same tile and window
+            adj1 = np.zeros(len(rk), bool); adj1[1:] = (hpos[1:] == tpos[:-1] + 1) & (rt[1:] == rt[:-1]) & (slot[1:] % window != 0)
+            prev1 = np.concatenate([[NONE], rk[:-1]]); prev1[~adj1] = NONE
+            adj2 = np.zeros(len(rk), bool); adj2[2:] = adj1[2:] & adj1[1:-1] & (slot[2:] % window != 1)
+            prev2 = np.concatenate([[NONE, NONE], rk[:-2]]); prev2[~adj2] = NONE
+            take1 = shared_corners(rk, prev1)
+            take2 = take1 & shared_corners(rk, prev2)
+            rz1 = np.concatenate([[True], rz[:-1]]); rz2 = np.concatenate([[True, True], rz[:-2]])
+            dead = [rz & ((((take1 >> k) & 1) == 0) | rz1) & ((((take2 >> k) & 1) == 0) | rz2) for k in range(8)]
         keys = []
         for k in range(8):
             emit = ((hand_on >> k) & 1) == 0
+            if dead is not None:
+                emit &= ~dead[k]
             rows = level_rows(_axis(rk, 0) + (k & 1), _axis(rk, 1) + ((k >> 1) & 1), _axis(rk, 2) + (k >> 2),
                               int(resolution[l]), int(size[l]), bool(hashed[l]))
             line = (np.int64(offset[l]) + rows) >> 3
