@@ -267,11 +267,12 @@ def main():
         dt = float(t.item())
     log(f'timed region done: {dt / args.steps * 1e3:.3f} ms/step')
     dom_ms = fld.kernel_times_ms().get(dominant) if dominant else None
-    # the product's default mode replays the step as ONE captured HIP graph (NerfRunner.train_loop / GraphedStep); the timed
-    # region above launches eagerly because the dominant kernel is bracketed by events there.  Same K steps, captured, for the record:
+    # cfg hip_graph = True replays the step as ONE captured HIP graph (NerfRunner.train_loop / GraphedStep): one chain instead of
+    # the eager step's two streams, i.e. a free host for a few per cent of step time.  Same K steps, captured, for the record:
     graph_ms = None
     if not dist.is_initialized() or world == 1:
         fld.profile, fld.profile_only = None, None
+        runner.cfg['hip_graph'] = True              # opt-in (the product default is the eager two-stream step)
         for _ in range(4):
             runner.train_loop()
             runner.global_step += 1
@@ -299,12 +300,15 @@ def main():
         it_s = args.steps / dt
         value = world * B * it_s
         # algorithmic work per launch of each kernel (DESIGN.md "Kernels")
+        zero_frac = float((fld._buffers(R, S)['draw'] == 0).all(-1).float().mean().item())     # last batch
         n_mlp = fld.n_mlp
         fl_fwd = 2.0 * (n_mlp - sum(o for o, _ in fld.layer_dims))      # 2*MAC per sample
         work = {
             'nof_hash_encode_fwd': ('hbm', B * (16 * 8 * 2 * 4 + 12 + 16 * 2 * 4)),
-            # dfeat read (L*C*4) + atomic read-modify-write of 8 corners x 2 channels per level (2*L*8*2*4) = 2112 B/sample
-            'nof_hash_encode_bwd': ('hbm', B * (16 * 2 * 4 + 2 * 16 * 8 * 2 * 4)),
+            # dfeat read (L*C*4) + atomic read-modify-write of 8 corners x 2 channels per level (2*L*8*2*4) = 2112 B/sample.
+            # The read-modify-write part only for the samples whose gradient is not exactly zero: the others are skipped by
+            # the kernel (and would add 0), so pricing them would credit work that is not done (frac > 1).
+            'nof_hash_encode_bwd': ('hbm', B * (16 * 2 * 4) + B * (1.0 - zero_frac) * (2 * 16 * 8 * 2 * 4)),
             'nof_mlp_fwd': ('mfma', B * fl_fwd),
             'nof_mlp_bwd': ('mfma', B * 3.0 * fl_fwd),
             'nof_mlp_wide_fwd': ('mfma', B * fl_fwd),
@@ -364,6 +368,9 @@ def main():
             "train_iters_per_sec": it_s * 1.0, "captured_step_ms_per_step": graph_ms,
             "kernel_ms_warmup": {k: round(v, 4) for k, v in sorted(ktimes.items(), key=lambda kv: -kv[1])},
             "valid_sample_fraction": losses['n_valid_samples'] / B,     # samples inside [-1,1]^3 (the rest still run the MLPs)
+            # ray-samples whose loss gradient is exactly zero in the last batch (background rays, saturated free-space samples):
+            # the backward skips 32- / 64-sample tiles made of them (exact: they contribute nothing)
+            "zero_grad_sample_fraction": zero_frac,
             "loss": losses['loss'], "flags": flags, "dp_param_checksum_spread": dp_spread, "param_checksum": checksum,
             "roofline": roof,
         }

@@ -569,14 +569,16 @@ extern "C" int nof_hash_encode_bwd_eik(const NofHashGrid* g, const float* pts_w,
     NOF_HIP(hipStreamWaitEvent(s2, side->fork, 0));
   }
   if (big.n > 0) {
-    // persistent waves, 2 workgroups per CU: the kernel is bound by the atomic rate of the memory side, which a
-    // few waves per CU saturate; more of them only take L2 bandwidth and CU slots from k_hash_dx / k_hash_bwd_lds running
-    // beside it (cfg2, whole call: 1 -> 646 us, 2 -> 439, 3 -> 474, 4 -> 525, 8 -> 537).  NOF_SCATTER_WGS_PER_CU overrides.
+    // persistent waves, 4 workgroups per CU.  With every sample contributing (6.9 M line requests at cfg2) the kernel is bound
+    // by the atomic rate of the memory side, two per CU saturate it and more only take L2 bandwidth from the kernels
+    // beside it (whole call 1 -> 646 us, 2 -> 439, 3 -> 474, 4 -> 525, 8 -> 537).  With the zero-gradient tiles skipped (two thirds
+    // of a settled cfg2 batch: 1.3 M requests) it is latency-bound again and wants more waves: step 0.636 / 0.631 / 0.639 ms with
+    // 3 / 4 / 6.  NOF_SCATTER_WGS_PER_CU overrides.
     int64_t blocks = nof_div_up(nof_div_up(B, 64) * big.n, 4);
     static const int wgs_per_cu = [] {
       const char* e = getenv("NOF_SCATTER_WGS_PER_CU");
-      const int v = e ? atoi(e) : 2;
-      return v >= 1 && v <= 10 ? v : 2;
+      const int v = e ? atoi(e) : 4;
+      return v >= 1 && v <= 10 ? v : 4;
     }();
     const int64_t cap = (int64_t)wgs_per_cu * nof_cu_count();
     if (blocks > cap) blocks = cap;

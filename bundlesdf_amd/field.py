@@ -369,11 +369,11 @@ class NeuralObjectField:
             side = self._side_stream()
             side.wait_stream(main)
             with torch.cuda.stream(side):
-                reduce_mlp()
                 if dpts is not None:
                     scatter(dpts, 0, 0)
                 pose_kernels()
             scatter(None, 0, self.L)
+            reduce_mlp()                             # (on this stream: with the zero-gradient tiles skipped the two chains balance)
             main.wait_stream(side)
         if self.optimize_poses and float(cfg.get('pose_reg_weight', 0)) > 0:
             self._call('nof_pose_reg', self.pose, self._seg(self.grads, 'pose'), self.F, C.c_float(cfg['pose_reg_weight']),

@@ -213,9 +213,10 @@ class NerfRunner:
             ids = self.data_loader.next_ids()
         seed = self.cfg.get('seed', 0) + 7919 * self.rank
         f = self.field
-        # captured-step mode (cfg hip_graph, default on): after a few eager steps (module load, buffers, the hash backward's side
+        # captured-step mode (cfg hip_graph, default OFF since the eager step overlaps its two backward chains on two streams and is
+        # 5-9 % faster than the single captured chain; the capture frees the host): after a few eager steps (module load, buffers, the hash backward's side
         # stream) the whole step is replayed as one HIP graph; eager otherwise (data parallel, per-kernel timing, truncation decay)
-        graph_ok = (self.cfg.get('hip_graph', True) and self.grad_sync is None and f.profile is None
+        graph_ok = (self.cfg.get('hip_graph', False) and self.grad_sync is None and f.profile is None
                     and not self.cfg.get('trunc_decay_type', ''))
         g = getattr(self, '_graph', None)
         if g is not None and (g.field is not f or g.R != ids.shape[0] or not g.usable() or not graph_ok):
