@@ -423,3 +423,31 @@ def test_scatter_chain_rules_partition_exactly():
         a, b = kernel_rules(keys, vals), direct(keys, vals)
         assert set(a) == set(b)
         assert max(abs(a[v] - b[v]) for v in b) < 1e-9
+
+
+def test_scatter_request_counter_zero_gradient_rules():
+    """tools/scatter_requests.py (bench.py's roofline.atomic): a mask of all-True gradients changes nothing, all-False emits nothing,
+    and zeroing whole rays removes exactly those rays' requests (rays = multiples of 64 samples here, so tiles do not mix)."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools'))
+    import scatter_requests as SR
+    from oracle import nof_oracle as O
+    geo = O.HashGeometry(16, 2, 16, 19, 256)
+    rng = np.random.default_rng(3)
+    n_rays, S = 24, 192
+    o = rng.uniform(-0.8, 0.8, size=(n_rays, 1, 3))
+    d = rng.normal(size=(n_rays, 1, 3))
+    d /= np.linalg.norm(d, axis=-1, keepdims=True)
+    pts = (o + d * np.linspace(0, 0.7, S)[None, :, None]).reshape(-1, 3).astype(np.float32)
+    N = len(pts)
+    args = (pts, geo.scale, geo.resolution, geo.offsets[:-1], geo.size, geo.hashed, range(1, 16))
+    base = SR.count_requests(*args)
+    assert SR.count_requests(*args, nonzero=np.ones((16, N), bool)) == base
+    assert sum(SR.count_requests(*args, nonzero=np.zeros((16, N), bool)).values()) == 0
+    keep = np.ones((n_rays, S), bool)
+    keep[::2] = False                                                    # every other ray has no gradient at all
+    half = SR.count_requests(*args, nonzero=np.broadcast_to(keep.reshape(-1), (16, N)))
+    only = SR.count_requests(pts.reshape(n_rays, S, 3)[1::2].reshape(-1, 3), *args[1:])
+    assert half == only
+    assert 0 < sum(half.values()) < sum(base.values())
