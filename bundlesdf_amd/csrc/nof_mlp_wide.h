@@ -187,7 +187,7 @@ __global__ __launch_bounds__(768) void k_wide_bwd_color(NofMlpDesc d, const char
                                                          int S, const float4* __restrict__ draw,
                                                          typename P::elem* __restrict__ gbuf, int64_t g_stride,
                                                          typename P::elem* __restrict__ dsig, float* __restrict__ dview,
-                                                         int64_t B) {
+                                                         uint8_t* __restrict__ zflag, int64_t B) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int NS = d.n_sigma, NC = d.n_color, NL = NS + NC;
   const int PA = pair_base(d, NS), PB = pair_base(d, NL);
@@ -208,11 +208,15 @@ __global__ __launch_bounds__(768) void k_wide_bwd_color(NofMlpDesc d, const char
     float dsdf1 = 0.0f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) gh[0][r] = 0.0f;
-    if (hi == 0 && ok) {
-      const float4 t = draw[b];
-      gh[0][0] = t.x * gscale; gh[0][1] = t.y * gscale; gh[0][2] = t.z * gscale;
-      dsdf1 = t.w * gscale;
-    }
+    float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (hi == 0 && ok) t = draw[b];
+    // a tile whose 32 loss gradients are all exactly zero contributes nothing to any gradient: flagged for the
+    // sigma kernel and the weight-gradient passes, nothing stored, nothing computed
+    const bool skip = __builtin_amdgcn_ballot_w64(t.x != 0.0f || t.y != 0.0f || t.z != 0.0f || t.w != 0.0f) == 0ull;
+    if (lane == 0) zflag[tile] = skip ? 1 : 0;
+    if (skip) continue;
+    gh[0][0] = t.x * gscale; gh[0][1] = t.y * gscale; gh[0][2] = t.z * gscale;
+    dsdf1 = t.w * gscale;
     if (ok) store_blk<P>(gbuf + (int64_t)(NL - 1) * g_stride + b * H, 0, hi, gh[0]);
     // head -> last hidden colour layer
     int woff = (pair_base(d, NL - 1) - PA) * WPAIR;
@@ -282,7 +286,8 @@ __global__ __launch_bounds__(768) void k_wide_bwd_sigma(NofMlpDesc d, const char
                                                          const typename P::elem* __restrict__ hid, int64_t hid_stride,
                                                          const typename P::elem* __restrict__ dsig,
                                                          typename P::elem* __restrict__ gbuf, int64_t g_stride,
-                                                         float2* __restrict__ dfeat, int L, int64_t B) {
+                                                         float2* __restrict__ dfeat, int L,
+                                                         const uint8_t* __restrict__ zflag, int64_t B) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int NS = d.n_sigma, NL = d.n_sigma + d.n_color;
   const int PB = pair_base(d, NL), PS = pair_base(d, NS);
@@ -302,6 +307,10 @@ __global__ __launch_bounds__(768) void k_wide_bwd_sigma(NofMlpDesc d, const char
     sig_to_o1<P>(dsn, gh[0]);
     pin16(gh[0]);
     dsn = load_sig_raw<P>(dsig, B, (tile + tstride) * 32 + j, hi);
+    float df1[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) df1[r] = 0.0f;
+    if (zflag[tile] == 0) {                                               // (flagged by k_wide_bwd_color: dfeat = 0, nothing else)
     if (ok) store_blk<P>(gbuf + (int64_t)(NS - 1) * g_stride + b * H, 0, hi, gh[0]);
     int woff = pair_base(d, NS - 1) * WPAIR;
     {
@@ -334,8 +343,8 @@ __global__ __launch_bounds__(768) void k_wide_bwd_sigma(NofMlpDesc d, const char
 #pragma unroll
       for (int p = 0; p < HB; ++p) store_blk<P>(gbuf + b * H, p, hi, g[p]);
     }
-    float df1[16];
     bwd_data<P, HB>(smem, 0, 0, g, df1, lane);
+    }
     store_dfeat_o1(dfeat, L, B, b, hi, df1, gunscale);
   }
 }
@@ -355,7 +364,8 @@ __global__ __launch_bounds__(256) void k_wide_dw(NofMlpDesc d, int l, const type
                                                   int H, const float2* __restrict__ feat, int L,
                                                   const typename P::elem* __restrict__ xrow,
                                                   const typename P::elem* __restrict__ sig, const float* __restrict__ view,
-                                                  int S, float* __restrict__ partials, int rows, int64_t B) {
+                                                  int S, float* __restrict__ partials, int rows,
+                                                  const uint8_t* __restrict__ zflag, int64_t B) {
   constexpr int KR = P::KR, NSTEP = 16 / KR, NST = 4 / PN, MAXQ = (QN + PN - 1) / PN;
   __shared__ typename P::frag xs[2][NST][QN][NSTEP][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -375,9 +385,11 @@ __global__ __launch_bounds__(256) void k_wide_dw(NofMlpDesc d, int l, const type
   const int n_it = (int)((ntiles + rows - 1) / rows);                  // the same trip count for every wave (barrier inside)
   // the NEXT tile's gradient block and this wave's share of the input blocks are loaded while the current tile is computed
   float g1[16], xn[MAXQ][16];
+  bool zn = true;                                                         // the next tile is flagged all-zero (or past the end)
   auto fetch = [&](int64_t tile) {
     const int64_t b = tile * 32 + j;
-    const bool ok = tile < ntiles && b < B;
+    zn = tile >= ntiles || zflag[tile] != 0;
+    const bool ok = !zn && b < B;
     load_blk<P>(grow + b * H, p, hi, ok, g1);
 #pragma unroll
     for (int m = 0; m < MAXQ; ++m) {
@@ -408,8 +420,10 @@ __global__ __launch_bounds__(256) void k_wide_dw(NofMlpDesc d, int l, const type
     for (int m = 0; m < MAXQ; ++m)
 #pragma unroll
       for (int r = 0; r < 16; ++r) x1[m][r] = xn[m][r];
+    const bool z0 = __builtin_amdgcn_readfirstlane(zn ? 1 : 0) != 0;      // this tile adds nothing: only the barrier is kept
     fetch((int64_t)row + (int64_t)(it + 1) * rows);
     const int buf = it & 1;
+    if (z0) { __syncthreads(); continue; }
 #pragma unroll
     for (int m = 0; m < MAXQ; ++m) {
       const int q = p + m * PN;
@@ -462,8 +476,8 @@ static int check_wide(const NofMlpDesc* d) {
 static int64_t wide_hid_layers(const NofMlpDesc* d) { return (d->n_sigma - 1) + (d->n_color - 1); }
 static const int kWideRows = 1024;                                        // wave-rows of `partials`: 4 waves per SIMD of the weight-gradient pass
 
-// workspace layout (bytes, 256-aligned): [hid : n_hid * B * H elems][gbuf : NL * B * H elems][sig : B * 16 elems][dsig : B * 16 elems]
-struct WideWs { char *hid, *gbuf, *sig, *dsig; int64_t total; };
+// workspace layout (bytes, 256-aligned): [hid : n_hid * B * H elems][gbuf : NL * B * H elems][sig : B * 16 elems][dsig : B * 16 elems][zflag : B/32 bytes]
+struct WideWs { char *hid, *gbuf, *sig, *dsig; uint8_t* zflag; int64_t total; };
 static WideWs wide_ws(const NofMlpDesc* d, void* base, int64_t B) {
   auto up = [](int64_t x) { return (x + 255) / 256 * 256; };
   const int64_t row = (int64_t)d->hidden * 2, nl = d->n_sigma + d->n_color;
@@ -473,6 +487,7 @@ static WideWs wide_ws(const NofMlpDesc* d, void* base, int64_t B) {
   w.gbuf = (char*)base + off; off += up(nl * B * row);
   w.sig = (char*)base + off; off += up(B * 32);
   w.dsig = (char*)base + off; off += up(B * 32);
+  w.zflag = (uint8_t*)base + off; off += up((B + 31) / 32);             // one byte per 32-sample tile: 1 = every loss gradient is exactly zero
   w.total = off;
   return w;
 }
@@ -562,9 +577,9 @@ static int wide_bwd_launch(const NofMlpDesc* d, const void* packed, const float*
   if (int e = set_smem(kc, shm_c)) return e;
   if (int e = set_smem(ks, shm_s)) return e;
   hipLaunchKernelGGL(kc, dim3(blocks), dim3(768), shm_c, st, *d, (const char*)packed, (const elem*)hid, hs, (int)S,
-                     (const float4*)draw, gbuf, hs, dsig, dview, B);
+                     (const float4*)draw, gbuf, hs, dsig, dview, ws->zflag, B);
   hipLaunchKernelGGL(ks, dim3(blocks), dim3(768), shm_s, st, *d, (const char*)packed, (const elem*)hid, hs, (const elem*)dsig, gbuf,
-                     hs, (float2*)dfeat, (int)L, B);
+                     hs, (float2*)dfeat, (int)L, (const uint8_t*)ws->zflag, B);
   // weight gradients, layer by layer (PN = output blocks of the layer: HB for the hidden layers, 1 for the two heads)
   for (int l = 0; l < nl; ++l) {
     const int PN = lay_pn(*d, l);
@@ -574,7 +589,7 @@ static int wide_bwd_launch(const NofMlpDesc* d, const void* packed, const float*
     const elem* xin = (l == 0 || l == ns) ? (const elem*)nullptr : (const elem*)(hid + (int64_t)hidx * hs);
 #define WIDE_DW(QN_, KIND_, PN_)                                                                          \
     hipLaunchKernelGGL((k_wide_dw<P, QN_, KIND_, PN_>), dim3(grid), dim3(256), 0, st, *d, l, grow, H, (const float2*)feat, \
-                       (int)L, xin, (const elem*)sig, view, (int)S, partials, kWideRows, B)
+                       (int)L, xin, (const elem*)sig, view, (int)S, partials, kWideRows, (const uint8_t*)ws->zflag, B)
     if (l == 0) { WIDE_DW(1, 0, HB); }
     else if (l == ns) { WIDE_DW(2, 2, HB); }
     else if (PN == 1) { WIDE_DW(HB, 1, 1); }
