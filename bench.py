@@ -362,7 +362,9 @@ def main():
                                    f"{R} rays/step x {S} samples, hash L=16 T=2^{args.log2_T} base16->{args.finest}, "
                                    f"MLP SDF {MLP_SHAPES[args.mlp][0]}x{MLP_SHAPES[args.mlp][2]} + colour "
                                    f"{MLP_SHAPES[args.mlp][1]}x{MLP_SHAPES[args.mlp][2]}, "
-                                   f"{PRECISION_NOTE[runner.precision]}, fp32 table/accumulators/Adam",
+                                   f"{PRECISION_NOTE[runner.precision]}, fp32 table/accumulators/Adam; every sample runs "
+                                   f"the forward and the loss, the backward skips 32-/64-sample tiles whose loss gradient is "
+                                   f"exactly zero (they add nothing: same sums; fraction in zero_grad_sample_fraction)",
                        "rays_per_step": R, "samples_per_ray": S, "keyframes_per_gpu": args.keyframes,
                        "pool_rays": int(runner.rays.shape[0]), "parallelism": f"dp{world}"},
             "train_iters_per_sec": it_s * 1.0, "captured_step_ms_per_step": graph_ms,
