@@ -23,7 +23,7 @@ def total(table, prefixes):
 out = {'_note': 'HBM-side bytes per launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, KiB * 1024), cfg2 batch '
                 '(4096 rays x 192 samples, L=16, T=2^19), summed over the kernels of each C-ABI entry point. RAW counter values: '
                 'on gfx950 FETCH_SIZE under-reports wide coalesced streaming reads by 2x (MI355X_MICROARCH.md, HBM section); for '
-                '8-byte gathers and atomics it is uncalibrated. Source: the pmc_counters file of the same round in profiles/',
+                '8-byte gathers and atomics it is uncalibrated. Source: the FETCH_SIZE / WRITE_SIZE summary of the same round in profiles/ (r02_h_pmc_fetch_write.txt; zero-gradient tiles skipped, 200 warm-up steps)',
        'workload': 'cfg2 batch, bench.py default precision (fp16x3), 16-keyframe pool'}
 for k, names in groups.items():
     f = total(fetch, names) * 1024
