@@ -138,7 +138,7 @@ def cpu_baseline(seconds=20.0, rays_per_step=4096, log2_T=19, mlp='baseline', fi
         if (time.time() - t_start > seconds and len(times) >= 1) or len(times) >= 20:
             break
     med = float(np.median(times))
-    return {"value": R * S / med, "unit": "ray-samples/s", "cores": ncores, "kind": "port",
+    return {"value": R * S / med, "unit": "ray-samples/s", "cores": ncores, "cores_total": os.cpu_count(), "kind": "port",
             "iters_per_s": 1.0 / med,
             "sample": f"{len(times)} timed steps (1 warm-up) of oracle/nof_oracle.py OracleField.train_step on the workload's own "
                       f"step: {R} rays x {S} samples, L=16 T=2^{log2_T}, MLP SDF {ns}x{hidden} + colour {nc}x{hidden}, fp32, rays of 4 "
@@ -177,7 +177,9 @@ def atomic_roofline(fld, runner, R, S, dom_ms):
     g = fld.grid
     lds = [l for l in range(fld.L) if int(g.size[l]) * 8 <= 48 * 1024]            # accumulated in LDS, flushed once (nof_hash.hip)
     levels = [l for l in range(fld.L) if l not in lds]
-    nonzero = (b['dfeat'][:, :n_rays * S] != 0).any(-1).cpu().numpy()               # [L, n]: the kernel skips exact zeros
+    # [L, n]: the samples that reach the scatter = those of the listed tiles (dfeat of the others is not even written) ...
+    live = (b['draw'][:n_rays * S] != 0).any(-1).reshape(-1, 32).any(-1).repeat_interleave(32)
+    nonzero = ((b['dfeat'][:, :n_rays * S] != 0).any(-1) & live[None]).cpu().numpy()   # ... and exact zeros emit nothing
     per = SR.count_requests(pts, list(g.scale), list(g.resolution), list(g.offset), list(g.size), list(g.hashed), levels,
                             nonzero=nonzero)
     req = sum(per.values()) * (R / n_rays)
@@ -237,8 +239,13 @@ def main():
     R, S = args.rays, cfg['N_samples'] + cfg['N_samples_around_depth']
     B = R * S
 
+    def zero_fraction():
+        """ray-samples of the last batch whose loss gradient is exactly zero (one device reduction + host sync: outside timing)"""
+        return float((fld._buffers(R, S)['draw'] == 0).all(-1).float().mean().item())
+
     # ---- warm-up with every launch bracketed by events: finds the dominant kernel --------------------------------
     fld.profile = {}
+    sync = runner.grad_sync if hasattr(runner.grad_sync, 'finish') else None
     for _ in range(args.warmup):
         runner.train_loop()
         runner.global_step += 1
@@ -248,30 +255,56 @@ def main():
     dominant = max(ktimes, key=ktimes.get) if ktimes else None
     fld.profile = {dominant: []} if dominant else None          # timed region: only the dominant kernel keeps its events
     fld.profile_only = dominant
+    # the hash lookup (north_star: ">= 40 % HBM roofline for hash lookup") is timed as well: two more events per step
+    if dominant != 'nof_hash_encode_fwd':
+        fld.profile_also = 'nof_hash_encode_fwd'
+    if sync is not None:
+        sync.timing = []
 
     def barrier():
         if dist.is_initialized():
             dist.barrier()
         torch.cuda.synchronize()
 
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        runner.train_loop()
-        runner.global_step += 1
-    barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    def timed(n):
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            runner.train_loop()
+            runner.global_step += 1
+        barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], device=device, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt
+
+    zero_first = zero_fraction() if args.warmup > 0 else None
+    dt = timed(args.steps)
     log(f'timed region done: {dt / args.steps * 1e3:.3f} ms/step')
-    dom_ms = fld.kernel_times_ms().get(dominant) if dominant else None
+    zero_last = zero_fraction()
+    kt = fld.kernel_times_ms()
+    dom_ms = kt.get(dominant) if dominant else None
+    hash_fwd_ms = kt.get('nof_hash_encode_fwd')
+    exposed_comm_ms = None
+    if sync is not None and sync.timing:
+        torch.cuda.synchronize()
+        exposed_comm_ms = float(np.mean([a.elapsed_time(b) for a, b in sync.timing]))
+        sync.timing = None
+    fld.profile, fld.profile_only, fld.profile_also = None, None, None
+    # The same K steps with EVERY tile in the backward's work list (nothing skipped, same kernels): what the step costs when no
+    # loss gradient is zero.  The headline depends on the data-dependent sparsity reported in zero_grad_sample_fraction; this
+    # figure does not.
+    fld.backward_tiles = 'all'
+    timed(2)
+    dense_ms = timed(args.steps) / args.steps * 1e3
+    fld.backward_tiles = 'list'
+    log(f'dense backward (every tile listed): {dense_ms:.3f} ms/step')
     # cfg hip_graph = True replays the step as ONE captured HIP graph (NerfRunner.train_loop / GraphedStep): one chain instead of
     # the eager step's two streams, i.e. a free host for a few per cent of step time.  Same K steps, captured, for the record:
     graph_ms = None
     if not dist.is_initialized() or world == 1:
-        fld.profile, fld.profile_only = None, None
         runner.cfg['hip_graph'] = True              # opt-in (the product default is the eager two-stream step)
         for _ in range(4):
             runner.train_loop()
@@ -300,30 +333,34 @@ def main():
         it_s = args.steps / dt
         value = world * B * it_s
         # algorithmic work per launch of each kernel (DESIGN.md "Kernels")
-        zero_frac = float((fld._buffers(R, S)['draw'] == 0).all(-1).float().mean().item())     # last batch
+        zero_frac = zero_last
         n_mlp = fld.n_mlp
         fl_fwd = 2.0 * (n_mlp - sum(o for o, _ in fld.layer_dims))      # 2*MAC per sample
+        hash_fwd_bytes = B * (16 * 8 * 2 * 4 + 12 + 16 * 2 * 4)
         work = {
-            'nof_hash_encode_fwd': ('hbm', B * (16 * 8 * 2 * 4 + 12 + 16 * 2 * 4)),
-            # dfeat read (L*C*4) + atomic read-modify-write of 8 corners x 2 channels per level (2*L*8*2*4) = 2112 B/sample.
-            # The read-modify-write part only for the samples whose gradient is not exactly zero: the others are skipped by
-            # the kernel (and would add 0), so pricing them would credit work that is not done (frac > 1).
-            'nof_hash_encode_bwd': ('hbm', B * (16 * 2 * 4) + B * (1.0 - zero_frac) * (2 * 16 * 8 * 2 * 4)),
+            'nof_hash_encode_fwd': ('hbm', hash_fwd_bytes),
+            # dfeat read (L*C*4) + atomic read-modify-write of 8 corners x 2 channels per level (2*L*8*2*4) = 2112 B/sample,
+            # both only for the samples the work list keeps: the others are not read and would add 0 -- pricing them would credit
+            # work that is not done (frac > 1).  This is the table scatter; dL/dx (k_hash_dx, 1048 B/sample) and the LDS-accumulated
+            # level run beside it on the step's second stream and are not part of the figure.
+            'hash_bwd[table]': ('hbm', B * (1.0 - zero_frac) * (16 * 2 * 4 + 2 * 16 * 8 * 2 * 4)),
+            'hash_bwd[table_lds+input]': ('hbm', B * (1.0 - zero_frac) * (16 * 2 * 4 + 16 * 8 * 2 * 4 + 12) + B * 12),
             'nof_mlp_fwd': ('mfma', B * fl_fwd),
-            'nof_mlp_bwd': ('mfma', B * 3.0 * fl_fwd),
+            'nof_mlp_bwd_tiles': ('mfma', B * (1.0 - zero_frac) * 3.0 * fl_fwd),
             'nof_mlp_wide_fwd': ('mfma', B * fl_fwd),
             'nof_mlp_wide_bwd': ('mfma', B * 2.0 * fl_fwd),           # no recompute on the wide path: data + weight gradients
             'nof_adam_step': ('hbm', fld.n_total * 32.0),
         }
-        # (dL/dx -- k_hash_dx, 1048 B/sample -- is its own launch on the step's second stream and is not part of this figure)
-        extra_bytes = {}
         traffic = None          # HBM bytes per launch from the committed PMC passes (profiles/pmc_traffic.json), same workload only
+        hash_fwd_traffic = None
         try:
             if args.mlp == 'baseline' and R == 4096 and args.log2_T == 19:
                 pm = json.load(open(os.path.join(ROOT, 'profiles', 'pmc_traffic.json')))
                 traffic = pm.get(dominant, {}).get('traffic_bytes')
+                hash_fwd_traffic = pm.get('nof_hash_encode_fwd', {}).get('traffic_bytes')
         except Exception:
             traffic = None
+        src = ("profiles/pmc_traffic.json (rocprofv3 --pmc passes of this workload, committed; not re-measured in this run)")
         roof = None
         if dominant in work and dom_ms:
             kind, amount = work[dominant]
@@ -331,11 +368,8 @@ def main():
                 ach = amount / (dom_ms * 1e-3) / 1e9
                 roof = {"kernel": dominant, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes": amount, "avg_ms": dom_ms,
-                        "traffic_source": "profiles/pmc_traffic.json (rocprofv3 --pmc passes of this workload, committed; "
-                                          "not re-measured in this run)" if traffic else None}
-                if dominant in extra_bytes:      # the same launch priced with everything it computes (scatter + dL/dx)
-                    roof["frac_incl_input_grad"] = (amount + extra_bytes[dominant]) / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
-                if dominant == 'nof_hash_encode_bwd':
+                        "traffic_source": src if traffic else None}
+                if dominant == 'hash_bwd[table]':
                     # what actually bounds the scatter: the memory side retires ~20.8 G atomic LINE REQUESTS per second
                     # (tools/atomic_probe.py; same for every scope, cache flag and data type), and the launch needs one request per
                     # 64-byte line per atomic instruction.  The requests of THIS batch are counted from its own sample points.
@@ -350,6 +384,15 @@ def main():
         elif dominant:
             roof = {"kernel": dominant, "bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None,
                     "traffic": None, "avg_ms": dom_ms}
+        if roof is not None and hash_fwd_ms:
+            # The hash lookup, both ways: SURVEY 8d's algorithmic bytes count every corner read as memory traffic (L2 hits
+            # included: this fraction can exceed 1), the memory-side figure is what the PMC counters saw leave / enter HBM.
+            ach = hash_fwd_bytes / (hash_fwd_ms * 1e-3) / 1e9
+            roof["hash_fwd"] = {"kernel": "nof_hash_encode_fwd", "avg_ms": hash_fwd_ms, "algorithmic_bytes": hash_fwd_bytes,
+                                "achieved_algorithmic": ach, "frac_algorithmic": ach / HBM_PEAK_GBS, "traffic": hash_fwd_traffic,
+                                "frac_memory_side": (hash_fwd_traffic / (hash_fwd_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if hash_fwd_traffic else None,
+                                "traffic_source": src if hash_fwd_traffic else None, "unit": "GB/s", "peak": HBM_PEAK_GBS,
+                                "note": "bound by the vector-memory instruction rate (8 gathers x 16 levels per sample), not by HBM"}
         shape_key = (args.keyframes, R, args.log2_T, args.mlp, args.width, args.height)
         cfg_name = {(64, 4096, 19, 'baseline', 640, 480): 'cfg2' if world == 1 else 'cfg3',
                     (4, 1024, 14, 'reference', 640, 480): 'cfg1 shapes',
@@ -363,17 +406,26 @@ def main():
                                    f"MLP SDF {MLP_SHAPES[args.mlp][0]}x{MLP_SHAPES[args.mlp][2]} + colour "
                                    f"{MLP_SHAPES[args.mlp][1]}x{MLP_SHAPES[args.mlp][2]}, "
                                    f"{PRECISION_NOTE[runner.precision]}, fp32 table/accumulators/Adam; every sample runs "
-                                   f"the forward and the loss, the backward skips 32-/64-sample tiles whose loss gradient is "
-                                   f"exactly zero (they add nothing: same sums; fraction in zero_grad_sample_fraction)",
+                                   f"the forward and the loss, the backward runs over the work list of the 32-sample tiles that hold a "
+                                   f"non-zero loss gradient (the others add exactly nothing: same sums; fraction of zero samples in "
+                                   f"zero_grad_sample_fraction, the step with every tile listed in ms_per_step_dense_backward)",
                        "rays_per_step": R, "samples_per_ray": S, "keyframes_per_gpu": args.keyframes,
                        "pool_rays": int(runner.rays.shape[0]), "parallelism": f"dp{world}"},
             "train_iters_per_sec": it_s * 1.0, "captured_step_ms_per_step": graph_ms,
+            # same run, same kernels, every tile of the batch in the backward's work list (no sparsity): DESIGN 2.9
+            "ms_per_step_dense_backward": dense_ms, "value_dense_backward": world * B / (dense_ms * 1e-3),
             "kernel_ms_warmup": {k: round(v, 4) for k, v in sorted(ktimes.items(), key=lambda kv: -kv[1])},
             "valid_sample_fraction": losses['n_valid_samples'] / B,     # samples inside [-1,1]^3 (the rest still run the MLPs)
             # ray-samples whose loss gradient is exactly zero in the last batch (background rays, saturated free-space samples):
             # the backward skips 32- / 64-sample tiles made of them (exact: they contribute nothing)
             "zero_grad_sample_fraction": zero_frac,
+            "zero_grad_sample_fraction_first_timed_step": zero_first, "zero_grad_sample_fraction_last_timed_step": zero_last,
             "loss": losses['loss'], "flags": flags, "dp_param_checksum_spread": dp_spread, "param_checksum": checksum,
+            # data parallel (N > 1): gradient bytes each rank hands to RCCL per step, in how many collectives, and how long the
+            # step's stream waited for them after the backward (events around GradSync.finish: what did not hide)
+            "allreduce_bytes_per_step": (sync.bytes_step if sync is not None else (fld.n_total * 4 if world > 1 else 0)),
+            "collectives_per_step": (sync.collectives_step if sync is not None else (1 if world > 1 else 0)),
+            "exposed_comm_ms": exposed_comm_ms,
             "roofline": roof,
         }
         if not args.no_cpu_baseline and world == 1:          # the CPU leg is timed on rank 0 at N = 1 only

@@ -215,7 +215,8 @@ __device__ __forceinline__ void wave_lds_sync() {
 template <bool EIK>
 __global__ __launch_bounds__(256) void k_hash_bwd_agg(NofHashGrid g, LevelList ll, const float* __restrict__ pts_w,
                                                        const float2* __restrict__ dfeat, float* __restrict__ grad_table,
-                                                       int64_t B, const float2* __restrict__ geik, const float* __restrict__ dedn) {
+                                                       int64_t B, const float2* __restrict__ geik, const float* __restrict__ dedn,
+                                                       const uint32_t* __restrict__ tile_list) {
   __shared__ __attribute__((aligned(16))) AggStage st;
   const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   float* val = st.val[w];
@@ -226,19 +227,26 @@ __global__ __launch_bounds__(256) void k_hash_bwd_agg(NofHashGrid g, LevelList l
   const unsigned long long le = (2ull << lane) - 1ull;                // lanes 0..lane
   // (64 samples, level) tiles, level fastest; tile = block * 4 + wave, then + gridDim * 4 per round -- kept as (sample block,
   // level slot) with a carry instead of dividing every round
-  const uint32_t n_lv = (uint32_t)ll.n, n_sb = (uint32_t)((B + 63) / 64), n_waves = gridDim.x * 4u;
+  // With a work list (NofTileList) a "sample block" is a PAIR of listed 32-sample tiles, lanes 0-31 / 32-63: the run / chain logic
+  // below only ever compares cell ids of neighbouring lanes, so two tiles from different rays in one wave are just a place where
+  // a run ends (or, by coincidence, continues -- same cell, same vertices, same sum).  An odd list ends in a tile past the batch.
+  const uint32_t n_items = tile_list ? ((uint32_t)__builtin_amdgcn_readfirstlane((int)tile_list[0]) + 1u) / 2u : (uint32_t)((B + 63) / 64);
+  const uint32_t n_lv = (uint32_t)ll.n, n_sb = n_items, n_waves = gridDim.x * 4u;
   const uint32_t t0 = blockIdx.x * 4u + (uint32_t)w, dq = n_waves / n_lv, dr = n_waves % n_lv;
   uint32_t sb = t0 / n_lv, slot_l = t0 % n_lv;
   for (; sb < n_sb; sb += dq, slot_l += dr, sb += slot_l >= n_lv ? 1u : 0u, slot_l -= slot_l >= n_lv ? n_lv : 0u) {
     const int level = ll.level[slot_l];
-    const int64_t b = (int64_t)sb * 64 + lane;
+    const int64_t b = tile_list ? (int64_t)tile_list[4 + 2 * sb + (lane >> 5)] * 32 + (lane & 31) : (int64_t)sb * 64 + lane;
     const HashLevel lv = load_level(g, level);
     // Ray-samples whose loss gradient is EXACTLY zero (background rays, free-space samples whose loss has saturated: two
     // thirds of a cfg2 batch once the field has settled, tools/zero_grad_probe.py) add nothing to the table: a tile of 64 such
     // samples is skipped as a whole, and a vertex total of exactly 0 is not emitted -- the same sums, fewer atomics.
+    // (Without a list only: a listed tile has a non-zero gradient by construction.)
     if constexpr (!EIK) {
-      const float2 g0 = dfeat[(int64_t)level * B + (b < B ? b : B - 1)];
-      if (__ballot(b < B && (g0.x != 0.0f || g0.y != 0.0f)) == 0ull) continue;
+      if (tile_list == nullptr) {
+        const float2 g0 = dfeat[(int64_t)level * B + (b < B ? b : B - 1)];
+        if (__ballot(b < B && (g0.x != 0.0f || g0.y != 0.0f)) == 0ull) continue;
+      }
     }
     Scatter sc = make_scatter(lv, pts_w, dfeat, level, b, B, EIK ? geik : nullptr, EIK ? dedn : nullptr);
     const bool valid = sc.key != AGG_NONE;
@@ -324,7 +332,8 @@ __global__ __launch_bounds__(256) void k_hash_bwd_agg(NofHashGrid g, LevelList l
 // levels whose slice fits LDS: accumulate privately, flush once
 __global__ __launch_bounds__(1024) void k_hash_bwd_lds(NofHashGrid g, LevelList ll, int chunks, const float* __restrict__ pts_w,
                                                         const float2* __restrict__ dfeat, float* __restrict__ grad_table,
-                                                        int64_t B, const float2* __restrict__ geik, const float* __restrict__ dedn) {
+                                                        int64_t B, const float2* __restrict__ geik, const float* __restrict__ dedn,
+                                                        const uint32_t* __restrict__ tile_list) {
   extern __shared__ __attribute__((aligned(16))) float acc[];
   const int level = ll.level[blockIdx.x % ll.n];
   const int chunk = blockIdx.x / ll.n;
@@ -332,16 +341,20 @@ __global__ __launch_bounds__(1024) void k_hash_bwd_lds(NofHashGrid g, LevelList 
   const int n2 = 2 * (int)lv.size;
   for (int e = threadIdx.x; e < n2; e += blockDim.x) acc[e] = 0.0f;
   __syncthreads();
-  const int64_t per = ((B + chunks - 1) / chunks + 63) / 64 * 64;     // whole waves per chunk
+  // wave items = 64 samples: 64 consecutive samples of the batch, or a pair of listed tiles (see k_hash_bwd_agg); a chunk is a
+  // contiguous range of items, its 16 waves stride over it
+  const int64_t n_items = tile_list ? ((int64_t)tile_list[0] + 1) / 2 : (B + 63) / 64;
+  const int64_t per = (n_items + chunks - 1) / chunks;
   const int64_t lo = (int64_t)chunk * per;
-  const int64_t hi = lo + per < B ? lo + per : B;
-  for (int64_t base = lo; base < hi; base += blockDim.x) {
-    const int64_t b = base + threadIdx.x;
-    if (geik == nullptr) {                                             // all 64 gradients exactly zero: nothing to add
-      const float2 g0 = dfeat[(int64_t)level * B + (b < hi ? b : hi - 1)];
-      if (__ballot(b < hi && (g0.x != 0.0f || g0.y != 0.0f)) == 0ull) continue;
+  const int64_t hi = lo + per < n_items ? lo + per : n_items;
+  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nw = blockDim.x >> 6;
+  for (int64_t it = lo + w; it < hi; it += nw) {
+    const int64_t b = tile_list ? (int64_t)tile_list[4 + 2 * it + (lane >> 5)] * 32 + (lane & 31) : it * 64 + lane;
+    if (geik == nullptr && tile_list == nullptr) {                     // all 64 gradients exactly zero: nothing to add
+      const float2 g0 = dfeat[(int64_t)level * B + (b < B ? b : B - 1)];
+      if (__ballot(b < B && (g0.x != 0.0f || g0.y != 0.0f)) == 0ull) continue;
     }
-    Scatter sc = make_scatter(lv, pts_w, dfeat, level, b < hi ? b : B, B, geik, dedn);
+    Scatter sc = make_scatter(lv, pts_w, dfeat, level, b < B ? b : B, B, geik, dedn);
     if (wave_merge_runs(sc)) {
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
@@ -362,9 +375,14 @@ __global__ __launch_bounds__(1024) void k_hash_bwd_lds(NofHashGrid g, LevelList 
 __global__ __launch_bounds__(256) void k_hash_dx(NofHashGrid g, const float* __restrict__ pts_w,
                                                   const float2* __restrict__ table, const float2* __restrict__ dfeat,
                                                   float* __restrict__ dpts, int64_t B, const float2* __restrict__ geik,
-                                                  const float* __restrict__ dedn) {
+                                                  const float* __restrict__ dedn, const uint8_t* __restrict__ tile_flags) {
   const int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (b >= B) return;
+  // work list given: the samples of an unflagged tile have dL/dx = 0 (and their dfeat was not written: do not read it)
+  if (tile_flags != nullptr && tile_flags[b >> 5] == 0) {
+    dpts[b * 3] = 0.0f; dpts[b * 3 + 1] = 0.0f; dpts[b * 3 + 2] = 0.0f;
+    return;
+  }
   float dx[3] = {0.f, 0.f, 0.f};
   // eikonal option: dE/dx through the normal's own dependence on x -- the mixed second derivatives of the trilinear blend
   // (d n_d / d x_e = 0.25 * scale^2 * sum_t w_t (F[d1,e1,t] - F[d1,e0,t] - F[d0,e1,t] + F[d0,e0,t]), F = g . corner features)
@@ -488,36 +506,6 @@ extern "C" int nof_hash_encode_fwd(const NofHashGrid* g, const float* pts_w, con
   return 0;
 }
 
-// Fork/join helper: the three backward kernels are independent of each other (they only share read-only inputs and write
-// disjoint outputs / disjoint levels of grad_table).  k_hash_bwd_agg is bound by memory-side atomic throughput and leaves the
-// CUs mostly idle, so the gather-bound k_hash_dx and the LDS-bound k_hash_bwd_lds run beside it on an internal stream.
-// Event record/wait pairs are legal during stream capture (they become graph edges).
-struct SideStream {
-  hipStream_t stream = nullptr;
-  hipEvent_t fork = nullptr, join = nullptr;
-  int device = -1;
-};
-static thread_local SideStream g_side;
-
-static int side_stream(SideStream** out) {
-  int dev = 0;
-  NOF_HIP(hipGetDevice(&dev));
-  if (g_side.stream == nullptr || g_side.device != dev) {
-    if (g_side.stream != nullptr) {                                    // device changed: the old stream and events belong to the other device
-      (void)hipEventDestroy(g_side.fork);
-      (void)hipEventDestroy(g_side.join);
-      (void)hipStreamDestroy(g_side.stream);
-      g_side = SideStream();
-    }
-    NOF_HIP(hipStreamCreateWithFlags(&g_side.stream, hipStreamNonBlocking));   // (stream priority made no measurable difference)
-    NOF_HIP(hipEventCreateWithFlags(&g_side.fork, hipEventDisableTiming));
-    NOF_HIP(hipEventCreateWithFlags(&g_side.join, hipEventDisableTiming));
-    g_side.device = dev;
-  }
-  *out = &g_side;
-  return 0;
-}
-
 extern "C" int nof_hash_encode_bwd(const NofHashGrid* g, const float* pts_w, const float* table, const float* dfeat,
                                     float* grad_table, float* dpts, int64_t B, void* stream) {
   if (int e = check_grid(g)) return e;
@@ -539,9 +527,29 @@ extern "C" int nof_hash_encode_bwd_levels(const NofHashGrid* g, const float* pts
 extern "C" int nof_hash_encode_bwd_eik(const NofHashGrid* g, const float* pts_w, const float* table, const float* dfeat,
                                         const float* geik_, const float* dedn, float* grad_table, float* dpts, int32_t level_lo,
                                         int32_t level_hi, int64_t B, void* stream) {
+  return nof_hash_encode_bwd_parts(g, pts_w, table, dfeat, geik_, dedn, grad_table, dpts, level_lo, level_hi, nullptr,
+                                   NOF_HASH_BWD_ALL, 0, B, stream);
+}
+
+// The full-featured entry point.  The backward is three independent kernels (they share read-only inputs and write disjoint
+// outputs / disjoint levels of grad_table); `parts` selects which of them THIS call launches, all on `stream`, one after the
+// other.  Running them beside each other is the caller's business -- it owns the streams: the training step puts
+// NOF_HASH_BWD_TABLE_BIG on its main stream and the other two on its side stream (field.py); the library creates no stream, no
+// event, reads no environment.
+//   NOF_HASH_BWD_TABLE_BIG    levels whose slice exceeds 48 KiB: run-merged global atomics (k_hash_bwd_agg), persistent waves,
+//                             `wgs_per_cu` workgroups per CU (0 = default: 4)
+//   NOF_HASH_BWD_TABLE_SMALL  the others: accumulated in LDS, flushed once per workgroup (k_hash_bwd_lds)
+//   NOF_HASH_BWD_INPUT        dL/dpts over ALL levels (k_hash_dx; needs dpts)
+// tile_list (NofTileList or NULL): only the listed tiles are read and scattered; dpts of unlisted tiles is written as 0.
+extern "C" int nof_hash_encode_bwd_parts(const NofHashGrid* g, const float* pts_w, const float* table, const float* dfeat,
+                                          const float* geik_, const float* dedn, float* grad_table, float* dpts, int32_t level_lo,
+                                          int32_t level_hi, const void* tile_list, int32_t parts, int32_t wgs_per_cu, int64_t B,
+                                          void* stream) {
   if (int e = check_grid(g)) return e;
   NOF_ARG(pts_w && table && dfeat && grad_table && B >= 0 && level_lo >= 0 && level_lo <= level_hi && level_hi <= g->L);
   NOF_ARG((geik_ == nullptr) == (dedn == nullptr));
+  NOF_ARG(parts >= 0 && parts <= NOF_HASH_BWD_ALL && wgs_per_cu >= 0 && wgs_per_cu <= 16);
+  NOF_ARG(tile_list == nullptr || geik_ == nullptr);                   // the eikonal term has a gradient at every sample
   const float2* geik = (const float2*)geik_;
   if (B == 0) return 0;
   hipStream_t st = (hipStream_t)stream;
@@ -558,54 +566,37 @@ extern "C" int nof_hash_encode_bwd_eik(const NofHashGrid* g, const float* pts_w,
     if (bytes <= lds_cap) { small.level[small.n++] = l; if (bytes > lds_need) lds_need = bytes; }
     else big.level[big.n++] = l;
   }
-  SideStream* side = nullptr;
-  const bool fork = big.n > 0 && (dpts != nullptr || small.n > 0);
-  if (big.n == 0 && small.n == 0 && dpts == nullptr) return 0;
-  hipStream_t s2 = st;
-  if (fork) {
-    if (int e = side_stream(&side)) return e;
-    s2 = side->stream;
-    NOF_HIP(hipEventRecord(side->fork, st));
-    NOF_HIP(hipStreamWaitEvent(s2, side->fork, 0));
-  }
-  if (big.n > 0) {
-    // persistent waves, 4 workgroups per CU.  With every sample contributing (6.9 M line requests at cfg2) the kernel is bound
-    // by the atomic rate of the memory side, two per CU saturate it and more only take L2 bandwidth from the kernels
-    // beside it (whole call 1 -> 646 us, 2 -> 439, 3 -> 474, 4 -> 525, 8 -> 537).  With the zero-gradient tiles skipped (two thirds
-    // of a settled cfg2 batch: 1.3 M requests) it is latency-bound again and wants more waves: step 0.636 / 0.631 / 0.639 ms with
-    // 3 / 4 / 6.  NOF_SCATTER_WGS_PER_CU overrides.
-    int64_t blocks = nof_div_up(nof_div_up(B, 64) * big.n, 4);
-    static const int wgs_per_cu = [] {
-      const char* e = getenv("NOF_SCATTER_WGS_PER_CU");
-      const int v = e ? atoi(e) : 4;
-      return v >= 1 && v <= 10 ? v : 4;
-    }();
-    const int64_t cap = (int64_t)wgs_per_cu * nof_cu_count();
-    if (blocks > cap) blocks = cap;
+  const uint32_t* tl = (const uint32_t*)tile_list;
+  if ((parts & NOF_HASH_BWD_TABLE_BIG) && big.n > 0) {
+    // persistent waves.  With every sample contributing (6.9 M line requests at cfg2) the kernel is bound by the atomic rate of
+    // the memory side: two workgroups per CU saturate it and more only take L2 bandwidth from the kernels beside it
+    // (whole call 1 -> 646 us, 2 -> 439, 3 -> 474, 4 -> 525, 8 -> 537).  With the zero-gradient tiles gone (two thirds of a settled
+    // cfg2 batch: 1.3 M requests) it wants more waves in flight: 4 is the default.
+    int64_t blocks = (int64_t)(wgs_per_cu > 0 ? wgs_per_cu : 4) * nof_cu_count();
+    if (tl == nullptr) {                                                // (the size of a list is only known on the device)
+      const int64_t need = nof_div_up(nof_div_up(B, 64) * big.n, 4);
+      if (blocks > need) blocks = need;
+    }
     if (geik != nullptr)
       hipLaunchKernelGGL(k_hash_bwd_agg<true>, dim3((unsigned)blocks), dim3(256), 0, st, *g, big, pts_w, (const float2*)dfeat,
-                         grad_table, B, geik, dedn);
+                         grad_table, B, geik, dedn, tl);
     else
       hipLaunchKernelGGL(k_hash_bwd_agg<false>, dim3((unsigned)blocks), dim3(256), 0, st, *g, big, pts_w, (const float2*)dfeat,
-                         grad_table, B, geik, dedn);
+                         grad_table, B, geik, dedn, tl);
     NOF_LAUNCH_OK();
   }
-  if (dpts) {
-    hipLaunchKernelGGL(k_hash_dx, dim3((unsigned)nof_div_up(B, 256)), dim3(256), 0, s2, *g, pts_w, (const float2*)table,
-                       (const float2*)dfeat, dpts, B, geik, dedn);
+  if ((parts & NOF_HASH_BWD_INPUT) && dpts) {
+    hipLaunchKernelGGL(k_hash_dx, dim3((unsigned)nof_div_up(B, 256)), dim3(256), 0, st, *g, pts_w, (const float2*)table,
+                       (const float2*)dfeat, dpts, B, geik, dedn, nof_tile_flags(tile_list, B));
     NOF_LAUNCH_OK();
   }
-  if (small.n > 0) {
+  if ((parts & NOF_HASH_BWD_TABLE_SMALL) && small.n > 0) {
     const int chunks = 64;
     if (lds_need > 64 * 1024)
       NOF_HIP(hipFuncSetAttribute((const void*)k_hash_bwd_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_need));
-    hipLaunchKernelGGL(k_hash_bwd_lds, dim3((unsigned)(chunks * small.n)), dim3(1024), lds_need, s2, *g, small, chunks, pts_w,
-                       (const float2*)dfeat, grad_table, B, geik, dedn);
+    hipLaunchKernelGGL(k_hash_bwd_lds, dim3((unsigned)(chunks * small.n)), dim3(1024), lds_need, st, *g, small, chunks, pts_w,
+                       (const float2*)dfeat, grad_table, B, geik, dedn, tl);
     NOF_LAUNCH_OK();
-  }
-  if (fork) {
-    NOF_HIP(hipEventRecord(side->join, s2));
-    NOF_HIP(hipStreamWaitEvent(st, side->join, 0));
   }
   return 0;
 }

@@ -28,7 +28,8 @@ __global__ __launch_bounds__(64) void k_composite_loss(NofLossCfg c, const float
                                                         const float* __restrict__ z_vals, const uint8_t* __restrict__ valid,
                                                         const float* __restrict__ batch, int64_t R, int S,
                                                         float* __restrict__ rgb_map, float* __restrict__ weights,
-                                                        float4* __restrict__ draw, float* __restrict__ loss_rows) {
+                                                        float4* __restrict__ draw, float* __restrict__ loss_rows,
+                                                        uint8_t* __restrict__ tile_flags) {
   const int64_t r = blockIdx.x;
   const int lane = threadIdx.x;
   const float* row = batch + r * NOF_RAY_COLS;
@@ -111,6 +112,14 @@ __global__ __launch_bounds__(64) void k_composite_loss(NofLossCfg c, const float
     g.w = gs;
     g.x *= c.grad_scale; g.y *= c.grad_scale; g.z *= c.grad_scale; g.w *= c.grad_scale;
     draw[base + s] = g;
+    if (tile_flags != nullptr) {
+      // work list of the backward (S % 32 == 0: this wave's 64 samples are exactly two 32-sample tiles of the batch): a tile is
+      // flagged when any of its rows of dL/draw is non-zero.  Everything the backward derives from a sample is linear in its row.
+      const unsigned long long nz = __ballot(g.x != 0.0f || g.y != 0.0f || g.z != 0.0f || g.w != 0.0f);
+      const int64_t t0 = (base + (s - lane)) >> 5;
+      if (lane == 0) tile_flags[t0] = (uint32_t)nz != 0u ? 1 : 0;
+      if (lane == 32) tile_flags[t0 + 1] = (uint32_t)(nz >> 32) != 0u ? 1 : 0;     // (lane 32 inactive = that tile does not exist)
+    }
   }
   l_fs = wave_sum(l_fs); l_empty = wave_sum(l_empty); l_sdf = wave_sum(l_sdf); l_fsrgb = wave_sum(l_fsrgb);
   if (lane == 0 && loss_rows) {
@@ -126,10 +135,77 @@ __global__ __launch_bounds__(64) void k_composite_loss(NofLossCfg c, const float
   }
 }
 
-__global__ __launch_bounds__(256) void k_loss_reduce(const float* __restrict__ rows, int64_t R, float* __restrict__ loss_out) {
+// ---- work list of the backward (include/nof_hip.h: NofTileList) --------------------------------------------------------------
+// flags of a batch whose S is not a multiple of 32 (tiles straddle rays): one wave per 64 samples = two tiles, straight from draw
+__global__ __launch_bounds__(256) void k_tile_flags(const float4* __restrict__ draw, int64_t B, uint8_t* __restrict__ tile_flags) {
+  const int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (b < B) g = draw[b];
+  const unsigned long long nz = __ballot(g.x != 0.0f || g.y != 0.0f || g.z != 0.0f || g.w != 0.0f);
+  const int64_t t0 = (b - lane) >> 5;
+  if (lane == 0 && b < B) tile_flags[t0] = (uint32_t)nz != 0u ? 1 : 0;
+  if (lane == 32 && b < B) tile_flags[t0 + 1] = (uint32_t)(nz >> 32) != 0u ? 1 : 0;
+}
+
+// flags -> ascending list of the flagged tiles + their number.  ONE workgroup (the list of a 786 432-sample batch is 24 576
+// flags): thread t owns a contiguous chunk, counts, the counts are scanned through LDS, every thread writes its chunk's tiles.
+// Deterministic (no atomics): the order of the list fixes the order in which the backward kernels sum their partial results.
+__device__ void tile_scan(const uint8_t* __restrict__ flags, uint32_t ntiles, uint32_t* __restrict__ head,
+                          uint32_t* __restrict__ tiles, int all) {
+  __shared__ uint32_t wsum[16];
+  const uint32_t nt = blockDim.x, t = threadIdx.x;
+  const uint32_t per = (ntiles + nt - 1) / nt;
+  const uint32_t lo = t * per < ntiles ? t * per : ntiles, hi = lo + per < ntiles ? lo + per : ntiles;
+  uint32_t cnt = 0;
+  for (uint32_t i = lo; i < hi; ++i) cnt += (all || flags[i]) ? 1u : 0u;
+  // inclusive scan inside the wave, then across the waves
+  uint32_t inc = cnt;
+  const int lane = t & 63;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const uint32_t v = __shfl_up(inc, o, 64);
+    if (lane >= o) inc += v;
+  }
+  if (lane == 63) wsum[t >> 6] = inc;
+  __syncthreads();
+  uint32_t base = 0, total = 0;
+  for (uint32_t w = 0; w < (nt + 63) / 64; ++w) {
+    if (w < (t >> 6)) base += wsum[w];
+    total += wsum[w];
+  }
+  uint32_t at = base + inc - cnt;
+  for (uint32_t i = lo; i < hi; ++i)
+    if (all || flags[i]) tiles[at++] = i;
+  if (t == 0) { head[0] = total; head[1] = ntiles; head[2] = 0; head[3] = 0; }
+  if (t == 0 && (total & 1u)) tiles[total] = ntiles;                   // an odd list ends in a tile that does not exist (pairs of tiles per wave)
+}
+
+__global__ __launch_bounds__(1024) void k_tile_scan(uint8_t* __restrict__ flags, uint32_t ntiles, uint32_t* __restrict__ head,
+                                                     uint32_t* __restrict__ tiles, int all) {
+  if (all)
+    for (uint32_t i = threadIdx.x; i < ntiles; i += blockDim.x) flags[i] = 1;
+  tile_scan(flags, ntiles, head, tiles, all);
+}
+
+extern "C" int64_t nof_tile_list_bytes(int64_t B) {
+  if (B < 0 || B >= (1ll << 36)) return -1;
+  const uint32_t nt = nof_tile_count(B);
+  return (int64_t)(nof_tile_list_words(nt) * 4 + (((size_t)nt + 15) & ~(size_t)15));
+}
+
+// workgroup 0: the per-ray loss rows -> loss_out; workgroup 1 (when a work list is asked for): the tile scan
+__global__ __launch_bounds__(1024) void k_loss_reduce(const float* __restrict__ rows, int64_t R, float* __restrict__ loss_out,
+                                                       const uint8_t* __restrict__ tile_flags, uint32_t ntiles,
+                                                       uint32_t* __restrict__ head, uint32_t* __restrict__ tiles) {
+  if (blockIdx.x == 1 || loss_out == nullptr) {
+    tile_scan(tile_flags, ntiles, head, tiles, 0);
+    return;
+  }
+  if (threadIdx.x >= 256) return;
   __shared__ float sm[4][8];
   float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  for (int64_t r = threadIdx.x; r < R; r += blockDim.x)
+  for (int64_t r = threadIdx.x; r < R; r += 256)
 #pragma unroll
     for (int k = 0; k < 8; ++k) acc[k] += rows[r * 8 + k];
 #pragma unroll
@@ -142,27 +218,59 @@ __global__ __launch_bounds__(256) void k_loss_reduce(const float* __restrict__ r
   if (threadIdx.x < 8) loss_out[threadIdx.x] += (sm[0][threadIdx.x] + sm[1][threadIdx.x]) + (sm[2][threadIdx.x] + sm[3][threadIdx.x]);
 }
 
-extern "C" int nof_composite_loss(const NofLossCfg* cfg, const float* raw, const float* z_vals, const uint8_t* valid,
-                                   const float* batch, int64_t R, int32_t S, float* rgb_map, float* weights, float* draw,
-                                   float* loss_rows, float* loss_out, void* stream) {
+// forward compositing + losses + dL/draw in one launch, and -- with `tile_list` -- the work list of the backward: the 32-sample
+// tiles that hold at least one non-zero row of dL/draw (NofTileList, include/nof_hip.h).  S % 32 == 0 (the reference's default
+// 128 + 64): the flags come out of the loss kernel itself and the scan rides in the second workgroup of the loss reduction, so the
+// list costs no launch; otherwise one extra pass over draw.
+extern "C" int nof_composite_loss_fwd_bwd(const NofLossCfg* cfg, const float* raw, const float* z_vals, const uint8_t* valid,
+                                           const float* batch, int64_t R, int32_t S, float* rgb_map, float* weights,
+                                           float* draw, float* loss_rows, float* loss_out, void* tile_list, void* stream) {
   NOF_ARG(cfg && raw && z_vals && valid && batch && rgb_map && draw && R >= 0 && S >= 1);
   NOF_ARG(loss_out == nullptr || loss_rows != nullptr);
+  NOF_ARG((int64_t)R * S < (1ll << 36));
   if (R == 0) return 0;
+  const int64_t B = R * (int64_t)S;
+  const uint32_t nt = nof_tile_count(B);
+  uint32_t* head = (uint32_t*)tile_list;
+  uint32_t* tiles = head ? head + 4 : nullptr;
+  uint8_t* flags = head ? (uint8_t*)(head + nof_tile_list_words(nt)) : nullptr;
+  const bool fused_flags = flags != nullptr && S % 32 == 0;
   hipLaunchKernelGGL(k_composite_loss, dim3((unsigned)R), dim3(64), 0, (hipStream_t)stream, *cfg, (const float4*)raw,
-                     z_vals, valid, batch, R, S, rgb_map, weights, (float4*)draw, loss_out ? loss_rows : nullptr);
+                     z_vals, valid, batch, R, S, rgb_map, weights, (float4*)draw, loss_out ? loss_rows : nullptr,
+                     fused_flags ? flags : nullptr);
   NOF_LAUNCH_OK();
-  if (loss_out) {
-    hipLaunchKernelGGL(k_loss_reduce, dim3(1), dim3(256), 0, (hipStream_t)stream, loss_rows, R, loss_out);
+  if (flags != nullptr && !fused_flags) {
+    hipLaunchKernelGGL(k_tile_flags, dim3((unsigned)nof_div_up(B, 256)), dim3(256), 0, (hipStream_t)stream, (const float4*)draw, B, flags);
+    NOF_LAUNCH_OK();
+  }
+  if (loss_out || flags) {
+    hipLaunchKernelGGL(k_loss_reduce, dim3(loss_out && flags ? 2 : 1), dim3(1024), 0, (hipStream_t)stream, loss_rows, R, loss_out,
+                       flags, nt, head, tiles);
     NOF_LAUNCH_OK();
   }
   return 0;
 }
 
-// the name SURVEY.md 8b lists for the same entry point (forward compositing + losses + dL/draw in one launch)
-extern "C" int nof_composite_loss_fwd_bwd(const NofLossCfg* cfg, const float* raw, const float* z_vals, const uint8_t* valid,
-                                           const float* batch, int64_t R, int32_t S, float* rgb_map, float* weights,
-                                           float* draw, float* loss_rows, float* loss_out, void* stream) {
-  return nof_composite_loss(cfg, raw, z_vals, valid, batch, R, S, rgb_map, weights, draw, loss_rows, loss_out, stream);
+extern "C" int nof_composite_loss(const NofLossCfg* cfg, const float* raw, const float* z_vals, const uint8_t* valid,
+                                   const float* batch, int64_t R, int32_t S, float* rgb_map, float* weights, float* draw,
+                                   float* loss_rows, float* loss_out, void* stream) {
+  return nof_composite_loss_fwd_bwd(cfg, raw, z_vals, valid, batch, R, S, rgb_map, weights, draw, loss_rows, loss_out, nullptr, stream);
+}
+
+// The work list on its own: from an existing dL/draw [B,4] (`all` == 0), or every tile of the batch (`all` != 0; draw may be NULL):
+// the list that makes the backward kernels do the whole batch without looking for zeros (the dense-backward measurement of bench.py).
+extern "C" int nof_tile_list_build(const float* draw, int64_t B, int32_t all, void* tile_list, void* stream) {
+  NOF_ARG(tile_list && B >= 0 && B < (1ll << 36) && (all || draw));
+  const uint32_t nt = nof_tile_count(B);
+  uint32_t* head = (uint32_t*)tile_list;
+  uint8_t* flags = (uint8_t*)(head + nof_tile_list_words(nt));
+  if (!all && B > 0) {
+    hipLaunchKernelGGL(k_tile_flags, dim3((unsigned)nof_div_up(B, 256)), dim3(256), 0, (hipStream_t)stream, (const float4*)draw, B, flags);
+    NOF_LAUNCH_OK();
+  }
+  hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, (hipStream_t)stream, flags, nt, head, head + 4, (int)(all != 0));
+  NOF_LAUNCH_OK();
+  return 0;
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -370,6 +370,27 @@ __device__ __forceinline__ void load_sig_o1(const typename P::elem* __restrict__
   }
 }
 
+
+// ---- work list of the backward (NofTileList, include/nof_hip.h; built by nof_composite_loss_fwd_bwd / nof_tile_list_build) ----
+// head[0] = number of listed tiles, head + 4 = their ids (ascending).  A persistent wave takes entries wave, wave + n_waves, ...
+// of the LIST, so every wave gets the same number of tiles that have work (+-1) whatever their position in the batch -- with
+// the tiles strided over the waves in batch order the slowest wave set the kernel's time (63 % of the tiles skipped bought 16 %).
+// Without a list (NULL): every tile of the batch, in order, each tested for an all-zero gradient in place.
+struct TileWork {
+  const uint32_t* tiles;                              // NULL: identity
+  int64_t n, ntiles;
+  __device__ __forceinline__ TileWork(const void* tile_list, int64_t ntiles_) : ntiles(ntiles_) {
+    const uint32_t* head = (const uint32_t*)tile_list;
+    tiles = head ? head + 4 : nullptr;
+    n = head ? (int64_t)__builtin_amdgcn_readfirstlane((int)head[0]) : ntiles_;
+  }
+  // tile id of work item i; past the end: a tile that does not exist (every guarded load / store of it is a no-op)
+  __device__ __forceinline__ int64_t at(int64_t i) const {
+    if (i >= n) return ntiles;
+    return tiles ? (int64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)tiles[i]) : i;
+  }
+};
+
 // compile-time byte offsets inside the dynamic LDS block: [fw frags | (bw frags) | bias | ...]
 #define PAIR_BYTES (16 * 64 * (int)sizeof(typename P::elem))
 #define FW_OFF(l) (SH::pair_base(l) * PAIR_BYTES)
@@ -691,7 +712,8 @@ template <class P, int NS, int NC>
 __global__ __launch_bounds__(256) void k_mlp_bwd(NofMlpDesc d, const char* __restrict__ image,
                                                   const float2* __restrict__ feat, int L, const float* __restrict__ view,
                                                   int S, const float4* __restrict__ draw, float2* __restrict__ dfeat,
-                                                  float* __restrict__ dview, float* __restrict__ partials, int64_t B) {
+                                                  float* __restrict__ dview, float* __restrict__ partials, int64_t B,
+                                                  const void* __restrict__ tile_list) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   typedef Shp<NS, NC> SH;
   constexpr int NL = NS + NC;
@@ -733,8 +755,10 @@ __global__ __launch_bounds__(256) void k_mlp_bwd(NofMlpDesc d, const char* __res
           if (p < SH::pn(l) && q < SH::qn(l) && r < SH::nacc(l)) dw[l][p][q][r] = 0.0f;
 
   const int64_t ntiles = (B + 31) / 32;
-  for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < ntiles; tile += (int64_t)gridDim.x * 4) {
+  const TileWork work(tile_list, ntiles);
+  for (int64_t wi = (int64_t)blockIdx.x * 4 + wave; wi < work.n; wi += (int64_t)gridDim.x * 4) {
     asm volatile("" ::: "memory");                    // keep the weight fragments in LDS (no hoisting into VGPRs)
+    const int64_t tile = work.at(wi);
     const int64_t t0 = tile * 32;
     const int64_t b = t0 + j;
     // ---------------- forward recompute (sample-per-lane), parking the transposed layer inputs ----------------
@@ -906,7 +930,8 @@ __global__ __launch_bounds__(256, 2) void k_mlp_bwd_color(NofMlpDesc d, const ch
                                                            const typename P::elem* __restrict__ sig,
                                                            const float* __restrict__ view, int S,
                                                            const float4* __restrict__ draw, typename P::elem* __restrict__ dsig,
-                                                           float* __restrict__ dview, float* __restrict__ partials, int64_t B) {
+                                                           float* __restrict__ dview, float* __restrict__ partials, int64_t B,
+                                                           const void* __restrict__ tile_list) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   typedef Shp<NS, NC> SH;
   constexpr int NL = NS + NC;
@@ -957,14 +982,19 @@ __global__ __launch_bounds__(256, 2) void k_mlp_bwd_color(NofMlpDesc d, const ch
   // the NEXT tile's inputs are loaded a whole tile ahead (latency hidden behind this tile's MFMA chain) where the 20 registers
   // cost no heavy spilling (two colour layers; with three: 244 B of scratch per lane), draw at the top of the tile
   constexpr bool AHEAD = NC == 2;
-  typename P::frag sign = load_sig_raw<P>(sig, B, AHEAD ? ((int64_t)blockIdx.x * 4 + wave) * 32 + j : B, hi);
+  const TileWork work(tile_list, ntiles);
+  const int64_t w0 = (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(wave);
+  int64_t tile_n = work.at(w0);                       // the tile whose inputs are in flight
+  typename P::frag sign = load_sig_raw<P>(sig, B, AHEAD ? tile_n * 32 + j : B, hi);
   float viewn[16];
-  load_view_o1(view, S, B, AHEAD ? ((int64_t)blockIdx.x * 4 + wave) * 32 + j : B, hi, viewn);
+  load_view_o1(view, S, B, AHEAD ? tile_n * 32 + j : B, hi, viewn);
   // draw[b] = (d rgb_raw[3], d sdf), also a tile ahead: it decides whether the tile has anything to do
   float4 drn = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (hi == 0 && ((int64_t)blockIdx.x * 4 + wave) * 32 + j < B) drn = draw[((int64_t)blockIdx.x * 4 + wave) * 32 + j];
-  for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < ntiles; tile += tstride) {
+  if (hi == 0 && tile_n * 32 + j < B) drn = draw[tile_n * 32 + j];
+  for (int64_t wi = w0; wi < work.n; wi += tstride) {
     asm volatile("" ::: "memory");
+    const int64_t tile = tile_n;
+    tile_n = work.at(wi + tstride);
     const int64_t t0 = tile * 32;
     const int64_t b = t0 + j;
     uint32_t m1[NL];
@@ -972,7 +1002,7 @@ __global__ __launch_bounds__(256, 2) void k_mlp_bwd_color(NofMlpDesc d, const ch
     float4 dr = drn;
     asm volatile("" : "+v"(dr.x), "+v"(dr.y), "+v"(dr.z), "+v"(dr.w));
     drn = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (hi == 0 && (tile + tstride) * 32 + j < B) drn = draw[(tile + tstride) * 32 + j];
+    if (hi == 0 && tile_n * 32 + j < B) drn = draw[tile_n * 32 + j];
     float cin[2][16];
     if constexpr (AHEAD) {
       sig_to_o1<P>(sign, cin[0]);
@@ -980,14 +1010,16 @@ __global__ __launch_bounds__(256, 2) void k_mlp_bwd_color(NofMlpDesc d, const ch
       for (int r = 0; r < 16; ++r) cin[1][r] = viewn[r];
       pin16(cin[0]);
       pin16(cin[1]);
-      sign = load_sig_raw<P>(sig, B, (tile + tstride) * 32 + j, hi);
-      load_view_o1(view, S, B, (tile + tstride) * 32 + j, hi, viewn);
+      sign = load_sig_raw<P>(sig, B, tile_n * 32 + j, hi);
+      load_view_o1(view, S, B, tile_n * 32 + j, hi, viewn);
     }
     // A tile whose 32 loss gradients are all EXACTLY zero (background rays, free-space samples whose loss has saturated: two
     // thirds of a cfg2 batch once the field has settled) contributes exactly nothing to dW, db, dview and dsig: skipped, with
     // dsig = 0 written for the sigma kernel.  Same sums, less work (north_star's per-wavefront compaction, applied where
     // the zeros are: tools/zero_grad_probe.py).
-    const bool skip = __builtin_amdgcn_ballot_w64(dr.x != 0.0f || dr.y != 0.0f || dr.z != 0.0f || dr.w != 0.0f) == 0ull;
+    // (with a work list the test is never true: the list holds exactly the tiles with a non-zero row)
+    const bool skip = tile_list == nullptr &&
+                      __builtin_amdgcn_ballot_w64(dr.x != 0.0f || dr.y != 0.0f || dr.z != 0.0f || dr.w != 0.0f) == 0ull;
     float ds1[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) ds1[r] = 0.0f;
@@ -1089,7 +1121,8 @@ template <class P, int NS, int NC>
 __global__ __launch_bounds__(256, 2) void k_mlp_bwd_sigma(NofMlpDesc d, const char* __restrict__ image,
                                                            const float2* __restrict__ feat, int L,
                                                            const typename P::elem* __restrict__ dsig, float2* __restrict__ dfeat,
-                                                           float* __restrict__ partials, int64_t B) {
+                                                           float* __restrict__ partials, int64_t B,
+                                                           const void* __restrict__ tile_list) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   typedef Shp<NS, NC> SH;
   constexpr int NL = NS + NC;
@@ -1138,27 +1171,32 @@ __global__ __launch_bounds__(256, 2) void k_mlp_bwd_sigma(NofMlpDesc d, const ch
   // 64 % of this kernel's wave cycles used to be s_waitcnt on global memory (SQ_WAIT_ANY): the tile's feature loads queued
   // behind the previous tile's dfeat stores (vmcnt retires in order) and were waited for where they were issued, like the dsig
   // load.  Now the NEXT tile's features are requested a whole tile ahead and dsig at the top of the tile: 111 -> 82 us at cfg2.
+  const TileWork work(tile_list, ntiles);
+  const int64_t w0 = (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(wave);
+  int64_t tile_n = work.at(w0);
   float xn[1][16];
-  load_feat_o1(feat, L, B, ((int64_t)blockIdx.x * 4 + wave) * 32 + j, hi, xn);
-  typename P::frag dsn = load_sig_raw<P>(dsig, B, ((int64_t)blockIdx.x * 4 + wave) * 32 + j, hi);
-  for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < ntiles; tile += tstride) {
+  load_feat_o1(feat, L, B, tile_n * 32 + j, hi, xn);
+  typename P::frag dsn = load_sig_raw<P>(dsig, B, tile_n * 32 + j, hi);
+  for (int64_t wi = w0; wi < work.n; wi += tstride) {
     asm volatile("" ::: "memory");
+    const int64_t tile = tile_n;
+    tile_n = work.at(wi + tstride);
     const int64_t b = tile * 32 + j;
     uint32_t m1[NS];
     float h[2][16];
     const typename P::frag dsr = dsn;                   // dL/d(sigma out) of this tile, requested a tile ahead like the features
-    dsn = load_sig_raw<P>(dsig, B, (tile + tstride) * 32 + j, hi);
+    dsn = load_sig_raw<P>(dsig, B, tile_n * 32 + j, hi);
     float x[1][16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) x[0][r] = xn[0][r];
     pin16(x[0]);
-    load_feat_o1(feat, L, B, (tile + tstride) * 32 + j, hi, xn);
+    load_feat_o1(feat, L, B, tile_n * 32 + j, hi, xn);
     bool skip;
     {
       // all 32 x 16 gradients exactly zero (the colour kernel skipped the tile, see there): dfeat = 0, nothing else to do
       typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
       const u32x4 bits = __builtin_bit_cast(u32x4, dsr);
-      skip = __builtin_amdgcn_ballot_w64(((bits.x | bits.y | bits.z | bits.w) & 0x7FFF7FFFu) != 0u) == 0ull;
+      skip = tile_list == nullptr && __builtin_amdgcn_ballot_w64(((bits.x | bits.y | bits.z | bits.w) & 0x7FFF7FFFu) != 0u) == 0ull;
     }
     float df1[16];
 #pragma unroll
@@ -1595,6 +1633,14 @@ extern "C" int nof_mlp_sdf(const NofMlpDesc* d, const void* packed, const float*
 extern "C" int nof_mlp_bwd(const NofMlpDesc* d, const void* packed, const float* feat, int32_t L, const float* view,
                             int32_t S, const float* draw, const void* sigma_out, void* dsigma_ws, float* dfeat, float* dview,
                             float* partials, int64_t B, void* stream) {
+  return nof_mlp_bwd_tiles(d, packed, feat, L, view, S, draw, sigma_out, dsigma_ws, dfeat, dview, partials, nullptr, B, stream);
+}
+
+// The same over a work list (NofTileList): only the listed 32-sample tiles are computed, dealt evenly to the persistent waves.
+// dfeat (and the dsigma workspace) of unlisted tiles is NOT written -- the consumers of the same step take the same list.
+extern "C" int nof_mlp_bwd_tiles(const NofMlpDesc* d, const void* packed, const float* feat, int32_t L, const float* view,
+                                  int32_t S, const float* draw, const void* sigma_out, void* dsigma_ws, float* dfeat, float* dview,
+                                  float* partials, const void* tile_list, int64_t B, void* stream) {
   if (int e = check_narrow(d)) return e;
   NOF_ARG(packed && feat && view && draw && dfeat && dview && partials && B >= 0 && S >= 32 && L * 2 == d->in_feat);
   NOF_ARG((int64_t)L * B * 8 < (1ll << 32));                   // level-major arrays are addressed with 32-bit lane offsets
@@ -1616,10 +1662,10 @@ extern "C" int nof_mlp_bwd(const NofMlpDesc* d, const void* packed, const float*
     if (int e = set_smem(ks, shm_s)) return e;                                                            \
     hipLaunchKernelGGL(kc, dim3(blocks), dim3(256), shm_c, (hipStream_t)stream, *d, (const char*)packed,  \
                        (const typename P::elem*)sigma_out, view, (int)S, (const float4*)draw,             \
-                       (typename P::elem*)dsigma_ws, dview, partials, B);                                 \
+                       (typename P::elem*)dsigma_ws, dview, partials, B, tile_list);                      \
     hipLaunchKernelGGL(ks, dim3(blocks), dim3(256), shm_s, (hipStream_t)stream, *d, (const char*)packed,  \
                        (const float2*)feat, (int)L, (const typename P::elem*)dsigma_ws, (float2*)dfeat,   \
-                       partials, B);                                                                      \
+                       partials, B, tile_list);                                                           \
   }
     if (is_bf16(d->precision)) { DISPATCH_SHAPE(PrecBF16, LAUNCH_SPLIT, 0) }
     else { DISPATCH_SHAPE(PrecF16, LAUNCH_SPLIT, 0) }
@@ -1637,7 +1683,7 @@ extern "C" int nof_mlp_bwd(const NofMlpDesc* d, const void* packed, const float*
     if (int e = set_smem(kern, shm)) return e;                                                            \
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), shm, (hipStream_t)stream, *d, (const char*)packed,  \
                        (const float2*)feat, (int)L, view, (int)S, (const float4*)draw, (float2*)dfeat,    \
-                       dview, partials, B);                                                               \
+                       dview, partials, B, tile_list);                                                    \
   }
   DISPATCH_PREC(LAUNCH_BWD, 0)
 #undef LAUNCH_BWD

@@ -2,8 +2,9 @@
 tests).  Keyframes are sharded by rank; the hash table, MLPs, the FULL pose/feature arrays and the occupancy grid are
 replicated.  Each rank draws N_rand rays from its own pool, so the global batch is world*N_rand; every loss term is a
 mean over rays/samples, hence gradients are pre-scaled by 1/world on the device (NofLossCfg.grad_scale) and SUMMED here:
-the result equals one process stepping on the concatenated batch.  There is exactly one collective per step: an
-all-reduce of the flat gradient buffer [table | MLP | features | poses]."""
+the result equals one process stepping on the concatenated batch.  The exchange is the all-reduce of the flat gradient buffer
+[table | MLP | features | poses], issued as TWO collectives per step: the fine hash levels + MLP slice (80 % of
+the bytes) as soon as it is final, overlapped with the rest of the backward, and everything else in one trailing call."""
 import os
 
 import torch
@@ -45,18 +46,35 @@ class GradSync:
 
     def __init__(self):
         self.pending = []
+        self.bytes_step = 0          # payload bytes handed to all-reduce in the last step (per rank)
+        self.collectives_step = 0
+        self._bytes = self._n = 0
+        self.timing = None           # list of (event before finish, event after finish): bench.py's exposed-communication time
 
     def __call__(self, flat):
         dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        self.bytes_step, self.collectives_step = flat.numel() * flat.element_size(), 1
 
     def start(self, part):
         if part.numel():
             self.pending.append(dist.all_reduce(part, op=dist.ReduceOp.SUM, async_op=True))
+            self._bytes += part.numel() * part.element_size()
+            self._n += 1
 
     def finish(self):
+        """the current stream waits for every collective in flight; what of them did not hide behind the backward is the time
+        between the two events (recorded when `timing` is a list and the tensors live on a GPU)"""
+        ev = None
+        if self.timing is not None and torch.cuda.is_available():
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
         for w in self.pending:
             w.wait()
+        if ev is not None:
+            ev[1].record()
+            self.timing.append(ev)
         self.pending = []
+        self.bytes_step, self.collectives_step, self._bytes, self._n = self._bytes, self._n, 0, 0
 
 
 def make_grad_sync(overlap=True):

@@ -7,9 +7,13 @@ streaming pass and the data-parallel gradient exchange is a single all-reduce):
     [ hash table rows*2 | MLP (PyTorch parameter order) | frame features F*ff | pose corrections F*6 ]
       `------------------------- param group 'basic' -------------------------' `--- 'pose_array' ---'
 
-Step (train_loop nerf_runner.py:679-763), 12 C-ABI calls = 16 kernel launches, no host synchronisation:
-    pose_fwd -> mlp_pack -> raymarch_sample -> hash_fwd -> mlp_fwd -> composite_loss -> mlp_bwd -> reduce_partials
-    -> hash_bwd -> pose_grad_accum -> pose_reduce_bwd (+small_regs) -> [all-reduce] -> adam
+Step (train_loop nerf_runner.py:679-763), no host synchronisation:
+    pose_fwd -> mlp_pack -> raymarch_sample -> hash_fwd -> mlp_fwd -> composite_loss (+ the work list of the backward)
+    -> mlp_bwd -> { hash_bwd table | reduce_partials } beside { hash_bwd input / LDS levels -> pose_grad_accum -> pose_reduce_bwd }
+    -> [all-reduce] -> adam
+The backward runs over a WORK LIST (NofTileList): the 32-sample tiles that hold a non-zero loss gradient, found by the loss kernel
+itself and dealt evenly to the persistent waves of every backward kernel -- the same sums as the whole batch at the cost of the
+tiles that have any (a third of a settled cfg2 batch).
 """
 import ctypes as C
 import math
@@ -65,7 +69,12 @@ class NeuralObjectField:
         self.max_rot = float(cfg['max_rot'] / 180.0 * np.pi)
         dev = self.device
         self.params = torch.zeros(self.n_total, device=dev)
-        self.grads = torch.zeros(self.n_total, device=dev)
+        # gradients: a few floats of headroom in FRONT of the flat buffer, so that the data-parallel step can put a copy of the tail
+        # [frame features | poses] next to the coarse table levels and reduce both in one collective (train_step, `bucketed`)
+        self._n_tail = self.n_feat + self.n_pose
+        self._head = (self._n_tail + 63) // 64 * 64
+        self._grads_store = torch.zeros(self._head + self.n_total, device=dev)
+        self.grads = self._grads_store[self._head:]
         self.exp_avg = torch.zeros(self.n_total, device=dev)
         self.exp_avg_sq = torch.zeros(self.n_total, device=dev)
         self.c2w = torch.as_tensor(np.asarray(c2w, dtype=np.float32)).reshape(self.F, 16).to(dev).contiguous()
@@ -84,20 +93,28 @@ class NeuralObjectField:
         self._packed_step = None     # optimiser step the fragment image was built for
         self.profile = None          # dict name -> [(start_event, end_event)] when per-kernel timing is on (bench.py)
         self.profile_only = None
+        self.profile_also = None     # a second entry point that keeps its events beside profile_only
+        # backward over the work list of non-zero tiles ('list'), over every tile through the same code path ('all': what the
+        # dense-backward figure of bench.py measures), or without a list ('off': every tile, zero tiles skipped in place)
+        self.backward_tiles = 'list'
+        self.scatter_wgs_per_cu = 0                  # persistent workgroups per CU of the table scatter (0 = the library's default)
         self._state = None           # NofStepState on the device (captured-step mode): see sync_step_state / GraphedStep
         if seed_init:
             self.init_parameters()
 
     # ---- per-kernel timing with events on the launch stream -------------------------------------
-    def _call(self, name, *args):
+    def _call(self, name, *args, tag=None):
+        """one C-ABI call on the current stream; with per-kernel timing on, bracketed by events recorded on that same stream
+        under `tag` (default: the entry point's name)"""
         prof = self.profile
-        if prof is None or (self.profile_only is not None and name != self.profile_only):
+        key = tag or name
+        if prof is None or (self.profile_only is not None and key != self.profile_only and key != self.profile_also):
             return lib.call(name, *args)
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record()
         lib.call(name, *args)
         b.record()
-        prof.setdefault(name, []).append((a, b))
+        prof.setdefault(key, []).append((a, b))
 
     def kernel_times_ms(self):
         """average launch duration per C-ABI entry point (ms); all launches go to torch's current stream, which is
@@ -208,6 +225,7 @@ class NeuralObjectField:
                 sig=e(B, 16, dt=torch.int16) if self.desc.precision != 0 and not self.wide else None,
                 dsig=e(B, 16, dt=torch.int16) if self.desc.precision != 0 and not self.wide else None,
                 wide_ws=e(int(lib.load().nof_mlp_wide_workspace_bytes(C.byref(self.desc), B)), dt=torch.uint8) if self.wide else None,
+                tiles=e(int(lib.load().nof_tile_list_bytes(B)), dt=torch.uint8),
                 # eikonal option: d sdf / d feature, dE/dn, and the sigma layers' weight-gradient rows (colour entries stay zero)
                 geik=e(self.L, B, 2) if self.eikonal else None, dedn=e(B, 3) if self.eikonal else None,
                 partials_e=torch.zeros(self.nblk, self.n_mlp, device=d) if self.eikonal else None)
@@ -250,8 +268,8 @@ class NeuralObjectField:
 
     # ---- forward pieces -----------------------------------------------------------------------------------
     def pack_weights(self, force=False):
-        force = force or getattr(self, '_dyn', False)      # a captured step must contain the launch whatever the host-side cache says
-        """fp32 PyTorch-layout MLP parameters -> MFMA fragment image (once per optimiser step)."""
+        """fp32 PyTorch-layout MLP parameters -> MFMA fragment image (once per optimiser step; `force`: a captured step must
+        contain the launch whatever the host-side cache says)."""
         if force or self._packed_step != self.global_step:
             self._call('nof_mlp_pack', C.byref(self.desc), self.mlp, self.packed)
             if self.eikonal:
@@ -268,7 +286,7 @@ class NeuralObjectField:
         S = cfg['N_samples'] + cfg['N_samples_around_depth']
         b = self._buffers(R, S)
         self.update_poses()
-        self.pack_weights()
+        self.pack_weights(force=dyn)
         cid = None
         if want_cells:
             cid = b.setdefault('cell_ids', torch.empty(R, self.max_hits, dtype=torch.int32, device=self.device))
@@ -292,20 +310,23 @@ class NeuralObjectField:
         step sizes) are read from the device-resident NofStepState instead of being passed by value, and the state is advanced
         by the step's last launch -- the form GraphedStep captures."""
         cfg = self.cfg
-        self._dyn = dyn
         b, S = self.forward_batch(pool, ids, R, u_occ, u_dep, seed, want_cells, dyn)
         B = R * S
         lc = self._loss_cfg()
         self.loss_out.zero_()
-        self._call('nof_composite_loss', C.byref(lc), b['raw'], b['z_vals'], b['valid'], b['batch'], R, S, b['rgb_map'],
-                 None, b['draw'], b['loss_rows'], self.loss_out)
+        # the work list of the backward; the eikonal term has a gradient at every sample, so it takes none
+        tiles = b['tiles'] if self.backward_tiles != 'off' and not self.eikonal else None
+        self._call('nof_composite_loss_fwd_bwd', C.byref(lc), b['raw'], b['z_vals'], b['valid'], b['batch'], R, S, b['rgb_map'],
+                   None, b['draw'], b['loss_rows'], self.loss_out, tiles)
+        if tiles is not None and self.backward_tiles == 'all':
+            self._call('nof_tile_list_build', None, B, 1, tiles)
         self._set_grad_scale(B)                    # (dview is zero: allocated so, and re-zeroed after its last use in every step)
         if self.wide:
             self._call('nof_mlp_wide_bwd', C.byref(self.desc), self.packed, b['feat'], self.L, b['view'], S, b['draw'],
                        b['wide_ws'], b['dfeat'], b['dview'], b['partials'], B)
         else:
-            self._call('nof_mlp_bwd', C.byref(self.desc), self.packed, b['feat'], self.L, b['view'], S, b['draw'], b['sig'],
-                       b['dsig'], b['dfeat'], b['dview'], b['partials'], B)
+            self._call('nof_mlp_bwd_tiles', C.byref(self.desc), self.packed, b['feat'], self.L, b['view'], S, b['draw'], b['sig'],
+                       b['dsig'], b['dfeat'], b['dview'], b['partials'], tiles, B)
         geik = dedn = None
         if self.eikonal:
             # nerf_runner.py:734-738: mean over the samples with sdf < 1 (their number stays on the device)
@@ -319,21 +340,22 @@ class NeuralObjectField:
         hashed = [l for l in range(self.L) if self.grid.hashed[l]]
         split = hashed[0] if hashed and 0 < hashed[0] < self.L else None
         bucketed = grad_sync is not None and hasattr(grad_sync, 'start') and split is not None
+        BIG, SMALL, INPUT, ALL = lib.HASH_BWD_TABLE_BIG, lib.HASH_BWD_TABLE_SMALL, lib.HASH_BWD_INPUT, lib.HASH_BWD_ALL
 
         def reduce_mlp():
             self._call('nof_reduce_partials', b['partials'], self.nblk, self.n_mlp, self._seg(self.grads, 'mlp'))
             if self.eikonal:
                 self._call('nof_reduce_partials', b['partials_e'], self.nblk, self.n_mlp, self._seg(self.grads, 'mlp'))
 
-        def scatter(dx, lo, hi):
-            """table gradient of levels [lo, hi) (+ dL/dx over all levels on the call's internal stream when dx is given)"""
-            if self.eikonal:
-                self._call('nof_hash_encode_bwd_eik', C.byref(self.grid), b['pts_w'], self.table, b['dfeat'], geik, dedn, gtab, dx,
-                           lo, hi, B)
-            elif (lo, hi) == (0, self.L):
-                self._call('nof_hash_encode_bwd', C.byref(self.grid), b['pts_w'], self.table, b['dfeat'], gtab, dx, B)
-            else:
-                self._call('nof_hash_encode_bwd_levels', C.byref(self.grid), b['pts_w'], self.table, b['dfeat'], gtab, dx, lo, hi, B)
+        def hash_bwd(parts, lo, hi):
+            """the kernels `parts` of the hash backward for the table levels [lo, hi), on the current stream (the library owns no
+            stream: what runs beside what is decided here)"""
+            if not self.optimize_poses:
+                parts &= ~INPUT
+            if parts:
+                tag = 'hash_bwd[' + '+'.join(n for n, m in (('table', BIG), ('table_lds', SMALL), ('input', INPUT)) if parts & m) + ']'
+                self._call('nof_hash_encode_bwd_parts', C.byref(self.grid), b['pts_w'], self.table, b['dfeat'], geik, dedn, gtab,
+                           dpts, lo, hi, tiles, parts, self.scatter_wgs_per_cu, B, tag=tag)
 
         def pose_kernels():
             if self.optimize_poses or self.ff > 0:
@@ -347,33 +369,36 @@ class NeuralObjectField:
                            self._seg(self.grads, 'feat') if self.ff > 0 else None, None, self.F)
             b['dview'].zero_()                       # for the next step's atomics
 
-        if bucketed:
-            # data parallel: the fine (hashed) levels first; their slice [rows of level `split` .., MLP] of the flat gradient
-            # buffer (80 % of its bytes at cfg2) is all-reduced while the coarse levels, dL/dx and the pose kernels still run
-            reduce_mlp()
-            a = 2 * int(self.offsets[split])
-            scatter(None, split, self.L)
-            grad_sync.start(self.grads[a:self.n_table + self.n_mlp])
-            scatter(dpts, 0, split)
-            pose_kernels()
-        elif dyn:
+        if dyn:
             # captured step: one chain (a second branch in the HIP graph costs more than the overlap returns)
             reduce_mlp()
-            scatter(dpts, 0, self.L)
+            hash_bwd(ALL, 0, self.L)
             pose_kernels()
         else:
-            # The table scatter is bound by the atomic rate of the memory side and is the longest launch of the step; the MLP
-            # partial-row reduction, dL/dx (an empty level range: k_hash_dx only) and the pose / frame-feature gradients that hang
-            # off it are independent of it and run beside it on a second stream (fork / join by events).
+            # The table scatter of the large levels (atomics that execute memory-side) is the longest launch of the backward; the
+            # input gradient, the LDS-accumulated small levels and the pose / frame-feature gradients that hang off them are
+            # independent of it and run beside it on a second stream (fork / join by events), the MLP partial-row reduction
+            # behind it.
             main = torch.cuda.current_stream()
             side = self._side_stream()
             side.wait_stream(main)
-            with torch.cuda.stream(side):
-                if dpts is not None:
-                    scatter(dpts, 0, 0)
-                pose_kernels()
-            scatter(None, 0, self.L)
-            reduce_mlp()                             # (on this stream: with the zero-gradient tiles skipped the two chains balance)
+            if bucketed:
+                # data parallel: the fine (hashed) levels first; their slice [rows of level `split` .., MLP] of the flat gradient
+                # buffer (80 % of its bytes at cfg2) is all-reduced while the coarse levels, dL/dx and the pose kernels still run
+                a = 2 * int(self.offsets[split])
+                reduce_mlp()
+                hash_bwd(BIG | SMALL, split, self.L)
+                grad_sync.start(self.grads[a:self.n_table + self.n_mlp])
+                with torch.cuda.stream(side):
+                    hash_bwd(INPUT | SMALL, 0, split)
+                    pose_kernels()
+                hash_bwd(BIG, 0, split)
+            else:
+                with torch.cuda.stream(side):
+                    hash_bwd(INPUT | SMALL, 0, self.L)
+                    pose_kernels()
+                hash_bwd(BIG, 0, self.L)
+                reduce_mlp()
             main.wait_stream(side)
         if self.optimize_poses and float(cfg.get('pose_reg_weight', 0)) > 0:
             self._call('nof_pose_reg', self.pose, self._seg(self.grads, 'pose'), self.F, C.c_float(cfg['pose_reg_weight']),
@@ -382,14 +407,20 @@ class NeuralObjectField:
             self._call('nof_small_regs', self.feat, self._seg(self.grads, 'feat'), self.n_feat,
                      C.c_float(cfg['feature_reg_weight']), C.c_float(1.0 / self.world_size))
         if bucketed:
-            grad_sync.start(self.grads[:a])
-            grad_sync.start(self.grads[self.n_table + self.n_mlp:])
+            # ONE more collective: everything that is not in flight yet.  [0, a) and the tail behind the MLP are not contiguous
+            # in the flat buffer, so a copy of the tail (frame features + poses: a few KB) rides in the headroom in front of it
+            nt, h = self._n_tail, self._head
+            tail = self.grads[self.n_table + self.n_mlp:]
+            if nt:
+                self._grads_store[h - nt:h].copy_(tail)
+            grad_sync.start(self._grads_store[h - nt:h + a])
             grad_sync.finish()
+            if nt:
+                tail.copy_(self._grads_store[h - nt:h])
         elif grad_sync is not None:
             grad_sync(self.grads)
         if do_step:
             self.adam_step(dyn)
-        self._dyn = False
         return b
 
     def adam_step(self, dyn=False):

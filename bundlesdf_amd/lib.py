@@ -17,6 +17,7 @@ NOF_MAX_LEVELS = 16
 NOF_MAX_LAYERS = 8
 RAY_COLS = 12
 VIEW_COLS = 16
+HASH_BWD_TABLE_BIG, HASH_BWD_TABLE_SMALL, HASH_BWD_INPUT, HASH_BWD_ALL = 1, 2, 4, 7
 
 
 class NofError(RuntimeError):
@@ -91,7 +92,11 @@ _SIGNATURES = {
     'nof_adam_step_dyn': ([_P, _P, _P, _P, _I64, _I64, _P, _F, _F, _F, _P], C.c_int),
     'nof_raymarch_sample': ([C.POINTER(NofSampleCfg), _P, _P, _P, _P, _I32, _I32, _P, _I32, _I64, _I32, _P, _P,
                              _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P], C.c_int),
-    'nof_composite_loss_fwd_bwd': ([C.POINTER(NofLossCfg), _P, _P, _P, _P, _I64, _I32, _P, _P, _P, _P, _P, _P], C.c_int),
+    'nof_composite_loss_fwd_bwd': ([C.POINTER(NofLossCfg), _P, _P, _P, _P, _I64, _I32, _P, _P, _P, _P, _P, _P, _P], C.c_int),
+    'nof_tile_list_bytes': ([_I64], C.c_int64),
+    'nof_tile_list_build': ([_P, _I64, _I32, _P, _P], C.c_int),
+    'nof_mlp_bwd_tiles': ([C.POINTER(NofMlpDesc), _P, _P, _I32, _P, _I32, _P, _P, _P, _P, _P, _P, _P, _I64, _P], C.c_int),
+    'nof_hash_encode_bwd_parts': ([C.POINTER(NofHashGrid), _P, _P, _P, _P, _P, _P, _P, _I32, _I32, _P, _I32, _I32, _I64, _P], C.c_int),
     'nof_mlp_bwd_workspace_bytes': ([C.POINTER(NofMlpDesc)], C.c_int64),
     'nof_sdf_grid_query': ([C.POINTER(NofHashGrid), C.POINTER(NofMlpDesc), _P, _P, _P, _I32, _P, _P, _P, _I32, _I32, _I32,
                             _F, _P, _P], C.c_int),

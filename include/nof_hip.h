@@ -64,6 +64,18 @@ int nof_hash_encode_bwd_levels(const NofHashGrid* h_grid, const float* pts_w, co
 int nof_hash_encode_bwd_eik(const NofHashGrid* h_grid, const float* pts_w, const float* table, const float* dfeat,
                             const float* geik, const float* dedn, float* grad_table, float* dpts, int32_t level_lo,
                             int32_t level_hi, int64_t B, void* stream);
+/* The full-featured form.  The backward is three independent kernels; `parts` selects which of them this call launches -- all on
+ * `stream`, one after the other.  Running them beside each other is the caller's business (it owns the streams; this library
+ * creates no stream and no event and reads no environment variable): the training step launches TABLE_BIG on its main stream and
+ * the other two on its side stream.  tile_list: NofTileList (below) or NULL; with a list only the listed tiles' dfeat is read,
+ * and dpts of the unlisted tiles is written as 0.  wgs_per_cu: persistent workgroups per CU of the TABLE_BIG kernel, 0 = default. */
+#define NOF_HASH_BWD_TABLE_BIG 1        /* levels larger than 48 KiB: run-merged global atomics */
+#define NOF_HASH_BWD_TABLE_SMALL 2      /* levels accumulated in LDS and flushed once per workgroup */
+#define NOF_HASH_BWD_INPUT 4            /* dL/dpts over all levels (needs dpts) */
+#define NOF_HASH_BWD_ALL 7
+int nof_hash_encode_bwd_parts(const NofHashGrid* h_grid, const float* pts_w, const float* table, const float* dfeat,
+                              const float* geik, const float* dedn, float* grad_table, float* dpts, int32_t level_lo,
+                              int32_t level_hi, const void* tile_list, int32_t parts, int32_t wgs_per_cu, int64_t B, void* stream);
 int nof_hash_corner_indices(const NofHashGrid* h_grid, const float* pts_w, int32_t* idx, int64_t B, void* stream);
 
 /* ---- pose corrections (replaces PoseArray.get_matrices + pytorch3d se3_exp_map) ---------------- */
@@ -205,6 +217,11 @@ int nof_mlp_bwd_blocks(void);
 int nof_mlp_bwd(const NofMlpDesc* h_desc, const void* packed, const float* feat, int32_t L,
                 const float* view, int32_t S, const float* draw, const void* sigma_out, void* dsigma_ws,
                 float* dfeat, float* dview, float* partials, int64_t B, void* stream);
+/* The same over a work list (NofTileList, below): only the listed 32-sample tiles are computed, dealt evenly to the persistent
+ * waves.  dfeat (and dsigma_ws) of UNLISTED tiles is not written; the hash backward of the same step takes the same list. */
+int nof_mlp_bwd_tiles(const NofMlpDesc* h_desc, const void* packed, const float* feat, int32_t L,
+                      const float* view, int32_t S, const float* draw, const void* sigma_out, void* dsigma_ws,
+                      float* dfeat, float* dview, float* partials, const void* tile_list, int64_t B, void* stream);
 /* out[j] += sum_i partials[i,j] */
 int nof_reduce_partials(const float* partials, int32_t n_rows, int32_t n_cols, float* out, void* stream);
 /* sigma_net only: feat [L,B,2] -> sdf [B]  (NeRFSmall.forward_sdf, nerf_helpers.py:296-302) */
@@ -295,10 +312,23 @@ int nof_composite_loss(const NofLossCfg* h_cfg, const float* raw, const float* z
                        const float* batch, int64_t R, int32_t S, float* rgb_map, float* weights, float* draw,
                        float* loss_rows, float* loss_out, void* stream);
 
-/* same entry point under the name SURVEY.md 8b lists */
+/* ---- work list of the backward: north_star's per-wavefront compaction ----------------------------------------------------
+ * A ray-sample whose row of dL/draw is EXACTLY zero (rays without a loss term; free-space samples whose loss has saturated: two
+ * thirds of a settled cfg2 batch) contributes exactly nothing to any gradient.  NofTileList names the 32-sample tiles (tile t =
+ * samples 32t .. 32t+31) that hold at least one non-zero row, in ascending order; the backward entry points that take one
+ * (nof_mlp_bwd_tiles, nof_hash_encode_bwd_parts) deal the LISTED tiles evenly to their persistent waves and touch nothing else:
+ * the same sums as the whole batch, none of the work of the zeros, balanced waves.  Device memory, caller-allocated,
+ * nof_tile_list_bytes(B) bytes:  uint32 count, n_tiles, 0, 0 | uint32 tiles[n_tiles (+ pad)] | uint8 flags[n_tiles].
+ * It lives on the device only (the count never visits the host: capturable). */
+int64_t nof_tile_list_bytes(int64_t B);
+/* the list from an existing dL/draw [B,4]; or, with all != 0 (draw may be NULL), every tile of the batch: the list that makes the
+ * backward entry points do the whole batch without looking for zeros */
+int nof_tile_list_build(const float* draw, int64_t B, int32_t all, void* tile_list, void* stream);
+/* nof_composite_loss + the work list of its dL/draw (tile_list may be NULL).  When S % 32 == 0 the list costs no launch and no
+ * pass over draw: the flags come out of the loss kernel and the scan rides beside the loss reduction. */
 int nof_composite_loss_fwd_bwd(const NofLossCfg* h_cfg, const float* raw, const float* z_vals, const uint8_t* valid,
                                const float* batch, int64_t R, int32_t S, float* rgb_map, float* weights, float* draw,
-                               float* loss_rows, float* loss_out, void* stream);
+                               float* loss_rows, float* loss_out, void* tile_list, void* stream);
 
 /* ---- pose / feature gradients of a batch ---------------------------------------------------------- */
 /* dpts [R*S,3] (from nof_hash_encode_bwd, may be NULL), dview [R,16] (from nof_mlp_bwd), batch, z_vals, c2w [F,16], tf [F,12]

@@ -68,6 +68,20 @@ def test_mlp_kernels_have_no_inline_assembly_instructions():
             assert m.group(1).strip() == '', (name, m.group(1))
 
 
+def test_library_owns_no_stream_and_reads_no_environment():
+    """include/nof_hip.h: "nothing here allocates or synchronises the host".  Round 2's hash backward created a hidden side stream
+    and two events on first use and read an environment variable; what runs beside what is the caller's business now
+    (nof_hash_encode_bwd_parts), so no source may create a stream / event, allocate device memory or call getenv."""
+    src = os.path.join(ROOT, 'bundlesdf_amd', 'csrc')
+    banned = re.compile(r'\b(hipStreamCreate\w*|hipEventCreate\w*|hipMalloc\w*|hipHostMalloc|getenv|hipDeviceSynchronize|'
+                        r'hipStreamSynchronize)\s*\(')
+    for name in sorted(os.listdir(src)):
+        if name.endswith(('.hip', '.h')):
+            text = re.sub(r'//[^\n]*', '', open(os.path.join(src, name)).read())
+            m = banned.search(text)
+            assert m is None, (name, m.group(0))
+
+
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     from bundlesdf_amd import lib
     monkeypatch.setattr(lib, '_lib', None)
