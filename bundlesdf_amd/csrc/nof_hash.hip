@@ -24,16 +24,26 @@ struct LevelList {
   int32_t level[NOF_MAX_LEVELS];
 };
 
-__global__ __launch_bounds__(256) void k_hash_fwd(NofHashGrid g, LevelList slots, const float* __restrict__ pts_w,
+// One workgroup = 256 samples x the levels of ONE slot group: block b works on slots b % G, b % G + G, ... (G = min(8, L)), so
+// with the dispatcher's block b -> XCD b % 8 placement every XCD keeps its L/8 levels' rows in its own L2 (xcd_level_slots deals a
+// large hashed and a small dense level to each).  A lane reads its point ONCE and encodes those levels one after the other: at
+// L = 16 that is 3 + 2 x 8 (or 4, see level_pairs) + 2 vector-memory instructions per lane instead of 2 x (3 + 8 + 1) -- the
+// kernel is bound by the vector-memory INSTRUCTION rate, not by bytes.
+__global__ __launch_bounds__(256) void k_hash_fwd(NofHashGrid g, LevelList slots, int G, const float* __restrict__ pts_w,
                                                    const float2* __restrict__ table, float2* __restrict__ feat,
                                                    int64_t B) {
-  const int level = slots.level[blockIdx.x % g.L];                   // slot -> level: see xcd_level_slots()
-  const int64_t b = (int64_t)(blockIdx.x / g.L) * 256 + threadIdx.x;
+  const int64_t b = (int64_t)(blockIdx.x / G) * 256 + threadIdx.x;
   if (b >= B) return;
-  const HashLevel lv = load_level(g, level);
-  const CellPos c = locate(pts_w, b, lv.scale);
-  const float2 acc = encode_level(lv, table, c);
-  feat[(int64_t)level * B + b] = acc;
+  const float p[3] = {pts_w[b * 3], pts_w[b * 3 + 1], pts_w[b * 3 + 2]};
+  for (int s = blockIdx.x % G; s < g.L; s += G) {
+    const int level = slots.level[s];                                  // slot -> level: see xcd_level_slots()
+    const HashLevel lv = load_level(g, level);
+    const CellPos c = locate3(p, lv.scale);
+    float2 acc;
+    if (level_pairs(lv)) acc = encode_level<true>(lv, table, c);       // (uniform branch: the level is the workgroup's)
+    else acc = encode_level<false>(lv, table, c);
+    feat[(int64_t)level * B + b] = acc;
+  }
 }
 
 // ---- backward -----------------------------------------------------------------------------------------
@@ -498,9 +508,10 @@ extern "C" int nof_hash_encode_fwd(const NofHashGrid* g, const float* pts_w, con
   if (int e = check_grid(g)) return e;
   NOF_ARG(pts_w && table && feat && B >= 0);
   if (B == 0) return 0;
-  const int64_t blocks = nof_div_up(B, 256) * g->L;
+  const int G = g->L < 8 ? g->L : 8;
+  const int64_t blocks = nof_div_up(B, 256) * G;
   NOF_ARG(blocks < (1ll << 31));
-  hipLaunchKernelGGL(k_hash_fwd, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, *g, xcd_level_slots(g), pts_w,
+  hipLaunchKernelGGL(k_hash_fwd, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, *g, xcd_level_slots(g), G, pts_w,
                      (const float2*)table, (float2*)feat, B);
   NOF_LAUNCH_OK();
   return 0;

@@ -77,7 +77,10 @@ __device__ __forceinline__ void gather_corners(const HashLevel& lv, const float2
   }
 }
 
-// features of one level at one point: 8 independent 8-byte gathers in flight, then the trilinear blend (gridencoder.cu:174-200)
+// features of one level at one point: 8 independent 8-byte gathers in flight, then the trilinear blend (gridencoder.cu:174-200).
+// PAIRS (a compile-time variant the caller selects with a WAVE-UNIFORM test, see level_pairs()): the x neighbour's row is the next
+// row, so the two come in one 16-byte load -- four gather instructions instead of eight; same values, same blend order.
+template <bool PAIRS = false>
 __device__ __forceinline__ float2 encode_level(const HashLevel& lv, const float2* __restrict__ table, const CellPos& c) {
   float2 acc = make_float2(0.f, 0.f);
   if (c.oob) return acc;
@@ -97,11 +100,28 @@ __device__ __forceinline__ float2 encode_level(const HashLevel& lv, const float2
     idx[k] = grid_index(lv, p[0], p[1], p[2]);
   }
   float2 v[8];
+  if constexpr (PAIRS) {
 #pragma unroll
-  for (int k = 0; k < 8; ++k) v[k] = tl[idx[k]];                       // (gather_corners' 16-byte pair loads: 5 % slower in k_hash_fwd)
+    for (int k = 0; k < 8; k += 2) {
+      const RowPair t = *reinterpret_cast<const RowPair*>(tl + idx[k]);
+      v[k] = make_float2(t.x, t.y);
+      v[k + 1] = make_float2(t.z, t.w);
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = tl[idx[k]];
+  }
 #pragma unroll
   for (int k = 0; k < 8; ++k) { acc.x += w[k] * v[k].x; acc.y += w[k] * v[k].y; }
   return acc;
+}
+
+// Is row(x+1, y, z) == row(x, y, z) + 1 for EVERY cell of the level?  True for a dense level whose linear index never reaches
+// the modulo wrap: (res+1)^3 <= size (false on the exact-power levels where the float32 resolution is one above the allocated
+// one, SURVEY 8a notes).  Depends on the level only, i.e. uniform for a workgroup that works on one level.
+__device__ __forceinline__ bool level_pairs(const HashLevel& lv) {
+  const uint32_t r1 = lv.res + 1u;
+  return !lv.hashed && r1 <= 1024u && r1 * r1 * r1 <= lv.size;
 }
 
 __device__ __forceinline__ HashLevel load_level(const NofHashGrid& g, int l) {

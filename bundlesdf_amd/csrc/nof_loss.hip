@@ -155,10 +155,25 @@ __device__ void tile_scan(const uint8_t* __restrict__ flags, uint32_t ntiles, ui
                           uint32_t* __restrict__ tiles, int all) {
   __shared__ uint32_t wsum[16];
   const uint32_t nt = blockDim.x, t = threadIdx.x;
-  const uint32_t per = (ntiles + nt - 1) / nt;
-  const uint32_t lo = t * per < ntiles ? t * per : ntiles, hi = lo + per < ntiles ? lo + per : ntiles;
+  // four flags per 32-bit word (the flag array is 16-byte aligned and padded to 16 bytes); a thread owns `wper` consecutive words
+  // and requests them eight at a time, so that their latencies overlap (a byte-by-byte loop waited ~0.5 us per flag: 15 us)
+  const uint32_t* __restrict__ fw = reinterpret_cast<const uint32_t*>(flags);
+  const uint32_t nwords = (ntiles + 3) / 4;
+  const uint32_t wper = (nwords + nt - 1) / nt;
+  const uint32_t lo = t * wper < nwords ? t * wper : nwords, hi = lo + wper < nwords ? lo + wper : nwords;
+  auto word = [&](uint32_t wi) -> uint32_t {                           // 0x01 in every byte whose tile is listed
+    const uint32_t left = ntiles - 4u * wi;                            // flags that exist in this word (the last one may be partial)
+    const uint32_t m = left >= 4u ? 0x01010101u : ((1u << (8u * left)) - 1u) & 0x01010101u;
+    return (all ? 0x01010101u : fw[wi]) & m;
+  };
   uint32_t cnt = 0;
-  for (uint32_t i = lo; i < hi; ++i) cnt += (all || flags[i]) ? 1u : 0u;
+  for (uint32_t base = lo; base < hi; base += 8) {
+    uint32_t w[8];
+#pragma unroll
+    for (uint32_t k = 0; k < 8; ++k) w[k] = base + k < hi ? word(base + k) : 0u;
+#pragma unroll
+    for (uint32_t k = 0; k < 8; ++k) cnt += __popc(w[k]);
+  }
   // inclusive scan inside the wave, then across the waves
   uint32_t inc = cnt;
   const int lane = t & 63;
@@ -169,14 +184,22 @@ __device__ void tile_scan(const uint8_t* __restrict__ flags, uint32_t ntiles, ui
   }
   if (lane == 63) wsum[t >> 6] = inc;
   __syncthreads();
-  uint32_t base = 0, total = 0;
+  uint32_t before = 0, total = 0;
   for (uint32_t w = 0; w < (nt + 63) / 64; ++w) {
-    if (w < (t >> 6)) base += wsum[w];
+    if (w < (t >> 6)) before += wsum[w];
     total += wsum[w];
   }
-  uint32_t at = base + inc - cnt;
-  for (uint32_t i = lo; i < hi; ++i)
-    if (all || flags[i]) tiles[at++] = i;
+  uint32_t at = before + inc - cnt;
+  for (uint32_t base = lo; base < hi; base += 8) {
+    uint32_t w[8];
+#pragma unroll
+    for (uint32_t k = 0; k < 8; ++k) w[k] = base + k < hi ? word(base + k) : 0u;
+#pragma unroll
+    for (uint32_t k = 0; k < 8; ++k)
+#pragma unroll
+      for (uint32_t e = 0; e < 4; ++e)
+        if ((w[k] >> (8u * e)) & 1u) tiles[at++] = 4u * (base + k) + e;
+  }
   if (t == 0) { head[0] = total; head[1] = ntiles; head[2] = 0; head[3] = 0; }
   if (t == 0 && (total & 1u)) tiles[total] = ntiles;                   // an odd list ends in a tile that does not exist (pairs of tiles per wave)
 }
@@ -197,17 +220,27 @@ extern "C" int64_t nof_tile_list_bytes(int64_t B) {
 // workgroup 0: the per-ray loss rows -> loss_out; workgroup 1 (when a work list is asked for): the tile scan
 __global__ __launch_bounds__(1024) void k_loss_reduce(const float* __restrict__ rows, int64_t R, float* __restrict__ loss_out,
                                                        const uint8_t* __restrict__ tile_flags, uint32_t ntiles,
-                                                       uint32_t* __restrict__ head, uint32_t* __restrict__ tiles) {
+                                                       uint32_t* __restrict__ head, uint32_t* __restrict__ tiles, int overwrite) {
   if (blockIdx.x == 1 || loss_out == nullptr) {
     tile_scan(tile_flags, ntiles, head, tiles, 0);
     return;
   }
-  if (threadIdx.x >= 256) return;
-  __shared__ float sm[4][8];
+  __shared__ float sm[16][8];
   float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  for (int64_t r = threadIdx.x; r < R; r += 256)
+  for (int64_t r0 = threadIdx.x; r0 < R; r0 += 4096) {                 // four rows per thread and round, all eight loads in flight
+    float4 v[4][2];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) acc[k] += rows[r * 8 + k];
+    for (int u = 0; u < 4; ++u) {
+      const int64_t r = r0 + 1024 * u;
+      v[u][0] = v[u][1] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (r < R) { v[u][0] = ((const float4*)rows)[2 * r]; v[u][1] = ((const float4*)rows)[2 * r + 1]; }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      acc[0] += v[u][0].x; acc[1] += v[u][0].y; acc[2] += v[u][0].z; acc[3] += v[u][0].w;
+      acc[4] += v[u][1].x; acc[5] += v[u][1].y; acc[6] += v[u][1].z; acc[7] += v[u][1].w;
+    }
+  }
 #pragma unroll
   for (int k = 0; k < 8; ++k) acc[k] = wave_sum(acc[k]);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -215,16 +248,21 @@ __global__ __launch_bounds__(1024) void k_loss_reduce(const float* __restrict__ 
 #pragma unroll
     for (int k = 0; k < 8; ++k) sm[wave][k] = acc[k];
   __syncthreads();
-  if (threadIdx.x < 8) loss_out[threadIdx.x] += (sm[0][threadIdx.x] + sm[1][threadIdx.x]) + (sm[2][threadIdx.x] + sm[3][threadIdx.x]);
+  if (threadIdx.x < 8) {
+    float s = 0.0f;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) s += sm[w][threadIdx.x];
+    loss_out[threadIdx.x] = overwrite ? s : loss_out[threadIdx.x] + s;
+  }
 }
 
 // forward compositing + losses + dL/draw in one launch, and -- with `tile_list` -- the work list of the backward: the 32-sample
 // tiles that hold at least one non-zero row of dL/draw (NofTileList, include/nof_hip.h).  S % 32 == 0 (the reference's default
 // 128 + 64): the flags come out of the loss kernel itself and the scan rides in the second workgroup of the loss reduction, so the
 // list costs no launch; otherwise one extra pass over draw.
-extern "C" int nof_composite_loss_fwd_bwd(const NofLossCfg* cfg, const float* raw, const float* z_vals, const uint8_t* valid,
-                                           const float* batch, int64_t R, int32_t S, float* rgb_map, float* weights,
-                                           float* draw, float* loss_rows, float* loss_out, void* tile_list, void* stream) {
+static int composite_loss(const NofLossCfg* cfg, const float* raw, const float* z_vals, const uint8_t* valid,
+                          const float* batch, int64_t R, int32_t S, float* rgb_map, float* weights,
+                          float* draw, float* loss_rows, float* loss_out, void* tile_list, int overwrite, void* stream) {
   NOF_ARG(cfg && raw && z_vals && valid && batch && rgb_map && draw && R >= 0 && S >= 1);
   NOF_ARG(loss_out == nullptr || loss_rows != nullptr);
   NOF_ARG((int64_t)R * S < (1ll << 36));
@@ -245,16 +283,22 @@ extern "C" int nof_composite_loss_fwd_bwd(const NofLossCfg* cfg, const float* ra
   }
   if (loss_out || flags) {
     hipLaunchKernelGGL(k_loss_reduce, dim3(loss_out && flags ? 2 : 1), dim3(1024), 0, (hipStream_t)stream, loss_rows, R, loss_out,
-                       flags, nt, head, tiles);
+                       flags, nt, head, tiles, overwrite);
     NOF_LAUNCH_OK();
   }
   return 0;
 }
 
+extern "C" int nof_composite_loss_fwd_bwd(const NofLossCfg* cfg, const float* raw, const float* z_vals, const uint8_t* valid,
+                                           const float* batch, int64_t R, int32_t S, float* rgb_map, float* weights,
+                                           float* draw, float* loss_rows, float* loss_out, void* tile_list, void* stream) {
+  return composite_loss(cfg, raw, z_vals, valid, batch, R, S, rgb_map, weights, draw, loss_rows, loss_out, tile_list, 1, stream);
+}
+
 extern "C" int nof_composite_loss(const NofLossCfg* cfg, const float* raw, const float* z_vals, const uint8_t* valid,
                                    const float* batch, int64_t R, int32_t S, float* rgb_map, float* weights, float* draw,
                                    float* loss_rows, float* loss_out, void* stream) {
-  return nof_composite_loss_fwd_bwd(cfg, raw, z_vals, valid, batch, R, S, rgb_map, weights, draw, loss_rows, loss_out, nullptr, stream);
+  return composite_loss(cfg, raw, z_vals, valid, batch, R, S, rgb_map, weights, draw, loss_rows, loss_out, nullptr, 0, stream);
 }
 
 // The work list on its own: from an existing dL/draw [B,4] (`all` == 0), or every tile of the batch (`all` != 0; draw may be NULL):
@@ -362,10 +406,10 @@ extern "C" int nof_adam_step(float* params, float* grads, float* exp_avg, float*
 }
 
 // ------------------------------------------------------------------------------------------------
-// out[col] += sum over rows of partials [n_rows, n_cols] (n_rows = 8 x CUs = 2048 on MI355X: 75 MB at cfg2).
-// A workgroup owns 32 columns (one 128-byte line per row) and one of RSPLIT row ranges; 32 row groups x 8 independent
-// loads in flight per lane; one fp32 atomic per (column, row range) at the end.
-#define RED_RSPLIT 4
+// out[col] += sum over rows of partials [n_rows, n_cols] (n_rows = one per workgroup of the MLP backward = 2 x CUs = 512 on
+// MI355X: 19 MB at cfg2).  A workgroup owns 32 columns (one 128-byte line per row) and one of RSPLIT row ranges; 32 row groups x 8
+// independent loads in flight per lane; one fp32 atomic per (column, row range) at the end.
+#define RED_RSPLIT 2
 __global__ __launch_bounds__(1024) void k_reduce_partials(const float* __restrict__ partials, int n_rows, int n_cols,
                                                            float* __restrict__ out) {
   __shared__ float sm[32][33];

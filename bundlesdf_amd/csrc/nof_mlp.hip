@@ -15,6 +15,7 @@
 //   * forward activations are recomputed in the backward (features are re-read, 128 B/sample) - nothing [B,64]
 //     ever goes to HBM.
 // Accumulator layout of v_mfma_f32_32x32x*: lane l = (hi = l>>5, j = l&31) holds column j, rows (r&3)+8(r>>2)+4hi.
+#include <type_traits>
 #include "nof_common.h"
 #include "nof_hash_dev.h"
 
@@ -668,18 +669,52 @@ __device__ __forceinline__ void dw_block(float (&dw)[2][16], float* db_lane, con
   }
 }
 
-// Every wave writes its dW / db accumulators of layers [LA, LB) as ITS OWN row of `partials` (row = 4 * workgroup + wave) with
-// plain global stores: for one register every lane owns a distinct (row, column) and the (lane, register) pairs cover every
-// parameter exactly once, so no zero-fill, no LDS and no atomics are needed (reducing the four waves in LDS with
-// ds_add_f32 cost ~70 us per workgroup: LDS float atomics retire ~1 lane per 4.5 cycles on gfx950).  nof_reduce_partials
-// sums the 4 * n_workgroups rows.
+// The workgroup's dW / db accumulators of layers [LA, LB) -> ITS row of `partials` (row = workgroup).  The four waves' registers are
+// summed through LDS first -- plain stores and lane-private read-modify-writes, one wave after the other with a barrier between
+// (the fragments at the start of the LDS block are dead once every wave has left the tile loop; LDS float ATOMICS cost ~70 us here:
+// they retire ~1 lane per 4.5 cycles on gfx950) -- and wave 0 writes the totals with plain global stores: for one register every
+// lane owns a distinct (row, column) and the (lane, register) pairs cover every parameter exactly once, so no zero-fill and no
+// global atomics are needed.  One row per workgroup instead of one per wave is a quarter of the bytes nof_reduce_partials reads
+// (cfg2: 75 MB -> 19 MB per step).  `db_stride`: floats between two waves' lane-private bias sums.  Deterministic: ((w0+w1)+w2)+w3.
 template <class SH, int LA, int LB>
-__device__ __forceinline__ void flush_dw(const NofMlpDesc& d, const float (&dw)[SH::NL][2][2][16], const float* dbw,
-                                         float* __restrict__ partials, float unscale) {
+__device__ __forceinline__ void flush_dw(const NofMlpDesc& d, float (&dw)[SH::NL][2][2][16], const float* dbw, int db_stride,
+                                         char* smem, float* __restrict__ partials, float unscale) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int hi = lane >> 5, j = lane & 31;
   const int hi_j = (j >> 2) & 1, r_j = (j & 3) + 4 * (j >> 3);      // dW column lane j = input slot (hi_j, r_j)
-  float* __restrict__ dst = partials + ((size_t)blockIdx.x * 4 + wave) * d.n_params;
+  float* red = reinterpret_cast<float*>(smem) + lane;
+  const int wv = __builtin_amdgcn_readfirstlane(wave);              // scalar: the phases below are whole-wave branches
+  // phase W: 0 = store, 1 / 2 = add into LDS, 3 = add LDS into the registers (the last wave keeps the totals).  Straight-line per
+  // phase, so that a wave's 70-110 LDS reads are all in flight together (one branch per element serialised their latencies: 30 us)
+  auto phase = [&](auto W) {
+    constexpr int w = decltype(W)::value;
+    int a = 0;
+#pragma unroll
+    for (int l = LA; l < LB; ++l)
+#pragma unroll
+      for (int p = 0; p < 2; ++p)
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            if (p < SH::pn(l) && q < SH::qn(l) && r < SH::nacc(l)) {
+              if constexpr (w == 0) red[a * 64] = dw[l][p][q][r];
+              else if constexpr (w < 3) red[a * 64] += dw[l][p][q][r];
+              else dw[l][p][q][r] += red[a * 64];
+              ++a;
+            }
+  };
+  __syncthreads();                                                  // every wave is out of the tile loop
+  if (wv == 0) phase(std::integral_constant<int, 0>());
+  __syncthreads();
+  if (wv == 1) phase(std::integral_constant<int, 1>());
+  __syncthreads();
+  if (wv == 2) phase(std::integral_constant<int, 2>());
+  __syncthreads();
+  if (wv == 3) phase(std::integral_constant<int, 3>());
+  if (wv != 3) return;
+  float* __restrict__ dst = partials + (size_t)blockIdx.x * d.n_params;
+  const float* db0 = dbw - 3 * db_stride;                          // wave 0's lane-private sums (this is wave 3)
 #pragma unroll
   for (int l = LA; l < LB; ++l) {
     const int in_dim = d.in_dim[l], out_dim = d.out_dim[l];
@@ -699,13 +734,21 @@ __device__ __forceinline__ void flush_dw(const NofMlpDesc& d, const float (&dw)[
             }
           }
         }
-        float v = dbw[(2 * l + p) * 64];                               // lane-private sums of lanes (hi, j): the pair shares row j
+        const float* dbp = db0 + (2 * l + p) * 64;                   // the four waves' sums of lanes (hi, j): the pair shares row j
+        float v = ((dbp[0] + dbp[db_stride]) + dbp[2 * db_stride]) + dbp[3 * db_stride];
         v += __shfl_xor(v, 32, 64);
         const int row = 32 * p + j;
         if (hi == 0 && row < out_dim) dst[d.b_off[l] + row] = v * unscale;
       }
     }
   }
+}
+// floats of LDS flush_dw's reduction needs (x 256 bytes): must end below the lane-private bias sums
+template <class SH, int LA, int LB>
+constexpr int flush_dw_accs() {
+  int a = 0;
+  for (int l = LA; l < LB; ++l) a += SH::pn(l) * SH::qn(l) * SH::nacc(l);
+  return a;
 }
 
 template <class P, int NS, int NC>
@@ -913,7 +956,8 @@ __global__ __launch_bounds__(256) void k_mlp_bwd(NofMlpDesc d, const char* __res
   }
 
   // ---------------- reduce the workgroup's dW/db and write its row of `partials` ----------------
-  flush_dw<SH, 0, NL>(d, dw, dbw, partials, gunscale);
+  static_assert(flush_dw_accs<SH, 0, NL>() * 256 <= DB_BASE, "flush_dw's LDS reduction would overwrite the bias sums");
+  flush_dw<SH, 0, NL>(d, dw, dbw, NSLOT * 64, smem, partials, gunscale);
 }
 
 // =====================================================================================================
@@ -1111,7 +1155,8 @@ __global__ __launch_bounds__(256, 2) void k_mlp_bwd_color(NofMlpDesc d, const ch
     }                                                    // if (!skip)
     store_sig_o1<P>(dsig, B, b, hi, ds1);                // zeros for a skipped tile
   }
-  flush_dw<SH, NS, NL>(d, dw, dbw, partials, gunscale);
+  static_assert(flush_dw_accs<SH, NS, NL>() * 256 <= DB_BASE, "flush_dw's LDS reduction would overwrite the bias sums");
+  flush_dw<SH, NS, NL>(d, dw, dbw, (2 * NC) * 64, smem, partials, gunscale);
 #undef CFW
 #undef CBW
 #undef CBIAS
@@ -1256,7 +1301,8 @@ __global__ __launch_bounds__(256, 2) void k_mlp_bwd_sigma(NofMlpDesc d, const ch
     }                                                                    // if (!skip)
     store_dfeat_o1(dfeat, L, B, b, hi, df1, gunscale);                   // zeros for a skipped tile
   }
-  flush_dw<SH, 0, NS>(d, dw, dbw, partials, gunscale);
+  static_assert(flush_dw_accs<SH, 0, NS>() * 256 <= DB_BASE, "flush_dw's LDS reduction would overwrite the bias sums");
+  flush_dw<SH, 0, NS>(d, dw, dbw, (2 * NS) * 64, smem, partials, gunscale);
 #undef SFW
 #undef SBW
 #undef SBIAS
@@ -1467,7 +1513,8 @@ __global__ __launch_bounds__(256) void k_eikonal(NofMlpDesc d, const char* __res
       }
     }
   }
-  flush_dw<SH, 0, NS>(d, dw, dbz, partials, 1.0f);
+  static_assert(flush_dw_accs<SH, 0, NS>() * 256 <= DB_BASE, "flush_dw's LDS reduction would overwrite the bias sums");
+  flush_dw<SH, 0, NS>(d, dw, dbz, (2 * NS + 1) * 64, smem, partials, 1.0f);
   // loss: one atomic pair per wave
   loss_acc += __shfl_xor(loss_acc, 1, 64);  loss_acc += __shfl_xor(loss_acc, 2, 64);  loss_acc += __shfl_xor(loss_acc, 4, 64);
   loss_acc += __shfl_xor(loss_acc, 8, 64);  loss_acc += __shfl_xor(loss_acc, 16, 64); loss_acc += __shfl_xor(loss_acc, 32, 64);
@@ -1577,7 +1624,7 @@ extern "C" int nof_mlp_bwd_blocks(void) {
       if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
     }
     (void)hipGetLastError();
-    g_bwd_blocks = 8 * cus;                                           // one partial row per wave: 2 workgroups x 4 waves per CU
+    g_bwd_blocks = 2 * cus;                                           // one partial row per workgroup: 2 persistent workgroups per CU
   }
   return g_bwd_blocks;
 }
@@ -1653,7 +1700,7 @@ extern "C" int nof_mlp_bwd_tiles(const NofMlpDesc* d, const void* packed, const 
                          (size_t)4 * (2 * d->n_color) * 2 * 64 * 16 + (size_t)4 * (2 * d->n_color) * 64 * 4;
     const size_t shm_s = (size_t)(n_pairs(*d, ns - 1) + n_pairs(*d, ns)) * pair_bytes + (size_t)n_oblk(*d, ns - 1) * 128 +
                          (size_t)4 * (2 * ns - 1) * 2 * 64 * 16 + (size_t)4 * (2 * ns) * 64 * 4;
-    const unsigned blocks = rows / 4;
+    const unsigned blocks = rows;
 #define LAUNCH_SPLIT(P, NS_, NC_, dummy)                                                                  \
   {                                                                                                       \
     auto kc = k_mlp_bwd_color<P, NS_, NC_>;                                                               \
@@ -1676,7 +1723,7 @@ extern "C" int nof_mlp_bwd_tiles(const NofMlpDesc* d, const void* packed, const 
   size_t shm = 2 * (size_t)n_pairs(*d, nl) * pair_bytes + (size_t)n_oblk(*d, nl) * 32 * 4;
   if (d->precision != 0) shm += (size_t)4 * (2 * nl) * 2 * 64 * 16;      // lane-private orientation-2 slots (16-bit modes)
   shm += (size_t)4 * (2 * nl) * 64 * 4;                                   // lane-private bias-gradient sums
-  const unsigned blocks = rows / 4;
+  const unsigned blocks = rows;
 #define LAUNCH_BWD(P, NS_, NC_, dummy)                                                                    \
   {                                                                                                       \
     auto kern = k_mlp_bwd<P, NS_, NC_>;                                                                   \
@@ -1768,7 +1815,7 @@ extern "C" int nof_eikonal(const NofMlpDesc* d, const void* packed32, const NofH
   if (B == 0) return 0;
   const int ns = d->n_sigma;
   const size_t shm = 2 * (size_t)n_pairs(*d, ns) * 16 * 64 * 4 + (size_t)n_oblk(*d, ns) * 128 + 2 * 128 + (size_t)4 * (2 * ns + 1) * 64 * 4;
-  const unsigned blocks = (unsigned)nof_mlp_bwd_blocks() / 4;
+  const unsigned blocks = (unsigned)nof_mlp_bwd_blocks();
 #define LAUNCH_EIK(P_, NS_, NC_, dummy)                                                                   \
   {                                                                                                       \
     auto kern = k_eikonal<NS_, NC_>;                                                                      \

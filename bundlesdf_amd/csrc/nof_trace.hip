@@ -169,8 +169,9 @@ __global__ __launch_bounds__(64) void k_trace_rays(const uint32_t* __restrict__ 
   int32_t* cid = cell_ids ? cell_ids + r * max_hits : nullptr;
   int overflow = 0;
   const int nh = trace_one(occ, n, o, d, max_hits, tio, cid, &overflow);
-  if (cid)                                                            // (t_in_out's zero padding = at::zeros in common.cu:158
-    for (int k = nh; k < max_hits; ++k) cid[k] = -1;                  //  is one memset before the launch)
+  for (int k = nh; k < max_hits; ++k) reinterpret_cast<float2*>(tio)[k] = make_float2(0.f, 0.f);   // zero padding (at::zeros, common.cu:158)
+  if (cid)
+    for (int k = nh; k < max_hits; ++k) cid[k] = -1;
   n_hits[r] = nh;
   if (overflow && flags) atomicOr(&flags[0], 1);
 }
@@ -249,6 +250,9 @@ __global__ __launch_bounds__(64) void k_batch_trace(const float* __restrict__ po
   int32_t* cid = cell_ids ? cell_ids + r * max_hits : nullptr;
   int overflow = 0;
   const int nh = trace_one(occ, n, o, d, max_hits, tio, cid, &overflow);
+  // zero padding of the interval list (at::zeros in common.cu:158) by the ray's own lane: a memset launch in front of this kernel
+  // cost 8 us of the step
+  for (int k = nh; k < max_hits; ++k) reinterpret_cast<float2*>(tio)[k] = make_float2(0.f, 0.f);
   if (cid)
     for (int k = nh; k < max_hits; ++k) cid[k] = -1;
   n_hits[r] = nh;
@@ -424,7 +428,6 @@ extern "C" int nof_trace_rays(const uint32_t* occ_bits, int32_t level, const flo
                                void* stream) {
   NOF_ARG(occ_bits && rays_o && rays_d && t_in_out && n_hits && level >= 0 && level <= 8 && max_hits >= 1 && R >= 0);
   if (R == 0) return 0;
-  NOF_HIP(hipMemsetAsync(t_in_out, 0, (size_t)R * max_hits * 2 * sizeof(float), (hipStream_t)stream));
   hipLaunchKernelGGL(k_trace_rays, dim3((unsigned)nof_div_up(R, 64)), dim3(64), occ_lds_bytes(level), (hipStream_t)stream, occ_bits,
                      1 << level, rays_o, rays_d, R, max_hits, t_in_out, cell_ids, n_hits, flags);
   NOF_LAUNCH_OK();
@@ -439,7 +442,6 @@ extern "C" int nof_batch_trace(const float* pool, const int64_t* ids, const floa
   NOF_ARG(level >= 0 && level <= 8 && max_hits >= 1 && R >= 0 && sh_degree >= 1 && sh_degree <= 4);
   NOF_ARG(ff >= 0 && ff + sh_degree * sh_degree <= NOF_VIEW_COLS && (ff == 0 || frame_feat));
   if (R == 0) return 0;
-  NOF_HIP(hipMemsetAsync(t_in_out, 0, (size_t)R * max_hits * 2 * sizeof(float), (hipStream_t)stream));
   hipLaunchKernelGGL(k_batch_trace, dim3((unsigned)nof_div_up(R, 64)), dim3(64), occ_lds_bytes(level), (hipStream_t)stream, pool, ids, tf,
                      frame_feat, ff, sh_degree, occ_bits, 1 << level, R, max_hits, batch, rays_o_w, viewdirs_w, view,
                      t_in_out, cell_ids, n_hits, flags);

@@ -51,19 +51,23 @@ def resize_nearest(img, W, H):
 
 
 class YcbineoatReader:
+    """Reader of the custom-data capture layout.  Attributes callers use: video_dir, color_files, id_strs, K (already scaled),
+    H, W (already scaled), downscale, gt_pose_files."""
+
     def __init__(self, video_dir, downscale=1, shorter_side=None):
+        def listing(sub, pattern):
+            return sorted(glob.glob(os.path.join(video_dir, sub, pattern)))
         self.video_dir = video_dir
-        self.downscale = downscale
-        self.color_files = sorted(glob.glob(f"{self.video_dir}/rgb/*.png"))
-        self.K = np.loadtxt(f'{video_dir}/cam_K.txt').reshape(3, 3)
-        self.id_strs = [os.path.basename(f).replace('.png', '') for f in self.color_files]
-        self.H, self.W = read_png(self.color_files[0]).shape[:2]
-        if shorter_side is not None:
-            self.downscale = shorter_side / min(self.H, self.W)
-        self.H = int(self.H * self.downscale)
-        self.W = int(self.W * self.downscale)
-        self.K[:2] *= self.downscale
-        self.gt_pose_files = sorted(glob.glob(f'{self.video_dir}/annotated_poses/*'))
+        self.color_files = listing('rgb', '*.png')
+        self.gt_pose_files = listing('annotated_poses', '*')
+        self.id_strs = [os.path.splitext(os.path.basename(f))[0] for f in self.color_files]
+        full_h, full_w = read_png(self.color_files[0]).shape[:2]
+        # `shorter_side` overrides `downscale`: the factor that brings min(H, W) to it; sizes truncate like int()
+        self.downscale = downscale if shorter_side is None else shorter_side / min(full_h, full_w)
+        self.H, self.W = int(full_h * self.downscale), int(full_w * self.downscale)
+        intrinsics = np.loadtxt(os.path.join(video_dir, 'cam_K.txt')).reshape(3, 3)
+        intrinsics[:2] *= self.downscale                              # fx, fy, cx, cy scale with the image; the last row stays
+        self.K = intrinsics
 
     def get_video_name(self):
         return self.video_dir.split('/')[-1]

@@ -285,8 +285,17 @@ class NeuralObjectField:
         cfg = self.cfg
         S = cfg['N_samples'] + cfg['N_samples_around_depth']
         b = self._buffers(R, S)
+        # the fragment image is first needed by the MLP forward: packed on the side stream beside the pose corrections, the ray
+        # marching and the hash encode (captured step: one chain)
+        pack_aside = not dyn and self._packed_step != self.global_step
+        if pack_aside:
+            main, side = torch.cuda.current_stream(), self._side_stream()
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                self.pack_weights()
         self.update_poses()
-        self.pack_weights(force=dyn)
+        if not pack_aside:
+            self.pack_weights(force=dyn)
         cid = None
         if want_cells:
             cid = b.setdefault('cell_ids', torch.empty(R, self.max_hits, dtype=torch.int32, device=self.device))
@@ -297,6 +306,8 @@ class NeuralObjectField:
                    self.flags)
         B = R * S
         self._call('nof_hash_encode_fwd', C.byref(self.grid), b['pts_w'], self.table, b['feat'], B)
+        if pack_aside:
+            main.wait_stream(side)
         if self.wide:
             self._call('nof_mlp_wide_fwd', C.byref(self.desc), self.packed, b['feat'], self.L, b['view'], S, b['raw'], b['wide_ws'], B)
         else:
@@ -313,7 +324,6 @@ class NeuralObjectField:
         b, S = self.forward_batch(pool, ids, R, u_occ, u_dep, seed, want_cells, dyn)
         B = R * S
         lc = self._loss_cfg()
-        self.loss_out.zero_()
         # the work list of the backward; the eikonal term has a gradient at every sample, so it takes none
         tiles = b['tiles'] if self.backward_tiles != 'off' and not self.eikonal else None
         self._call('nof_composite_loss_fwd_bwd', C.byref(lc), b['raw'], b['z_vals'], b['valid'], b['batch'], R, S, b['rgb_map'],
@@ -366,8 +376,9 @@ class NeuralObjectField:
                            b['g_ray'] if self.optimize_poses else None, b['dview'], b['batch'], R, self.ff,
                            C.c_float(self.max_trans), C.c_float(self.max_rot),
                            self._seg(self.grads, 'pose') if self.optimize_poses else None,
-                           self._seg(self.grads, 'feat') if self.ff > 0 else None, None, self.F)
-            b['dview'].zero_()                       # for the next step's atomics
+                           self._seg(self.grads, 'feat') if self.ff > 0 else None, None, self.F, 1)   # (zeroes dview for the next step's atomics)
+            else:
+                b['dview'].zero_()
 
         if dyn:
             # captured step: one chain (a second branch in the HIP graph costs more than the overlap returns)
@@ -376,9 +387,8 @@ class NeuralObjectField:
             pose_kernels()
         else:
             # The table scatter of the large levels (atomics that execute memory-side) is the longest launch of the backward; the
-            # input gradient, the LDS-accumulated small levels and the pose / frame-feature gradients that hang off them are
-            # independent of it and run beside it on a second stream (fork / join by events), the MLP partial-row reduction
-            # behind it.
+            # input gradient and the pose / frame-feature gradients that hang off it are independent of it and run beside it on a
+            # second stream (fork / join by events); the LDS-accumulated small levels and the MLP row reduction follow it.
             main = torch.cuda.current_stream()
             side = self._side_stream()
             side.wait_stream(main)
@@ -390,14 +400,16 @@ class NeuralObjectField:
                 hash_bwd(BIG | SMALL, split, self.L)
                 grad_sync.start(self.grads[a:self.n_table + self.n_mlp])
                 with torch.cuda.stream(side):
-                    hash_bwd(INPUT | SMALL, 0, split)
+                    hash_bwd(INPUT, 0, self.L)
                     pose_kernels()
-                hash_bwd(BIG, 0, split)
+                hash_bwd(BIG | SMALL, 0, split)
             else:
+                # measured chains at cfg2 over the work list: { table scatter 95 us (beside dL/dx), LDS levels 30, row reduction 10 }
+                # | { dL/dx 125 us (beside the scatter), pose kernels 35 }
                 with torch.cuda.stream(side):
-                    hash_bwd(INPUT | SMALL, 0, self.L)
+                    hash_bwd(INPUT, 0, self.L)
                     pose_kernels()
-                hash_bwd(BIG, 0, self.L)
+                hash_bwd(BIG | SMALL, 0, self.L)
                 reduce_mlp()
             main.wait_stream(side)
         if self.optimize_poses and float(cfg.get('pose_reg_weight', 0)) > 0:

@@ -2,11 +2,70 @@
 
 The reference extracts with skimage.measure.marching_cubes on the host (nerf_runner.py:1388-1394) and wraps the result
 in trimesh.Trimesh (:1404); neither package exists in this image.  The SDF grid itself is produced on the GPU
-(NeuralObjectField.query_sdf); the surface is extracted here with marching tetrahedra (6 tetrahedra per cell around the
-main diagonal: no ambiguous cases, vertices on grid edges by linear interpolation exactly like marching cubes), which
-agrees with marching cubes to well below the voxel size -- the quantity the Chamfer parity metric measures.
+(NeuralObjectField.query_sdf_grid) and the surface is extracted there as well (mesh_gpu.py): marching cubes by default -- this
+file derives its case table, `mc_case_table` -- or marching tetrahedra (6 tetrahedra per cell around the main diagonal; the
+NumPy version below is what the GPU kernels are compared with).
 """
 import numpy as np
+
+# ---- marching cubes: the case table ---------------------------------------------------------------------------------------------
+# corner c = x + 2 y + 4 z of the cell; edge e joins corners MC_EDGES[e] = (a, b), a < b, in lexicographic order:
+# (0,1) (0,2) (0,4) (1,3) (1,5) (2,3) (2,6) (3,7) (4,5) (4,6) (5,7) (6,7)
+MC_EDGES = tuple((a, a | (1 << d)) for a in range(8) for d in range(3) if not a & (1 << d))
+
+
+def mc_case_table():
+    """[256, 16] int8: row `case` (bit c = corner c is inside, value < iso) = [number of triangles T <= 5, 3 T cube-edge ids].
+
+    Derived, not typed in.  On every cube face the iso-contour is drawn as DIRECTED segments between the crossed face edges, with
+    the inside corners on the segment's right as seen from outside the cube: two crossings give one segment; four (the ambiguous
+    face) give two segments that cut off the inside corners -- a rule that only looks at that face's corner signs, so the two
+    cells sharing the face draw the same contour and the surface is watertight.  Every crossed cube edge then has exactly one
+    segment arriving and one leaving: the segments are a permutation of the crossed edges, its cycles are the polygons, already
+    oriented with their normals from the inside to the outside.  A polygon starts at its smallest edge id (polygons in the
+    order of those ids) and is cut into a triangle fan from there."""
+    edge_id = {e: i for i, e in enumerate(MC_EDGES)}
+    faces = []                                                       # corner cycles, counter-clockwise seen from outside
+    for axis in range(3):
+        u, v = 1 << ((axis + 1) % 3), 1 << ((axis + 2) % 3)          # (axis, u, v) right-handed
+        for side in (0, 1):
+            base = side << axis
+            cyc = (base, base | u, base | u | v, base | v)           # counter-clockwise seen from +axis ...
+            faces.append(cyc if side else cyc[::-1])                 # ... which is outside only for the far face
+    table = np.zeros((256, 16), dtype=np.int8)
+    for case in range(256):
+        nxt = {}
+        for cyc in faces:
+            ins = [(case >> c) & 1 for c in cyc]
+            fe = [edge_id[tuple(sorted((cyc[k], cyc[(k + 1) % 4])))] for k in range(4)]     # face edge k joins corners k, k+1
+            cross = [k for k in range(4) if ins[k] != ins[(k + 1) % 4]]
+            if len(cross) == 2:
+                k1, k2 = cross
+                # the corners k1+1 .. k2 lie to the right of the chord from edge k1 to edge k2
+                a, b = (fe[k1], fe[k2]) if ins[k2] else (fe[k2], fe[k1])
+                assert a not in nxt
+                nxt[a] = b
+            elif len(cross) == 4:
+                for k in range(4):
+                    if ins[k]:
+                        assert fe[k - 1] not in nxt
+                        nxt[fe[k - 1]] = fe[k]
+        tris, left = [], set(nxt)
+        while left:
+            start = min(left)
+            poly, e = [], start
+            while True:
+                poly.append(e)
+                left.discard(e)
+                e = nxt[e]
+                if e == start:
+                    break
+            tris += [(poly[0], poly[i], poly[i + 1]) for i in range(1, len(poly) - 1)]
+        assert len(tris) <= 5
+        table[case, 0] = len(tris)
+        table[case, 1:1 + 3 * len(tris)] = np.asarray(tris, dtype=np.int8).reshape(-1)
+    return table
+
 
 _CORNERS = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0], [1, 1, 0], [0, 0, 1], [1, 0, 1], [0, 1, 1], [1, 1, 1]], dtype=np.int64)
 _TETS = np.array([[0, 1, 3, 7], [0, 1, 5, 7], [0, 2, 3, 7], [0, 2, 6, 7], [0, 4, 5, 7], [0, 4, 6, 7]], dtype=np.int64)
@@ -113,7 +172,8 @@ class Mesh:
         n = int(np.ceil(np.sqrt((F + 1) // 2))) or 1
         cell = (tex_res - 1) / n                                   # texels per cell side
         if cell < 4:
-            raise ValueError(f'{F} triangles do not fit a {tex_res}^2 texture (cell {cell:.2f} texels): raise tex_res or simplify')
+            raise ValueError(f'{F} triangles do not fit a {tex_res}^2 texture (cell {cell:.2f} texels): raise tex_res '
+                             f'(Mesh.atlas_resolution gives the size that fits) or simplify')
         k = np.arange(F)
         c, upper = k // 2, (k % 2).astype(bool)
         cx, cy = (c % n) * cell, (c // n) * cell
@@ -126,6 +186,14 @@ class Mesh:
         verts = self.vertices[self.faces].reshape(-1, 3)
         faces = np.arange(3 * F, dtype=np.int64).reshape(F, 3)
         return Mesh(verts, faces, uv=uv_tex.reshape(-1, 2) / (tex_res - 1))
+
+    def atlas_resolution(self, wanted=1024, texels_per_cell=8, limit=16384):
+        """The texture size `unwrap` needs for this face count: `wanted` when every triangle's cell gets at least
+        `texels_per_cell` texels there, else the next multiple of 256 that does (capped).  The reference's xatlas unwrap has no
+        such limit; a 2 mm mesh of a hand-sized object has ~200 k triangles, which a 1024^2 per-triangle atlas cannot hold."""
+        n = int(np.ceil(np.sqrt((len(self.faces) + 1) // 2))) or 1
+        need = n * texels_per_cell + 1
+        return int(min(max(wanted, (need + 255) // 256 * 256), limit))
 
     @property
     def face_normals(self):

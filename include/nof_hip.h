@@ -208,8 +208,8 @@ int nof_mlp_pack(const NofMlpDesc* h_desc, const float* mlp_params, void* packed
 int nof_mlp_fwd(const NofMlpDesc* h_desc, const void* packed, const float* feat, int32_t L,
                 const float* view, int32_t S, float* raw, void* sigma_out, int64_t B, void* stream);
 /* draw [B,4] -> dfeat [L,B,2] (overwritten), dview [R,16] ACCUMULATED, partials [n_rows, n_params]
- * overwritten with per-wave weight-gradient partial sums (reduce with nof_reduce_partials).
- * n_rows must equal nof_mlp_bwd_blocks() (= 4 waves x 2 workgroups per CU of the persistent grid).
+ * overwritten with per-workgroup weight-gradient partial sums (reduce with nof_reduce_partials).
+ * n_rows must equal nof_mlp_bwd_blocks() (= the 2 persistent workgroups per CU of the grid; their four waves are summed in LDS).
  * 16-bit modes: with sigma_out (as written by nof_mlp_fwd) and dsigma_ws (scratch of the same size, [B,16] x 2 bytes) the
  * backward runs as two kernels (colour net, sigma net) at twice the occupancy; with either NULL, and always in fp32 mode,
  * one fused kernel recomputes everything.  Both paths produce the same values. */
@@ -248,7 +248,7 @@ int nof_mlp_wide_bwd(const NofMlpDesc* h_desc, const void* packed, const float* 
  * E = w * mean over {sdf < 1} of (|d sdf / d x| - 1)^2, evaluated with the exact-fp32 MFMA.  h_desc32 / packed32: the network
  * packed with precision 0.  pts_w [B,3], valid [B] u8, n_sel: DEVICE scalar (float) = number of samples with sdf < 1, weight =
  * eikonal_weight, grad_scale = 1/world_size (applied to the gradients only).  Writes geik [L,B,2] (d sdf / d feature) and dedn [B,3] (dE/dn) for nof_hash_encode_bwd_eik,
- * the sigma layers' weight gradient as per-wave rows of partials_e [nof_mlp_bwd_blocks(), n_params] (the colour layers'
+ * the sigma layers' weight gradient as per-workgroup rows of partials_e [nof_mlp_bwd_blocks(), n_params] (the colour layers'
  * entries are never written: zero the buffer once), and ADDS the term to loss_out[0] and loss_out[7]. */
 int nof_eikonal(const NofMlpDesc* h_desc32, const void* packed32, const NofHashGrid* h_grid, const float* table,
                 const float* pts_w, const uint8_t* valid, const float* n_sel, float weight, float grad_scale, float* geik,
@@ -324,8 +324,9 @@ int64_t nof_tile_list_bytes(int64_t B);
 /* the list from an existing dL/draw [B,4]; or, with all != 0 (draw may be NULL), every tile of the batch: the list that makes the
  * backward entry points do the whole batch without looking for zeros */
 int nof_tile_list_build(const float* draw, int64_t B, int32_t all, void* tile_list, void* stream);
-/* nof_composite_loss + the work list of its dL/draw (tile_list may be NULL).  When S % 32 == 0 the list costs no launch and no
- * pass over draw: the flags come out of the loss kernel and the scan rides beside the loss reduction. */
+/* nof_composite_loss + the work list of its dL/draw (tile_list may be NULL), with loss_out OVERWRITTEN instead of accumulated
+ * (the first writer of a step's loss terms: no zero-fill launch in front of it).  When S % 32 == 0 the list costs no launch and
+ * no pass over draw: the flags come out of the loss kernel and the scan rides beside the loss reduction. */
 int nof_composite_loss_fwd_bwd(const NofLossCfg* h_cfg, const float* raw, const float* z_vals, const uint8_t* valid,
                                const float* batch, int64_t R, int32_t S, float* rgb_map, float* weights, float* draw,
                                float* loss_rows, float* loss_out, void* tile_list, void* stream);
@@ -337,10 +338,12 @@ int nof_pose_grad_accum(const float* dpts, const float* dview, const float* batc
                         const float* c2w, const float* tf, int32_t ff, int32_t sh_degree, int64_t R, int32_t S,
                         float* g_ray, void* stream);
 /* one workgroup per frame: g_delta[f] = sum of its rays' rows (written when non-NULL), grad_pose [F,6] += se3 backward,
- * grad_feat [F,ff] += sum of its rays' dview[:, :ff] (either gradient pointer may be NULL). */
-int nof_pose_reduce_bwd(const float* pose_data, const float* g_ray, const float* dview, const float* batch, int64_t R,
+ * grad_feat [F,ff] += sum of its rays' dview[:, :ff] (either gradient pointer may be NULL).  zero_dview != 0: the rows of dview
+ * are set to 0 once read (this is their last reader in a step; every ray's frame must lie in [0, F)): ready for the next step's
+ * nof_mlp_bwd, which accumulates into them. */
+int nof_pose_reduce_bwd(const float* pose_data, const float* g_ray, float* dview, const float* batch, int64_t R,
                         int32_t ff, float max_trans, float max_rot_rad, float* grad_pose, float* grad_feat,
-                        float* g_delta, int32_t F, void* stream);
+                        float* g_delta, int32_t F, int32_t zero_dview, void* stream);
 /* grad += 2*w*data/numel  (feature_reg, nerf_runner.py:745-747) and pose_reg (:749-752) */
 int nof_small_regs(const float* feat_data, float* grad_feat, int32_t n_feat, float feature_reg_weight,
                    float grad_scale, void* stream);

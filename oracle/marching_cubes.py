@@ -11,8 +11,11 @@ identically by the two cubes sharing the face, which is what makes the surface w
 closed loops, every loop is fan-triangulated.  skimage's 'lewiner' variant resolves ambiguous configurations with extra
 interior tests; like every marching-cubes variant it puts its vertices on the same grid-edge crossings.
 
-It bounds what the product's marching-TETRAHEDRA extractor (nof_mt_*, bundlesdf_amd/mesh.py) may differ from a
-marching-cubes surface by: tests/test_mesh.py asserts a symmetric Hausdorff distance below half a voxel on noisy SDFs.
+It is the yardstick of the product's marching-cubes extractor (nof_mc_*, bundlesdf_amd/mesh_gpu.py: the same vertices and the
+same triangles, tests/test_gpu_mesh.py; the product derives its own case table by a different construction -- directed face
+segments, cycles of the resulting permutation -- and tests/test_mesh.py compares the two tables case by case), and it bounds what
+the marching-TETRAHEDRA option (nof_mt_*, bundlesdf_amd/mesh.py) may differ from a marching-cubes surface by (symmetric Hausdorff
+distance below half a voxel on noisy SDFs).
 """
 import numpy as np
 
@@ -28,6 +31,12 @@ def _eid(a, b):
 
 
 def _build_table():
+    """case -> [T,3] cube-edge ids.  Loops are found as UNDIRECTED chains of face segments and then given their direction by
+    geometry: a loop's edges each join one inside and one outside corner, the sum of those (outside - inside) vectors is the
+    side the surface normal must point to, and the loop's area vector (Newell's formula over the edge midpoints) is made to
+    agree with it -- normals point from the inside (value < iso) to the outside.  Every loop starts at its smallest edge id,
+    loops are ordered by that id, and are fan-triangulated from it: a canonical, oriented table."""
+    mid = np.array([(_C[a] + _C[b]) / 2.0 for a, b in _EDGES])
     table = []
     for case in range(256):
         inside = [(case >> c) & 1 for c in range(8)]
@@ -55,8 +64,22 @@ def _build_table():
                 else:
                     raise AssertionError(f'open loop in case {case}')
             loops.append(loop[:-1])
-        tris = []
+        canon = []
         for lp in loops:
+            out_dir = np.zeros(3)
+            for eid in lp:
+                a, b = _EDGES[eid]
+                out_dir += (_C[b] - _C[a]) * (1.0 if inside[a] else -1.0)
+            pts = mid[lp]
+            area = sum(np.cross(pts[i], pts[(i + 1) % len(lp)]) for i in range(len(lp)))
+            assert abs(float(area @ out_dir)) > 1e-9, case
+            if float(area @ out_dir) < 0:
+                lp = lp[::-1]
+            k = lp.index(min(lp))
+            canon.append(lp[k:] + lp[:k])
+        canon.sort(key=lambda lp: lp[0])
+        tris = []
+        for lp in canon:
             for i in range(1, len(lp) - 1):
                 tris.append((lp[0], lp[i], lp[i + 1]))
         table.append(np.array(tris, dtype=np.int64).reshape(-1, 3))
@@ -69,8 +92,9 @@ _EB = np.array([b for a, b in _EDGES])
 
 
 def marching_cubes(vol, iso=0.0):
-    """vol [nx,ny,nz] -> (vertices [V,3] in index coordinates, faces [T,3]); 'inside' = value < iso.  Triangle orientation is
-    not normalised (the distance tests that use this do not need it)."""
+    """vol [nx,ny,nz] -> (vertices [V,3] in index coordinates, faces [T,3]); 'inside' = value < iso.  Triangles are oriented
+    with their normals from the inside to the outside (see _build_table); vertices are sorted by their edge key
+    lo * (nx ny nz) + hi, faces are listed case by case (compare them as a set of rows)."""
     vol = np.asarray(vol, dtype=np.float64)
     nx, ny, nz = vol.shape
     inside = vol < iso

@@ -30,8 +30,9 @@ def test_bench_two_ranks_one_gpu_gloo(nof):
     d = _run('1', 29533)               # bucketed: fine hash levels reduced asynchronously beside the rest of the backward
     d0 = _run('0', 29534)              # one blocking all-reduce of the whole buffer
     assert d0['dp_param_checksum_spread'] == 0.0
-    # element-wise sums: bucketing cannot change the result beyond the atomics' summation order inside each rank
-    assert abs(d['param_checksum'] - d0['param_checksum']) <= 1e-6 * d0['param_checksum']
+    # element-wise sums: bucketing cannot change the result beyond the atomics' summation order inside each rank -- which Adam
+    # (eps 1e-15) turns into +-lr on entries whose gradient is rounding noise: a few dozen of 9 M parameters over the run's 16 steps
+    assert abs(d['param_checksum'] - d0['param_checksum']) <= 2e-5 * d0["param_checksum"]
     assert d['n_gpus'] == 2 and d['scaling'] == 'weak' and d['config']['parallelism'] == 'dp2'
     assert d['flags'] == 0 and d['loss'] == d['loss']                  # finite
     assert d['dp_param_checksum_spread'] == 0.0
