@@ -1,6 +1,6 @@
-// Iso-surface extraction from the dense SDF grid on the GPU: marching tetrahedra (6 tetrahedra per cell around the main
-// diagonal), three launches around two device-side primitives the host supplies (exclusive scan of the per-cell triangle
-// counts, sort/unique of the edge keys):
+// Iso-surface extraction from the dense SDF grid on the GPU: marching cubes (nof_mc_*, further down: what the reference's
+// skimage call computes) and marching tetrahedra (6 tetrahedra per cell around the main diagonal), each as three launches around
+// two device-side primitives the host supplies (exclusive scan of the per-cell triangle counts, sort/unique of the edge keys):
 //     nof_mt_count     per cell: number of triangles (0..12)
 //     nof_mt_emit      per cell: its triangles as three EDGE KEYS each (key = lo * npts + hi of the edge's grid points),
 //                      oriented so that the normal points from the tetrahedron's inside (value < iso) to its outside
@@ -165,6 +165,37 @@ __global__ __launch_bounds__(256) void k_mt_vertices(const float* __restrict__ v
   verts[i * 3 + 2] = v[2];
 }
 
+// ---- marching cubes: the same three-launch scheme with a 256-row case table the HOST derives (bundlesdf_amd/mesh.py:
+// mc_case_table; row = [T, 3 T cube-edge ids], edge e joins corners kMcEdge[e], corner c = x + 2 y + 4 z).  Keys, key order and the
+// vertex rule are the ones of marching tetrahedra above, so nof_mt_vertices serves both.
+__device__ __constant__ int kMcEdge[12][2] = {{0, 1}, {0, 2}, {0, 4}, {1, 3}, {1, 5}, {2, 3}, {2, 6}, {3, 7}, {4, 5}, {4, 6}, {5, 7}, {6, 7}};
+
+__global__ __launch_bounds__(256) void k_mc_count(const float* __restrict__ vol, int nx, int ny, int nz, float iso,
+                                                   const int8_t* __restrict__ table, int64_t ncell, int32_t* __restrict__ counts) {
+  const int64_t cell = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (cell >= ncell) return;
+  MtCell m;
+  mt_load(vol, nx, ny, nz, iso, cell, m);
+  counts[cell] = table[m.in * 16];
+}
+
+__global__ __launch_bounds__(256) void k_mc_emit(const float* __restrict__ vol, int nx, int ny, int nz, float iso,
+                                                  const int8_t* __restrict__ table, int64_t ncell,
+                                                  const int64_t* __restrict__ offsets, int64_t* __restrict__ keys) {
+  const int64_t cell = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (cell >= ncell) return;
+  MtCell m;
+  if (!mt_load(vol, nx, ny, nz, iso, cell, m)) return;
+  const int8_t* row = table + m.in * 16;
+  const int n = row[0];
+  const int64_t npts = (int64_t)nx * ny * nz;
+  int64_t* out = keys + offsets[cell] * 3;
+  for (int t = 0; t < 3 * n; ++t) {
+    const int e = row[1 + t];
+    out[t] = m.id[kMcEdge[e][0]] * npts + m.id[kMcEdge[e][1]];        // the lower corner has the lower grid id
+  }
+}
+
 static int mt_dims_ok(int nx, int ny, int nz) { return nx >= 2 && ny >= 2 && nz >= 2 && nx <= 2048 && ny <= 2048 && nz <= 2048; }
 
 extern "C" int nof_mt_count(const float* vol, int32_t nx, int32_t ny, int32_t nz, float iso, int32_t* counts, void* stream) {
@@ -182,6 +213,26 @@ extern "C" int nof_mt_emit(const float* vol, int32_t nx, int32_t ny, int32_t nz,
   const int64_t ncell = (int64_t)(nx - 1) * (ny - 1) * (nz - 1);
   hipLaunchKernelGGL(k_mt_emit, dim3((unsigned)nof_div_up(ncell, 256)), dim3(256), 0, (hipStream_t)stream, vol, nx, ny, nz, iso,
                      ncell, offsets, keys);
+  NOF_LAUNCH_OK();
+  return 0;
+}
+
+extern "C" int nof_mc_count(const float* vol, int32_t nx, int32_t ny, int32_t nz, float iso, const int8_t* case_table,
+                             int32_t* counts, void* stream) {
+  NOF_ARG(vol && counts && case_table && mt_dims_ok(nx, ny, nz));
+  const int64_t ncell = (int64_t)(nx - 1) * (ny - 1) * (nz - 1);
+  hipLaunchKernelGGL(k_mc_count, dim3((unsigned)nof_div_up(ncell, 256)), dim3(256), 0, (hipStream_t)stream, vol, nx, ny, nz, iso,
+                     case_table, ncell, counts);
+  NOF_LAUNCH_OK();
+  return 0;
+}
+
+extern "C" int nof_mc_emit(const float* vol, int32_t nx, int32_t ny, int32_t nz, float iso, const int8_t* case_table,
+                            const int64_t* offsets, int64_t* keys, void* stream) {
+  NOF_ARG(vol && offsets && keys && case_table && mt_dims_ok(nx, ny, nz));
+  const int64_t ncell = (int64_t)(nx - 1) * (ny - 1) * (nz - 1);
+  hipLaunchKernelGGL(k_mc_emit, dim3((unsigned)nof_div_up(ncell, 256)), dim3(256), 0, (hipStream_t)stream, vol, nx, ny, nz, iso,
+                     case_table, ncell, offsets, keys);
   NOF_LAUNCH_OK();
   return 0;
 }

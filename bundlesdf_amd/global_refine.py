@@ -33,6 +33,10 @@ def run_global_nerf(debug_dir, cfg_nerf, reader=None, get_texture=False, tex_res
     data = trk.load(keys)
     frame_ids, cam_in_obs = data['frame_ids'], data['cam_in_obs']
     out_dir = f"{debug_dir}/final/nerf"
+    # a previous global refine's own final/nerf/config.yml would otherwise be the last match of the glob below ('final' sorts
+    # after the numeric stamps) and its normalisation silently re-used; the reference empties the directory first (bundlesdf.py:665)
+    import shutil
+    shutil.rmtree(out_dir, ignore_errors=True)
     os.makedirs(out_dir, exist_ok=True)
     cfg['save_dir'] = cfg.get('save_dir') or out_dir
     os.makedirs(cfg['save_dir'], exist_ok=True)
@@ -63,7 +67,9 @@ def run_global_nerf(debug_dir, cfg_nerf, reader=None, get_texture=False, tex_res
                                                           masks=masks.copy(), normal_maps=None, poses=glcam_in_obs.copy(),
                                                           sc_factor=cfg['sc_factor'], translation=cfg['translation'])
     cfg['sampled_frame_ids'] = np.arange(len(rgbs_p))
-    np.savetxt(f"{cfg['save_dir']}/trainval_poses.txt", glcam_in_obs.reshape(-1, 4))
+    # the NORMALISED OpenGL poses: the reference's preprocess_data shifts / scales its `poses` argument in place, and that array is
+    # what it then writes (bundlesdf.py:711-715, nerf_helpers.py:238-240)
+    np.savetxt(f"{cfg['save_dir']}/trainval_poses.txt", poses.reshape(-1, 4))
     nerf = NerfRunner(cfg, rgbs_p, depths=depths_p.astype(np.float32), masks=masks_p, normal_maps=None, occ_masks=None,
                       poses=poses.astype(np.float32), K=K, build_octree_pcd=pcd_normalized, **(runner_kwargs or {}))
     logging.info('Start training')
@@ -82,7 +88,15 @@ def run_global_nerf(debug_dir, cfg_nerf, reader=None, get_texture=False, tex_res
     m = Mesh(np.asarray(m.vertices), np.asarray(m.faces))
     m.export(f'{debug_dir}/mesh_cleaned.obj')
     if get_texture:
-        m = nerf.mesh_texture_from_train_images(m, rgbs_raw=rgbs_raw.astype(np.float32), train_texture=False, tex_res=tex_res)
+        # the per-triangle atlas needs a few texels per triangle: a 2 mm mesh (~200 k triangles) does not fit 1024^2, so the
+        # size follows the face count; and a failed bake must not cost the trained field -- the untextured mesh is exported
+        res = m.atlas_resolution(tex_res)
+        if res != tex_res:
+            logging.info(f'texture: {len(m.faces)} triangles need a {res}^2 atlas (asked for {tex_res}^2)')
+        try:
+            m = nerf.mesh_texture_from_train_images(m, rgbs_raw=rgbs_raw.astype(np.float32), train_texture=False, tex_res=res)
+        except Exception as e:                                       # noqa: BLE001  (reported, the result below is still written)
+            logging.error(f'texture bake failed ({e!r}): exporting the untextured mesh')
     m = mesh_to_real_world(m, pose_offset=offset, translation=cfg['translation'], sc_factor=cfg['sc_factor'])
     m.export(f'{debug_dir}/textured_mesh.obj')
     return dict(mesh=m, optimized_cvcam_in_obs=optimized_cvcam_in_obs, offset=offset, runner=nerf, frame_ids=frame_ids)

@@ -102,6 +102,8 @@ _SIGNATURES = {
                             _F, _P, _P], C.c_int),
     'nof_mt_count': ([_P, _I32, _I32, _I32, _F, _P, _P], C.c_int),
     'nof_mt_emit': ([_P, _I32, _I32, _I32, _F, _P, _P, _P], C.c_int),
+    'nof_mc_count': ([_P, _I32, _I32, _I32, _F, _P, _P, _P], C.c_int),
+    'nof_mc_emit': ([_P, _I32, _I32, _I32, _F, _P, _P, _P, _P], C.c_int),
     'nof_mt_vertices': ([_P, _I32, _I32, _I32, _F, _P, _I64, _P, _P], C.c_int),
     'nof_mask_dilate': ([_P, _I32, _I32, _I32, _P, _P, _P], C.c_int),
     'nof_frame_rays': ([C.POINTER(NofFrameRaysCfg), _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _P, _P, _P], C.c_int),

@@ -23,7 +23,7 @@ import torch
 from . import lib
 from .checkpoint import load_reference_checkpoint, to_reference_checkpoint
 from .field import GraphedStep, NeuralObjectField
-from .mesh_gpu import marching_tetrahedra_gpu
+from .mesh_gpu import marching_cubes_gpu, marching_tetrahedra_gpu
 from .mesh import make_mesh, marching_tetrahedra
 from .nerf_helpers import *          # noqa: F401,F403  (re-exported on purpose, like the reference module does)
 from .nerf_helpers import set_seed, get_optimized_poses_in_real_world, mesh_to_real_world, glcam_in_cvcam
@@ -86,6 +86,9 @@ class NerfRunner:
         self.world_size, self.rank, self.grad_sync = world_size, rank, grad_sync
         # data parallel: `images/depths/masks` hold this rank's keyframes, which are frames frame_offset.. of `poses`
         self.frame_offset = int(frame_offset)
+        # local keyframe i of this rank is global frame frame_ids[i] (a row of `poses` / of the pose and feature arrays); a
+        # contiguous shard at construction, whatever add_new_frames appends afterwards
+        self.frame_ids = self.frame_offset + np.arange(len(images), dtype=np.int64)
         self.device = torch.device('cuda')
 
         r = int(cfg['down_scale_ratio'])
@@ -157,14 +160,14 @@ class NerfRunner:
         if self.cfg.get('device_ray_pool', True):
             cloud = self.build_octree_pts if self.cfg['denoise_depth_use_octree_cloud'] else None
             return frame_rays_device(self.field, list(frame_ids), self.images, self.depths, self.masks, self.poses, self.K,
-                                     self.cfg, frame_offset=self.frame_offset, occ_masks=self.occ_masks, cloud_pts=cloud)
+                                     self.cfg, occ_masks=self.occ_masks, cloud_pts=cloud, global_ids=self.frame_ids)
         return torch.tensor(self._frame_rays(frame_ids), dtype=torch.float, device=self.device)
 
     def _frame_rays(self, frame_ids):
         rays_ = []
         for i in frame_ids:
             occ = self.occ_masks[i] if self.occ_masks is not None else None
-            g = i + self.frame_offset
+            g = int(self.frame_ids[i])
             rays_.append(make_frame_rays(g, self.images[i], self.depths[i], self.masks[i], self.poses[g], self.K, self.cfg,
                                          occ_mask=occ, trace_fn=self._trace_hits if self.cfg['use_octree'] else None))
         rays = np.concatenate(rays_, axis=0)
@@ -175,10 +178,20 @@ class NerfRunner:
 
     # ---- growing the keyframe pool (nerf_runner.py:352-433) ----------------------------------------------
     def add_new_frames(self, images, depths, masks, normal_maps, poses, occ_masks=None, new_pcd=None, reuse_weights=False):
+        """`poses` holds ALL frames (old + new), the image arrays the new frames only (bundlesdf.py:223).  Data parallel
+        (world_size > 1): every rank is handed the same new frames -- global ids n_old .. n_old + n_new - 1 -- and keeps a
+        contiguous share of them (dist.shard_frames); its local -> global frame map `frame_ids` grows accordingly, so rays,
+        pose corrections and frame features stay addressed by global frame id on every rank."""
+        n_old_total = self.field.F
+        new_global = np.arange(n_old_total, n_old_total + len(images), dtype=np.int64)
+        if len(poses) != n_old_total + len(images):
+            raise ValueError(f'add_new_frames: {len(poses)} poses for {n_old_total} old + {len(images)} new frames')
         if self.world_size > 1:
-            # a rank's local frame i is global frame i + frame_offset; frames appended to one rank's shard would take ids that
-            # belong to the next rank's shard.  Growing a sharded pool needs a per-rank local->global id map: not built.
-            raise NotImplementedError('add_new_frames with world_size > 1 (keyframe-sharded data parallel) is not supported')
+            from .dist import shard_frames
+            lo, hi = shard_frames(len(images), self.rank, self.world_size)
+            images, depths, masks, new_global = images[lo:hi], depths[lo:hi], masks[lo:hi], new_global[lo:hi]
+            if occ_masks is not None:
+                occ_masks = occ_masks[lo:hi]
         prev = len(self.images)
         r = int(self.cfg['down_scale_ratio'])
         images, depths, masks = images[:, ::r, ::r], depths[:, ::r, ::r], masks[:, ::r, ::r]
@@ -187,6 +200,7 @@ class NerfRunner:
         self.images = np.concatenate((self.images, images), axis=0)
         self.depths = np.concatenate((self.depths, depths), axis=0)
         self.masks = np.concatenate((self.masks, masks), axis=0)
+        self.frame_ids = np.concatenate((self.frame_ids, new_global))
         self.poses = poses.copy()
         old = self.field
         # new frame count -> new pose/feature arrays; reuse_weights keeps table + MLPs (+ old frame features)
@@ -195,14 +209,15 @@ class NerfRunner:
             self.field.load_parameters(table=old.table, mlp=old.mlp)
             if old.ff > 0:
                 f = self.field.feat.view(self.field.F, old.ff)
-                f[:prev] = old.feat.view(old.F, old.ff)
+                f[:old.F] = old.feat.view(old.F, old.ff)             # rows are GLOBAL frames: the old ones keep their features
         if self.cfg['use_octree']:
             pcd = new_pcd.voxel_down_sample(0.005)
             self.build_octree_pts = np.asarray(pcd.points).copy()
             self.build_octree()
         self.create_optimizer()
         self.global_step = 0
-        self.rays = torch.cat((self.rays, self._frame_rays_tensor(range(prev, len(self.masks)))), dim=0)
+        if len(self.masks) > prev:                                   # (a rank's share of the new frames can be empty)
+            self.rays = torch.cat((self.rays, self._frame_rays_tensor(range(prev, len(self.masks)))), dim=0)
         self.data_loader = DataLoader(rays=self.rays, batch_size=self.cfg['N_rand'])
 
     # ---- training (nerf_runner.py:679-763, 855-863) --------------------------------------------------------
@@ -265,7 +280,10 @@ class NerfRunner:
         logging.info(f'query grid:{tuple(sigma_dev.shape)}, valid:{int((sigma_dev != 1.0).sum().item())}')
         logging.info('Running iso-surface extraction')
         try:
-            vertices, triangles = marching_tetrahedra_gpu(sigma_dev, isolevel)
+            # marching cubes like the reference's skimage call (:1388-1394); cfg mesh_extractor: 'tetrahedra' selects the
+            # marching-tetrahedra kernels instead (no ambiguous cases, ~4x the triangles)
+            extract = marching_tetrahedra_gpu if self.cfg.get('mesh_extractor', 'cubes') == 'tetrahedra' else marching_cubes_gpu
+            vertices, triangles = extract(sigma_dev, isolevel)
         except Exception as e:
             logging.info(f"ERROR Marching Cubes {e}")
             return None
@@ -294,7 +312,7 @@ class NerfRunner:
         assert len(self.images) == len(rgbs_raw)
         f = self.field
         dev = self.device
-        ids = torch.arange(len(self.images), device=dev) + self.frame_offset
+        ids = torch.as_tensor(self.frame_ids, device=dev)
         tf = f.c2w.view(-1, 4, 4)[ids]
         if self.models['pose_array'] is not None:
             tf = self.models['pose_array'].get_matrices(ids) @ tf

@@ -21,9 +21,9 @@ def _cmp_threshold(arr_dtype, value):
 
 
 def frame_rays_device(field, frame_ids, images, depths, masks, poses, K, cfg, frame_offset=0, occ_masks=None,
-                      cloud_pts=None):
+                      cloud_pts=None, global_ids=None):
     """[N,12] float32 CUDA tensor of the rays make_frame_rays (+ denoise_rays when cloud_pts is given) would return for
-    the local frames `frame_ids` (global id = local + frame_offset)."""
+    the local frames `frame_ids` (global id = global_ids[local] when given, else local + frame_offset)."""
     dev = field.device
     H, W = images[0].shape[:2]
     npx = H * W
@@ -34,7 +34,7 @@ def frame_rays_device(field, frame_ids, images, depths, masks, poses, K, cfg, fr
     rows_all, keep_all = [], []
     tmp = torch.empty(npx, dtype=torch.uint8, device=dev)
     for i in frame_ids:
-        g = i + frame_offset
+        g = int(global_ids[i]) if global_ids is not None else i + frame_offset
         img = torch.from_numpy(np.ascontiguousarray(images[i], dtype=np.float32)).to(dev)
         dep = torch.from_numpy(np.ascontiguousarray(depths[i][..., 0], dtype=np.float32)).to(dev)
         m_in = torch.from_numpy(np.ascontiguousarray(masks[i][..., 0]).astype(np.uint8)).to(dev)

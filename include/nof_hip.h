@@ -280,6 +280,15 @@ int nof_mt_emit(const float* vol, int32_t nx, int32_t ny, int32_t nz, float iso,
 int nof_mt_vertices(const float* vol, int32_t nx, int32_t ny, int32_t nz, float iso, const int64_t* keys, int64_t V,
                     double* verts, void* stream);
 
+/* Marching cubes, the extractor the reference calls (skimage.measure.marching_cubes, nerf_runner.py:1388-1394): same three steps,
+ * same edge keys, vertices through nof_mt_vertices.  case_table [256,16] int8 (device): row `case` (bit c set = corner c = x + 2y +
+ * 4z of the cell has value < iso) = [T <= 5, 3 T cube-edge ids]; edge e joins the corners (0,1) (0,2) (0,4) (1,3) (1,5) (2,3) (2,6)
+ * (3,7) (4,5) (4,6) (5,7) (6,7)[e].  The host derives the table (bundlesdf_amd/mesh.py:mc_case_table: oriented, watertight). */
+int nof_mc_count(const float* vol, int32_t nx, int32_t ny, int32_t nz, float iso, const int8_t* case_table, int32_t* counts,
+                 void* stream);
+int nof_mc_emit(const float* vol, int32_t nx, int32_t ny, int32_t nz, float iso, const int8_t* case_table,
+                const int64_t* offsets, int64_t* keys, void* stream);
+
 /* ---- texture bake helper (replaces common.rayColorToTextureImageCUDA, mycuda/common.h:30, common.cu:171-238) ----------
  * faces [nf,3] int64, verts [nv,3] f32, hit_locations [n,3] f32 (points on the mesh), hit_face_ids [n] int64,
  * uvs_tex [nv,2] f32 per-vertex texture coordinates -> uvs [n,2]: barycentric blend of the hit triangle's uvs. */

@@ -60,14 +60,21 @@ def _worker(rank, world, port, R, out):
     assert sync is not None
     bucketed = flat.clone()
     sync(flat)                                           # one blocking all-reduce of the whole buffer
-    # the bucketed asynchronous form the device step uses (three slices, the middle one first): same bits
+    # the bucketed asynchronous form the device step uses: TWO collectives -- the middle slice (fine levels + MLP) first, then
+    # [copy of the tail | head slice] as one contiguous range (the tail rides in headroom in front of the buffer): same bits
     a, b = flat.numel() // 3, 2 * flat.numel() // 3
-    sync.start(bucketed[a:b])
-    sync.start(bucketed[:a])
-    sync.start(bucketed[b:])
-    sync.start(bucketed[:0])                             # empty slices are skipped
+    nt = flat.numel() - b
+    store = torch.zeros(nt + flat.numel())
+    store[nt:] = bucketed
+    view = store[nt:]
+    sync.start(view[a:b])
+    store[:nt] = view[b:]
+    sync.start(store[:nt + a])
+    sync.start(view[:0])                                 # empty slices are skipped
     sync.finish()
-    assert not sync.pending and torch.equal(bucketed, flat)
+    view[b:] = store[:nt]
+    assert not sync.pending and torch.equal(view, flat)
+    assert sync.collectives_step == 2 and sync.bytes_step == 4 * (b - a + nt + a)
     if rank == 0:
         out.put(flat.numpy())
     dist.barrier()

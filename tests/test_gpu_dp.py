@@ -14,8 +14,8 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run(overlap, port):
-    env = dict(os.environ, NOF_DIST_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0', NOF_DP_OVERLAP=overlap)
+def _run(overlap, port, backend='gloo'):
+    env = dict(os.environ, NOF_DIST_BACKEND=backend, HSA_ENABLE_IPC_MODE_LEGACY='0', NOF_DP_OVERLAP=overlap)
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
            '--master-port', str(port), os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '6', '--warmup', '2',
            '--keyframes', '3', '--no-cpu-baseline']
@@ -37,3 +37,23 @@ def test_bench_two_ranks_one_gpu_gloo(nof):
     assert d['flags'] == 0 and d['loss'] == d['loss']                  # finite
     assert d['dp_param_checksum_spread'] == 0.0
     assert d['value'] > 0 and abs(d['value'] - 2 * 4096 * 192 * 1e3 / d['ms_per_step']) < 1e-3 * d['value']
+    # two collectives per step in the bucketed form (fine levels + MLP early, everything else in one trailing call), one otherwise;
+    # the trailing one carries a copy of the [features | poses] tail in the headroom in front of the gradient buffer
+    assert d['collectives_per_step'] == 2 and d0['collectives_per_step'] == 1
+    assert d['allreduce_bytes_per_step'] >= d0['allreduce_bytes_per_step'] > 4 * 9_000_000
+
+
+def test_bench_two_ranks_two_gpus_rccl(nof):
+    """The same launch over RCCL ('nccl' backend, one rank per GPU, xGMI): the transport the driver's scaling run uses.  Needs two
+    visible devices -- the test box has one, where this skips; on a multi-GPU node it checks what the gloo variant checks, plus the
+    communication fields of the bench line."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip(f'{torch.cuda.device_count()} GPU visible: RCCL refuses two ranks on one device')
+    d = _run('1', 29535, backend='nccl')
+    d0 = _run('0', 29536, backend='nccl')
+    assert d['dp_param_checksum_spread'] == 0.0 and d0['dp_param_checksum_spread'] == 0.0
+    assert abs(d['param_checksum'] - d0['param_checksum']) <= 2e-5 * d0['param_checksum']
+    assert d['n_gpus'] == 2 and d['collectives_per_step'] == 2 and d0['collectives_per_step'] == 1
+    assert d['allreduce_bytes_per_step'] >= d0['allreduce_bytes_per_step'] > 4 * 9_000_000
+    assert d['exposed_comm_ms'] is not None and d['exposed_comm_ms'] >= 0

@@ -85,16 +85,62 @@ def test_marching_tetrahedra_gpu_matches_numpy(nof, shape_):
         marching_tetrahedra_gpu(torch.ones(8, 8, 8, device='cuda'), 0.0)
 
 
+@pytest.mark.parametrize("shape_", [(33, 29, 41), (64, 64, 64), (3, 3, 3), (97, 5, 3)])
+def test_marching_cubes_gpu_equals_the_oracle(nof, shape_):
+    """The device extractor the runner uses by default against oracle/marching_cubes.py (the restatement of what the reference's
+    skimage call computes, nerf_runner.py:1388-1394): the SAME vertices in the same order (sorted edge keys, float64
+    interpolation) and the SAME triangles with the same winding (compared as a set of rows: the oracle lists them case by case,
+    the device cell by cell)."""
+    from bundlesdf_amd.mesh_gpu import marching_cubes_gpu
+    from oracle import marching_cubes as MC
+    nx, ny, nz = shape_
+    g = np.stack(np.meshgrid(np.linspace(-1, 1, nx), np.linspace(-1, 1, ny), np.linspace(-1, 1, nz), indexing='ij'), -1)
+    rng = np.random.default_rng(nx)
+    vol = (np.sqrt((g[..., 0] / 0.8) ** 2 + (g[..., 1] / 0.55) ** 2 + (g[..., 2] / 0.7) ** 2) - 1.0).astype(np.float32)
+    vol += (rng.normal(size=vol.shape) * 0.05).astype(np.float32)    # noise: every sign configuration, ambiguous faces included
+    if nx > 8:
+        vol[5, min(5, ny - 2), 2] = 0.0                                # a value exactly on the iso level
+        vol[:3] = 1.0                                                 # the 'outside the octree' plateau
+    v_ref, f_ref = MC.marching_cubes(vol, 0.0)
+    v_gpu, f_gpu = marching_cubes_gpu(torch.from_numpy(vol).cuda(), 0.0)
+    assert v_gpu.shape == v_ref.shape and np.abs(v_gpu - v_ref).max() == 0.0
+    order = lambda f: f[np.lexsort(f.T[::-1])]
+    assert f_gpu.shape == f_ref.shape and np.array_equal(order(f_gpu), order(f_ref))
+    with pytest.raises(ValueError):
+        marching_cubes_gpu(torch.ones(8, 8, 8, device='cuda'), 0.0)
+
+
+def test_marching_cubes_gpu_covers_all_256_cases(nof):
+    """one 2x2x2 volume per sign configuration, values of random magnitude: every row of the case table is exercised"""
+    from bundlesdf_amd.mesh_gpu import marching_cubes_gpu
+    from oracle import marching_cubes as MC
+    rng = np.random.default_rng(0)
+    for case in range(1, 255):
+        mag = rng.uniform(0.1, 1.0, 8).astype(np.float32)
+        sign = np.array([-1.0 if (case >> c) & 1 else 1.0 for c in range(8)], np.float32)
+        vol = np.zeros((2, 2, 2), np.float32)
+        for c in range(8):
+            vol[c & 1, (c >> 1) & 1, c >> 2] = sign[c] * mag[c]
+        v_ref, f_ref = MC.marching_cubes(vol, 0.0)
+        v_gpu, f_gpu = marching_cubes_gpu(torch.from_numpy(vol).cuda(), 0.0)
+        assert np.array_equal(v_gpu, v_ref) and np.array_equal(f_gpu, f_ref), case
+
+
 def test_extract_mesh_sphere_end_to_end(nof):
     """A field whose SDF grid is replaced by an analytic sphere is not reachable through NerfRunner, so this drives the
     two device stages directly at a 192^3 grid and checks the surface: vertices within half a voxel of the sphere,
     closed orientable surface (every edge shared by exactly two faces, opposite directions), outward normals."""
-    from bundlesdf_amd.mesh_gpu import marching_tetrahedra_gpu
+    from bundlesdf_amd.mesh_gpu import marching_cubes_gpu, marching_tetrahedra_gpu
     n = 192
     ax = torch.linspace(-1, 1, n, device='cuda')
     gx, gy, gz = torch.meshgrid(ax, ax, ax, indexing='ij')
     vol = (torch.sqrt(gx * gx + gy * gy + gz * gz) - 0.6).contiguous()
-    v, f = marching_tetrahedra_gpu(vol, 0.0)
+    for extract in (marching_cubes_gpu, marching_tetrahedra_gpu):
+        v, f = extract(vol, 0.0)
+        _check_sphere(v, f, n)
+
+
+def _check_sphere(v, f, n):
     p = v * (2.0 / (n - 1)) - 1.0
     assert np.abs(np.linalg.norm(p, axis=1) - 0.6).max() < 0.5 * 2.0 / (n - 1)
     e = np.concatenate([f[:, [0, 1]], f[:, [1, 2]], f[:, [2, 0]]], 0)

@@ -100,6 +100,48 @@ def test_runner_surface_end_to_end(nof, precision):
     assert m2 is not None and m2[1].ndim == 3
 
 
+def test_add_new_frames_on_a_sharded_pool(nof):
+    """add_new_frames under keyframe-sharded data parallel (nerf_runner.py:352-433 has no such mode: SURVEY 8e): two ranks'
+    runners on the one GPU (no process group needed: the ray tables are what is checked).  Every rank is handed the same new
+    frames and keeps its share; rays stay addressed by GLOBAL frame id, and the ranks' tables together are exactly the table of
+    one process that owns every frame."""
+    from bundlesdf_amd import synthetic
+    from bundlesdf_amd.config import default_cfg
+    from bundlesdf_amd.nerf_runner import NerfRunner
+    pool = synthetic.make_pool(n_frames=9, H=120, W=160, fx=150.0, seed=2)
+    n0, world = 4, 2
+
+    def make(rank, world_size):
+        cfg = default_cfg(n_step=10, N_rand=512, num_levels=8, log2_hashmap_size=14, finest_res=128, far=1.0,
+                          sc_factor=pool['sc_factor'], translation=pool['translation'], frame_features=2)
+        lo, hi = (0, n0) if world_size == 1 else (rank * 2, rank * 2 + 2)
+        return NerfRunner(cfg, pool['rgbs'][lo:hi], depths=pool['depths'][lo:hi], masks=pool['masks'][lo:hi], normal_maps=None,
+                          poses=pool['poses'][:n0].copy(), K=pool['K'], build_octree_pcd=synthetic.PointCloud(pool['pcd_normalized']),
+                          precision='fp16x3', world_size=world_size, rank=rank, frame_offset=lo)
+    single = make(0, 1)
+    ranks = [make(r, world) for r in range(world)]
+    feat_before = [r.field.feat.clone() for r in ranks]
+    new = slice(n0, 9)
+    for r in [single] + ranks:
+        r.add_new_frames(pool['rgbs'][new], pool['depths'][new], pool['masks'][new], None, pool['poses'].copy(),
+                         new_pcd=synthetic.PointCloud(pool['pcd_normalized']), reuse_weights=True)
+    assert list(ranks[0].frame_ids) == [0, 1, 4, 5, 6] and list(ranks[1].frame_ids) == [2, 3, 7, 8]
+    assert all(r.field.F == 9 for r in ranks) and single.field.F == 9
+    for r, fb in zip(ranks, feat_before):                                  # reuse_weights: the old GLOBAL rows keep their features
+        assert torch.equal(r.field.feat.view(9, 2)[:n0], fb.view(n0, 2))
+    rows = torch.cat([r.rays for r in ranks]).cpu().numpy()
+    want = single.rays.cpu().numpy()
+    assert rows.shape == want.shape
+    key = lambda a: a[np.lexsort(a.T[::-1])]
+    assert np.array_equal(key(rows), key(want))                            # the same rays, each on exactly one rank
+    for r in ranks:                                                        # and a step runs on the grown shard
+        r.train_loop()
+        assert np.isfinite(r.field.losses()['loss']) and int(r.field.flags[0].item()) == 0
+    with pytest.raises(ValueError):
+        ranks[0].add_new_frames(pool['rgbs'][new], pool['depths'][new], pool['masks'][new], None, pool['poses'].copy(),
+                                new_pcd=synthetic.PointCloud(pool['pcd_normalized']))
+
+
 def test_checkpoint_roundtrip(nof, tmp_path):
     from tests.test_gpu_step import _pair
     from tests import util as U

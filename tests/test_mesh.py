@@ -104,3 +104,46 @@ def test_marching_cubes_table_is_complete_and_symmetric():
         tri = MC._TABLE[c]
         corner = int(np.log2(c))
         assert len(tri) == 1 and all(corner in MC._EDGES[e] for e in tri[0])
+
+
+def test_product_case_table_equals_the_oracle_table():
+    """bundlesdf_amd/mesh.py derives its marching-cubes table from DIRECTED face segments (cycles of a permutation of the crossed
+    edges); the oracle from undirected chains oriented afterwards by geometry (Newell area vector against the inside -> outside
+    direction).  Two constructions, one table: all 256 cases, triangle for triangle."""
+    from bundlesdf_amd.mesh import MC_EDGES, mc_case_table
+    from oracle import marching_cubes as MC
+    assert list(MC_EDGES) == MC._EDGES
+    t = mc_case_table()
+    assert t.shape == (256, 16) and t.dtype == np.int8
+    for c in range(256):
+        n = int(t[c, 0])
+        assert np.array_equal(t[c, 1:1 + 3 * n].reshape(-1, 3).astype(np.int64), MC._TABLE[c]), c
+        assert (t[c, 1 + 3 * n:] == 0).all()
+
+
+@pytest.mark.parametrize("seed,noise", [(0, 0.0), (2, 0.6), (3, 1.0)])
+def test_oracle_marching_cubes_is_an_oriented_closed_surface(seed, noise):
+    """every directed edge once, its reverse once (closed + consistently oriented), normals from value < iso to value >= iso
+    (positive enclosed volume for an SDF that is negative inside)"""
+    from oracle import marching_cubes as MC
+    vol = _noisy_sdf(40, seed, noise)
+    v, f = MC.marching_cubes(vol, 0.0)
+    e = np.concatenate([f[:, [0, 1]], f[:, [1, 2]], f[:, [2, 0]]])
+    key, rkey = e[:, 0] * len(v) + e[:, 1], e[:, 1] * len(v) + e[:, 0]
+    assert len(np.unique(key)) == len(key) and set(key.tolist()) == set(rkey.tolist())
+    a, b, c = v[f[:, 0]], v[f[:, 1]], v[f[:, 2]]
+    vol6 = float(np.einsum('ij,ij->i', a, np.cross(b, c)).sum())
+    assert vol6 > 0 and abs(vol6 / 6.0 - float((vol < 0).sum())) < 0.05 * float((vol < 0).sum())      # ~ the number of inside voxels
+
+
+def test_atlas_resolution_follows_the_face_count():
+    """a 2 mm mesh (~200 k triangles) does not fit the per-triangle atlas at 1024^2; the size follows the face count."""
+    v = np.zeros((3, 3))
+    small, big = Mesh(v, np.zeros((5000, 3), np.int64)), Mesh(v, np.zeros((228000, 3), np.int64))
+    assert small.atlas_resolution(1024) == 1024
+    r = big.atlas_resolution(1024)
+    assert r > 1024 and r % 256 == 0
+    with pytest.raises(ValueError):
+        big.unwrap(1024)
+    n = int(np.ceil(np.sqrt((228000 + 1) // 2)))
+    assert (r - 1) / n >= 4                                                   # what unwrap() asks for
