@@ -16,6 +16,7 @@
 //       k_hash_bwd_agg all other levels: lanes of a wave are consecutive samples of ONE ray, so lanes falling into the
 //                      same cell form contiguous runs; each run is summed out of an LDS stage and emitted once by 16
 //                      adjacent lanes (cfg2: 3..15 samples per run at the hashed levels).
+#include <type_traits>
 #include "nof_hash_dev.h"
 #pragma clang fp contract(off)
 
@@ -381,8 +382,75 @@ __global__ __launch_bounds__(1024) void k_hash_bwd_lds(NofHashGrid g, LevelList 
   }
 }
 
-// dL/dpts_w per sample: gathers only (kernel_input_backward + the dy_dx part of kernel_grid, gridencoder.cu:202-245,340-365)
-__global__ __launch_bounds__(256) void k_hash_dx(NofHashGrid g, const float* __restrict__ pts_w,
+// dL/dpts_w per sample: gathers only (kernel_input_backward + the dy_dx part of kernel_grid, gridencoder.cu:202-245,340-365).
+// One level's contribution: dy/dx01[gd] = scale * sum over the 4 corner pairs along gd of w' * (f_right - f_left), dotted with the
+// level's feature gradient; PAIRS as in encode_level (x neighbour in the same 16-byte load).
+template <bool PAIRS, bool EIK>
+__device__ __forceinline__ void dx_level(const HashLevel& lv, const float2* __restrict__ table, const CellPos& c, float2 gr,
+                                         float2 ge, const float (&dn)[3], float (&dx)[3], float (&dxe)[3]) {
+  const float2* __restrict__ tl = table + lv.offset;
+  uint32_t idx[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) idx[k] = grid_index(lv, c.g[0] + (k & 1), c.g[1] + ((k >> 1) & 1), c.g[2] + ((k >> 2) & 1));
+  float2 v[8];
+  if constexpr (PAIRS) {
+#pragma unroll
+    for (int k = 0; k < 8; k += 2) {
+      const RowPair t = *reinterpret_cast<const RowPair*>(tl + idx[k]);
+      v[k] = make_float2(t.x, t.y);
+      v[k + 1] = make_float2(t.z, t.w);
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = tl[idx[k]];
+  }
+#pragma unroll
+  for (int gd = 0; gd < 3; ++gd) {
+    float s = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      if (k & (1 << gd)) continue;
+      float wk = lv.scale;
+#pragma unroll
+      for (int d = 0; d < 3; ++d) {
+        if (d == gd) continue;
+        wk *= (k & (1 << d)) ? c.f[d] : (1.0f - c.f[d]);
+      }
+      const float2 l = v[k], r = v[k | (1 << gd)];
+      s += wk * ((r.x - l.x) * gr.x + (r.y - l.y) * gr.y);
+    }
+    dx[gd] += s;
+  }
+  if constexpr (EIK) {
+    // eikonal option: dE/dx through the normal's own dependence on x -- the mixed second derivatives of the trilinear blend
+    // (d n_d / d x_e = 0.25 * scale^2 * sum_t w_t (F[d1,e1,t] - F[d1,e0,t] - F[d0,e1,t] + F[d0,e0,t]), F = g . corner features)
+    float Fk[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) Fk[k] = ge.x * v[k].x + ge.y * v[k].y;
+#pragma unroll
+    for (int e = 0; e < 3; ++e)
+#pragma unroll
+      for (int d = 0; d < 3; ++d) {
+        if (d == e) continue;
+        const int t = 3 - d - e;                                       // the third dimension
+        float m = 0.0f;
+#pragma unroll
+        for (int bt = 0; bt < 2; ++bt) {
+          const int base = bt << t;
+          const float wt = bt ? c.f[t] : 1.0f - c.f[t];
+          m += wt * (((Fk[base | (1 << d) | (1 << e)] - Fk[base | (1 << d)]) - Fk[base | (1 << e)]) + Fk[base]);
+        }
+        dxe[e] += dn[d] * 0.25f * lv.scale * lv.scale * m;
+      }
+  }
+}
+
+// lane = sample, all levels.  The levels come as two lists (pair-loadable dense levels, the others) so that each loop is free of
+// branches and the compiler can keep the gathers of two levels in flight (the former single loop tested `gradient == 0` and the
+// pair condition per level: one level's latency at a time).  A zero gradient or an out-of-range point contributes exact zeros
+// through its factors instead of through a branch.
+template <bool EIK>
+__global__ __launch_bounds__(256) void k_hash_dx(NofHashGrid g, LevelList pairs, LevelList singles, const float* __restrict__ pts_w,
                                                   const float2* __restrict__ table, const float2* __restrict__ dfeat,
                                                   float* __restrict__ dpts, int64_t B, const float2* __restrict__ geik,
                                                   const float* __restrict__ dedn, const uint8_t* __restrict__ tile_flags) {
@@ -393,67 +461,26 @@ __global__ __launch_bounds__(256) void k_hash_dx(NofHashGrid g, const float* __r
     dpts[b * 3] = 0.0f; dpts[b * 3 + 1] = 0.0f; dpts[b * 3 + 2] = 0.0f;
     return;
   }
-  float dx[3] = {0.f, 0.f, 0.f};
-  // eikonal option: dE/dx through the normal's own dependence on x -- the mixed second derivatives of the trilinear blend
-  // (d n_d / d x_e = 0.25 * scale^2 * sum_t w_t (F[d1,e1,t] - F[d1,e0,t] - F[d0,e1,t] + F[d0,e0,t]), F = g . corner features)
-  float dxe[3] = {0.f, 0.f, 0.f};
-  float dn[3] = {0.f, 0.f, 0.f};
-  if (geik != nullptr) { dn[0] = dedn[b * 3]; dn[1] = dedn[b * 3 + 1]; dn[2] = dedn[b * 3 + 2]; }
-  for (int level = 0; level < g.L; ++level) {
+  const float p[3] = {pts_w[b * 3], pts_w[b * 3 + 1], pts_w[b * 3 + 2]};
+  float dx[3] = {0.f, 0.f, 0.f}, dxe[3] = {0.f, 0.f, 0.f}, dn[3] = {0.f, 0.f, 0.f};
+  if constexpr (EIK) { dn[0] = dedn[b * 3]; dn[1] = dedn[b * 3 + 1]; dn[2] = dedn[b * 3 + 2]; }
+  auto one = [&](int level, auto PAIRS) {
     const HashLevel lv = load_level(g, level);
-    const CellPos c = locate(pts_w, b, lv.scale);
-    if (c.oob) break;                                                  // the point is out of range for every level
-    const float2 gr = dfeat[(int64_t)level * B + b];
-    if (geik == nullptr && gr.x == 0.0f && gr.y == 0.0f) continue;     // a zero gradient contributes exactly 0 to dL/dx: no gathers
-    const float2* __restrict__ tl = table + lv.offset;
-    float2 v[8];
-    uint32_t idx[8];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      const uint32_t p0 = c.g[0] + (k & 1), p1 = c.g[1] + ((k >> 1) & 1), p2 = c.g[2] + ((k >> 2) & 1);
-      idx[k] = grid_index(lv, p0, p1, p2);
+    CellPos c = locate3(p, lv.scale);
+    float2 gr = dfeat[(int64_t)level * B + b];
+    float2 ge = make_float2(0.f, 0.f);
+    if constexpr (EIK) ge = geik[(int64_t)level * B + b];
+    if (c.oob) {                                                       // out of range for every level (gridencoder.cu:131): zero factors,
+      gr = ge = make_float2(0.f, 0.f);                                 // an in-range cell for the (discarded) gathers
+      c.g[0] = c.g[1] = c.g[2] = 0u;
+      c.f[0] = c.f[1] = c.f[2] = 0.0f;
     }
-    gather_corners(lv, tl, idx, v);
-    // dy/dx01[gd] = scale * sum_{other two dims} w' * (f_right - f_left)   (gridencoder.cu:202-245)
-#pragma unroll
-    for (int gd = 0; gd < 3; ++gd) {
-      float s = 0.0f;
-#pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        if (k & (1 << gd)) continue;
-        float wk = lv.scale;
-#pragma unroll
-        for (int d = 0; d < 3; ++d) {
-          if (d == gd) continue;
-          wk *= (k & (1 << d)) ? c.f[d] : (1.0f - c.f[d]);
-        }
-        const float2 l = v[k], r = v[k | (1 << gd)];
-        s += wk * ((r.x - l.x) * gr.x + (r.y - l.y) * gr.y);
-      }
-      dx[gd] += s;
-    }
-    if (geik != nullptr) {
-      const float2 ge = geik[(int64_t)level * B + b];
-      float Fk[8];
-#pragma unroll
-      for (int k = 0; k < 8; ++k) Fk[k] = ge.x * v[k].x + ge.y * v[k].y;
-#pragma unroll
-      for (int e = 0; e < 3; ++e)
-#pragma unroll
-        for (int d = 0; d < 3; ++d) {
-          if (d == e) continue;
-          const int t = 3 - d - e;                                     // the third dimension
-          float m = 0.0f;
-#pragma unroll
-          for (int bt = 0; bt < 2; ++bt) {
-            const int base = bt << t;
-            const float wt = bt ? c.f[t] : 1.0f - c.f[t];
-            m += wt * (((Fk[base | (1 << d) | (1 << e)] - Fk[base | (1 << d)]) - Fk[base | (1 << e)]) + Fk[base]);
-          }
-          dxe[e] += dn[d] * 0.25f * lv.scale * lv.scale * m;
-        }
-    }
-  }
+    dx_level<decltype(PAIRS)::value, EIK>(lv, table, c, gr, ge, dn, dx, dxe);
+  };
+#pragma unroll 2
+  for (int i = 0; i < pairs.n; ++i) one(pairs.level[i], std::true_type());
+#pragma unroll 2
+  for (int i = 0; i < singles.n; ++i) one(singles.level[i], std::false_type());
 #pragma unroll
   for (int gd = 0; gd < 3; ++gd) dpts[b * 3 + gd] = dx[gd] * 0.5f + dxe[gd];    // d x01 / d x = 1/2 (grid.py:160)
 }
@@ -597,8 +624,19 @@ extern "C" int nof_hash_encode_bwd_parts(const NofHashGrid* g, const float* pts_
     NOF_LAUNCH_OK();
   }
   if ((parts & NOF_HASH_BWD_INPUT) && dpts) {
-    hipLaunchKernelGGL(k_hash_dx, dim3((unsigned)nof_div_up(B, 256)), dim3(256), 0, st, *g, pts_w, (const float2*)table,
-                       (const float2*)dfeat, dpts, B, geik, dedn, nof_tile_flags(tile_list, B));
+    LevelList pairs, singles;                                          // the same test as level_pairs() on the device
+    pairs.n = singles.n = 0;
+    for (int l = 0; l < g->L; ++l) {
+      const uint64_t r1 = (uint64_t)g->resolution[l] + 1;
+      if (!g->hashed[l] && r1 <= 1024 && r1 * r1 * r1 <= g->size[l]) pairs.level[pairs.n++] = l;
+      else singles.level[singles.n++] = l;
+    }
+    if (geik != nullptr)
+      hipLaunchKernelGGL(k_hash_dx<true>, dim3((unsigned)nof_div_up(B, 256)), dim3(256), 0, st, *g, pairs, singles, pts_w,
+                         (const float2*)table, (const float2*)dfeat, dpts, B, geik, dedn, nof_tile_flags(tile_list, B));
+    else
+      hipLaunchKernelGGL(k_hash_dx<false>, dim3((unsigned)nof_div_up(B, 256)), dim3(256), 0, st, *g, pairs, singles, pts_w,
+                         (const float2*)table, (const float2*)dfeat, dpts, B, geik, dedn, nof_tile_flags(tile_list, B));
     NOF_LAUNCH_OK();
   }
   if ((parts & NOF_HASH_BWD_TABLE_SMALL) && small.n > 0) {

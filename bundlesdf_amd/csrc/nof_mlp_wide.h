@@ -19,28 +19,82 @@
 // operand split: the residual fragments would double the LDS image).
 #pragma once
 
-// ---- rows of the staging buffers: [B][H] elements in REGISTER order -------------------------------------------------------
-// The buffers are private to these kernels, so a row is laid out the way a lane holds it: the 16 values of block p that lane
-// (sample j, hi) keeps in registers r = 0..15 (neurons 32p + nloc(hi, r)) are contiguous at element 32p + 16hi + r: two
-// 16-byte accesses per block instead of four 8-byte ones (these kernels are bound by the number of lane-addresses, not bytes).
+// ---- staging buffers: [tile][block p][half][lane][8 elements] -- FRAGMENT order -------------------------------------------------
+// The buffers are private to these kernels and every kernel touches them with the same lane <-> (sample j, hi) mapping, so a
+// 32-sample tile's block p is laid out exactly as the wave holds it: the 8 values lane (hi, j) keeps in registers r = 8 half ..
+// 8 half + 7 of block p (neurons 32p + nloc(hi, r)) sit at fragment (p, half), lane hi * 32 + j.  One store / load instruction of a
+// wave is then ONE contiguous kilobyte (sample-major rows made it 64 separate 16-byte pieces of 64 different 256-byte rows: the
+// forward kernels ran at 2.5 TB/s of write traffic).  `tile_row` = the address of the lane's first fragment of its tile; the
+// stride between a tile's fragments is 64 lanes.  A layer's buffer holds ceil(B / 32) * 32 * H elements.
+// Addressing: ONE 32-bit byte offset per lane (the lane's first fragment of its tile) + a wave-uniform layer base + an immediate
+// per fragment -- the form global_load / global_store take directly (saddr + voffset + imm).  64-bit per-lane pointers per layer
+// cost these kernels, which sit at their register cap, 15-20 VGPRs and sent the sigma forward to scratch.  A layer's buffer stays
+// below 4 GiB (checked on the host).
+struct TileRow {
+  char* base;                                                          // wave-uniform: the layer's buffer
+  uint32_t voff;                                                       // this lane's byte offset of fragment (0, 0) of its tile
+};
 template <class P>
-__device__ __forceinline__ void store_blk(typename P::elem* __restrict__ row, int p, int hi, const float (&v)[16]) {
-  typename P::frag* dst = reinterpret_cast<typename P::frag*>(row + 32 * p + 16 * hi);
-  dst[0] = P::pack(&v[0]);
-  dst[1] = P::pack(&v[8]);
+__device__ __forceinline__ TileRow tile_row(const typename P::elem* __restrict__ base, int64_t b, int hi, int hb) {
+  TileRow t;
+  t.base = reinterpret_cast<char*>(const_cast<typename P::elem*>(base));
+  t.voff = (uint32_t)(((b >> 5) * (int64_t)(hb * 2 * 64) + (hi * 32 + (int)(b & 31))) * 16);
+  return t;
 }
 template <class P>
-__device__ __forceinline__ void load_blk(const typename P::elem* __restrict__ row, int p, int hi, bool ok, float (&v)[16]) {
+__device__ __forceinline__ void store_blk(const TileRow& row, int p, const float (&v)[16]) {
+  *reinterpret_cast<typename P::frag*>(row.base + row.voff + (2 * p) * 1024) = P::pack(&v[0]);
+  *reinterpret_cast<typename P::frag*>(row.base + row.voff + (2 * p + 1) * 1024) = P::pack(&v[8]);
+}
+template <class P>
+__device__ __forceinline__ void load_blk(const TileRow& row, int p, bool ok, float (&v)[16]) {
   typename P::frag a, b;
 #pragma unroll
   for (int k = 0; k < 8; ++k) { a[k] = (typename P::elem)0.0f; b[k] = (typename P::elem)0.0f; }
   if (ok) {
-    const typename P::frag* src = reinterpret_cast<const typename P::frag*>(row + 32 * p + 16 * hi);
-    a = src[0];
-    b = src[1];
+    a = *reinterpret_cast<const typename P::frag*>(row.base + row.voff + (2 * p) * 1024);
+    b = *reinterpret_cast<const typename P::frag*>(row.base + row.voff + (2 * p + 1) * 1024);
   }
 #pragma unroll
   for (int k = 0; k < 8; ++k) { v[k] = (float)a[k]; v[8 + k] = (float)b[k]; }
+}
+
+// ReLU in place + the 16 PN derivative bits of the lane (relu_mask of nof_mlp.hip, two blocks per 32-bit word): the backward
+// kernels read these 8 bytes per lane and hidden layer instead of the whole stored activation row (256 bytes per sample at H = 128)
+// just to know which units were on.
+template <int HB>
+__device__ __forceinline__ uint2 relu_bits(float (&h)[HB][16]) {
+  static_assert(HB == 2 || HB == 4, "hidden width 64 or 128");
+  uint32_t off[2] = {0u, 0u};
+#pragma unroll
+  for (int p = 0; p < HB; ++p)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {                                     // (plain indexing: a reinterpret_cast of the array sent it to scratch)
+      const int bits = __float_as_int(h[p][r]);
+      off[p >> 1] = __builtin_amdgcn_alignbit(off[p >> 1], (uint32_t)bits, 31);
+      h[p][r] = __int_as_float(bits > 0 ? bits : 0);
+    }
+  return make_uint2(~off[0], HB == 4 ? ~off[1] : 0u);
+}
+// element (p, r) of word p >> 1 sits at bit 31 - (16 (p & 1) + r), 1 = the unit was on
+template <int HB>
+__device__ __forceinline__ void apply_bits(float (&g)[HB][16], uint2 m) {
+#pragma unroll
+  for (int p = 0; p < HB; ++p)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const uint32_t keep = (uint32_t)__builtin_amdgcn_sbfe((int)(p < 2 ? m.x : m.y), 31 - (16 * (p & 1) + r), 1);
+      g[p][r] = __uint_as_float(__float_as_uint(g[p][r]) & keep);
+    }
+}
+// [hidden layer][tile][lane] uint2: uniform layer base + 32-bit lane offset
+__device__ __forceinline__ uint2* bits_at(uint2* __restrict__ base, int64_t ntiles, int layer, int64_t tile, int lane) {
+  char* lb = reinterpret_cast<char*>(base + (int64_t)layer * ntiles * 64);
+  return reinterpret_cast<uint2*>(lb + (uint32_t)((tile * 64 + lane) * 8));
+}
+__device__ __forceinline__ const uint2* bits_at(const uint2* __restrict__ base, int64_t ntiles, int layer, int64_t tile, int lane) {
+  const char* lb = reinterpret_cast<const char*>(base + (int64_t)layer * ntiles * 64);
+  return reinterpret_cast<const uint2*>(lb + (uint32_t)((tile * 64 + lane) * 8));
 }
 
 template <int PN>
@@ -59,12 +113,16 @@ __device__ __forceinline__ void relu_inplace(float (&h)[PN][16]) {
 // =====================================================================================================
 // forward, sigma net: features -> hidden layers (stored) -> head: sdf -> raw[b].w (or sdf[b]), sig[b] = 16 head outputs
 // =====================================================================================================
+// threads per workgroup of the forward kernels: 768 (3 waves per SIMD, 168 registers) where that fits without scratch (hidden 64);
+// hidden 128 needs ~190 (two 64-register activation sets + the operand and weight fragments of a chain): 512 threads
+template <int HB> struct WideFwdThreads { static constexpr int value = HB >= 4 ? 512 : 768; };
+
 template <class P, int HB>
-__global__ __launch_bounds__(768) void k_wide_fwd_sigma(NofMlpDesc d, const char* __restrict__ image,
+__global__ __launch_bounds__(WideFwdThreads<HB>::value) void k_wide_fwd_sigma(NofMlpDesc d, const char* __restrict__ image,
                                                          const float2* __restrict__ feat, int L,
                                                          typename P::elem* __restrict__ hid, int64_t hid_stride,
                                                          float* __restrict__ out, int out_stride, int out_off,
-                                                         typename P::elem* __restrict__ sig, int64_t B) {
+                                                         typename P::elem* __restrict__ sig, uint2* __restrict__ bits, int64_t B) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int NS = d.n_sigma, NL = d.n_sigma + d.n_color;
   const int bias_base = pair_base(d, NS) * WPAIR;
@@ -75,28 +133,36 @@ __global__ __launch_bounds__(768) void k_wide_fwd_sigma(NofMlpDesc d, const char
   const int hi = lane >> 5, j = lane & 31;
   const int H = 32 * HB;
   const int64_t ntiles = (B + 31) / 32, tstride = (int64_t)gridDim.x * nw;
-  float xn[1][16];                                    // the NEXT tile's features, requested a whole tile ahead
-  load_feat_o1(feat, L, B, ((int64_t)blockIdx.x * nw + wave) * 32 + j, hi, xn);
+  // the NEXT tile's features are requested a whole tile ahead where the 16 registers are to be had (hidden 64); at hidden 128 the
+  // kernel sits at its 168-register cap (768 threads) and the look-ahead spilled 42 of them
+  constexpr bool AHEAD = true;
+  float xn[1][16];
+  if constexpr (AHEAD) load_feat_o1(feat, L, B, ((int64_t)blockIdx.x * nw + wave) * 32 + j, hi, xn);
   for (int64_t tile = (int64_t)blockIdx.x * nw + wave; tile < ntiles; tile += tstride) {
     asm volatile("" ::: "memory");
     const int64_t b = tile * 32 + j;
     const bool ok = b < B;
     float x[1][16], h[HB][16], so[1][16];
+    if constexpr (AHEAD) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) x[0][r] = xn[0][r];
-    pin16(x[0]);
-    load_feat_o1(feat, L, B, (tile + tstride) * 32 + j, hi, xn);
+      for (int r = 0; r < 16; ++r) x[0][r] = xn[0][r];
+      pin16(x[0]);
+      load_feat_o1(feat, L, B, (tile + tstride) * 32 + j, hi, xn);
+    } else {
+      load_feat_o1(feat, L, B, b, hi, x);
+    }
     dense_o1<P, 1, HB>(smem, 0, bias_base, x, h, lane);
-    relu_inplace<HB>(h);
+    uint2 mb = relu_bits<HB>(h);
     int foff = HB * WPAIR, boff = bias_base + HB * 128;
     for (int l = 1; l < NS - 1; ++l) {
       if (hid != nullptr && ok) {
+        *bits_at(bits, ntiles, l - 1, tile, lane) = mb;
 #pragma unroll
-        for (int p = 0; p < HB; ++p) store_blk<P>(hid + (int64_t)(l - 1) * hid_stride + b * H, p, hi, h[p]);
+        for (int p = 0; p < HB; ++p) store_blk<P>(tile_row<P>(hid + (int64_t)(l - 1) * hid_stride, b, hi, HB), p, h[p]);
       }
       float h2[HB][16];
       dense_o1<P, HB, HB>(smem, foff, boff, h, h2, lane);
-      relu_inplace<HB>(h2);
+      mb = relu_bits<HB>(h2);
 #pragma unroll
       for (int p = 0; p < HB; ++p)
 #pragma unroll
@@ -105,8 +171,9 @@ __global__ __launch_bounds__(768) void k_wide_fwd_sigma(NofMlpDesc d, const char
       boff += HB * 128;
     }
     if (hid != nullptr && ok) {
+      *bits_at(bits, ntiles, NS - 2, tile, lane) = mb;
 #pragma unroll
-      for (int p = 0; p < HB; ++p) store_blk<P>(hid + (int64_t)(NS - 2) * hid_stride + b * H, p, hi, h[p]);
+      for (int p = 0; p < HB; ++p) store_blk<P>(tile_row<P>(hid + (int64_t)(NS - 2) * hid_stride, b, hi, HB), p, h[p]);
     }
     dense_o1<P, HB, 1>(smem, foff, boff, h, so, lane);
     if (sig != nullptr) store_sig_o1<P>(sig, B, b, hi, so[0]);
@@ -118,11 +185,11 @@ __global__ __launch_bounds__(768) void k_wide_fwd_sigma(NofMlpDesc d, const char
 // forward, colour net: [sig | view] -> hidden layers (stored) -> rgb_raw -> raw[b].xyz
 // =====================================================================================================
 template <class P, int HB>
-__global__ __launch_bounds__(768) void k_wide_fwd_color(NofMlpDesc d, const char* __restrict__ image,
+__global__ __launch_bounds__(WideFwdThreads<HB>::value) void k_wide_fwd_color(NofMlpDesc d, const char* __restrict__ image,
                                                          const typename P::elem* __restrict__ sig,
                                                          const float* __restrict__ view, int S,
                                                          typename P::elem* __restrict__ hid, int64_t hid_stride,
-                                                         float* __restrict__ raw, int64_t B) {
+                                                         float* __restrict__ raw, uint2* __restrict__ bits, int64_t B) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int NS = d.n_sigma, NC = d.n_color, NL = NS + NC;
   const int PA = pair_base(d, NS), PB = pair_base(d, NL), OA = oblk_base(d, NS), OB = oblk_base(d, NL);
@@ -142,16 +209,17 @@ __global__ __launch_bounds__(768) void k_wide_fwd_color(NofMlpDesc d, const char
     load_sig_o1<P>(sig, B, b, hi, cin[0]);            // (requested a tile ahead: 4-10 % slower at cfg5, measured twice)
     load_view_o1(view, S, B, b, hi, cin[1]);
     dense_o1<P, 2, HB>(smem, 0, bias_base, cin, h, lane);
-    relu_inplace<HB>(h);
+    uint2 mb = relu_bits<HB>(h);
     int foff = 2 * HB * WPAIR, boff = bias_base + HB * 128;
     for (int l = 1; l < NC - 1; ++l) {
       if (hid != nullptr && ok) {
+        *bits_at(bits, ntiles, NS - 1 + l - 1, tile, lane) = mb;
 #pragma unroll
-        for (int p = 0; p < HB; ++p) store_blk<P>(hid + (int64_t)(NS - 1 + l - 1) * hid_stride + b * H, p, hi, h[p]);
+        for (int p = 0; p < HB; ++p) store_blk<P>(tile_row<P>(hid + (int64_t)(NS - 1 + l - 1) * hid_stride, b, hi, HB), p, h[p]);
       }
       float h2[HB][16];
       dense_o1<P, HB, HB>(smem, foff, boff, h, h2, lane);
-      relu_inplace<HB>(h2);
+      mb = relu_bits<HB>(h2);
 #pragma unroll
       for (int p = 0; p < HB; ++p)
 #pragma unroll
@@ -160,21 +228,13 @@ __global__ __launch_bounds__(768) void k_wide_fwd_color(NofMlpDesc d, const char
       boff += HB * 128;
     }
     if (hid != nullptr && ok) {
+      *bits_at(bits, ntiles, NS - 1 + NC - 2, tile, lane) = mb;
 #pragma unroll
-      for (int p = 0; p < HB; ++p) store_blk<P>(hid + (int64_t)(NS - 1 + NC - 2) * hid_stride + b * H, p, hi, h[p]);
+      for (int p = 0; p < HB; ++p) store_blk<P>(tile_row<P>(hid + (int64_t)(NS - 1 + NC - 2) * hid_stride, b, hi, HB), p, h[p]);
     }
     dense_o1<P, HB, 1>(smem, foff, boff, h, co, lane);
     if (hi == 0 && ok) { raw[b * 4] = co[0][0]; raw[b * 4 + 1] = co[0][1]; raw[b * 4 + 2] = co[0][2]; }
   }
-}
-
-// mask a sample-per-lane gradient block by the stored post-ReLU activation of the same units (on <=> activation > 0)
-template <class P>
-__device__ __forceinline__ void mask_by_row(const typename P::elem* __restrict__ row, int p, int hi, bool ok, float (&g)[16]) {
-  float a[16];
-  load_blk<P>(row, p, hi, ok, a);
-#pragma unroll
-  for (int r = 0; r < 16; ++r) g[r] = a[r] > 0.0f ? g[r] : 0.0f;
 }
 
 // =====================================================================================================
@@ -187,7 +247,8 @@ __global__ __launch_bounds__(768) void k_wide_bwd_color(NofMlpDesc d, const char
                                                          int S, const float4* __restrict__ draw,
                                                          typename P::elem* __restrict__ gbuf, int64_t g_stride,
                                                          typename P::elem* __restrict__ dsig, float* __restrict__ dview,
-                                                         uint8_t* __restrict__ zflag, int64_t B) {
+                                                         uint8_t* __restrict__ zflag, int64_t B, const void* __restrict__ tile_list,
+                                                         const uint2* __restrict__ bits) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int NS = d.n_sigma, NC = d.n_color, NL = NS + NC;
   const int PA = pair_base(d, NS), PB = pair_base(d, NL);
@@ -200,8 +261,10 @@ __global__ __launch_bounds__(768) void k_wide_bwd_color(NofMlpDesc d, const char
   I.init(lane);
   const float gscale = d.grad_scale > 0.0f ? d.grad_scale : 1.0f, gunscale = 1.0f / gscale;
   const int64_t ntiles = (B + 31) / 32;
-  for (int64_t tile = (int64_t)blockIdx.x * nw + wave; tile < ntiles; tile += (int64_t)gridDim.x * nw) {
+  const TileWork work(tile_list, ntiles);              // the backward's work list (NofTileList) or every tile of the batch
+  for (int64_t wi = (int64_t)blockIdx.x * nw + __builtin_amdgcn_readfirstlane(wave); wi < work.n; wi += (int64_t)gridDim.x * nw) {
     asm volatile("" ::: "memory");
+    const int64_t tile = work.at(wi);
     const int64_t t0 = tile * 32, b = t0 + j;
     const bool ok = b < B;
     float gh[1][16], g[HB][16];
@@ -212,35 +275,32 @@ __global__ __launch_bounds__(768) void k_wide_bwd_color(NofMlpDesc d, const char
     if (hi == 0 && ok) t = draw[b];
     // a tile whose 32 loss gradients are all exactly zero contributes nothing to any gradient: flagged for the
     // sigma kernel and the weight-gradient passes, nothing stored, nothing computed
-    const bool skip = __builtin_amdgcn_ballot_w64(t.x != 0.0f || t.y != 0.0f || t.z != 0.0f || t.w != 0.0f) == 0ull;
-    if (lane == 0) zflag[tile] = skip ? 1 : 0;
-    if (skip) continue;
+    // (with a work list every listed tile has a non-zero row and zflag is not used)
+    if (tile_list == nullptr) {
+      const bool skip = __builtin_amdgcn_ballot_w64(t.x != 0.0f || t.y != 0.0f || t.z != 0.0f || t.w != 0.0f) == 0ull;
+      if (lane == 0) zflag[tile] = skip ? 1 : 0;
+      if (skip) continue;
+    }
     gh[0][0] = t.x * gscale; gh[0][1] = t.y * gscale; gh[0][2] = t.z * gscale;
     dsdf1 = t.w * gscale;
-    if (ok) store_blk<P>(gbuf + (int64_t)(NL - 1) * g_stride + b * H, 0, hi, gh[0]);
+    if (ok) store_blk<P>(tile_row<P>(gbuf + (int64_t)(NL - 1) * g_stride, b, hi, HB), 0, gh[0]);
     // head -> last hidden colour layer
     int woff = (pair_base(d, NL - 1) - PA) * WPAIR;
     {
-      const typename P::elem* arow = hid + (int64_t)(NS - 1 + NC - 2) * hid_stride + b * H;
 #pragma unroll
-      for (int q = 0; q < HB; ++q) {
-        bwd_data<P, 1>(smem, woff, q, gh, g[q], lane);
-        mask_by_row<P>(arow, q, hi, ok, g[q]);
-      }
+      for (int q = 0; q < HB; ++q) bwd_data<P, 1>(smem, woff, q, gh, g[q], lane);
+      apply_bits<HB>(g, *bits_at(bits, ntiles, NS - 1 + NC - 2, tile, lane));
     }
     for (int l = NL - 2; l > NS; --l) {                               // hidden colour layers above layer 0
       if (ok) {
 #pragma unroll
-        for (int p = 0; p < HB; ++p) store_blk<P>(gbuf + (int64_t)l * g_stride + b * H, p, hi, g[p]);
+        for (int p = 0; p < HB; ++p) store_blk<P>(tile_row<P>(gbuf + (int64_t)l * g_stride, b, hi, HB), p, g[p]);
       }
       woff = (pair_base(d, l) - PA) * WPAIR;
-      const typename P::elem* arow = hid + (int64_t)(NS - 1 + (l - 1 - NS)) * hid_stride + b * H;
       float g2[HB][16];
 #pragma unroll
-      for (int q = 0; q < HB; ++q) {
-        bwd_data<P, HB>(smem, woff, q, g, g2[q], lane);
-        mask_by_row<P>(arow, q, hi, ok, g2[q]);
-      }
+      for (int q = 0; q < HB; ++q) bwd_data<P, HB>(smem, woff, q, g, g2[q], lane);
+      apply_bits<HB>(g2, *bits_at(bits, ntiles, NS - 1 + (l - 1 - NS), tile, lane));
 #pragma unroll
       for (int p = 0; p < HB; ++p)
 #pragma unroll
@@ -249,7 +309,7 @@ __global__ __launch_bounds__(768) void k_wide_bwd_color(NofMlpDesc d, const char
     // colour layer 0: inputs [sigma-out block | view block]
     if (ok) {
 #pragma unroll
-      for (int p = 0; p < HB; ++p) store_blk<P>(gbuf + (int64_t)NS * g_stride + b * H, p, hi, g[p]);
+      for (int p = 0; p < HB; ++p) store_blk<P>(tile_row<P>(gbuf + (int64_t)NS * g_stride, b, hi, HB), p, g[p]);
     }
     float ds1[16], dv1[16], dv2[16];
     bwd_data<P, HB>(smem, 0, 0, g, ds1, lane);
@@ -287,7 +347,8 @@ __global__ __launch_bounds__(768) void k_wide_bwd_sigma(NofMlpDesc d, const char
                                                          const typename P::elem* __restrict__ dsig,
                                                          typename P::elem* __restrict__ gbuf, int64_t g_stride,
                                                          float2* __restrict__ dfeat, int L,
-                                                         const uint8_t* __restrict__ zflag, int64_t B) {
+                                                         const uint8_t* __restrict__ zflag, int64_t B,
+                                                         const void* __restrict__ tile_list, const uint2* __restrict__ bits) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int NS = d.n_sigma, NL = d.n_sigma + d.n_color;
   const int PB = pair_base(d, NL), PS = pair_base(d, NS);
@@ -298,42 +359,41 @@ __global__ __launch_bounds__(768) void k_wide_bwd_sigma(NofMlpDesc d, const char
   const int H = 32 * HB;
   const float gunscale = d.grad_scale > 0.0f ? 1.0f / d.grad_scale : 1.0f;
   const int64_t ntiles = (B + 31) / 32, tstride = (int64_t)gridDim.x * nw;
-  typename P::frag dsn = load_sig_raw<P>(dsig, B, ((int64_t)blockIdx.x * nw + wave) * 32 + j, hi);   // a tile ahead
-  for (int64_t tile = (int64_t)blockIdx.x * nw + wave; tile < ntiles; tile += tstride) {
+  const TileWork work(tile_list, ntiles);
+  const int64_t w0 = (int64_t)blockIdx.x * nw + __builtin_amdgcn_readfirstlane(wave);
+  int64_t tile_n = work.at(w0);
+  typename P::frag dsn = load_sig_raw<P>(dsig, B, tile_n * 32 + j, hi);   // a tile ahead
+  for (int64_t wi = w0; wi < work.n; wi += tstride) {
     asm volatile("" ::: "memory");
+    const int64_t tile = tile_n;
+    tile_n = work.at(wi + tstride);
     const int64_t b = tile * 32 + j;
     const bool ok = b < B;
     float gh[1][16], g[HB][16];
     sig_to_o1<P>(dsn, gh[0]);
     pin16(gh[0]);
-    dsn = load_sig_raw<P>(dsig, B, (tile + tstride) * 32 + j, hi);
+    dsn = load_sig_raw<P>(dsig, B, tile_n * 32 + j, hi);
     float df1[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) df1[r] = 0.0f;
-    if (zflag[tile] == 0) {                                               // (flagged by k_wide_bwd_color: dfeat = 0, nothing else)
-    if (ok) store_blk<P>(gbuf + (int64_t)(NS - 1) * g_stride + b * H, 0, hi, gh[0]);
+    if (tile_list != nullptr || zflag[tile] == 0) {                       // (flagged by k_wide_bwd_color: dfeat = 0, nothing else)
+    if (ok) store_blk<P>(tile_row<P>(gbuf + (int64_t)(NS - 1) * g_stride, b, hi, HB), 0, gh[0]);
     int woff = pair_base(d, NS - 1) * WPAIR;
     {
-      const typename P::elem* arow = hid + (int64_t)(NS - 2) * hid_stride + b * H;
 #pragma unroll
-      for (int q = 0; q < HB; ++q) {
-        bwd_data<P, 1>(smem, woff, q, gh, g[q], lane);
-        mask_by_row<P>(arow, q, hi, ok, g[q]);
-      }
+      for (int q = 0; q < HB; ++q) bwd_data<P, 1>(smem, woff, q, gh, g[q], lane);
+      apply_bits<HB>(g, *bits_at(bits, ntiles, NS - 2, tile, lane));
     }
     for (int l = NS - 2; l >= 1; --l) {
       if (ok) {
 #pragma unroll
-        for (int p = 0; p < HB; ++p) store_blk<P>(gbuf + (int64_t)l * g_stride + b * H, p, hi, g[p]);
+        for (int p = 0; p < HB; ++p) store_blk<P>(tile_row<P>(gbuf + (int64_t)l * g_stride, b, hi, HB), p, g[p]);
       }
       woff = pair_base(d, l) * WPAIR;
-      const typename P::elem* arow = hid + (int64_t)(l - 1) * hid_stride + b * H;
       float g2[HB][16];
 #pragma unroll
-      for (int q = 0; q < HB; ++q) {
-        bwd_data<P, HB>(smem, woff, q, g, g2[q], lane);
-        mask_by_row<P>(arow, q, hi, ok, g2[q]);
-      }
+      for (int q = 0; q < HB; ++q) bwd_data<P, HB>(smem, woff, q, g, g2[q], lane);
+      apply_bits<HB>(g2, *bits_at(bits, ntiles, l - 1, tile, lane));
 #pragma unroll
       for (int p = 0; p < HB; ++p)
 #pragma unroll
@@ -341,7 +401,7 @@ __global__ __launch_bounds__(768) void k_wide_bwd_sigma(NofMlpDesc d, const char
     }
     if (ok) {
 #pragma unroll
-      for (int p = 0; p < HB; ++p) store_blk<P>(gbuf + b * H, p, hi, g[p]);
+      for (int p = 0; p < HB; ++p) store_blk<P>(tile_row<P>(gbuf, b, hi, HB), p, g[p]);
     }
     bwd_data<P, HB>(smem, 0, 0, g, df1, lane);
     }
@@ -365,7 +425,8 @@ __global__ __launch_bounds__(256) void k_wide_dw(NofMlpDesc d, int l, const type
                                                   const typename P::elem* __restrict__ xrow,
                                                   const typename P::elem* __restrict__ sig, const float* __restrict__ view,
                                                   int S, float* __restrict__ partials, int rows,
-                                                  const uint8_t* __restrict__ zflag, int64_t B) {
+                                                  const uint8_t* __restrict__ zflag, int64_t B,
+                                                  const void* __restrict__ tile_list) {
   constexpr int KR = P::KR, NSTEP = 16 / KR, NST = 4 / PN, MAXQ = (QN + PN - 1) / PN;
   __shared__ typename P::frag xs[2][NST][QN][NSTEP][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -382,62 +443,91 @@ __global__ __launch_bounds__(256) void k_wide_dw(NofMlpDesc d, int l, const type
     for (int r = 0; r < 16; ++r) acc[q][r] = 0.0f;
   float db = 0.0f;
   const int64_t ntiles = (B + 31) / 32;
-  const int n_it = (int)((ntiles + rows - 1) / rows);                  // the same trip count for every wave (barrier inside)
-  // the NEXT tile's gradient block and this wave's share of the input blocks are loaded while the current tile is computed
-  float g1[16], xn[MAXQ][16];
-  bool zn = true;                                                         // the next tile is flagged all-zero (or past the end)
-  auto fetch = [&](int64_t tile) {
+  const TileWork work(tile_list, ntiles);
+  const int n_it = (int)((work.n + rows - 1) / rows);                  // the same trip count for every wave (barrier inside)
+  // The gradient block and this wave's share of the input blocks of the tiles TWO iterations ahead are in flight while a tile is
+  // computed, kept as the raw 16-byte fragments they are stored as (one tile ahead, held as 32 floats, left ~4 KB per wave in
+  // flight: 3.6 TB/s of a pass that does nothing but stream its two operand rows); the stored fragments are the A operands of the
+  // transposing MFMA as they are.
+  typedef typename P::frag frag;
+  struct Pre {
+    frag g[2];
+    frag xf[KIND == 1 ? MAXQ : 1][2];                                    // KIND 1: stored activation blocks
+    float xr[KIND == 1 ? 1 : MAXQ][16];                                  // KIND 0 / 2: hash features, [sig | view]
+    bool z;                                                              // flagged all-zero (or past the end)
+  };
+  auto zero_frag = [] { frag f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) f[k] = (typename P::elem)0.0f;
+    return f; };
+  auto fetch = [&](int64_t wi, Pre& t) {
+    const int64_t tile = work.at(wi);
     const int64_t b = tile * 32 + j;
-    zn = tile >= ntiles || zflag[tile] != 0;
-    const bool ok = !zn && b < B;
-    load_blk<P>(grow + b * H, p, hi, ok, g1);
+    t.z = tile >= ntiles || (tile_list == nullptr && zflag[tile] != 0);
+    const bool ok = !t.z && b < B;
+    const TileRow gr = tile_row<P>(grow, b, hi, H / 32);
+    t.g[0] = t.g[1] = zero_frag();
+    if (ok) {
+      t.g[0] = *reinterpret_cast<const frag*>(gr.base + gr.voff + (2 * p) * 1024);
+      t.g[1] = *reinterpret_cast<const frag*>(gr.base + gr.voff + (2 * p + 1) * 1024);
+    }
 #pragma unroll
     for (int m = 0; m < MAXQ; ++m) {
       const int q = p + m * PN;
+      if constexpr (KIND == 1) {
+        t.xf[m][0] = t.xf[m][1] = zero_frag();
+        if (q < QN && ok) {
+          const TileRow xr = tile_row<P>(xrow, b, hi, H / 32);
+          t.xf[m][0] = *reinterpret_cast<const frag*>(xr.base + xr.voff + (2 * q) * 1024);
+          t.xf[m][1] = *reinterpret_cast<const frag*>(xr.base + xr.voff + (2 * q + 1) * 1024);
+        }
+      } else {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) xn[m][r] = 0.0f;
-      if (q < QN) {
-        if constexpr (KIND == 0) {
-          float xf[1][16];
-          load_feat_o1(feat, L, ok ? B : 0, b, hi, xf);
+        for (int r = 0; r < 16; ++r) t.xr[m][r] = 0.0f;
+        if (q < QN) {
+          if constexpr (KIND == 0) {
+            float xf[1][16];
+            load_feat_o1(feat, L, ok ? B : 0, b, hi, xf);
 #pragma unroll
-          for (int r = 0; r < 16; ++r) xn[m][r] = xf[0][r];
-        } else if constexpr (KIND == 1) {
-          load_blk<P>(xrow + b * H, q, hi, ok, xn[m]);
-        } else {
-          if (q == 0) load_sig_o1<P>(sig, ok ? B : 0, b, hi, xn[m]);
-          else load_view_o1(view, S, ok ? B : 0, b, hi, xn[m]);
+            for (int r = 0; r < 16; ++r) t.xr[m][r] = xf[0][r];
+          } else {
+            if (q == 0) load_sig_o1<P>(sig, ok ? B : 0, b, hi, t.xr[m]);
+            else load_view_o1(view, S, ok ? B : 0, b, hi, t.xr[m]);
+          }
         }
       }
     }
   };
-  fetch(row);
-  for (int it = 0; it < n_it; ++it) {
-    float g0[16], x1[MAXQ][16], g2[16];
+  // block held sample-per-lane as two operand fragments -> slot-per-lane (see transpose32)
+  auto transpose_raw = [&](frag a, frag b, float (&y)[16]) {
+    static_assert(NSTEP == 2, "16-bit operand types");
+    f32x16 t;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) g0[r] = g1[r];
+    for (int r = 0; r < 16; ++r) t[r] = 0.0f;
+    t = P::mma(a, I.f[0], t);
+    t = P::mma(b, I.f[1], t);
 #pragma unroll
-    for (int m = 0; m < MAXQ; ++m)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) x1[m][r] = xn[m][r];
-    const bool z0 = __builtin_amdgcn_readfirstlane(zn ? 1 : 0) != 0;      // this tile adds nothing: only the barrier is kept
-    fetch((int64_t)row + (int64_t)(it + 1) * rows);
+    for (int r = 0; r < 16; ++r) y[r] = t[r];
+  };
+  auto step = [&](const Pre& t, int it) {
     const int buf = it & 1;
-    if (z0) { __syncthreads(); continue; }
+    if (__builtin_amdgcn_readfirstlane(t.z ? 1 : 0) != 0) { __syncthreads(); return; }   // adds nothing: only the barrier is kept
 #pragma unroll
     for (int m = 0; m < MAXQ; ++m) {
       const int q = p + m * PN;
       if (q < QN) {
         float x2[16];
-        transpose32<P>(I, x1[m], x2);
+        if constexpr (KIND == 1) transpose_raw(t.xf[m][0], t.xf[m][1], x2);
+        else transpose32<P>(I, t.xr[m], x2);
 #pragma unroll
         for (int s = 0; s < NSTEP; ++s) xs[buf][stream][q][s][lane] = P::pack(&x2[KR * s]);
       }
     }
-    transpose32<P>(I, g0, g2);
+    float g2[16];
+    transpose_raw(t.g[0], t.g[1], g2);
 #pragma unroll
     for (int r = 0; r < 16; ++r) db += g2[r];
-    typename P::frag ga[NSTEP];
+    frag ga[NSTEP];
 #pragma unroll
     for (int s = 0; s < NSTEP; ++s) ga[s] = P::pack(&g2[KR * s]);
     __syncthreads();
@@ -445,6 +535,17 @@ __global__ __launch_bounds__(256) void k_wide_dw(NofMlpDesc d, int l, const type
     for (int q = 0; q < QN; ++q)
 #pragma unroll
       for (int s = 0; s < NSTEP; ++s) acc[q] = P::mma(ga[s], xs[buf][stream][q][s][lane], acc[q]);
+  };
+  Pre ta, tb;
+  fetch(row, ta);
+  fetch((int64_t)row + rows, tb);
+  for (int it = 0; it < n_it; it += 2) {                                 // (n_it is the same for every wave: the barriers match)
+    step(ta, it);
+    fetch((int64_t)row + (int64_t)(it + 2) * rows, ta);
+    if (it + 1 < n_it) {
+      step(tb, it + 1);
+      fetch((int64_t)row + (int64_t)(it + 3) * rows, tb);
+    }
   }
   // flush: lane j = input slot (hi_j, r_j) of block q, register r = neuron 32p + nloc(hi, r)
   const int hi_j = (j >> 2) & 1, r_j = (j & 3) + 4 * (j >> 3);
@@ -474,20 +575,22 @@ static int check_wide(const NofMlpDesc* d) {
   return 0;
 }
 static int64_t wide_hid_layers(const NofMlpDesc* d) { return (d->n_sigma - 1) + (d->n_color - 1); }
-static const int kWideRows = 1024;                                        // wave-rows of `partials`: 4 waves per SIMD of the weight-gradient pass
+static const int kWideRows = 768;                                         // wave-rows of `partials`: the weight-gradient pass runs 3 waves per SIMD (164 registers), all resident in one round
 
-// workspace layout (bytes, 256-aligned): [hid : n_hid * B * H elems][gbuf : NL * B * H elems][sig : B * 16 elems][dsig : B * 16 elems][zflag : B/32 bytes]
-struct WideWs { char *hid, *gbuf, *sig, *dsig; uint8_t* zflag; int64_t total; };
+// workspace layout (bytes, 256-aligned; Bt = B rounded up to whole tiles): [hid : n_hid * Bt * H elems][gbuf : NL * Bt * H elems][sig : B * 16 elems][dsig : B * 16 elems][zflag : B/32 bytes][bits : n_hid * Bt/32 * 64 * 8 bytes]
+struct WideWs { char *hid, *gbuf, *sig, *dsig; uint8_t* zflag; uint2* bits; int64_t total; };
 static WideWs wide_ws(const NofMlpDesc* d, void* base, int64_t B) {
   auto up = [](int64_t x) { return (x + 255) / 256 * 256; };
   const int64_t row = (int64_t)d->hidden * 2, nl = d->n_sigma + d->n_color;
+  const int64_t Bt = (B + 31) / 32 * 32;                                // staging buffers hold whole 32-sample tiles
   WideWs w;
   int64_t off = 0;
-  w.hid = (char*)base + off; off += up(wide_hid_layers(d) * B * row);
-  w.gbuf = (char*)base + off; off += up(nl * B * row);
+  w.hid = (char*)base + off; off += up(wide_hid_layers(d) * Bt * row);
+  w.gbuf = (char*)base + off; off += up(nl * Bt * row);
   w.sig = (char*)base + off; off += up(B * 32);
   w.dsig = (char*)base + off; off += up(B * 32);
   w.zflag = (uint8_t*)base + off; off += up((B + 31) / 32);             // one byte per 32-sample tile: 1 = every loss gradient is exactly zero
+  w.bits = (uint2*)((char*)base + off); off += up(wide_hid_layers(d) * (Bt / 32) * 64 * 8);   // ReLU derivative bits: 8 B per lane, tile and hidden layer
   w.total = off;
   return w;
 }
@@ -506,19 +609,20 @@ static int wide_fwd_launch(const NofMlpDesc* d, const void* packed, const float*
   const size_t shm_s = (size_t)pair_base(*d, ns) * pair_bytes + (size_t)oblk_base(*d, ns) * 128;
   const size_t shm_c = (size_t)(pair_base(*d, nl) - pair_base(*d, ns)) * pair_bytes + (size_t)(oblk_base(*d, nl) - oblk_base(*d, ns)) * 128;
   const int64_t ntiles = (B + 31) / 32;
-  const unsigned blocks = (unsigned)(nof_div_up(ntiles, 12) < (int64_t)nof_cu_count() ? nof_div_up(ntiles, 12) : nof_cu_count());
+  constexpr int NT = WideFwdThreads<HB>::value;
+  const unsigned blocks = (unsigned)(nof_div_up(ntiles, NT / 64) < (int64_t)nof_cu_count() ? nof_div_up(ntiles, NT / 64) : nof_cu_count());
   typedef typename P::elem elem;
-  const int64_t hs = B * (int64_t)d->hidden;
+  const int64_t hs = (B + 31) / 32 * 32 * (int64_t)d->hidden;
   auto ks = k_wide_fwd_sigma<P, HB>;
   if (int e = set_smem(ks, shm_s)) return e;
-  hipLaunchKernelGGL(ks, dim3(blocks), dim3(768), shm_s, st, *d, (const char*)packed, (const float2*)feat, (int)L,
+  hipLaunchKernelGGL(ks, dim3(blocks), dim3(NT), shm_s, st, *d, (const char*)packed, (const float2*)feat, (int)L,
                      store_hidden ? (elem*)ws->hid : (elem*)nullptr, hs, out, out_stride, out_off,
-                     sdf_only ? (elem*)nullptr : (elem*)ws->sig, B);
+                     sdf_only ? (elem*)nullptr : (elem*)ws->sig, store_hidden ? ws->bits : (uint2*)nullptr, B);
   if (!sdf_only) {
     auto kc = k_wide_fwd_color<P, HB>;
     if (int e = set_smem(kc, shm_c)) return e;
-    hipLaunchKernelGGL(kc, dim3(blocks), dim3(768), shm_c, st, *d, (const char*)packed, (const elem*)ws->sig, view, (int)S,
-                       store_hidden ? (elem*)ws->hid : (elem*)nullptr, hs, out, B);
+    hipLaunchKernelGGL(kc, dim3(blocks), dim3(NT), shm_c, st, *d, (const char*)packed, (const elem*)ws->sig, view, (int)S,
+                       store_hidden ? (elem*)ws->hid : (elem*)nullptr, hs, out, store_hidden ? ws->bits : (uint2*)nullptr, B);
   }
   return 0;
 }
@@ -562,7 +666,7 @@ extern "C" int nof_mlp_wide_sdf(const NofMlpDesc* d, const void* packed, const f
 template <class P, int HB>
 static int wide_bwd_launch(const NofMlpDesc* d, const void* packed, const float* feat, int32_t L, const float* view, int32_t S,
                            const float* draw, const WideWs* ws, float* dfeat, float* dview, float* partials, int64_t B,
-                           hipStream_t st) {
+                           hipStream_t st, const void* tile_list, int parts) {
   typedef typename P::elem elem;
   const int ns = d->n_sigma, nc = d->n_color, nl = ns + nc, H = d->hidden;
   const size_t pair_bytes = 16 * 64 * 2;
@@ -570,18 +674,21 @@ static int wide_bwd_launch(const NofMlpDesc* d, const void* packed, const float*
   const size_t shm_c = (size_t)(pair_base(*d, nl) - pair_base(*d, ns)) * pair_bytes;
   const int64_t ntiles = (B + 31) / 32;
   const unsigned blocks = (unsigned)(nof_div_up(ntiles, 12) < (int64_t)nof_cu_count() ? nof_div_up(ntiles, 12) : nof_cu_count());
-  const int64_t hs = B * (int64_t)H;
+  const int64_t hs = (B + 31) / 32 * 32 * (int64_t)H;
   elem *hid = (elem*)ws->hid, *gbuf = (elem*)ws->gbuf, *sig = (elem*)ws->sig, *dsig = (elem*)ws->dsig;
   auto kc = k_wide_bwd_color<P, HB>;
   auto ks = k_wide_bwd_sigma<P, HB>;
   if (int e = set_smem(kc, shm_c)) return e;
   if (int e = set_smem(ks, shm_s)) return e;
-  hipLaunchKernelGGL(kc, dim3(blocks), dim3(768), shm_c, st, *d, (const char*)packed, (const elem*)hid, hs, (int)S,
-                     (const float4*)draw, gbuf, hs, dsig, dview, ws->zflag, B);
-  hipLaunchKernelGGL(ks, dim3(blocks), dim3(768), shm_s, st, *d, (const char*)packed, (const elem*)hid, hs, (const elem*)dsig, gbuf,
-                     hs, (float2*)dfeat, (int)L, (const uint8_t*)ws->zflag, B);
+  if (parts & NOF_WIDE_BWD_DATA_COLOR)
+    hipLaunchKernelGGL(kc, dim3(blocks), dim3(768), shm_c, st, *d, (const char*)packed, (const elem*)hid, hs, (int)S,
+                       (const float4*)draw, gbuf, hs, dsig, dview, ws->zflag, B, tile_list, (const uint2*)ws->bits);
+  if (parts & NOF_WIDE_BWD_DATA_SIGMA)
+    hipLaunchKernelGGL(ks, dim3(blocks), dim3(768), shm_s, st, *d, (const char*)packed, (const elem*)hid, hs, (const elem*)dsig, gbuf,
+                       hs, (float2*)dfeat, (int)L, (const uint8_t*)ws->zflag, B, tile_list, (const uint2*)ws->bits);
   // weight gradients, layer by layer (PN = output blocks of the layer: HB for the hidden layers, 1 for the two heads)
   for (int l = 0; l < nl; ++l) {
+    if (!(parts & (l < ns ? NOF_WIDE_BWD_DW_SIGMA : NOF_WIDE_BWD_DW_COLOR))) continue;
     const int PN = lay_pn(*d, l);
     const unsigned grid = (unsigned)(kWideRows * PN / 4);              // 4 / PN tile streams per workgroup
     const elem* grow = gbuf + (int64_t)l * hs;
@@ -589,7 +696,7 @@ static int wide_bwd_launch(const NofMlpDesc* d, const void* packed, const float*
     const elem* xin = (l == 0 || l == ns) ? (const elem*)nullptr : (const elem*)(hid + (int64_t)hidx * hs);
 #define WIDE_DW(QN_, KIND_, PN_)                                                                          \
     hipLaunchKernelGGL((k_wide_dw<P, QN_, KIND_, PN_>), dim3(grid), dim3(256), 0, st, *d, l, grow, H, (const float2*)feat, \
-                       (int)L, xin, (const elem*)sig, view, (int)S, partials, kWideRows, (const uint8_t*)ws->zflag, B)
+                       (int)L, xin, (const elem*)sig, view, (int)S, partials, kWideRows, (const uint8_t*)ws->zflag, B, tile_list)
     if (l == 0) { WIDE_DW(1, 0, HB); }
     else if (l == ns) { WIDE_DW(2, 2, HB); }
     else if (PN == 1) { WIDE_DW(HB, 1, 1); }
@@ -604,12 +711,31 @@ static int wide_bwd_launch(const NofMlpDesc* d, const void* packed, const float*
 extern "C" int nof_mlp_wide_bwd(const NofMlpDesc* d, const void* packed, const float* feat, int32_t L, const float* view,
                                  int32_t S, const float* draw, void* workspace, float* dfeat, float* dview, float* partials,
                                  int64_t B, void* stream) {
+  return nof_mlp_wide_bwd_tiles(d, packed, feat, L, view, S, draw, workspace, dfeat, dview, partials, nullptr, B, stream);
+}
+
+/* the same over a work list (NofTileList): only the listed tiles are computed (data path and weight-gradient passes), dealt evenly
+ * to the waves; dfeat of unlisted tiles is not written */
+extern "C" int nof_mlp_wide_bwd_tiles(const NofMlpDesc* d, const void* packed, const float* feat, int32_t L, const float* view,
+                                       int32_t S, const float* draw, void* workspace, float* dfeat, float* dview, float* partials,
+                                       const void* tile_list, int64_t B, void* stream) {
+  return nof_mlp_wide_bwd_parts(d, packed, feat, L, view, S, draw, workspace, dfeat, dview, partials, tile_list, NOF_WIDE_BWD_ALL, B, stream);
+}
+
+/* The same, restricted to `parts` (all on `stream`): the data path of the colour net (needs draw; writes dsigma / dview), of the
+ * sigma net (needs the colour part; writes dfeat), and the two nets' weight-gradient passes, each of which only needs its own
+ * net's data part.  What runs beside what is the caller's business: the training step starts the colour net's weight gradients
+ * beside the sigma net's data path, and both nets' beside the hash backward (which only needs dfeat). */
+extern "C" int nof_mlp_wide_bwd_parts(const NofMlpDesc* d, const void* packed, const float* feat, int32_t L, const float* view,
+                                       int32_t S, const float* draw, void* workspace, float* dfeat, float* dview, float* partials,
+                                       const void* tile_list, int32_t parts, int64_t B, void* stream) {
   if (int e = check_wide(d)) return e;
+  NOF_ARG(parts >= 0 && parts <= NOF_WIDE_BWD_ALL);
   NOF_ARG(packed && feat && view && draw && workspace && dfeat && dview && partials && B >= 0 && S >= 32 && L * 2 == d->in_feat);
   NOF_ARG((int64_t)L * B * 8 < (1ll << 32));                   // level-major arrays are addressed with 32-bit lane offsets
   if (B == 0) return 0;
   const WideWs ws = wide_ws(d, workspace, B);
-  WIDE_DISPATCH(wide_bwd_launch, d, packed, feat, L, view, S, draw, &ws, dfeat, dview, partials, B, (hipStream_t)stream)
+  WIDE_DISPATCH(wide_bwd_launch, d, packed, feat, L, view, S, draw, &ws, dfeat, dview, partials, B, (hipStream_t)stream, tile_list, (int)parts)
   NOF_LAUNCH_OK();
   return 0;
 }

@@ -236,6 +236,11 @@ class NeuralObjectField:
             self._side = torch.cuda.Stream(device=self.device)
         return self._side
 
+    def _aux_stream(self):
+        if getattr(self, '_aux', None) is None:
+            self._aux = torch.cuda.Stream(device=self.device)
+        return self._aux
+
     def _sample_cfg(self, seed, step, dyn=False):
         cfg = self.cfg
         return lib.NofSampleCfg(cfg['N_samples'], cfg['N_samples_around_depth'], cfg['near'] * cfg['sc_factor'],
@@ -331,9 +336,28 @@ class NeuralObjectField:
         if tiles is not None and self.backward_tiles == 'all':
             self._call('nof_tile_list_build', None, B, 1, tiles)
         self._set_grad_scale(B)                    # (dview is zero: allocated so, and re-zeroed after its last use in every step)
+        # wide networks: the weight-gradient passes (8 launches that re-read the staged gradients / activations: the longest part
+        # of that backward) only need their own net's data path, and the hash backward only needs dfeat: on a third stream the
+        # colour net's passes run beside the sigma net's data path and both beside the table scatter (captured step: one chain)
+        wide_aux = None
         if self.wide:
-            self._call('nof_mlp_wide_bwd', C.byref(self.desc), self.packed, b['feat'], self.L, b['view'], S, b['draw'],
-                       b['wide_ws'], b['dfeat'], b['dview'], b['partials'], B)
+            def wide_bwd(parts, tag):
+                self._call('nof_mlp_wide_bwd_parts', C.byref(self.desc), self.packed, b['feat'], self.L, b['view'], S, b['draw'],
+                           b['wide_ws'], b['dfeat'], b['dview'], b['partials'], tiles, parts, B, tag=tag)
+            if dyn:
+                wide_bwd(15, 'nof_mlp_wide_bwd')
+            else:
+                main = torch.cuda.current_stream()
+                wide_aux = self._aux_stream()
+                wide_bwd(1, 'wide_bwd[data colour]')
+                wide_aux.wait_stream(main)
+                with torch.cuda.stream(wide_aux):
+                    wide_bwd(4, 'wide_bwd[dW colour]')
+                wide_bwd(2, 'wide_bwd[data sigma]')
+                wide_aux.wait_stream(main)
+                with torch.cuda.stream(wide_aux):
+                    wide_bwd(8, 'wide_bwd[dW sigma]')
+                    self._call('nof_reduce_partials', b['partials'], self.nblk, self.n_mlp, self._seg(self.grads, 'mlp'))
         else:
             self._call('nof_mlp_bwd_tiles', C.byref(self.desc), self.packed, b['feat'], self.L, b['view'], S, b['draw'], b['sig'],
                        b['dsig'], b['dfeat'], b['dview'], b['partials'], tiles, B)
@@ -353,7 +377,8 @@ class NeuralObjectField:
         BIG, SMALL, INPUT, ALL = lib.HASH_BWD_TABLE_BIG, lib.HASH_BWD_TABLE_SMALL, lib.HASH_BWD_INPUT, lib.HASH_BWD_ALL
 
         def reduce_mlp():
-            self._call('nof_reduce_partials', b['partials'], self.nblk, self.n_mlp, self._seg(self.grads, 'mlp'))
+            if wide_aux is None:                                     # (the wide path reduced its rows on its third stream)
+                self._call('nof_reduce_partials', b['partials'], self.nblk, self.n_mlp, self._seg(self.grads, 'mlp'))
             if self.eikonal:
                 self._call('nof_reduce_partials', b['partials_e'], self.nblk, self.n_mlp, self._seg(self.grads, 'mlp'))
 
@@ -398,6 +423,8 @@ class NeuralObjectField:
                 a = 2 * int(self.offsets[split])
                 reduce_mlp()
                 hash_bwd(BIG | SMALL, split, self.L)
+                if wide_aux is not None:                             # the MLP gradient is part of the slice that goes out next
+                    main.wait_stream(wide_aux)
                 grad_sync.start(self.grads[a:self.n_table + self.n_mlp])
                 with torch.cuda.stream(side):
                     hash_bwd(INPUT, 0, self.L)
@@ -412,6 +439,8 @@ class NeuralObjectField:
                 hash_bwd(BIG | SMALL, 0, self.L)
                 reduce_mlp()
             main.wait_stream(side)
+            if wide_aux is not None:
+                main.wait_stream(wide_aux)
         if self.optimize_poses and float(cfg.get('pose_reg_weight', 0)) > 0:
             self._call('nof_pose_reg', self.pose, self._seg(self.grads, 'pose'), self.F, C.c_float(cfg['pose_reg_weight']),
                        C.c_float(1.0 / self.world_size), self.loss_out)

@@ -155,6 +155,52 @@ def test_mlp_backward_over_the_list_equals_whole_batch(nof, ns, nc, precision, R
         assert np.abs(dv - dv_w).max() <= 2e-5 * max(np.abs(dv_w).max(), 1e-30), mode
 
 
+@pytest.mark.parametrize("ns,nc,hidden,precision", [(4, 4, 128, 2), (2, 3, 128, 1), (4, 4, 64, 2)])
+def test_wide_backward_over_the_list_equals_whole_batch(nof, ns, nc, hidden, precision):
+    from oracle import nof_oracle as O
+    L, ff, R, S = 16, 2, 40, 192
+    B = R * S
+    torch.manual_seed(9)
+    shape = O.FieldShape(input_ch=2 * L, input_ch_views=9 + ff, num_layers=ns, hidden_dim=hidden, num_layers_color=nc,
+                         hidden_dim_color=hidden)
+    params = O.init_mlp_params(shape)
+    desc, dims = nof.make_mlp_desc(ns, nc, 2 * L, 9 + ff, precision, hidden=hidden)
+    desc.grad_scale = 1024.0 if precision == 2 else 0.0
+    flat = torch.cat([torch.cat([W.reshape(-1), b.reshape(-1)]) for W, b in params])
+    feat = (torch.randn(L, B, 2) * 0.5).cuda()
+    view = torch.zeros(R, 16)
+    view[:, :9 + ff] = torch.randn(R, 9 + ff)
+    view = view.cuda()
+    draw = U.dev(_sparse_draw(R, S, seed=ns + hidden))
+    packed = _pack(nof, desc, flat)
+    ws = torch.zeros(int(nof.load().nof_mlp_wide_workspace_bytes(C.byref(desc), B)), dtype=torch.uint8, device='cuda')
+    raw = torch.zeros(B, 4, device='cuda')
+    nof.call('nof_mlp_wide_fwd', C.byref(desc), packed, feat, L, view, S, raw, ws, B)
+    rows = nof.load().nof_mlp_wide_partial_rows()
+    tl = torch.zeros(int(nof.load().nof_tile_list_bytes(B)), dtype=torch.uint8, device='cuda')
+    nof.call('nof_tile_list_build', draw, B, 0, tl)
+    out = {}
+    for mode in ('whole', 'list'):
+        dfeat = torch.full((L, B, 2), 3.0, device='cuda')
+        dview = torch.zeros(R, 16, device='cuda')
+        partials = torch.full((rows, desc.n_params), 5.0, device='cuda')
+        nof.call('nof_mlp_wide_bwd_tiles', C.byref(desc), packed, feat, L, view, S, draw, ws, dfeat, dview, partials,
+                 None if mode == 'whole' else tl, B)
+        g = torch.zeros(desc.n_params, device='cuda')
+        nof.call('nof_reduce_partials', partials, rows, desc.n_params, g)
+        torch.cuda.synchronize()
+        out[mode] = (cpu(dfeat), cpu(dview), cpu(g))
+    nt = (B + 31) // 32
+    pad = np.zeros((nt * 32, 4), np.float32)
+    pad[:B] = cpu(draw)
+    live = np.repeat((pad.reshape(nt, 128) != 0).any(1), 32)[:B]
+    (df_w, dv_w, g_w), (df, dv, g) = out['whole'], out['list']
+    assert (df_w[:, ~live] == 0).all() and (df[:, ~live] == 3.0).all()
+    assert np.array_equal(df[:, live], df_w[:, live])
+    assert np.abs(g - g_w).max() <= 2e-5 * np.abs(g_w).max()
+    assert np.abs(dv - dv_w).max() <= 2e-5 * max(np.abs(dv_w).max(), 1e-30)
+
+
 @pytest.mark.parametrize("T,finest,R,S", [(19, 256, 512, 192), (14, 128, 33, 96), (22, 512, 256, 192)])
 def test_hash_backward_over_the_list_equals_whole_batch(nof, T, finest, R, S):
     from tests.test_gpu_fullsize import _ray_like_points
