@@ -207,6 +207,7 @@ def main():
                          'cfg5: SDF 4x128 + colour 4x128 (BASELINE.json cfg5, with --rays 16384 --log2_T 22 --width 1280 --height 720 '
                          '--precision fp16)')
     ap.add_argument('--finest', type=int, default=256, help='finest hash resolution (256: cfg1-3; 512: cfg4/5)')
+    ap.add_argument('--scatter-wgs', type=int, default=0, help='persistent workgroups per CU of the table scatter (0 = library default)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-seconds', type=float, default=25.0)
     args = ap.parse_args()
@@ -235,6 +236,7 @@ def main():
     log(f'rank {rank}/{world}: building the keyframe pool and ray table')
     runner, cfg = build_runner(args, rank, world, device)
     fld = runner.field
+    fld.scatter_wgs_per_cu = args.scatter_wgs
     log(f'pool ready: {runner.rays.shape[0]} rays, level {fld.level}, table {fld.n_entries} rows')
     R, S = args.rays, cfg['N_samples'] + cfg['N_samples_around_depth']
     B = R * S
@@ -251,8 +253,11 @@ def main():
         runner.global_step += 1
     torch.cuda.synchronize()
     log('warm-up done')
-    ktimes = fld.kernel_times_ms()
-    dominant = max(ktimes, key=ktimes.get) if ktimes else None
+    # median over the warm-up steps, the first two left out: a kernel's first launch loads its code object (with the mean, a
+    # 5-microsecond kernel that happened to go first looked like the longest launch of a 5-step warm-up)
+    ktimes = fld.kernel_times_ms(stat='median', skip=2)
+    # (no warm-up step to look at: the launch that is the longest in every committed trace of this workload)
+    dominant = max(ktimes, key=ktimes.get) if ktimes else 'hash_bwd[table+table_lds]'
     fld.profile = {dominant: []} if dominant else None          # timed region: only the dominant kernel keeps its events
     fld.profile_only = dominant
     # the hash lookup (north_star: ">= 40 % HBM roofline for hash lookup") is timed as well: two more events per step
@@ -336,19 +341,25 @@ def main():
         zero_frac = zero_last
         n_mlp = fld.n_mlp
         fl_fwd = 2.0 * (n_mlp - sum(o for o, _ in fld.layer_dims))      # 2*MAC per sample
+        fl_net = [2.0 * sum(o * i for o, i in fld.layer_dims[:fld.n_sigma]), 2.0 * sum(o * i for o, i in fld.layer_dims[fld.n_sigma:])]
         hash_fwd_bytes = B * (16 * 8 * 2 * 4 + 12 + 16 * 2 * 4)
         work = {
             'nof_hash_encode_fwd': ('hbm', hash_fwd_bytes),
             # dfeat read (L*C*4) + atomic read-modify-write of 8 corners x 2 channels per level (2*L*8*2*4) = 2112 B/sample,
             # both only for the samples the work list keeps: the others are not read and would add 0 -- pricing them would credit
-            # work that is not done (frac > 1).  This is the table scatter; dL/dx (k_hash_dx, 1048 B/sample) and the LDS-accumulated
-            # level run beside it on the step's second stream and are not part of the figure.
-            'hash_bwd[table]': ('hbm', B * (1.0 - zero_frac) * (16 * 2 * 4 + 2 * 16 * 8 * 2 * 4)),
-            'hash_bwd[table_lds+input]': ('hbm', B * (1.0 - zero_frac) * (16 * 2 * 4 + 16 * 8 * 2 * 4 + 12) + B * 12),
+            # work that is not done (frac > 1).  This is the table scatter (the run-merged global atomics of the large levels + the
+            # LDS-accumulated small level behind them); dL/dx (k_hash_dx, 1048 B/sample) runs beside it on the step's second
+            # stream and is its own entry.
+            'hash_bwd[table+table_lds]': ('hbm', B * (1.0 - zero_frac) * (16 * 2 * 4 + 2 * 16 * 8 * 2 * 4)),
+            'hash_bwd[input]': ('hbm', B * (1.0 - zero_frac) * (16 * 2 * 4 + 16 * 8 * 2 * 4 + 12) + B * 12),
             'nof_mlp_fwd': ('mfma', B * fl_fwd),
             'nof_mlp_bwd_tiles': ('mfma', B * (1.0 - zero_frac) * 3.0 * fl_fwd),
             'nof_mlp_wide_fwd': ('mfma', B * fl_fwd),
-            'nof_mlp_wide_bwd': ('mfma', B * 2.0 * fl_fwd),           # no recompute on the wide path: data + weight gradients
+            'nof_mlp_wide_bwd': ('mfma', B * (1.0 - zero_frac) * 2.0 * fl_fwd),   # no recompute on the wide path: data + weight gradients
+            # the wide backward as the step launches it (nof_mlp_wide_bwd_parts): data path / weight-gradient passes per network,
+            # over the listed tiles only; one pass of a network = its 2 * MAC
+            'wide_bwd[data colour]': ('mfma', B * (1.0 - zero_frac) * fl_net[1]), 'wide_bwd[data sigma]': ('mfma', B * (1.0 - zero_frac) * fl_net[0]),
+            'wide_bwd[dW colour]': ('mfma', B * (1.0 - zero_frac) * fl_net[1]), 'wide_bwd[dW sigma]': ('mfma', B * (1.0 - zero_frac) * fl_net[0]),
             'nof_adam_step': ('hbm', fld.n_total * 32.0),
         }
         traffic = None          # HBM bytes per launch from the committed PMC passes (profiles/pmc_traffic.json), same workload only
@@ -369,7 +380,7 @@ def main():
                 roof = {"kernel": dominant, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes": amount, "avg_ms": dom_ms,
                         "traffic_source": src if traffic else None}
-                if dominant == 'hash_bwd[table]':
+                if dominant == 'hash_bwd[table+table_lds]':
                     # what actually bounds the scatter: the memory side retires ~20.8 G atomic LINE REQUESTS per second
                     # (tools/atomic_probe.py; same for every scope, cache flag and data type), and the launch needs one request per
                     # 64-byte line per atomic instruction.  The requests of THIS batch are counted from its own sample points.

@@ -68,5 +68,23 @@ def build(force=False, verbose=True):
     return LIB
 
 
+PERTURB_LIB = os.path.join(HERE, 'libnof_hash_perturb.so')
+
+
+def build_perturb(force=False, verbose=True):
+    """Test build of the hash kernels with -DNOF_AGG_PERTURB (extra live registers across the scatter's hand-written DPP block:
+    a different register allocation around it).  tests/test_gpu_ops.py runs the table scatter through it."""
+    srcs = [os.path.join(CSRC, x) for x in ('nof_hash.hip', 'nof_capi.hip')]
+    if not force and not _stale(PERTURB_LIB, srcs + HEADERS):
+        return PERTURB_LIB
+    # -Bsymbolic: this library's references bind to its OWN kernels and helpers even when libnof_hip.so (same symbol names) is
+    # already loaded in the process -- without it the dynamic linker would hand it the first library's kernel stubs
+    cmd = [hipcc()] + FLAGS + ['-DNOF_AGG_PERTURB=1', '-shared', '-Wl,-Bsymbolic', '-x', 'hip'] + srcs + ['-o', PERTURB_LIB]
+    if verbose:
+        print(' '.join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return PERTURB_LIB
+
+
 if __name__ == '__main__':
     print(build(force='--force' in sys.argv))

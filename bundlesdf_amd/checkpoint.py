@@ -80,12 +80,12 @@ def optimizer_state_dict(field, lrs=None):
     if pose_at is not None:
         groups.append({'name': 'pose_array', 'params': params[n_basic:], 'lr': lr_pose})
     opt = torch.optim.Adam(groups, betas=(0.9, 0.999), weight_decay=0, eps=1e-15)
-    if field.global_step > 0:
+    if field.adam_steps > 0:
         for p, (seg, off, shape) in zip(params, shapes):
             n = int(np.prod(shape))
             m = field._seg(field.exp_avg, seg)[off:off + n].detach().cpu().reshape(shape).clone()
             v = field._seg(field.exp_avg_sq, seg)[off:off + n].detach().cpu().reshape(shape).clone()
-            opt.state[p] = {'step': torch.tensor(float(field.global_step)), 'exp_avg': m, 'exp_avg_sq': v}
+            opt.state[p] = {'step': torch.tensor(float(field.adam_steps)), 'exp_avg': m, 'exp_avg_sq': v}
     return opt.state_dict()
 
 
@@ -149,8 +149,11 @@ def load_reference_checkpoint(field, ck):
     field.exp_avg.zero_()
     field.exp_avg_sq.zero_()
     field.grads.zero_()
+    # Adam's own step count is the age of ITS moments (bias correction), not the runner's iteration count: zero moments restart
+    # at 0 whatever global_step says (steps skipped by the reference's GradScaler make the two differ, too)
+    field.adam_steps = 0
     if 'optimizer' in ck:
         step = load_optimizer_state_dict(field, ck['optimizer'])
         if step is not None:
-            field.global_step = step
+            field.adam_steps = int(step)
     return int(ck.get('global_step', 0))

@@ -274,14 +274,38 @@ __global__ __launch_bounds__(256) void k_hash_bwd_agg(NofHashGrid g, LevelList l
     const int dist = lane - (63 - __builtin_clzll((heads & le) | 1ull));   // distance to the run's first lane (valid lanes)
     const float t1 = dist >= 1 ? 1.0f : 0.0f, t2 = dist >= 2 ? 1.0f : 0.0f, t4 = dist >= 4 ? 1.0f : 0.0f,
                 t8 = dist >= 8 ? 1.0f : 0.0f, t15 = dist > (lane & 15) ? 1.0f : 0.0f, t31 = dist >= lane - 31 ? 1.0f : 0.0f;
+#ifdef NOF_AGG_PERTURB
+    // Test build only (libnof_hash_perturb.so, tests/test_gpu_ops.py): two dozen extra values stay live across the hand-written DPP
+    // block below, which moves every register the block uses.  The block's hazard padding (the s_nop, the >= 16-instruction
+    // spacing) must not depend on where the allocator put things: round 2 saw inline-assembly VALU code in the MLP kernels
+    // miscompute after an unrelated change moved the allocation.
+    float pert[24];
+#pragma unroll
+    for (int i = 0; i < 24; ++i) pert[i] = sc.vx[i & 7] * (float)(i + 1) + (float)lane;
+#define AGG_PIN_PERT()                                                                                                  \
+  _Pragma("unroll") for (int i = 0; i < 24; ++i) asm volatile("" : "+v"(pert[i]))
+#else
+#define AGG_PIN_PERT()
+#endif
     AGG_SCAN_STEP(sc, t1, "row_shr:1 row_mask:0xf bank_mask:0xf");
+    AGG_PIN_PERT();
     AGG_SCAN_STEP(sc, t2, "row_shr:2 row_mask:0xf bank_mask:0xf");
+    AGG_PIN_PERT();
     if (__ballot(valid && dist >= 4)) {
       AGG_SCAN_STEP(sc, t4, "row_shr:4 row_mask:0xf bank_mask:0xf");
       if (__ballot(valid && dist >= 8)) AGG_SCAN_STEP(sc, t8, "row_shr:8 row_mask:0xf bank_mask:0xf");
     }
     AGG_SCAN_STEP(sc, t15, "row_bcast:15 row_mask:0xa bank_mask:0xf");   // lane 15 / 47 into rows 1 / 3
     AGG_SCAN_STEP(sc, t31, "row_bcast:31 row_mask:0xc bank_mask:0xf");   // lane 31 into rows 2, 3
+    AGG_PIN_PERT();
+#ifdef NOF_AGG_PERTURB
+    {
+      float ps = 0.0f;
+#pragma unroll
+      for (int i = 0; i < 24; ++i) ps += pert[i];
+      if (ps == 1.2345678e30f) sc.vx[0] += ps;                        // keeps the values alive; never true
+    }
+#endif
     // 2. how a run chains to the runs next to it (lane-adjacent runs only: an out-of-range sample breaks the chain).  The
     //    cell before the run's first lane and the one before that come through ds_bpermute.
     const int hd = lane - dist;                                       // first lane of this lane's run

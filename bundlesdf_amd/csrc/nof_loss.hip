@@ -411,7 +411,7 @@ extern "C" int nof_adam_step(float* params, float* grads, float* exp_avg, float*
 // independent loads in flight per lane; one fp32 atomic per (column, row range) at the end.
 #define RED_RSPLIT 2
 __global__ __launch_bounds__(1024) void k_reduce_partials(const float* __restrict__ partials, int n_rows, int n_cols,
-                                                           float* __restrict__ out) {
+                                                           float* __restrict__ out, int32_t* __restrict__ flags) {
   __shared__ float sm[32][33];
   const int c = threadIdx.x & 31, grp = threadIdx.x >> 5;
   const int col = blockIdx.x * 32 + c;
@@ -433,14 +433,17 @@ __global__ __launch_bounds__(1024) void k_reduce_partials(const float* __restric
 #pragma unroll
     for (int g = 0; g < 32; ++g) s += sm[g][c];
     atomicAdd(&out[col], s);
+    // a non-finite weight gradient = an overflow inside the 16-bit backward (the reference's GradScaler would skip the step and
+    // back its scale off, nerf_runner.py:756-761): raised as bit 2 of flags[0] for the host to act on, no host sync here
+    if (flags != nullptr && !(fabsf(s) <= 3.0e38f)) atomicOr(&flags[0], 4);
   }
 }
 
-extern "C" int nof_reduce_partials(const float* partials, int32_t n_rows, int32_t n_cols, float* out, void* stream) {
+extern "C" int nof_reduce_partials(const float* partials, int32_t n_rows, int32_t n_cols, float* out, int32_t* flags, void* stream) {
   NOF_ARG(partials && out && n_rows >= 0 && n_cols >= 0);
   if (n_cols == 0 || n_rows == 0) return 0;
   hipLaunchKernelGGL(k_reduce_partials, dim3((unsigned)nof_div_up(n_cols, 32), RED_RSPLIT), dim3(1024), 0, (hipStream_t)stream,
-                     partials, n_rows, n_cols, out);
+                     partials, n_rows, n_cols, out, flags);
   NOF_LAUNCH_OK();
   return 0;
 }

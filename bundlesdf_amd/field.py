@@ -84,7 +84,10 @@ class NeuralObjectField:
         self.flags = torch.zeros(4, dtype=torch.int32, device=dev)
         self.occ_bits = None
         self.level = None
-        self.global_step = 0
+        self.global_step = 0         # drives the schedules (learning rate, truncation) and the sampler's Philox step
+        self.adam_steps = 0          # optimiser steps behind the Adam moments (bias correction): equal to global_step unless a
+                                     # checkpoint brought parameters without moments, or moments of a different age
+        self._scale_backoff = 0      # halvings of the fp16 loss scale after a reported overflow (poll_flags)
         self._bufs = {}
         self.nblk = lib.load().nof_mlp_wide_partial_rows() if self.wide else lib.load().nof_mlp_bwd_blocks()
         self.packed = torch.empty(int(lib.load().nof_mlp_packed_bytes(C.byref(self.desc))), dtype=torch.uint8, device=dev)
@@ -116,13 +119,21 @@ class NeuralObjectField:
         b.record()
         prof.setdefault(key, []).append((a, b))
 
-    def kernel_times_ms(self):
-        """average launch duration per C-ABI entry point (ms); all launches go to torch's current stream, which is
-        also the stream the events are recorded on."""
+    def kernel_times_ms(self, stat='mean', skip=0):
+        """launch duration per timed call (ms; `stat`: 'mean' or 'median' over the recorded launches, the first `skip` of each
+        left out: a kernel's first launch includes loading its code object); the events are recorded on the stream the launch
+        goes to."""
         if not self.profile:
             return {}
         torch.cuda.synchronize()
-        return {k: float(np.mean([a.elapsed_time(b) for a, b in v])) for k, v in self.profile.items() if v}
+        f = np.median if stat == 'median' else np.mean
+        out = {}
+        for k, v in self.profile.items():
+            t = [a.elapsed_time(b) for a, b in v]
+            t = t[skip:] if len(t) > skip else t
+            if t:
+                out[k] = float(f(t))
+        return out
 
     # ---- views into the flat buffers ------------------------------------------------------------
     def _seg(self, buf, which):
@@ -262,7 +273,19 @@ class NeuralObjectField:
         loss gradient is O(weight / B): the scale brings it to O(weight / 16), far inside binary16's normal range and
         three orders of magnitude below its maximum.  Applied and removed inside nof_mlp_bwd; exact (power of two)."""
         if self.desc.precision in FP16_MODES:
-            self.desc.grad_scale = float(2 ** int(min(16, max(0, math.floor(math.log2(max(B, 16) / 16.0))))))
+            e = int(min(16, max(0, math.floor(math.log2(max(B, 16) / 16.0))))) - self._scale_backoff
+            self.desc.grad_scale = float(2 ** max(e, 0))
+
+    def poll_flags(self):
+        """Host side of the device flags (ONE sync; the runner calls it at its print interval and at the end of training, never
+        inside a step).  Bit 2 = a non-finite weight gradient came out of the 16-bit backward: where the reference's GradScaler
+        skips the step and halves its scale (nerf_runner.py:756-761), the loss scale of the following steps is halved here and the
+        bit is cleared; the other bits (1 = a ray exceeded max_hits, 2 = inconsistent sample walk) are returned as they are."""
+        v = int(self.flags[0].item())
+        if v & 4:
+            self._scale_backoff += 1
+            self.flags[0] = v & ~4
+        return v
 
     def _loss_cfg(self):
         cfg = self.cfg
@@ -357,7 +380,7 @@ class NeuralObjectField:
                 wide_aux.wait_stream(main)
                 with torch.cuda.stream(wide_aux):
                     wide_bwd(8, 'wide_bwd[dW sigma]')
-                    self._call('nof_reduce_partials', b['partials'], self.nblk, self.n_mlp, self._seg(self.grads, 'mlp'))
+                    self._call('nof_reduce_partials', b['partials'], self.nblk, self.n_mlp, self._seg(self.grads, 'mlp'), self.flags)
         else:
             self._call('nof_mlp_bwd_tiles', C.byref(self.desc), self.packed, b['feat'], self.L, b['view'], S, b['draw'], b['sig'],
                        b['dsig'], b['dfeat'], b['dview'], b['partials'], tiles, B)
@@ -378,9 +401,9 @@ class NeuralObjectField:
 
         def reduce_mlp():
             if wide_aux is None:                                     # (the wide path reduced its rows on its third stream)
-                self._call('nof_reduce_partials', b['partials'], self.nblk, self.n_mlp, self._seg(self.grads, 'mlp'))
+                self._call('nof_reduce_partials', b['partials'], self.nblk, self.n_mlp, self._seg(self.grads, 'mlp'), self.flags)
             if self.eikonal:
-                self._call('nof_reduce_partials', b['partials_e'], self.nblk, self.n_mlp, self._seg(self.grads, 'mlp'))
+                self._call('nof_reduce_partials', b['partials_e'], self.nblk, self.n_mlp, self._seg(self.grads, 'mlp'), self.flags)
 
         def hash_bwd(parts, lo, hi):
             """the kernels `parts` of the hash backward for the table levels [lo, hi), on the current stream (the library owns no
@@ -472,12 +495,14 @@ class NeuralObjectField:
             self._call('nof_step_state_advance', self._state, C.c_float(cfg['lrate']), C.c_float(cfg['lrate_pose']),
                        C.c_float(cfg['decay_rate']), int(cfg['n_step']) + 1, C.c_float(0.9), C.c_float(0.999), -1)
             self.global_step += 1
+            self.adam_steps += 1
             return
         lr, lr_pose = self.learning_rates()
         self._call('nof_adam_step', self.params, self.grads, self.exp_avg, self.exp_avg_sq, self.n_total, self.n_basic,
                  C.c_float(lr), C.c_float(lr_pose), C.c_float(0.9), C.c_float(0.999), C.c_float(1e-15),
-                 self.global_step + 1)
+                 self.adam_steps + 1)
         self.global_step += 1
+        self.adam_steps += 1
 
     # ---- renderer side ------------------------------------------------------------------------------------
     def query_sdf(self, pts, chunk=1 << 22):
@@ -539,8 +564,12 @@ class GraphedStep:
     def __init__(self, field, pool, R, seed):
         self.field, self.R = field, R
         self.ids = torch.zeros(R, dtype=torch.int64, device=field.device)
+        # every persistent buffer of the step exists BEFORE the capture starts: allocated inside it they would live in the graph's
+        # private pool (and be reused by eager steps after the graph is dropped)
+        field._buffers(R, field.cfg['N_samples'] + field.cfg['N_samples_around_depth'])
+        field._side_stream()
         field.sync_step_state()
-        step0 = field.global_step
+        step0, adam0 = field.global_step, field.adam_steps
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
         s = torch.cuda.Stream()
@@ -549,16 +578,18 @@ class GraphedStep:
             with torch.cuda.graph(self.graph, stream=s):
                 field.train_step(pool, self.ids, R, seed=seed, dyn=True)
         torch.cuda.current_stream().wait_stream(s)
-        field.global_step = step0              # capturing executes nothing: only the host-side counter moved
+        field.global_step, field.adam_steps = step0, adam0       # capturing executes nothing: only the host-side counters moved
         field._packed_step = None
         self.trunc = field.truncation()
 
     def usable(self):
         f = self.field
-        return f.profile is None and f.truncation() == self.trunc
+        # (the device step state drives the schedule AND Adam's bias correction from one counter)
+        return f.profile is None and f.truncation() == self.trunc and f.adam_steps == f.global_step
 
     def __call__(self, ids):
         self.ids.copy_(ids)
         self.graph.replay()
         self.field.global_step += 1
+        self.field.adam_steps += 1
         self.field._packed_step = None         # the fragment image inside the graph belongs to the parameters before this step

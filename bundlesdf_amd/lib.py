@@ -80,7 +80,7 @@ _SIGNATURES = {
     'nof_mlp_fwd': ([C.POINTER(NofMlpDesc), _P, _P, _I32, _P, _I32, _P, _P, _I64, _P], C.c_int),
     'nof_mlp_bwd_blocks': ([], C.c_int),
     'nof_mlp_bwd': ([C.POINTER(NofMlpDesc), _P, _P, _I32, _P, _I32, _P, _P, _P, _P, _P, _P, _I64, _P], C.c_int),
-    'nof_reduce_partials': ([_P, _I32, _I32, _P, _P], C.c_int),
+    'nof_reduce_partials': ([_P, _I32, _I32, _P, _P, _P], C.c_int),
     'nof_mlp_sdf': ([C.POINTER(NofMlpDesc), _P, _P, _I32, _P, _I64, _P], C.c_int),
     'nof_composite_loss': ([C.POINTER(NofLossCfg), _P, _P, _P, _P, _I64, _I32, _P, _P, _P, _P, _P, _P], C.c_int),
     'nof_pose_grad_accum': ([_P, _P, _P, _P, _P, _P, _I32, _I32, _I64, _I32, _P, _P], C.c_int),

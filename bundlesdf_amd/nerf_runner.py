@@ -135,6 +135,7 @@ class NerfRunner:
         self.field.exp_avg_sq.zero_()
         self.field.grads.zero_()
         self.field.global_step = 0
+        self.field.adam_steps = 0
         self.field._packed_step = None
 
     # ---- occupancy ---------------------------------------------------------------------------------------
@@ -246,6 +247,8 @@ class NerfRunner:
             self._eager_steps += 1
             f.train_step(self.rays, ids, ids.shape[0], seed=seed, grad_sync=self.grad_sync)
         if self.global_step % self.cfg['i_print'] == 0 and self.global_step > 0:
+            if self.field.poll_flags() & 4:
+                logging.warning('non-finite weight gradient in the fp16 backward: loss scale halved for the following steps')
             m = self.field.losses()
             logging.info(f"Iter: {self.global_step}, " + ", ".join(f"{k}: {v:.7f}" for k, v in m.items()))
         if self.global_step % self.cfg['i_weights'] == 0 and self.global_step > 0 and self.cfg.get('save_dir'):
@@ -259,9 +262,10 @@ class NerfRunner:
             self.train_loop()
             self.global_step += 1
         torch.cuda.synchronize()
-        flags = int(self.field.flags[0].item())
+        flags = self.field.poll_flags()
         if flags:
-            logging.warning(f"nof flags={flags}: 1 = ray exceeded max_hits, 2 = inconsistent sample walk (common.cu:66-72)")
+            logging.warning(f"nof flags={flags}: 1 = ray exceeded max_hits, 2 = inconsistent sample walk (common.cu:66-72), "
+                            f"4 = non-finite weight gradient in the 16-bit backward (loss scale halved)")
 
     def get_truncation(self):
         return self.field.truncation()
@@ -355,7 +359,7 @@ class NerfRunner:
             torch.save(to_reference_checkpoint(f, self.global_step), out_file)
         else:
             torch.save({'global_step': self.global_step, 'params': f.params.cpu(), 'exp_avg': f.exp_avg.cpu(),
-                        'exp_avg_sq': f.exp_avg_sq.cpu(), 'field_step': f.global_step,
+                        'exp_avg_sq': f.exp_avg_sq.cpu(), 'field_step': f.global_step, 'adam_steps': f.adam_steps,
                         'octree': (f.occ_bits.cpu() if f.occ_bits is not None else None, f.level, f.max_level)}, out_file)
         print('Saved checkpoints at', out_file)
 
@@ -365,10 +369,8 @@ class NerfRunner:
         ck = torch.load(ckpt_path)
         f = self.field
         if 'params' not in ck and 'model' in ck:
-            f.global_step = 0
-            self.global_step = load_reference_checkpoint(f, ck)      # sets f.global_step from the optimiser state when present
-            if f.global_step == 0:
-                f.global_step = self.global_step
+            self.global_step = load_reference_checkpoint(f, ck)      # (sets f.adam_steps: the age of the Adam moments it found)
+            f.global_step = self.global_step                         # schedules follow the runner's iteration count
             return
         f._packed_step = None                   # the MFMA weight image belongs to the old parameters
         f.grads.zero_()
@@ -376,4 +378,5 @@ class NerfRunner:
         f.exp_avg.copy_(ck['exp_avg'].to(f.device))
         f.exp_avg_sq.copy_(ck['exp_avg_sq'].to(f.device))
         f.global_step = ck['field_step']
+        f.adam_steps = ck.get('adam_steps', ck['field_step'])
         self.global_step = ck['global_step']

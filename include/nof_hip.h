@@ -222,8 +222,10 @@ int nof_mlp_bwd(const NofMlpDesc* h_desc, const void* packed, const float* feat,
 int nof_mlp_bwd_tiles(const NofMlpDesc* h_desc, const void* packed, const float* feat, int32_t L,
                       const float* view, int32_t S, const float* draw, const void* sigma_out, void* dsigma_ws,
                       float* dfeat, float* dview, float* partials, const void* tile_list, int64_t B, void* stream);
-/* out[j] += sum_i partials[i,j] */
-int nof_reduce_partials(const float* partials, int32_t n_rows, int32_t n_cols, float* out, void* stream);
+/* out[j] += sum_i partials[i,j].  flags (int32, may be NULL): flags[0] |= 4 when a column sum is not finite -- an overflow inside the
+ * 16-bit backward, where the reference's GradScaler would skip the step and back off (nerf_runner.py:756-761); the host polls the
+ * flag and lowers NofMlpDesc.grad_scale (bundlesdf_amd/field.py), the step itself never synchronises. */
+int nof_reduce_partials(const float* partials, int32_t n_rows, int32_t n_cols, float* out, int32_t* flags, void* stream);
 /* sigma_net only: feat [L,B,2] -> sdf [B]  (NeRFSmall.forward_sdf, nerf_helpers.py:296-302) */
 int nof_mlp_sdf(const NofMlpDesc* h_desc, const void* packed, const float* feat, int32_t L,
                 float* sdf, int64_t B, void* stream);

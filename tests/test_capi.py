@@ -68,6 +68,25 @@ def test_mlp_kernels_have_no_inline_assembly_instructions():
             assert m.group(1).strip() == '', (name, m.group(1))
 
 
+def test_inline_assembly_is_confined_to_the_listed_blocks():
+    """Every asm statement that emits an instruction, in every source: the scatter's DPP scan step (nof_hash.hip: AGG_SCAN_STEP =
+    one s_nop + sixteen v_fmac_f32_dpp, hazard padding inside the statement; a register-perturbed build of it runs in
+    tests/test_gpu_ops.py) and the atomic / hardware-register probes of the test hook in nof_capi.hip.  Anything else fails."""
+    src = os.path.join(ROOT, 'bundlesdf_amd', 'csrc')
+    allowed = {'nof_hash.hip': re.compile(r'^(s_nop 4|v_fmac_f32_dpp\b.*)$'),
+               'nof_capi.hip': re.compile(r'^(global_atomic_(pk_)?add_f(16|32)\b.*|s_getreg_b32\b.*|s_waitcnt vmcnt\(0\))$')}
+    for name in sorted(os.listdir(src)):
+        if not name.endswith(('.hip', '.h')):
+            continue
+        text = open(os.path.join(src, name)).read().replace('\\\n', ' ')       # (macro line continuations)
+        text = re.sub(r'#define AGG_F\(i, ctrl\) "v_fmac_f32_dpp %" #i ", %" #i ", %16 " ctrl "\\n\\t"', '#define AGG_F(i, ctrl) "v_fmac_f32_dpp x"', text)
+        for m in re.finditer(r'asm\s*(?:volatile)?\s*\(((?:\s*"(?:[^"\\]|\\.)*"|\s*AGG_F\([^)]*\))+)', text):
+            body = re.sub(r'AGG_F\([^)]*\)', '"v_fmac_f32_dpp x\\n\\t"', m.group(1))
+            code = ''.join(re.findall(r'"((?:[^"\\]|\\.)*)"', body)).replace('\\n', '\n').replace('\\t', ' ')
+            for line in filter(None, (l.strip() for l in code.split('\n'))):
+                assert name in allowed and allowed[name].match(line), (name, line)
+
+
 def test_library_owns_no_stream_and_reads_no_environment():
     """include/nof_hip.h: "nothing here allocates or synchronises the host".  Round 2's hash backward created a hidden side stream
     and two events on first use and read an environment variable; what runs beside what is the caller's business now

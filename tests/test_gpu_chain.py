@@ -20,7 +20,7 @@ def test_oracle_is_pinned_on_this_box():
     assert RN.load() is not None, 'oracle/_ref/libnof_ref.so is missing: the compiled reference kernels did not travel'
     r = subprocess.run([sys.executable, '-m', 'pytest', '-q', '-x', '-p', 'no:cacheprovider', 'tests/test_oracle.py',
                         'tests/test_ref_native.py', 'tests/test_host_logic.py', 'tests/test_scene_io.py', 'tests/test_mesh.py'],
-                       cwd=ROOT, capture_output=True, text=True, timeout=1500)
+                       cwd=ROOT, capture_output=True, text=True, timeout=600)
     tail = '\n'.join(r.stdout.splitlines()[-15:])
     print(tail)
     assert r.returncode == 0, tail + '\n' + r.stderr[-2000:]

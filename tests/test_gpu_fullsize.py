@@ -107,7 +107,7 @@ def test_mlp_tile_independence_and_split_equals_fused(nof, precision):
         nof.call('nof_mlp_bwd', C.byref(desc), packed, feat, L, view, S, draw, sig if split else None, dsig if split else None,
                  dfeat, dview, partials, B)
         gflat = torch.zeros(desc.n_params, device='cuda')
-        nof.call('nof_reduce_partials', partials, nblk, desc.n_params, gflat)
+        nof.call('nof_reduce_partials', partials, nblk, desc.n_params, gflat, None)
         out.append((dfeat, dview, gflat))
     torch.cuda.synchronize()
     (df0, dv0, g0), (df1, dv1, g1) = out

@@ -32,6 +32,45 @@ def test_mfma_operand_layout(nof, precision, K, tol):
 
 
 # ------------------------------------------------------------------------------------------------
+def test_scatter_survives_a_different_register_allocation(nof):
+    """libnof_hash_perturb.so = nof_hash.hip built with -DNOF_AGG_PERTURB: two dozen extra values live across the scatter's
+    hand-written DPP scan block, so every register the block touches sits somewhere else.  The table gradient of ray-coherent
+    samples (long runs, chains across cells: the paths the block serves) must equal the regular build's up to the atomics' order."""
+    import os
+    from bundlesdf_amd import build as B
+    path = B.PERTURB_LIB
+    assert os.path.exists(path), f'{path} is missing: __graft_entry__.build() builds it'
+    alt = C.CDLL(path)
+    fn = alt.nof_hash_encode_bwd
+    fn.restype = C.c_int
+    fn.argtypes = [C.POINTER(nof.NofHashGrid)] + [C.c_void_p] * 5 + [C.c_int64, C.c_void_p]
+    g, geo = U.make_grids(nof, L=16, T=19, finest=256)
+    R, S = 256, 192
+    Bn = R * S
+    gen = torch.Generator(device='cuda').manual_seed(2)
+    o = torch.randn(R, 3, device='cuda', generator=gen)
+    o = o / o.norm(dim=1, keepdim=True) * 1.6
+    d = (torch.rand(R, 3, device='cuda', generator=gen) - 0.5) * 1.2 - o
+    d = d / d.norm(dim=1, keepdim=True)
+    t = torch.linspace(0.55, 2.4, S, device='cuda')[None, :, None] + torch.rand(R, S, 1, device='cuda', generator=gen) * 0.004
+    pts = (o[:, None, :] + t * d[:, None, :]).reshape(Bn, 3).contiguous()
+    table = (torch.rand(geo.n_entries, 2, device='cuda', generator=gen) - 0.5) * 0.2
+    dfeat = torch.randn(16, Bn, 2, device='cuda', generator=gen)
+    want = torch.zeros(geo.n_entries, 2, device='cuda')
+    nof.call('nof_hash_encode_bwd', C.byref(g), pts, table, dfeat, want, None, Bn)
+    got = torch.zeros(geo.n_entries, 2, device='cuda')
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    rc = fn(C.byref(g), C.c_void_p(pts.data_ptr()), C.c_void_p(table.data_ptr()), C.c_void_p(dfeat.data_ptr()),
+            C.c_void_p(got.data_ptr()), None, Bn, st)
+    torch.cuda.synchronize()
+    assert rc == 0
+    assert (got - want).abs().max().item() <= 2e-5 * want.abs().max().item()
+    off = geo.offsets
+    for l in range(16):                                          # level by level: a coarse level cannot hide a fine one
+        a, b = got[off[l]:off[l + 1]], want[off[l]:off[l + 1]]
+        assert (a - b).norm().item() <= 1e-5 * b.norm().item(), l
+
+
 @pytest.mark.parametrize("L,T,finest", [(16, 14, 256), (4, 22, 128), (16, 19, 512)])
 def test_hash_forward_backward(nof, L, T, finest):
     g, geo = U.make_grids(nof, L=L, T=T, finest=finest)
@@ -362,7 +401,7 @@ def test_mlp_backward(nof, ns, nc, ff, L, precision, split):
         nof.call('nof_mlp_fwd', C.byref(desc), packed, d_feat, L, view.cuda(), S, raw, sig, B)
     nof.call('nof_mlp_bwd', C.byref(desc), packed, d_feat, L, view.cuda(), S, draw.cuda(), sig, dsig, dfeat, dview, partials, B)
     gflat = torch.zeros(desc.n_params, device='cuda')
-    nof.call('nof_reduce_partials', partials, nblk, desc.n_params, gflat)
+    nof.call('nof_reduce_partials', partials, nblk, desc.n_params, gflat, None)
     torch.cuda.synchronize()
     ref_df = feat.grad.numpy()
     got_df = cpu(dfeat).transpose(1, 0, 2).reshape(B, 2 * L)
@@ -423,7 +462,7 @@ def test_mlp_wide_forward_backward(nof, ns, nc, hidden, ff, L, precision):
     partials = torch.full((rows, desc.n_params), 5.0, device='cuda')
     nof.call('nof_mlp_wide_bwd', C.byref(desc), packed, d_feat, L, view.cuda(), S, draw.cuda(), ws, dfeat, dview, partials, B)
     gflat = torch.zeros(desc.n_params, device='cuda')
-    nof.call('nof_reduce_partials', partials, rows, desc.n_params, gflat)
+    nof.call('nof_reduce_partials', partials, rows, desc.n_params, gflat, None)
     torch.cuda.synchronize()
     scale = np.abs(ref32).max()
     e32, em = np.abs(cpu(raw) - ref32).max() / scale, np.abs(cpu(raw) - ref_m).max() / scale
@@ -480,7 +519,7 @@ def test_mlp_backward_fp16_loss_scale(nof):
         nof.call('nof_mlp_fwd', C.byref(desc), packed, d_feat, L, view.cuda(), S, raw, sig, B)
         nof.call('nof_mlp_bwd', C.byref(desc), packed, d_feat, L, view.cuda(), S, draw.cuda(), sig, dsig, dfeat, dview, partials, B)
         gflat = torch.zeros(desc.n_params, device='cuda')
-        nof.call('nof_reduce_partials', partials, nblk, desc.n_params, gflat)
+        nof.call('nof_reduce_partials', partials, nblk, desc.n_params, gflat, None)
         torch.cuda.synchronize()
         errs[scale] = (rel_l2(cpu(dfeat).transpose(1, 0, 2).reshape(B, 2 * L), ref_df), rel_l2(cpu(gflat), ref_g))
     print('fp16 backward, |draw| ~ 3e-7: rel-L2 (dfeat, dW) without / with the loss scale:', errs)

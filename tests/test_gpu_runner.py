@@ -150,12 +150,12 @@ def test_checkpoint_roundtrip(nof, tmp_path):
     for _ in range(3):
         fld.train_step(pool, None, 128, seed=1)
     snap = {k: getattr(fld, k).clone() for k in ('params', 'exp_avg', 'exp_avg_sq')}
-    step = fld.global_step
+    step, adam = fld.global_step, fld.adam_steps
     fld.train_step(pool, None, 128, seed=1)
     after = fld.params.clone()
     for k, v in snap.items():
         getattr(fld, k).copy_(v)
-    fld.global_step = step
+    fld.global_step, fld.adam_steps = step, adam
     fld.grads.zero_()
     fld.train_step(pool, None, 128, seed=1)
     torch.cuda.synchronize()
@@ -182,11 +182,17 @@ def test_reference_format_checkpoint_roundtrip(nof, tmp_path):
     assert ck2['embed_fn']['embeddings'].shape == (fld.n_entries, 2) and ck2['pose_array']['data'].shape == (fld.F, 6)
     before, m, v = fld.params.clone(), fld.exp_avg.clone(), fld.exp_avg_sq.clone()
     fld.params.zero_()
-    fld.global_step = 0
+    fld.global_step = fld.adam_steps = 0
     assert load_reference_checkpoint(fld, ck2) == 3
     torch.cuda.synchronize()
     assert torch.equal(fld.params, before)
-    assert torch.equal(fld.exp_avg, m) and torch.equal(fld.exp_avg_sq, v) and fld.global_step == 3 and float(m.abs().sum()) > 0
+    # the Adam moments come back with THEIR step count (bias correction); the schedule step is the caller's (ck['global_step'])
+    assert torch.equal(fld.exp_avg, m) and torch.equal(fld.exp_avg_sq, v) and fld.adam_steps == 3 and float(m.abs().sum()) > 0
+    # a checkpoint without optimiser state: parameters at iteration 3, moments of age 0 (a bias correction for step 4 on
+    # zero moments would shrink the first updates by 1 - beta^4)
+    ck3 = {k: v for k, v in ck2.items() if k != 'optimizer'}
+    ck3['embed_fn'] = ck['embed_fn']
+    assert load_reference_checkpoint(fld, ck3) == 3 and fld.adam_steps == 0 and float(fld.exp_avg.abs().sum()) == 0
     ck2['embed_fn']['embeddings'] = ck2['embed_fn']['embeddings'][:-8]
     with pytest.raises(ValueError):
         load_reference_checkpoint(fld, ck2)

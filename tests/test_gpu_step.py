@@ -183,13 +183,19 @@ def test_wide_network_step_matches_oracle(nof):
     both = cpu(b['valid']).reshape(R, S).astype(bool) & ref['fwd']['valid_samples'].numpy()
     raw_ref = ref['fwd']['raw'].detach().numpy()
     raw = cpu(b['raw']).reshape(R, S, 4)
-    e = rel_max(raw[both], raw_ref[both])
-    print(f'wide 4x128 fp16 step: raw rel-max {e:.2e}')
-    assert e < 3e-3
+    e_rgb, e_sdf = rel_max(raw[both][:, :3], raw_ref[both][:, :3]), rel_max(raw[both][:, 3], raw_ref[both][:, 3])
+    # beside it, for the record: the distance to the PURE fp32 oracle (north_star's yardstick; no operand split on this path)
+    orc32 = O.OracleField(cfg, orc.geo, orc.shape, fld.F, cpu(fld.c2w).reshape(-1, 4, 4), orc.occ_l, table=cpu(fld.table).reshape(-1, 2),
+                          mlp=[[W.clone(), bb.clone()] for W, bb in fld.mlp_state()], pose=cpu(fld.pose).reshape(-1, 6))
+    with torch.no_grad():
+        raw32 = orc32.forward(torch.from_numpy(batch), ref['z_vals'])['raw'].numpy()
+    print(f'wide 4x128 fp16 step: colour {e_rgb:.2e} sdf {e_sdf:.2e} (max-norm, vs the oracle with fp16 operand rounding); '
+          f'vs the pure fp32 oracle: colour {rel_max(raw[both][:, :3], raw32[both][:, :3]):.2e} sdf {rel_max(raw[both][:, 3], raw32[both][:, 3]):.2e}')
+    assert e_rgb < 1e-3 and e_sdf < 1e-3                  # north_star's bar, SDF / colour separately
     Lo = fld.losses()
     for k in ('loss', 'rgb_loss', 'fs_loss', 'sdf_loss'):
         r = float(ref['losses'][k])
-        assert abs(Lo[k] - r) <= 5e-3 * abs(r) + 1e-7, (k, Lo[k], r)
+        assert abs(Lo[k] - r) <= 2e-3 * abs(r) + 1e-7, (k, Lo[k], r)
     names = ['table'] + [f'mlp{i}' for i in range(2 * (ns + nc))] + ['pose']
     g_ref = dict(zip(names, ref['grads']))
     gt = cpu(fld._seg(fld.grads, 'table')).reshape(-1, 2)

@@ -134,7 +134,7 @@ def test_mlp_backward_over_the_list_equals_whole_batch(nof, ns, nc, precision, R
         nof.call('nof_mlp_bwd_tiles', C.byref(desc), packed, feat, L, view, S, draw, sig, dsig, dfeat, dview, partials,
                  None if mode == 'whole' else tl, B)
         g = torch.zeros(desc.n_params, device='cuda')
-        nof.call('nof_reduce_partials', partials, nblk, desc.n_params, g)
+        nof.call('nof_reduce_partials', partials, nblk, desc.n_params, g, None)
         torch.cuda.synchronize()
         out[mode] = (cpu(dfeat), cpu(dview), cpu(g))
     nt = (B + 31) // 32
@@ -187,7 +187,7 @@ def test_wide_backward_over_the_list_equals_whole_batch(nof, ns, nc, hidden, pre
         nof.call('nof_mlp_wide_bwd_tiles', C.byref(desc), packed, feat, L, view, S, draw, ws, dfeat, dview, partials,
                  None if mode == 'whole' else tl, B)
         g = torch.zeros(desc.n_params, device='cuda')
-        nof.call('nof_reduce_partials', partials, rows, desc.n_params, g)
+        nof.call('nof_reduce_partials', partials, rows, desc.n_params, g, None)
         torch.cuda.synchronize()
         out[mode] = (cpu(dfeat), cpu(dview), cpu(g))
     nt = (B + 31) // 32

@@ -279,6 +279,7 @@ def test_reference_checkpoint_carries_a_loadable_adam_state():
             self.params, self.grads = torch.randn(n, generator=g), torch.zeros(n)
             self.exp_avg, self.exp_avg_sq = torch.randn(n, generator=g), torch.rand(n, generator=g)
             self.global_step = 37
+            self.adam_steps = 37                  # the age of the Adam moments (bias correction): what 'optimizer' carries
             self._packed_step = 0
 
         def learning_rates(self):
@@ -314,9 +315,9 @@ def test_reference_checkpoint_carries_a_loadable_adam_state():
     # ... and back: a fresh field takes parameters, moments and the step count from the reference-format file
     g = CpuField()
     g.params.zero_(), g.exp_avg.zero_(), g.exp_avg_sq.zero_()
-    g.global_step = 0
-    assert ck.load_reference_checkpoint(g, data) == 37
-    assert g.global_step == 37
+    g.global_step = g.adam_steps = 0
+    assert ck.load_reference_checkpoint(g, data) == 37   # the runner's iteration count: the caller sets its schedules from it
+    assert g.adam_steps == 37
     assert torch.equal(g.params, f.params) and torch.equal(g.exp_avg, f.exp_avg) and torch.equal(g.exp_avg_sq, f.exp_avg_sq)
 
 

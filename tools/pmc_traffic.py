@@ -1,8 +1,9 @@
-"""profiles/pmc_traffic.json from the FETCH_SIZE / WRITE_SIZE passes of tools/gpu_pmc.sh (run on the GPU box, where the
+"""profiles/pmc_traffic.json from the FETCH_SIZE / WRITE_SIZE passes of tools/gpu_evidence.sh (leg "traffic") (run on the GPU box, where the
 rocprofv3 databases are): HBM-side bytes per launch of every C-ABI entry point bench.py can name as dominant."""
 import glob, json, sqlite3, sys
 
 out_path = sys.argv[1] if len(sys.argv) > 1 else 'gpurun_out/pmc_traffic.json'
+source = sys.argv[2] if len(sys.argv) > 2 else 'the FETCH_SIZE / WRITE_SIZE summary of the same round in profiles/'
 
 
 def per_kernel(dbdir, counter):
@@ -14,8 +15,10 @@ def per_kernel(dbdir, counter):
 
 fetch, write = per_kernel('pmc_fetch', 'FETCH_SIZE'), per_kernel('pmc_write', 'WRITE_SIZE')
 # kernels of each C-ABI entry point, by name prefix (the template arguments follow the bench's precision / network shape)
-groups = {'nof_hash_encode_bwd': ['k_hash_bwd_agg', 'k_hash_dx', 'k_hash_bwd_lds'], 'nof_hash_encode_fwd': ['k_hash_fwd'],
-          'nof_mlp_bwd': ['k_mlp_bwd_color<', 'k_mlp_bwd_sigma<'], 'nof_mlp_fwd': ['k_mlp_fwd<'], 'nof_adam_step': ['k_adam']}
+# (keys = the tags NeuralObjectField._call times its launches under: what bench.py names as the dominant entry)
+groups = {'hash_bwd[table+table_lds]': ['k_hash_bwd_agg', 'k_hash_bwd_lds'], 'hash_bwd[input]': ['k_hash_dx'],
+          'nof_hash_encode_fwd': ['k_hash_fwd'], 'nof_mlp_bwd_tiles': ['k_mlp_bwd_color<', 'k_mlp_bwd_sigma<'],
+          'nof_mlp_fwd': ['k_mlp_fwd<'], 'nof_adam_step': ['k_adam']}
 
 
 def total(table, prefixes):
@@ -23,7 +26,8 @@ def total(table, prefixes):
 out = {'_note': 'HBM-side bytes per launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, KiB * 1024), cfg2 batch '
                 '(4096 rays x 192 samples, L=16, T=2^19), summed over the kernels of each C-ABI entry point. RAW counter values: '
                 'on gfx950 FETCH_SIZE under-reports wide coalesced streaming reads by 2x (MI355X_MICROARCH.md, HBM section); for '
-                '8-byte gathers and atomics it is uncalibrated. Source: the FETCH_SIZE / WRITE_SIZE summary of the same round in profiles/ (r02_h_pmc_fetch_write.txt; zero-gradient tiles skipped, 200 warm-up steps)',
+                '8-byte gathers and atomics it is uncalibrated. Source: profiles/' + source + ' (backward over the work list of non-zero '
+                'tiles, 200 warm-up steps)',
        'workload': 'cfg2 batch, bench.py default precision (fp16x3), 16-keyframe pool'}
 for k, names in groups.items():
     f = total(fetch, names) * 1024
