@@ -77,9 +77,11 @@ def build_runner(args, rank, world, device):
     precision = args.precision
     if hidden != 64 or ns > 3 or nc > 3:        # the wide kernels have no operand split: fp16x3 / bf16x3 run as fp16 / bf16 there
         precision = {'fp16x3': 'fp16', 'bf16x3': 'bf16'}.get(precision, precision)
-    runner = NerfRunner(cfg, pool['rgbs'], depths=pool['depths'], masks=pool['masks'], normal_maps=None, poses=poses,
-                        K=pool['K'], build_octree_pcd=synthetic.PointCloud(cloud), precision=precision, n_sigma=ns,
-                        n_color=nc, world_size=world, rank=rank, grad_sync=sync, frame_offset=rank * F_local, hidden=hidden)
+    import contextlib
+    with contextlib.redirect_stdout(sys.stderr):    # the runner prints like the reference's does; stdout carries the ONE result line
+        runner = NerfRunner(cfg, pool['rgbs'], depths=pool['depths'], masks=pool['masks'], normal_maps=None, poses=poses,
+                            K=pool['K'], build_octree_pcd=synthetic.PointCloud(cloud), precision=precision, n_sigma=ns,
+                            n_color=nc, world_size=world, rank=rank, grad_sync=sync, frame_offset=rank * F_local, hidden=hidden)
     return runner, cfg
 
 

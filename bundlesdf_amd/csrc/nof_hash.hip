@@ -36,7 +36,7 @@ __global__ __launch_bounds__(256) void k_hash_fwd(NofHashGrid g, LevelList slots
   const int64_t b = (int64_t)(blockIdx.x / G) * 256 + threadIdx.x;
   if (b >= B) return;
   const float p[3] = {pts_w[b * 3], pts_w[b * 3 + 1], pts_w[b * 3 + 2]};
-  for (int s = blockIdx.x % G; s < g.L; s += G) {
+  for (int s = blockIdx.x % G; s < g.L; s += G) {                    // (unrolled by two: the same 80 us)
     const int level = slots.level[s];                                  // slot -> level: see xcd_level_slots()
     const HashLevel lv = load_level(g, level);
     const CellPos c = locate3(p, lv.scale);

@@ -459,7 +459,7 @@ class NeuralObjectField:
                 with torch.cuda.stream(side):
                     hash_bwd(INPUT, 0, self.L)
                     pose_kernels()
-                hash_bwd(BIG | SMALL, 0, self.L)
+                hash_bwd(BIG | SMALL, 0, self.L)                     # (the LDS levels on a third stream beside both: no gain)
                 reduce_mlp()
             main.wait_stream(side)
             if wide_aux is not None:

@@ -1,0 +1,5 @@
+#!/bin/bash
+# a few GPU tests with hard per-test timeouts:  gpurun -- 'bash tools/gpu_quick.sh "<pytest selection>"'
+cd "$GRAFT_REPO_ROOT" || exit 1
+mkdir -p gpurun_out; export TMPDIR=/tmp
+timeout ${2:-400} python -m pytest $1 -q -x --timeout=150 -p no:cacheprovider --durations=5 2>&1 | tail -25
