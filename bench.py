@@ -67,8 +67,10 @@ def build_runner(args, rank, world, device):
         dist.all_gather(cs, c)
         cloud = torch.cat(cs, 0).cpu().numpy()
     sync = None
-    if dist.is_initialized() and world > 1:  # RCCL sum; gradients are pre-scaled by 1/world_size on the device (a sum over one
-                                             # rank is the identity: a world-size-1 launch issues no collective at all)
+    # RCCL sum; gradients are pre-scaled by 1/world_size on the device.  A sum over one rank is the identity: a world-size-1
+    # launch issues no collective at all -- unless NOF_DP_FORCE=1 asks for them (tests/test_gpu_dp.py: the RCCL calls of the
+    # bucketed step, exercised on the one GPU a test box has)
+    if dist.is_initialized() and (world > 1 or os.environ.get('NOF_DP_FORCE') == '1'):
         from bundlesdf_amd.dist import GradSync
         sync = GradSync()                   # bucketed: the fine hash levels' slice is reduced beside the rest of the backward
         if os.environ.get('NOF_DP_OVERLAP', '1') == '0':
@@ -266,7 +268,7 @@ def main():
     if dominant != 'nof_hash_encode_fwd':
         fld.profile_also = 'nof_hash_encode_fwd'
     if sync is not None:
-        sync.timing = []
+        sync.timing, sync.timed_steps = [], 0
 
     def barrier():
         if dist.is_initialized():
@@ -297,7 +299,7 @@ def main():
     exposed_comm_ms = None
     if sync is not None and sync.timing:
         torch.cuda.synchronize()
-        exposed_comm_ms = float(np.mean([a.elapsed_time(b) for a, b in sync.timing]))
+        exposed_comm_ms = float(np.sum([a.elapsed_time(b) for a, b in sync.timing])) / max(sync.timed_steps, 1)
         sync.timing = None
     fld.profile, fld.profile_only, fld.profile_also = None, None, None
     # The same K steps with EVERY tile in the backward's work list (nothing skipped, same kernels): what the step costs when no
@@ -362,7 +364,8 @@ def main():
             # over the listed tiles only; one pass of a network = its 2 * MAC
             'wide_bwd[data colour]': ('mfma', B * (1.0 - zero_frac) * fl_net[1]), 'wide_bwd[data sigma]': ('mfma', B * (1.0 - zero_frac) * fl_net[0]),
             'wide_bwd[dW colour]': ('mfma', B * (1.0 - zero_frac) * fl_net[1]), 'wide_bwd[dW sigma]': ('mfma', B * (1.0 - zero_frac) * fl_net[0]),
-            'nof_adam_step': ('hbm', fld.n_total * 32.0),
+            # one GPU: the table's share of Adam runs early (field.py); the few KB behind it are 'nof_adam_step[rest]'
+            'nof_adam_step': ('hbm', (fld.n_table if world == 1 else fld.n_total) * 32.0),
         }
         traffic = None          # HBM bytes per launch from the committed PMC passes (profiles/pmc_traffic.json), same workload only
         hash_fwd_traffic = None

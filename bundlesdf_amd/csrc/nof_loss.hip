@@ -320,21 +320,47 @@ extern "C" int nof_tile_list_build(const float* draw, int64_t B, int32_t all, vo
 // ------------------------------------------------------------------------------------------------
 // torch.optim.Adam, single tensor form: m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2;
 // p -= (lr/bc1) * m / (sqrt(v)/sqrt(bc2) + eps).  HBM streaming: 16 B read + 16 B written per parameter.
+struct AdamK { float step_basic, step_pose, b1, b2, eps, inv_sqrt_bc2; };
+
+__device__ __forceinline__ void adam_one(float& p, float& g, float& m, float& v, float ss, const AdamK& k) {
+  const float mi = k.b1 * m + (1.0f - k.b1) * g;
+  const float vi = k.b2 * v + (1.0f - k.b2) * g * g;
+  const float denom = sqrtf(vi) * k.inv_sqrt_bc2 + k.eps;
+  p = p - ss * (mi / denom);
+  m = mi;
+  v = vi;
+  g = 0.0f;                                                            // optimizer.zero_grad() for the next step
+}
+
+// Entries [0, n) of the four flat buffers.  When they share their offset from a 16-byte boundary (they do: same index range of
+// four allocations) the body moves 16 bytes per lane and array -- 4x the bytes in flight of the scalar form, which is what a
+// 59 M-parameter table (cfg5: nothing of it stays in the MALL) needs to approach the HBM rate; element arithmetic is unchanged.
+__device__ __forceinline__ void adam_range(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
+                                           float* __restrict__ v, int64_t n, int64_t n_basic, const AdamK& k) {
+  const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (int64_t)gridDim.x * blockDim.x;
+  const unsigned mis = (unsigned)((uintptr_t)p >> 2) & 3u;
+  const bool same = (((uintptr_t)g >> 2) & 3u) == mis && (((uintptr_t)m >> 2) & 3u) == mis && (((uintptr_t)v >> 2) & 3u) == mis;
+  int64_t head = same ? (int64_t)((4u - mis) & 3u) : n;
+  if (head > n) head = n;
+  const int64_t nvec = (n - head) >> 2, tail = head + (nvec << 2);
+  for (int64_t i = tid; i < head; i += stride) adam_one(p[i], g[i], m[i], v[i], i < n_basic ? k.step_basic : k.step_pose, k);
+  float4* p4 = (float4*)(p + head); float4* g4 = (float4*)(g + head); float4* m4 = (float4*)(m + head); float4* v4 = (float4*)(v + head);
+  for (int64_t q = tid; q < nvec; q += stride) {
+    float4 pp = p4[q], gg = g4[q], mm = m4[q], vv = v4[q];
+    const int64_t i = head + (q << 2);
+    adam_one(pp.x, gg.x, mm.x, vv.x, i < n_basic ? k.step_basic : k.step_pose, k);
+    adam_one(pp.y, gg.y, mm.y, vv.y, i + 1 < n_basic ? k.step_basic : k.step_pose, k);
+    adam_one(pp.z, gg.z, mm.z, vv.z, i + 2 < n_basic ? k.step_basic : k.step_pose, k);
+    adam_one(pp.w, gg.w, mm.w, vv.w, i + 3 < n_basic ? k.step_basic : k.step_pose, k);
+    p4[q] = pp; m4[q] = mm; v4[q] = vv; g4[q] = gg;
+  }
+  for (int64_t i = tail + tid; i < n; i += stride) adam_one(p[i], g[i], m[i], v[i], i < n_basic ? k.step_basic : k.step_pose, k);
+}
+
 __global__ __launch_bounds__(256) void k_adam(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
                                                float* __restrict__ v, int64_t n, int64_t n_basic, float step_basic,
                                                float step_pose, float b1, float b2, float eps, float inv_sqrt_bc2) {
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-    const float gi = g[i];
-    const float mi = b1 * m[i] + (1.0f - b1) * gi;
-    const float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
-    const float denom = sqrtf(vi) * inv_sqrt_bc2 + eps;
-    const float ss = (i < n_basic) ? step_basic : step_pose;
-    p[i] = p[i] - ss * (mi / denom);
-    m[i] = mi;
-    v[i] = vi;
-    g[i] = 0.0f;                                                       // optimizer.zero_grad() for the next step
-  }
+  adam_range(p, g, m, v, n, n_basic, AdamK{step_basic, step_pose, b1, b2, eps, inv_sqrt_bc2});
 }
 
 // ---- the same with the per-step scalars in device memory (replayable captured step) ----------------------------------
@@ -356,19 +382,7 @@ __global__ void k_step_advance(NofStepState* st, float lrate, float lrate_pose, 
 __global__ __launch_bounds__(256) void k_adam_dyn(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
                                                    float* __restrict__ v, int64_t n, int64_t n_basic,
                                                    const NofStepState* __restrict__ st, float b1, float b2, float eps) {
-  const float step_basic = st->step_basic, step_pose = st->step_pose, inv_sqrt_bc2 = st->inv_sqrt_bc2;
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-    const float gi = g[i];
-    const float mi = b1 * m[i] + (1.0f - b1) * gi;
-    const float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
-    const float denom = sqrtf(vi) * inv_sqrt_bc2 + eps;
-    const float ss = (i < n_basic) ? step_basic : step_pose;
-    p[i] = p[i] - ss * (mi / denom);
-    m[i] = mi;
-    v[i] = vi;
-    g[i] = 0.0f;
-  }
+  adam_range(p, g, m, v, n, n_basic, AdamK{st->step_basic, st->step_pose, b1, b2, eps, st->inv_sqrt_bc2});
 }
 
 extern "C" int nof_step_state_advance(NofStepState* d_state, float lrate, float lrate_pose, float decay_rate, int32_t n_iters,
@@ -384,7 +398,7 @@ extern "C" int nof_adam_step_dyn(float* params, float* grads, float* exp_avg, fl
                                   const NofStepState* d_state, float beta1, float beta2, float eps, void* stream) {
   NOF_ARG(params && grads && exp_avg && exp_avg_sq && d_state && n >= 0 && n_basic >= 0 && n_basic <= n);
   if (n == 0) return 0;
-  const int64_t blocks = nof_div_up(n, 256) < 4096 ? nof_div_up(n, 256) : 4096;
+  const int64_t blocks = nof_div_up(n, 1024) < 4096 ? nof_div_up(n, 1024) : 4096;
   hipLaunchKernelGGL(k_adam_dyn, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, params, grads, exp_avg, exp_avg_sq, n,
                      n_basic, d_state, beta1, beta2, eps);
   NOF_LAUNCH_OK();
@@ -398,7 +412,7 @@ extern "C" int nof_adam_step(float* params, float* grads, float* exp_avg, float*
   const double bc1 = 1.0 - pow((double)beta1, (double)step);
   const double bc2 = 1.0 - pow((double)beta2, (double)step);
   const float inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
-  const int64_t blocks = nof_div_up(n, 256) < 4096 ? nof_div_up(n, 256) : 4096;
+  const int64_t blocks = nof_div_up(n, 1024) < 4096 ? nof_div_up(n, 1024) : 4096;
   hipLaunchKernelGGL(k_adam, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, params, grads, exp_avg,
                      exp_avg_sq, n, n_basic, (float)(lr / bc1), (float)(lr_pose / bc1), beta1, beta2, eps, inv_sqrt_bc2);
   NOF_LAUNCH_OK();

@@ -41,7 +41,8 @@ class GradSync:
     Called as a function it is one blocking all-reduce of the whole buffer.  `start(slice)` / `finish()` is the bucketed
     form the step uses: the fine hash levels' slice (80 % of the bytes) is reduced asynchronously -- torch's process group runs
     the collective on its own stream, ordered after the launches already enqueued on the current one -- while the scatter
-    of the coarse levels and the pose kernels still run; `finish()` makes the current stream wait before Adam.  Sums are
+    of the coarse levels and the pose kernels still run; `finish_first()` / `finish()` make the current stream wait before the
+    slice's share of Adam.  Sums are
     element-wise, so bucketing does not change a single bit of the result."""
 
     def __init__(self):
@@ -49,7 +50,8 @@ class GradSync:
         self.bytes_step = 0          # payload bytes handed to all-reduce in the last step (per rank)
         self.collectives_step = 0
         self._bytes = self._n = 0
-        self.timing = None           # list of (event before finish, event after finish): bench.py's exposed-communication time
+        self.timing = None           # list of (event before a wait, event after it): bench.py's exposed-communication time
+        self.timed_steps = 0
 
     def __call__(self, flat):
         dist.all_reduce(flat, op=dist.ReduceOp.SUM)
@@ -61,19 +63,30 @@ class GradSync:
             self._bytes += part.numel() * part.element_size()
             self._n += 1
 
-    def finish(self):
-        """the current stream waits for every collective in flight; what of them did not hide behind the backward is the time
-        between the two events (recorded when `timing` is a list and the tensors live on a GPU)"""
+    def _wait(self, works):
         ev = None
         if self.timing is not None and torch.cuda.is_available():
             ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             ev[0].record()
-        for w in self.pending:
+        for w in works:
             w.wait()
         if ev is not None:
             ev[1].record()
             self.timing.append(ev)
+
+    def finish_first(self):
+        """the current stream waits for the OLDEST collective in flight only (the step then runs that slice's share of Adam
+        while the trailing collective is still on the wire)"""
+        if self.pending:
+            self._wait([self.pending.pop(0)])
+
+    def finish(self):
+        """the current stream waits for every collective in flight; what of them did not hide behind the backward is the time
+        between the event pairs recorded around the waits (when `timing` is a list and the tensors live on a GPU:
+        `timed_steps` counts the steps they belong to)"""
+        self._wait(self.pending)
         self.pending = []
+        self.timed_steps += 1
         self.bytes_step, self.collectives_step, self._bytes, self._n = self._bytes, self._n, 0, 0
 
 

@@ -398,6 +398,7 @@ class NeuralObjectField:
         split = hashed[0] if hashed and 0 < hashed[0] < self.L else None
         bucketed = grad_sync is not None and hasattr(grad_sync, 'start') and split is not None
         BIG, SMALL, INPUT, ALL = lib.HASH_BWD_TABLE_BIG, lib.HASH_BWD_TABLE_SMALL, lib.HASH_BWD_INPUT, lib.HASH_BWD_ALL
+        adam_from, adam_done = 0, None                 # flat entries [0, adam_from) / [adam_done) have had their Adam update already
 
         def reduce_mlp():
             if wide_aux is None:                                     # (the wide path reduced its rows on its third stream)
@@ -456,11 +457,20 @@ class NeuralObjectField:
             else:
                 # measured chains at cfg2 over the work list: { table scatter 95 us (beside dL/dx), LDS levels 30, row reduction 10 }
                 # | { dL/dx 125 us (beside the scatter), pose kernels 35 }
+                # Adam is element-wise: the table's share of it (99 % of the parameters) starts as soon as the scatter has
+                # finished, beside the tail of the side stream (and, wide networks, the weight-gradient passes of the third one)
+                early_adam = do_step and grad_sync is None
                 with torch.cuda.stream(side):
                     hash_bwd(INPUT, 0, self.L)
                     pose_kernels()
+                    if early_adam:
+                        reduce_mlp()
                 hash_bwd(BIG | SMALL, 0, self.L)                     # (the LDS levels on a third stream beside both: no gain)
-                reduce_mlp()
+                if early_adam:
+                    adam_from = self.n_table
+                    self.adam_step(False, 0, adam_from, advance=False)
+                else:
+                    reduce_mlp()
             main.wait_stream(side)
             if wide_aux is not None:
                 main.wait_stream(wide_aux)
@@ -478,31 +488,42 @@ class NeuralObjectField:
             if nt:
                 self._grads_store[h - nt:h].copy_(tail)
             grad_sync.start(self._grads_store[h - nt:h + a])
+            if do_step and not dyn and hasattr(grad_sync, 'finish_first'):
+                # Adam is element-wise: the first slice's share of it runs while the trailing collective is on the wire
+                grad_sync.finish_first()
+                self.adam_step(False, a, self.n_table + self.n_mlp, advance=False)
+                adam_done = (a, self.n_table + self.n_mlp)
             grad_sync.finish()
             if nt:
                 tail.copy_(self._grads_store[h - nt:h])
         elif grad_sync is not None:
             grad_sync(self.grads)
         if do_step:
-            self.adam_step(dyn)
+            if adam_done is not None:                                  # (data parallel: everything on either side of the early slice)
+                self.adam_step(dyn, 0, adam_done[0], advance=False)
+                self.adam_step(dyn, adam_done[1])
+            else:
+                self.adam_step(dyn, adam_from)
         return b
 
-    def adam_step(self, dyn=False):
+    def adam_step(self, dyn=False, lo=0, hi=None, advance=True):
+        """Adam over the flat entries [lo, hi) (default: all); `advance` = this call completes the optimiser step."""
+        hi = self.n_total if hi is None else hi
+        n, nb = hi - lo, min(max(self.n_basic - lo, 0), hi - lo)
+        bufs = [x[lo:hi] for x in (self.params, self.grads, self.exp_avg, self.exp_avg_sq)]
         if dyn:
             cfg = self.cfg
-            self._call('nof_adam_step_dyn', self.params, self.grads, self.exp_avg, self.exp_avg_sq, self.n_total, self.n_basic,
-                       self._state, C.c_float(0.9), C.c_float(0.999), C.c_float(1e-15))
-            self._call('nof_step_state_advance', self._state, C.c_float(cfg['lrate']), C.c_float(cfg['lrate_pose']),
-                       C.c_float(cfg['decay_rate']), int(cfg['n_step']) + 1, C.c_float(0.9), C.c_float(0.999), -1)
+            self._call('nof_adam_step_dyn', *bufs, n, nb, self._state, C.c_float(0.9), C.c_float(0.999), C.c_float(1e-15))
+            if advance:
+                self._call('nof_step_state_advance', self._state, C.c_float(cfg['lrate']), C.c_float(cfg['lrate_pose']),
+                           C.c_float(cfg['decay_rate']), int(cfg['n_step']) + 1, C.c_float(0.9), C.c_float(0.999), -1)
+        else:
+            lr, lr_pose = self.learning_rates()
+            self._call('nof_adam_step', *bufs, n, nb, C.c_float(lr), C.c_float(lr_pose), C.c_float(0.9), C.c_float(0.999),
+                       C.c_float(1e-15), self.adam_steps + 1, tag=None if lo == 0 and hi >= self.n_table else 'nof_adam_step[rest]')
+        if advance:
             self.global_step += 1
             self.adam_steps += 1
-            return
-        lr, lr_pose = self.learning_rates()
-        self._call('nof_adam_step', self.params, self.grads, self.exp_avg, self.exp_avg_sq, self.n_total, self.n_basic,
-                 C.c_float(lr), C.c_float(lr_pose), C.c_float(0.9), C.c_float(0.999), C.c_float(1e-15),
-                 self.adam_steps + 1)
-        self.global_step += 1
-        self.adam_steps += 1
 
     # ---- renderer side ------------------------------------------------------------------------------------
     def query_sdf(self, pts, chunk=1 << 22):

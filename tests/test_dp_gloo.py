@@ -71,10 +71,14 @@ def _worker(rank, world, port, R, out):
     store[:nt] = view[b:]
     sync.start(store[:nt + a])
     sync.start(view[:0])                                 # empty slices are skipped
+    # the step runs the first slice's share of Adam between the two waits: that slice is final after finish_first()
+    assert len(sync.pending) == 2
+    sync.finish_first()
+    assert len(sync.pending) == 1 and torch.equal(view[a:b], flat[a:b])
     sync.finish()
     view[b:] = store[:nt]
     assert not sync.pending and torch.equal(view, flat)
-    assert sync.collectives_step == 2 and sync.bytes_step == 4 * (b - a + nt + a)
+    assert sync.collectives_step == 2 and sync.bytes_step == 4 * (b - a + nt + a) and sync.timed_steps == 1
     if rank == 0:
         out.put(flat.numpy())
     dist.barrier()

@@ -14,10 +14,10 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run(overlap, port, backend='gloo'):
-    env = dict(os.environ, NOF_DIST_BACKEND=backend, HSA_ENABLE_IPC_MODE_LEGACY='0', NOF_DP_OVERLAP=overlap)
-    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
-           '--master-port', str(port), os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '6', '--warmup', '2',
+def _run(overlap, port, backend='gloo', ranks=2, force='0'):
+    env = dict(os.environ, NOF_DIST_BACKEND=backend, HSA_ENABLE_IPC_MODE_LEGACY='0', NOF_DP_OVERLAP=overlap, NOF_DP_FORCE=force)
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(ranks), '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.join(ROOT, 'bench.py'), '--gpus', str(ranks), '--steps', '6', '--warmup', '2',
            '--keyframes', '3', '--no-cpu-baseline']
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-3000:]
@@ -41,6 +41,21 @@ def test_bench_two_ranks_one_gpu_gloo(nof):
     # the trailing one carries a copy of the [features | poses] tail in the headroom in front of the gradient buffer
     assert d['collectives_per_step'] == 2 and d0['collectives_per_step'] == 1
     assert d['allreduce_bytes_per_step'] >= d0['allreduce_bytes_per_step'] > 4 * 9_000_000
+
+
+def test_rccl_calls_of_the_bucketed_step_one_rank(nof):
+    """RCCL on the one GPU a test box has: a one-rank 'nccl' process group whose collectives are forced on (NOF_DP_FORCE).  Every
+    all-reduce is then an identity performed by RCCL on its own stream -- which is what this exercises: asynchronous collectives on
+    slices of the flat gradient buffer and on the headroom in front of it, the stream hand-over at start() / finish(), the
+    communication fields of the bench line.  The parameters must come out as without any collective."""
+    d = _run('1', 29537, backend='nccl', ranks=1, force='1')
+    d0 = _run('1', 29538, backend='nccl', ranks=1)
+    assert d['collectives_per_step'] == 2 and d0['collectives_per_step'] == 0
+    assert d['allreduce_bytes_per_step'] > 4 * 9_000_000 and d0['allreduce_bytes_per_step'] == 0
+    assert d['exposed_comm_ms'] is not None and d['exposed_comm_ms'] >= 0 and d0['exposed_comm_ms'] is None
+    assert d['flags'] == 0 and d['loss'] == d['loss']
+    assert abs(d['param_checksum'] - d0['param_checksum']) <= 2e-5 * d0['param_checksum']
+    print(f"one-rank RCCL, bucketed: {d['ms_per_step']:.3f} ms/step (exposed {d['exposed_comm_ms']:.3f} ms) vs {d0['ms_per_step']:.3f} without collectives")
 
 
 def test_bench_two_ranks_two_gpus_rccl(nof):

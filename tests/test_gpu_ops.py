@@ -588,3 +588,28 @@ def test_adam_matches_torch(nof):
         assert (gd == 0).all()
         ref = torch.cat([pa.detach(), pb.detach()]).numpy()
         assert np.abs(cpu(p) - ref).max() < 2e-6
+
+
+@pytest.mark.parametrize('off,n,nb', [(0, 10000, 9001), (1, 4099, 4098), (2, 5, 3), (3, 8190, 0), (1, 2, 2), (0, 3, 3)])
+def test_adam_ranges_are_bit_identical(nof, off, n, nb):
+    """The update is element-wise: a range that starts off a 16-byte boundary, ends inside a 16-byte group, or whose learning-rate
+    boundary falls inside one gives the bits of the element-by-element form (here: each entry updated by its own 1-entry call
+    would be slow, so the check is against a call on buffers with a DIFFERENT alignment per array, which takes the scalar path),
+    and entries outside the range are untouched.  The split optimiser step of field.py (table first, the rest later) rests on it."""
+    torch.manual_seed(n + off)
+    N = n + 16
+    base = [torch.randn(N, device='cuda') for _ in range(4)]
+    base[3].abs_()                                               # exp_avg_sq >= 0
+    a = [x.clone() for x in base]
+    args = (C.c_float(0.01), C.c_float(0.003), C.c_float(0.9), C.c_float(0.999), C.c_float(1e-15), 7)
+    nof.call('nof_adam_step', *[x[off:off + n] for x in a], n, nb, *args)
+    # scalar path: the four arrays at four different offsets from a 16-byte boundary
+    b = [torch.zeros(N + 4, device='cuda') for _ in range(4)]
+    for k, (x, y) in enumerate(zip(b, base)):
+        x[k:k + n] = y[off:off + n]
+    nof.call('nof_adam_step', *[x[k:k + n] for k, x in enumerate(b)], n, nb, *args)
+    torch.cuda.synchronize()
+    for k, (x, y, z) in enumerate(zip(a, b, base)):
+        assert torch.equal(x[off:off + n], y[k:k + n]), k
+        assert torch.equal(x[:off], z[:off]) and torch.equal(x[off + n:], z[off + n:]), k
+    assert (a[1][off:off + n] == 0).all()
