@@ -249,12 +249,16 @@ def main():
         """ray-samples of the last batch whose loss gradient is exactly zero (one device reduction + host sync: outside timing)"""
         return float((fld._buffers(R, S)['draw'] == 0).all(-1).float().mean().item())
 
+    def step():
+        """one iteration of NerfRunner.train()"""
+        runner.train_loop()
+        runner.global_step += 1
+
     # ---- warm-up with every launch bracketed by events: finds the dominant kernel --------------------------------
     fld.profile = {}
     sync = runner.grad_sync if hasattr(runner.grad_sync, 'finish') else None
     for _ in range(args.warmup):
-        runner.train_loop()
-        runner.global_step += 1
+        step()
     torch.cuda.synchronize()
     log('warm-up done')
     # median over the warm-up steps, the first two left out: a kernel's first launch loads its code object (with the mean, a
@@ -279,8 +283,7 @@ def main():
         barrier()
         t0 = time.perf_counter()
         for _ in range(n):
-            runner.train_loop()
-            runner.global_step += 1
+            step()
         barrier()
         dt = time.perf_counter() - t0
         if world > 1:
@@ -316,14 +319,12 @@ def main():
     if not dist.is_initialized() or world == 1:
         runner.cfg['hip_graph'] = True              # opt-in (the product default is the eager two-stream step)
         for _ in range(4):
-            runner.train_loop()
-            runner.global_step += 1
+            step()
         if getattr(runner, '_graph', None) is not None:
             torch.cuda.synchronize()
             t1 = time.perf_counter()
             for _ in range(args.steps):
-                runner.train_loop()
-                runner.global_step += 1
+                step()
             torch.cuda.synchronize()
             graph_ms = (time.perf_counter() - t1) / args.steps * 1e3
             log(f'captured-step mode: {graph_ms:.3f} ms/step')
@@ -364,8 +365,7 @@ def main():
             # over the listed tiles only; one pass of a network = its 2 * MAC
             'wide_bwd[data colour]': ('mfma', B * (1.0 - zero_frac) * fl_net[1]), 'wide_bwd[data sigma]': ('mfma', B * (1.0 - zero_frac) * fl_net[0]),
             'wide_bwd[dW colour]': ('mfma', B * (1.0 - zero_frac) * fl_net[1]), 'wide_bwd[dW sigma]': ('mfma', B * (1.0 - zero_frac) * fl_net[0]),
-            # one GPU: the table's share of Adam runs early (field.py); the few KB behind it are 'nof_adam_step[rest]'
-            'nof_adam_step': ('hbm', (fld.n_table if world == 1 else fld.n_total) * 32.0),
+            'nof_adam_step': ('hbm', fld.n_total * 32.0),
         }
         traffic = None          # HBM bytes per launch from the committed PMC passes (profiles/pmc_traffic.json), same workload only
         hash_fwd_traffic = None
@@ -439,8 +439,8 @@ def main():
             "loss": losses['loss'], "flags": flags, "dp_param_checksum_spread": dp_spread, "param_checksum": checksum,
             # data parallel (N > 1): gradient bytes each rank hands to RCCL per step, in how many collectives, and how long the
             # step's stream waited for them after the backward (events around GradSync.finish: what did not hide)
-            "allreduce_bytes_per_step": (sync.bytes_step if sync is not None else (fld.n_total * 4 if world > 1 else 0)),
-            "collectives_per_step": (sync.collectives_step if sync is not None else (1 if world > 1 else 0)),
+            "allreduce_bytes_per_step": (sync.bytes_step if sync is not None else (fld.n_total * 4 if runner.grad_sync is not None else 0)),
+            "collectives_per_step": (sync.collectives_step if sync is not None else (1 if runner.grad_sync is not None else 0)),
             "exposed_comm_ms": exposed_comm_ms,
             "roofline": roof,
         }

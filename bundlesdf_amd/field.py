@@ -308,22 +308,15 @@ class NeuralObjectField:
         self._call('nof_pose_fwd', self.pose if self.optimize_poses else None, self.c2w, C.c_float(self.max_trans),
                  C.c_float(self.max_rot), self.tf, self.F)
 
-    def forward_batch(self, pool, ids, R, u_occ=None, u_dep=None, seed=0, want_cells=False, dyn=False):
-        """render_rays up to raw (nerf_runner.py:1044-1088); returns the buffer dict."""
-        cfg = self.cfg
-        S = cfg['N_samples'] + cfg['N_samples_around_depth']
-        b = self._buffers(R, S)
-        # the fragment image is first needed by the MLP forward: packed on the side stream beside the pose corrections, the ray
-        # marching and the hash encode (captured step: one chain)
-        pack_aside = not dyn and self._packed_step != self.global_step
-        if pack_aside:
-            main, side = torch.cuda.current_stream(), self._side_stream()
-            side.wait_stream(main)
-            with torch.cuda.stream(side):
-                self.pack_weights()
+    def _prologue(self, b, pool, ids, R, u_occ, u_dep, seed, want_cells, dyn):
+        """What a step needs before it touches the hash table: the MFMA fragment image of the MLPs (5 us on the main stream:
+        packing it on the side stream cost more in the cross-stream hand-over than the overlap returned), the pose corrections,
+        occupancy ray marching + stratified sampling + sample points of the batch (nerf_runner.py:1044-1060 via :918-1000).
+        (Running the NEXT batch's prologue at the end of a step, on the side stream beside Adam -- it needs only the few KB of
+        poses / features / MLPs, updated first -- was built and measured: 0.526 vs 0.515 ms/step.  The fork and the join cost what
+        the overlap returns, and the ray marcher's dependent loads slow down under Adam's streaming.)"""
         self.update_poses()
-        if not pack_aside:
-            self.pack_weights(force=dyn)
+        self.pack_weights(force=dyn)
         cid = None
         if want_cells:
             cid = b.setdefault('cell_ids', torch.empty(R, self.max_hits, dtype=torch.int32, device=self.device))
@@ -332,10 +325,15 @@ class NeuralObjectField:
                    self.sh_degree, self.occ_bits, self.level, R, self.max_hits, u_occ, u_dep, b['batch'], b['rays_o_w'],
                    b['viewdirs_w'], b['view'], b['t_in_out'], cid, b['n_hits'], b['z_vals'], b['pts_w'], b['valid'],
                    self.flags)
+
+    def forward_batch(self, pool, ids, R, u_occ=None, u_dep=None, seed=0, want_cells=False, dyn=False):
+        """render_rays up to raw (nerf_runner.py:1044-1088); returns the buffer dict."""
+        cfg = self.cfg
+        S = cfg['N_samples'] + cfg['N_samples_around_depth']
+        b = self._buffers(R, S)
+        self._prologue(b, pool, ids, R, u_occ, u_dep, seed, want_cells, dyn)
         B = R * S
         self._call('nof_hash_encode_fwd', C.byref(self.grid), b['pts_w'], self.table, b['feat'], B)
-        if pack_aside:
-            main.wait_stream(side)
         if self.wide:
             self._call('nof_mlp_wide_fwd', C.byref(self.desc), self.packed, b['feat'], self.L, b['view'], S, b['raw'], b['wide_ws'], B)
         else:
@@ -398,7 +396,7 @@ class NeuralObjectField:
         split = hashed[0] if hashed and 0 < hashed[0] < self.L else None
         bucketed = grad_sync is not None and hasattr(grad_sync, 'start') and split is not None
         BIG, SMALL, INPUT, ALL = lib.HASH_BWD_TABLE_BIG, lib.HASH_BWD_TABLE_SMALL, lib.HASH_BWD_INPUT, lib.HASH_BWD_ALL
-        adam_from, adam_done = 0, None                 # flat entries [0, adam_from) / [adam_done) have had their Adam update already
+        adam_done = None                               # flat entries [adam_done) that have had their Adam update already
 
         def reduce_mlp():
             if wide_aux is None:                                     # (the wide path reduced its rows on its third stream)
@@ -457,20 +455,14 @@ class NeuralObjectField:
             else:
                 # measured chains at cfg2 over the work list: { table scatter 95 us (beside dL/dx), LDS levels 30, row reduction 10 }
                 # | { dL/dx 125 us (beside the scatter), pose kernels 35 }
-                # Adam is element-wise: the table's share of it (99 % of the parameters) starts as soon as the scatter has
-                # finished, beside the tail of the side stream (and, wide networks, the weight-gradient passes of the third one)
-                early_adam = do_step and grad_sync is None
                 with torch.cuda.stream(side):
                     hash_bwd(INPUT, 0, self.L)
                     pose_kernels()
-                    if early_adam:
-                        reduce_mlp()
-                hash_bwd(BIG | SMALL, 0, self.L)                     # (the LDS levels on a third stream beside both: no gain)
-                if early_adam:
-                    adam_from = self.n_table
-                    self.adam_step(False, 0, adam_from, advance=False)
-                else:
-                    reduce_mlp()
+                hash_bwd(BIG | SMALL, 0, self.L)                     # (the LDS levels on a third stream beside both: no gain; the
+                reduce_mlp()                                         #  two chains swapped between the streams: 2 % slower)
+                # (Adam is element-wise and could start per range as soon as a range's gradient is final -- the table's share right
+                # here, the rest at the end of the side stream.  Measured: 0.518 vs 0.521 ms at cfg2 (noise), 4.9-5.0 vs 4.7-4.8 ms
+                # at cfg5, where it takes HBM bandwidth from the weight-gradient passes that are the critical path: not done)
             main.wait_stream(side)
             if wide_aux is not None:
                 main.wait_stream(wide_aux)
@@ -479,7 +471,7 @@ class NeuralObjectField:
                        C.c_float(1.0 / self.world_size), self.loss_out)
         if self.ff > 0:
             self._call('nof_small_regs', self.feat, self._seg(self.grads, 'feat'), self.n_feat,
-                     C.c_float(cfg['feature_reg_weight']), C.c_float(1.0 / self.world_size))
+                       C.c_float(cfg['feature_reg_weight']), C.c_float(1.0 / self.world_size))
         if bucketed:
             # ONE more collective: everything that is not in flight yet.  [0, a) and the tail behind the MLP are not contiguous
             # in the flat buffer, so a copy of the tail (frame features + poses: a few KB) rides in the headroom in front of it
@@ -503,7 +495,7 @@ class NeuralObjectField:
                 self.adam_step(dyn, 0, adam_done[0], advance=False)
                 self.adam_step(dyn, adam_done[1])
             else:
-                self.adam_step(dyn, adam_from)
+                self.adam_step(dyn)
         return b
 
     def adam_step(self, dyn=False, lo=0, hi=None, advance=True):

@@ -47,15 +47,17 @@ def test_rccl_calls_of_the_bucketed_step_one_rank(nof):
     """RCCL on the one GPU a test box has: a one-rank 'nccl' process group whose collectives are forced on (NOF_DP_FORCE).  Every
     all-reduce is then an identity performed by RCCL on its own stream -- which is what this exercises: asynchronous collectives on
     slices of the flat gradient buffer and on the headroom in front of it, the stream hand-over at start() / finish(), the
-    communication fields of the bench line.  The parameters must come out as without any collective."""
-    d = _run('1', 29537, backend='nccl', ranks=1, force='1')
-    d0 = _run('1', 29538, backend='nccl', ranks=1)
-    assert d['collectives_per_step'] == 2 and d0['collectives_per_step'] == 0
-    assert d['allreduce_bytes_per_step'] > 4 * 9_000_000 and d0['allreduce_bytes_per_step'] == 0
+    communication fields of the bench line.  The parameters must come out as with ONE blocking all-reduce of the whole buffer."""
+    d = _run('1', 29537, backend='nccl', ranks=1, force='1')        # two asynchronous collectives per step, Adam in three ranges
+    d1 = _run('0', 29539, backend='nccl', ranks=1, force='1')       # one blocking all-reduce of the whole buffer, one Adam
+    d0 = _run('1', 29538, backend='nccl', ranks=1)                  # no collective at all (and bench.py's captured-step leg: more steps)
+    assert d['collectives_per_step'] == 2 and d1['collectives_per_step'] == 1 and d0['collectives_per_step'] == 0
+    assert d['allreduce_bytes_per_step'] >= d1['allreduce_bytes_per_step'] > 4 * 9_000_000 and d0['allreduce_bytes_per_step'] == 0
     assert d['exposed_comm_ms'] is not None and d['exposed_comm_ms'] >= 0 and d0['exposed_comm_ms'] is None
     assert d['flags'] == 0 and d['loss'] == d['loss']
-    assert abs(d['param_checksum'] - d0['param_checksum']) <= 2e-5 * d0['param_checksum']
-    print(f"one-rank RCCL, bucketed: {d['ms_per_step']:.3f} ms/step (exposed {d['exposed_comm_ms']:.3f} ms) vs {d0['ms_per_step']:.3f} without collectives")
+    assert abs(d['param_checksum'] - d1['param_checksum']) <= 2e-5 * d1['param_checksum']
+    print(f"one-rank RCCL: bucketed {d['ms_per_step']:.3f} ms/step (exposed {d['exposed_comm_ms']:.3f} ms), blocking {d1['ms_per_step']:.3f}, "
+          f"no collectives {d0['ms_per_step']:.3f}")
 
 
 def test_bench_two_ranks_two_gpus_rccl(nof):
