@@ -402,8 +402,14 @@ struct TileWork {
 // =====================================================================================================
 // forward: raw[b] = (rgb_raw[3], sdf)
 // =====================================================================================================
+// Waves per workgroup of the forward kernel.  The LDS image of the weight fragments (57 KB with the operand split at 3 + 2
+// layers) limits a CU to two workgroups: with 4 waves each that is 2 waves per SIMD, and the three dependent MFMAs of a split
+// product leave the matrix pipe idle 60 % of the time.  The 16-bit kernels need <= 120 registers, so 8 waves share one image:
+// 4 waves per SIMD from the same LDS.  (fp32 fragments: 127-129 registers, stays at 4 waves per workgroup.)
+template <class P> struct FwdWaves { static constexpr int value = P::KR == 8 ? 8 : 4; };
+
 template <class P, int NS, int NC, bool SDF_ONLY, bool SPLIT>
-__global__ __launch_bounds__(256, 2) void k_mlp_fwd(      // >= 2 waves/SIMD: no AGPRs, so MFMA results land in VGPRs directly
+__global__ __launch_bounds__(64 * FwdWaves<P>::value, FwdWaves<P>::value == 8 ? 4 : 2) void k_mlp_fwd(   // no AGPRs: MFMA results land in VGPRs
 NofMlpDesc d, const char* __restrict__ image,
                                                   const float2* __restrict__ feat, int L, const float* __restrict__ view,
                                                   int S, float* __restrict__ out, typename P::elem* __restrict__ sig, int64_t B) {
@@ -420,11 +426,12 @@ NofMlpDesc d, const char* __restrict__ image,
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int hi = lane >> 5, j = lane & 31;
+  constexpr int NW = FwdWaves<P>::value;
   const int64_t ntiles = (B + 31) / 32;
-  const int64_t tstride = (int64_t)gridDim.x * 4;
+  const int64_t tstride = (int64_t)gridDim.x * NW;
   float xn[1][16];                                    // the NEXT tile's features: loaded a whole tile ahead (latency hidden)
-  load_feat_o1(feat, L, B, ((int64_t)blockIdx.x * 4 + wave) * 32 + j, hi, xn);
-  for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < ntiles; tile += tstride) {
+  load_feat_o1(feat, L, B, ((int64_t)blockIdx.x * NW + wave) * 32 + j, hi, xn);
+  for (int64_t tile = (int64_t)blockIdx.x * NW + wave; tile < ntiles; tile += tstride) {
     asm volatile("" ::: "memory");                    // keep the weight fragments in LDS (no hoisting into VGPRs)
     const int64_t b = tile * 32 + j;
     float x[1][16];
@@ -1629,6 +1636,13 @@ extern "C" int nof_mlp_bwd_blocks(void) {
   return g_bwd_blocks;
 }
 
+// workgroups of the forward kernel: one tile per wave up to 4 workgroups of 4 waves / 2 of 8 per CU (what LDS or registers admit)
+template <class P> static unsigned fwd_blocks(int64_t ntiles) {
+  constexpr int NW = FwdWaves<P>::value;
+  const int64_t cap = NW == 8 ? 512 : 1024;
+  return (unsigned)(nof_div_up(ntiles, NW) < cap ? nof_div_up(ntiles, NW) : cap);
+}
+
 extern "C" int nof_mlp_fwd(const NofMlpDesc* d, const void* packed, const float* feat, int32_t L, const float* view,
                             int32_t S, float* raw, void* sigma_out, int64_t B, void* stream) {
   if (int e = check_narrow(d)) return e;
@@ -1639,13 +1653,12 @@ extern "C" int nof_mlp_fwd(const NofMlpDesc* d, const void* packed, const float*
   const size_t shm = (is_split(d->precision) ? 2 : 1) * (size_t)n_pairs(*d, nl) * 16 * 64 * elem_size(d->precision) +
                      (size_t)n_oblk(*d, nl) * 32 * 4;
   const int64_t ntiles = (B + 31) / 32;
-  const unsigned blocks = (unsigned)(nof_div_up(ntiles, 4) < 1024 ? nof_div_up(ntiles, 4) : 1024);
 #define LAUNCH_FWD(P, NS_, NC_, SPLIT_)                                                                   \
   {                                                                                                       \
     auto kern = k_mlp_fwd<P, NS_, NC_, false, SPLIT_>;                                                    \
     if (int e = set_smem(kern, shm)) return e;                                                            \
-    hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), shm, (hipStream_t)stream, *d, (const char*)packed,  \
-                       (const float2*)feat, (int)L, view, (int)S, raw, (typename P::elem*)sigma_out, B);  \
+    hipLaunchKernelGGL(kern, dim3(fwd_blocks<P>(ntiles)), dim3(64 * FwdWaves<P>::value), shm, (hipStream_t)stream, *d, \
+                       (const char*)packed, (const float2*)feat, (int)L, view, (int)S, raw, (typename P::elem*)sigma_out, B); \
   }
   DISPATCH_PREC_FWD(LAUNCH_FWD)
 #undef LAUNCH_FWD
@@ -1663,13 +1676,12 @@ extern "C" int nof_mlp_sdf(const NofMlpDesc* d, const void* packed, const float*
   const size_t shm = (is_split(d->precision) ? 2 : 1) * (size_t)n_pairs(*d, nl) * 16 * 64 * elem_size(d->precision) +
                      (size_t)n_oblk(*d, nl) * 32 * 4;
   const int64_t ntiles = (B + 31) / 32;
-  const unsigned blocks = (unsigned)(nof_div_up(ntiles, 4) < 1024 ? nof_div_up(ntiles, 4) : 1024);
 #define LAUNCH_SDF(P, NS_, NC_, SPLIT_)                                                                   \
   {                                                                                                       \
     auto kern = k_mlp_fwd<P, NS_, NC_, true, SPLIT_>;                                                     \
     if (int e = set_smem(kern, shm)) return e;                                                            \
-    hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), shm, (hipStream_t)stream, *d, (const char*)packed,  \
-                       (const float2*)feat, (int)L, (const float*)nullptr, 1, sdf, (typename P::elem*)nullptr, B); \
+    hipLaunchKernelGGL(kern, dim3(fwd_blocks<P>(ntiles)), dim3(64 * FwdWaves<P>::value), shm, (hipStream_t)stream, *d, \
+                       (const char*)packed, (const float2*)feat, (int)L, (const float*)nullptr, 1, sdf, (typename P::elem*)nullptr, B); \
   }
   DISPATCH_PREC_FWD(LAUNCH_SDF)
 #undef LAUNCH_SDF

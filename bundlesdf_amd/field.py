@@ -71,6 +71,7 @@ class NeuralObjectField:
         self.params = torch.zeros(self.n_total, device=dev)
         # gradients: a few floats of headroom in FRONT of the flat buffer, so that the data-parallel step can put a copy of the tail
         # [frame features | poses] next to the coarse table levels and reduce both in one collective (train_step, `bucketed`)
+        self._st, self._sh, self._events = None, None, {}     # the step's stream (torch object, raw handle), fork / join events
         self._n_tail = self.n_feat + self.n_pose
         self._head = (self._n_tail + 63) // 64 * 64
         self._grads_store = torch.zeros(self._head + self.n_total, device=dev)
@@ -107,17 +108,47 @@ class NeuralObjectField:
 
     # ---- per-kernel timing with events on the launch stream -------------------------------------
     def _call(self, name, *args, tag=None):
-        """one C-ABI call on the current stream; with per-kernel timing on, bracketed by events recorded on that same stream
-        under `tag` (default: the entry point's name)"""
+        """one C-ABI call on the step's stream (`_on`; torch's current stream outside a step); with per-kernel timing on,
+        bracketed by events recorded on that same stream under `tag` (default: the entry point's name)"""
         prof = self.profile
         key = tag or name
         if prof is None or (self.profile_only is not None and key != self.profile_only and key != self.profile_also):
-            return lib.call(name, *args)
+            return lib.call(name, *args, stream=self._sh)
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        a.record()
-        lib.call(name, *args)
-        b.record()
+        st = self._st if self._st is not None else torch.cuda.current_stream()
+        a.record(st)
+        lib.call(name, *args, stream=self._sh)
+        b.record(st)
         prof.setdefault(key, []).append((a, b))
+
+    # ---- which stream the step's launches go to --------------------------------------------------------------------------
+    # The host needs ~0.45 ms to enqueue a 0.5 ms step (tools/host_probe.py), so the step does not ask torch for its current
+    # stream at every launch, does not enter torch's stream context manager to launch on another one, and re-uses its fork / join
+    # events: `_on(stream)` switches where `_call` launches (torch operations inside such a block still need torch's own context).
+    class _On:
+        __slots__ = ('f', 'st', 'prev')
+
+        def __init__(self, f, st):
+            self.f, self.st = f, st
+
+        def __enter__(self):
+            f = self.f
+            self.prev = (f._st, f._sh)
+            f._st, f._sh = self.st, self.st.cuda_stream
+
+        def __exit__(self, *exc):
+            self.f._st, self.f._sh = self.prev
+
+    def _on(self, stream):
+        return NeuralObjectField._On(self, stream)
+
+    def _after(self, waiter, src, key):
+        """`waiter` waits for everything enqueued on `src` so far (wait_stream with a re-used event)"""
+        ev = self._events.get(key)
+        if ev is None:
+            ev = self._events[key] = torch.cuda.Event()
+        ev.record(src)
+        waiter.wait_event(ev)
 
     def kernel_times_ms(self, stat='mean', skip=0):
         """launch duration per timed call (ms; `stat`: 'mean' or 'median' over the recorded launches, the first `skip` of each
@@ -342,6 +373,10 @@ class NeuralObjectField:
 
     def train_step(self, pool, ids, R, u_occ=None, u_dep=None, seed=0, do_step=True, want_cells=False,
                    grad_sync=None, dyn=False):
+        with self._on(torch.cuda.current_stream()):
+            return self._train_step(pool, ids, R, u_occ, u_dep, seed, do_step, want_cells, grad_sync, dyn)
+
+    def _train_step(self, pool, ids, R, u_occ, u_dep, seed, do_step, want_cells, grad_sync, dyn):
         """One train_loop iteration (nerf_runner.py:679-763).  `grad_sync(flat_grads)` is the data-parallel hook
         (RCCL all-reduce); gradients are already scaled by 1/world_size.  dyn=True: the per-step scalars (Philox step, Adam
         step sizes) are read from the device-resident NofStepState instead of being passed by value, and the state is advanced
@@ -368,15 +403,15 @@ class NeuralObjectField:
             if dyn:
                 wide_bwd(15, 'nof_mlp_wide_bwd')
             else:
-                main = torch.cuda.current_stream()
+                main = self._st
                 wide_aux = self._aux_stream()
                 wide_bwd(1, 'wide_bwd[data colour]')
-                wide_aux.wait_stream(main)
-                with torch.cuda.stream(wide_aux):
+                self._after(wide_aux, main, 'aux0')
+                with self._on(wide_aux):
                     wide_bwd(4, 'wide_bwd[dW colour]')
                 wide_bwd(2, 'wide_bwd[data sigma]')
-                wide_aux.wait_stream(main)
-                with torch.cuda.stream(wide_aux):
+                self._after(wide_aux, main, 'aux1')
+                with self._on(wide_aux):
                     wide_bwd(8, 'wide_bwd[dW sigma]')
                     self._call('nof_reduce_partials', b['partials'], self.nblk, self.n_mlp, self._seg(self.grads, 'mlp'), self.flags)
         else:
@@ -425,7 +460,8 @@ class NeuralObjectField:
                            self._seg(self.grads, 'pose') if self.optimize_poses else None,
                            self._seg(self.grads, 'feat') if self.ff > 0 else None, None, self.F, 1)   # (zeroes dview for the next step's atomics)
             else:
-                b['dview'].zero_()
+                with torch.cuda.stream(self._st):
+                    b['dview'].zero_()
 
         if dyn:
             # captured step: one chain (a second branch in the HIP graph costs more than the overlap returns)
@@ -436,9 +472,9 @@ class NeuralObjectField:
             # The table scatter of the large levels (atomics that execute memory-side) is the longest launch of the backward; the
             # input gradient and the pose / frame-feature gradients that hang off it are independent of it and run beside it on a
             # second stream (fork / join by events); the LDS-accumulated small levels and the MLP row reduction follow it.
-            main = torch.cuda.current_stream()
+            main = self._st
             side = self._side_stream()
-            side.wait_stream(main)
+            self._after(side, main, 'fork')
             if bucketed:
                 # data parallel: the fine (hashed) levels first; their slice [rows of level `split` .., MLP] of the flat gradient
                 # buffer (80 % of its bytes at cfg2) is all-reduced while the coarse levels, dL/dx and the pose kernels still run
@@ -446,16 +482,16 @@ class NeuralObjectField:
                 reduce_mlp()
                 hash_bwd(BIG | SMALL, split, self.L)
                 if wide_aux is not None:                             # the MLP gradient is part of the slice that goes out next
-                    main.wait_stream(wide_aux)
+                    self._after(main, wide_aux, 'aux_dp')
                 grad_sync.start(self.grads[a:self.n_table + self.n_mlp])
-                with torch.cuda.stream(side):
+                with self._on(side):
                     hash_bwd(INPUT, 0, self.L)
                     pose_kernels()
                 hash_bwd(BIG | SMALL, 0, split)
             else:
                 # measured chains at cfg2 over the work list: { table scatter 95 us (beside dL/dx), LDS levels 30, row reduction 10 }
                 # | { dL/dx 125 us (beside the scatter), pose kernels 35 }
-                with torch.cuda.stream(side):
+                with self._on(side):
                     hash_bwd(INPUT, 0, self.L)
                     pose_kernels()
                 hash_bwd(BIG | SMALL, 0, self.L)                     # (the LDS levels on a third stream beside both: no gain; the
@@ -463,9 +499,9 @@ class NeuralObjectField:
                 # (Adam is element-wise and could start per range as soon as a range's gradient is final -- the table's share right
                 # here, the rest at the end of the side stream.  Measured: 0.518 vs 0.521 ms at cfg2 (noise), 4.9-5.0 vs 4.7-4.8 ms
                 # at cfg5, where it takes HBM bandwidth from the weight-gradient passes that are the critical path: not done)
-            main.wait_stream(side)
+            self._after(main, side, 'join')
             if wide_aux is not None:
-                main.wait_stream(wide_aux)
+                self._after(main, wide_aux, 'join_aux')
         if self.optimize_poses and float(cfg.get('pose_reg_weight', 0)) > 0:
             self._call('nof_pose_reg', self.pose, self._seg(self.grads, 'pose'), self.F, C.c_float(cfg['pose_reg_weight']),
                        C.c_float(1.0 / self.world_size), self.loss_out)

@@ -156,27 +156,35 @@ def load():
     return lib
 
 
-def _ptr(t):
-    if t is None:
-        return None
-    if isinstance(t, torch.Tensor):
-        assert t.is_cuda and t.is_contiguous(), 'device pointer arguments must be contiguous CUDA tensors'
-        return C.c_void_p(t.data_ptr())
-    raise TypeError(type(t))
-
-
 def _stream():
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    return torch.cuda.current_stream().cuda_stream
 
 
-def call(name, *args):
-    lib = load()
+_Tensor = torch.Tensor
+
+
+def call(name, *args, stream=None):
+    """One C-ABI call.  Tensors go in as their device address (contiguous CUDA tensors only), everything else as given; the
+    last argument of every entry point is the HIP stream: `stream` (a raw handle) or torch's current stream.  This runs ~20 times
+    per optimisation step, where the host is within 10 % of being the bottleneck (tools/host_probe.py): no per-argument wrapper
+    objects, no stream lookup when the caller already knows its stream."""
+    fn = _fns.get(name)
+    if fn is None:
+        fn = _fns[name] = getattr(load(), name)
     conv = []
     for a in args:
-        conv.append(_ptr(a) if (a is None or isinstance(a, torch.Tensor)) else a)
-    rc = getattr(lib, name)(*conv, _stream())
+        if isinstance(a, _Tensor):
+            if not (a.is_cuda and a.is_contiguous()):
+                raise NofError(f'{name}: device pointer arguments must be contiguous CUDA tensors')
+            conv.append(a.data_ptr())
+        else:
+            conv.append(a)
+    rc = fn(*conv, torch.cuda.current_stream().cuda_stream if stream is None else stream)
     if rc != 0:
-        raise NofError(f'{name} failed with code {rc}: {lib.nof_last_error().decode()}')
+        raise NofError(f'{name} failed with code {rc}: {load().nof_last_error().decode()}')
+
+
+_fns = {}
 
 
 # ---------------------------------------------------------------------------------------------------
