@@ -211,6 +211,7 @@ def main():
                          'cfg5: SDF 4x128 + colour 4x128 (BASELINE.json cfg5, with --rays 16384 --log2_T 22 --width 1280 --height 720 '
                          '--precision fp16)')
     ap.add_argument('--finest', type=int, default=256, help='finest hash resolution (256: cfg1-3; 512: cfg4/5)')
+    ap.add_argument('--settle', type=int, default=200, help='untimed steps between the warm-up and the timed region (the zero-gradient fraction settles; 0: time right after the warm-up)')
     ap.add_argument('--scatter-wgs', type=int, default=0, help='persistent workgroups per CU of the table scatter (0 = library default)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-seconds', type=float, default=25.0)
@@ -292,7 +293,25 @@ def main():
             dt = float(t.item())
         return dt
 
-    zero_first = zero_fraction() if args.warmup > 0 else None
+    # The step's cost depends on how many ray-samples carry a loss gradient (the backward runs over their tiles only), and that
+    # fraction moves during the first few hundred steps of a run (0.49 -> 0.67 at cfg2) before it stays put for the thousands
+    # that follow.  So: the K steps right after the W warm-up steps are timed for the record (`ms_per_step_first_steps`), then
+    # `--settle` more untimed steps bring the field to the regime a run spends its time in, and the K steps that make `value`
+    # are timed there.  Both figures, the fractions at both ends and the sparsity-independent dense figure are in the line.
+    early_ms, zero_early = None, None
+    if args.settle > 0:
+        zero_early = zero_fraction() if args.warmup > 0 else None
+        early_ms = timed(args.steps) / args.steps * 1e3
+        keep = fld.profile, fld.profile_only, fld.profile_also
+        fld.profile = None                            # (no events for the settling steps)
+        for _ in range(args.settle):
+            step()
+        torch.cuda.synchronize()
+        fld.profile, fld.profile_only, fld.profile_also = {k: [] for k in keep[0]} if keep[0] is not None else None, keep[1], keep[2]
+        if sync is not None:
+            sync.timing, sync.timed_steps = [], 0
+        log(f'first {args.steps} steps after the warm-up: {early_ms:.3f} ms/step (zero-gradient fraction {zero_early}); {args.settle} settling steps done')
+    zero_first = zero_fraction() if args.warmup + args.settle > 0 else None
     dt = timed(args.steps)
     log(f'timed region done: {dt / args.steps * 1e3:.3f} ms/step')
     zero_last = zero_fraction()
@@ -424,11 +443,14 @@ def main():
                                    f"{PRECISION_NOTE[runner.precision]}, fp32 table/accumulators/Adam; every sample runs "
                                    f"the forward and the loss, the backward runs over the work list of the 32-sample tiles that hold a "
                                    f"non-zero loss gradient (the others add exactly nothing: same sums; fraction of zero samples in "
-                                   f"zero_grad_sample_fraction, the step with every tile listed in ms_per_step_dense_backward)",
+                                   f"zero_grad_sample_fraction, the step with every tile listed in ms_per_step_dense_backward); "
+                                   f"timed after {args.warmup} warm-up + {args.settle} settling steps (the steps right after the "
+                                   f"warm-up: ms_per_step_first_steps)",
                        "rays_per_step": R, "samples_per_ray": S, "keyframes_per_gpu": args.keyframes,
                        "pool_rays": int(runner.rays.shape[0]), "parallelism": f"dp{world}"},
             "train_iters_per_sec": it_s * 1.0, "captured_step_ms_per_step": graph_ms,
             # same run, same kernels, every tile of the batch in the backward's work list (no sparsity): DESIGN 2.9
+            "settle_steps": args.settle, "ms_per_step_first_steps": early_ms, "zero_grad_sample_fraction_after_warmup": zero_early,
             "ms_per_step_dense_backward": dense_ms, "value_dense_backward": world * B / (dense_ms * 1e-3),
             "kernel_ms_warmup": {k: round(v, 4) for k, v in sorted(ktimes.items(), key=lambda kv: -kv[1])},
             "valid_sample_fraction": losses['n_valid_samples'] / B,     # samples inside [-1,1]^3 (the rest still run the MLPs)

@@ -18,7 +18,7 @@ def _run(overlap, port, backend='gloo', ranks=2, force='0'):
     env = dict(os.environ, NOF_DIST_BACKEND=backend, HSA_ENABLE_IPC_MODE_LEGACY='0', NOF_DP_OVERLAP=overlap, NOF_DP_FORCE=force)
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(ranks), '--master-addr', '127.0.0.1',
            '--master-port', str(port), os.path.join(ROOT, 'bench.py'), '--gpus', str(ranks), '--steps', '6', '--warmup', '2',
-           '--keyframes', '3', '--no-cpu-baseline']
+           '--keyframes', '3', '--no-cpu-baseline', '--settle', '0']
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-3000:]
     line = [l for l in out.stdout.splitlines() if l.startswith('{"metric"')]
