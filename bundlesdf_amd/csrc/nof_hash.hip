@@ -664,7 +664,10 @@ extern "C" int nof_hash_encode_bwd_parts(const NofHashGrid* g, const float* pts_
     NOF_LAUNCH_OK();
   }
   if ((parts & NOF_HASH_BWD_TABLE_SMALL) && small.n > 0) {
-    const int chunks = 64;
+    // Two workgroups per CU (78 of the 160 KB of LDS): over the work list a workgroup's 16 waves then have about one item each
+    // and the kernel is its fixed parts (zero 39 KB, one item's latency chain, flush).  64 workgroups: 33 us and the step 15 us
+    // longer (dense backward: 60 us); 1024 / 2048 smaller workgroups: the same as 512 (A/B on one box)
+    const int chunks = 2 * nof_cu_count();
     if (lds_need > 64 * 1024)
       NOF_HIP(hipFuncSetAttribute((const void*)k_hash_bwd_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_need));
     hipLaunchKernelGGL(k_hash_bwd_lds, dim3((unsigned)(chunks * small.n)), dim3(1024), lds_need, st, *g, small, chunks, pts_w,

@@ -143,78 +143,105 @@ __device__ __forceinline__ float wave_sum_p(float v) {
 
 // one wave per ray: G += g (x) [q,1] over the ray's samples, q = c2w (rays_d z) (the point BEFORE the correction),
 // plus the view-direction path through the SH Jacobian.
-__global__ __launch_bounds__(64) void k_pose_grad_accum(const float* __restrict__ dpts, const float* __restrict__ dview,
+__global__ __launch_bounds__(64) void k_pose_grad_accum(const float* __restrict__ dpts, float* __restrict__ dview,
                                                          const float* __restrict__ batch, const float* __restrict__ z_vals,
                                                          const float* __restrict__ c2w, const float* __restrict__ tf, int ff,
-                                                         int sh_degree, int64_t R, int S, float* __restrict__ g_ray) {
+                                                         int sh_degree, int64_t R, int S, float* __restrict__ g_ray,
+                                                         float* __restrict__ slots) {
   const int64_t r = blockIdx.x;
   const int lane = threadIdx.x;
   const float* row = batch + r * NOF_RAY_COLS;
   const int f = (int)row[8];
-  if (f == 0) {                                                         // frame 0 carries no correction
-    if (lane < 12) g_ray[r * 12 + lane] = 0.0f;
-    return;
-  }
-  const float* M = c2w + (size_t)f * 16;
-  const float dx = row[0], dy = row[1], dz = row[2];
-  float G[12];
+  // the frame-feature gradient of the ray (slot mode): lanes 12 .. 12 + ff - 1
+  float fpart = 0.0f;
+  if (slots != nullptr && lane >= 12 && lane < 12 + ff) fpart = dview[r * NOF_VIEW_COLS + (lane - 12)];
+  float mine = 0.0f;                                                    // lane k keeps component k: one coalesced 48-byte store
+  if (f != 0) {                                                         // frame 0 carries no correction: its rows stay 0
+    const float* M = c2w + (size_t)f * 16;
+    const float dx = row[0], dy = row[1], dz = row[2];
+    float G[12];
 #pragma unroll
-  for (int k = 0; k < 12; ++k) G[k] = 0.0f;
-  if (dpts != nullptr) {
-    for (int s = lane; s < S; s += 64) {
-      const int64_t b = r * S + s;
-      const float z = z_vals[b];
-      const float px = dx * z, py = dy * z, pz = dz * z;
-      float q[3];
+    for (int k = 0; k < 12; ++k) G[k] = 0.0f;
+    if (dpts != nullptr) {
+      for (int s = lane; s < S; s += 64) {
+        const int64_t b = r * S + s;
+        const float z = z_vals[b];
+        const float px = dx * z, py = dy * z, pz = dz * z;
+        float q[3];
 #pragma unroll
-      for (int k = 0; k < 3; ++k) q[k] = ((M[k * 4] * px + M[k * 4 + 1] * py) + M[k * 4 + 2] * pz) + M[k * 4 + 3];
+        for (int k = 0; k < 3; ++k) q[k] = ((M[k * 4] * px + M[k * 4 + 1] * py) + M[k * 4 + 2] * pz) + M[k * 4 + 3];
 #pragma unroll
-      for (int i = 0; i < 3; ++i) {
-        const float g = dpts[b * 3 + i];
-        G[i * 4 + 0] += g * q[0];
-        G[i * 4 + 1] += g * q[1];
-        G[i * 4 + 2] += g * q[2];
-        G[i * 4 + 3] += g;
+        for (int i = 0; i < 3; ++i) {
+          const float g = dpts[b * 3 + i];
+          G[i * 4 + 0] += g * q[0];
+          G[i * 4 + 1] += g * q[1];
+          G[i * 4 + 2] += g * q[2];
+          G[i * 4 + 3] += g;
+        }
       }
     }
-  }
-  if (lane == 0 && dview != nullptr && sh_degree > 1) {
-    // world view dir d = tf_R v ; dL/dd through SH (nerf_helpers.py:72-85), then dL/dDelta_R += g (x) (c2w_R v)
-    const float nrm = sqrtf(dx * dx + dy * dy + dz * dz);
-    const float v[3] = {dx / nrm, dy / nrm, dz / nrm};
-    const float* T = tf + (size_t)f * 12;
-    float d[3], cv[3];
+    if (lane == 0 && dview != nullptr && sh_degree > 1) {
+      // world view dir d = tf_R v ; dL/dd through SH (nerf_helpers.py:72-85), then dL/dDelta_R += g (x) (c2w_R v)
+      const float nrm = sqrtf(dx * dx + dy * dy + dz * dz);
+      const float v[3] = {dx / nrm, dy / nrm, dz / nrm};
+      const float* T = tf + (size_t)f * 12;
+      float d[3], cv[3];
 #pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      d[k] = (T[k * 4] * v[0] + T[k * 4 + 1] * v[1]) + T[k * 4 + 2] * v[2];
-      cv[k] = (M[k * 4] * v[0] + M[k * 4 + 1] * v[1]) + M[k * 4 + 2] * v[2];
-    }
-    const float* gs = dview + r * NOF_VIEW_COLS + ff;
-    const float x = d[0], y = d[1], z = d[2];
-    const float C1 = 0.4886025119029199f;
-    float gx = -C1 * gs[3], gy = -C1 * gs[1], gz = C1 * gs[2];
-    if (sh_degree > 2) {
-      const float a0 = 1.0925484305920792f, a1 = -1.0925484305920792f, a2 = 0.31539156525252005f,
-                  a3 = -1.0925484305920792f, a4 = 0.5462742152960396f;
-      gx += gs[4] * a0 * y + gs[6] * a2 * (-2.0f * x) + gs[7] * a3 * z + gs[8] * a4 * (2.0f * x);
-      gy += gs[4] * a0 * x + gs[5] * a1 * z + gs[6] * a2 * (-2.0f * y) + gs[8] * a4 * (-2.0f * y);
-      gz += gs[5] * a1 * y + gs[6] * a2 * (4.0f * z) + gs[7] * a3 * x;
-    }
-    const float gd[3] = {gx, gy, gz};
+      for (int k = 0; k < 3; ++k) {
+        d[k] = (T[k * 4] * v[0] + T[k * 4 + 1] * v[1]) + T[k * 4 + 2] * v[2];
+        cv[k] = (M[k * 4] * v[0] + M[k * 4 + 1] * v[1]) + M[k * 4 + 2] * v[2];
+      }
+      const float* gs = dview + r * NOF_VIEW_COLS + ff;
+      const float x = d[0], y = d[1], z = d[2];
+      const float C1 = 0.4886025119029199f;
+      float gx = -C1 * gs[3], gy = -C1 * gs[1], gz = C1 * gs[2];
+      if (sh_degree > 2) {
+        const float a0 = 1.0925484305920792f, a1 = -1.0925484305920792f, a2 = 0.31539156525252005f,
+                    a3 = -1.0925484305920792f, a4 = 0.5462742152960396f;
+        gx += gs[4] * a0 * y + gs[6] * a2 * (-2.0f * x) + gs[7] * a3 * z + gs[8] * a4 * (2.0f * x);
+        gy += gs[4] * a0 * x + gs[5] * a1 * z + gs[6] * a2 * (-2.0f * y) + gs[8] * a4 * (-2.0f * y);
+        gz += gs[5] * a1 * y + gs[6] * a2 * (4.0f * z) + gs[7] * a3 * x;
+      }
+      const float gd[3] = {gx, gy, gz};
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
-      G[i * 4 + 0] += gd[i] * cv[0];
-      G[i * 4 + 1] += gd[i] * cv[1];
-      G[i * 4 + 2] += gd[i] * cv[2];
+      for (int i = 0; i < 3; ++i) {
+        G[i * 4 + 0] += gd[i] * cv[0];
+        G[i * 4 + 1] += gd[i] * cv[1];
+        G[i * 4 + 2] += gd[i] * cv[2];
+      }
     }
-  }
-  float mine = 0.0f;                                                    // lane k keeps component k: one coalesced 48-byte store
 #pragma unroll
-  for (int k = 0; k < 12; ++k) {
-    const float t = wave_sum_p(G[k]);
-    if (lane == k) mine = t;
+    for (int k = 0; k < 12; ++k) {
+      const float t = wave_sum_p(G[k]);
+      if (lane == k) mine = t;
+    }
   }
   if (lane < 12) g_ray[r * 12 + lane] = mine;
+  if (slots != nullptr) {
+    // one atomic instruction per ray into slot (frame, ray % 16): 28 consecutive floats = two 64-byte lines; a slot collects
+    // R / (16 F) rays (4 at 4096 rays and 64 frames), so the same-line serialisation of the memory-side atomics stays short
+    const float v = lane < 12 ? mine : fpart;
+    float* slot = slots + ((size_t)f * NOF_POSE_SLOTS + (size_t)(r & (NOF_POSE_SLOTS - 1))) * NOF_POSE_SLOT_W;
+    if (lane < 12 + ff && v != 0.0f) atomicAdd(slot + lane, v);
+    // every value of the row has been consumed above (`mine` / `fpart` depend on the loads): ready for the next step's atomics
+    if (lane < NOF_VIEW_COLS) dview[r * NOF_VIEW_COLS + lane] = 0.0f;
+  }
+}
+
+// a frame's summed row (in LDS, visible to the workgroup) -> its gradients
+__device__ __forceinline__ void pose_frame_epilogue(const float* sm0, int f, int ff, const float* __restrict__ pose, float max_trans,
+                                                    float max_rot, float* __restrict__ grad_pose, float* __restrict__ grad_feat,
+                                                    float* __restrict__ g_delta) {
+  if (threadIdx.x < ff && grad_feat) grad_feat[(size_t)f * ff + threadIdx.x] += sm0[12 + threadIdx.x];
+  if (threadIdx.x < 12 && g_delta) g_delta[(size_t)f * 12 + threadIdx.x] = sm0[threadIdx.x];
+  if (threadIdx.x == 0 && pose && grad_pose && f != 0) {
+    float G[12], gp[6];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) G[k] = sm0[k];
+    se3_backward(pose + (size_t)f * 6, G, max_trans, max_rot, gp);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) grad_pose[(size_t)f * 6 + k] += gp[k];
+  }
 }
 
 // One workgroup per frame: sums the per-ray rows of its frame (no atomics: gfx950 atomics serialise per 64-byte line and
@@ -223,10 +250,30 @@ __global__ __launch_bounds__(256) void k_pose_reduce_bwd(const float* __restrict
                                                           float* __restrict__ dview, const float* __restrict__ batch,
                                                           int64_t R, int ff, float max_trans, float max_rot,
                                                           float* __restrict__ grad_pose, float* __restrict__ grad_feat,
-                                                          float* __restrict__ g_delta, int zero_dview) {
+                                                          float* __restrict__ g_delta, int zero_dview,
+                                                          float* __restrict__ slots) {
   __shared__ float sm[4][32];
   const int f = blockIdx.x;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (slots != nullptr) {
+    // slot mode: k_pose_grad_accum left NOF_POSE_SLOTS partial sums per frame; add them in slot order, hand them back zeroed
+    if (threadIdx.x < NOF_POSE_SLOT_W) {
+      float* sl = slots + (size_t)f * NOF_POSE_SLOTS * NOF_POSE_SLOT_W + threadIdx.x;
+      float v[NOF_POSE_SLOTS];
+#pragma unroll
+      for (int k = 0; k < NOF_POSE_SLOTS; ++k) v[k] = sl[k * NOF_POSE_SLOT_W];
+      float t = 0.0f;
+#pragma unroll
+      for (int k = 0; k < NOF_POSE_SLOTS; ++k) {
+        t += v[k];
+        if (v[k] != 0.0f) sl[k * NOF_POSE_SLOT_W] = 0.0f;
+      }
+      sm[0][threadIdx.x] = t;
+    }
+    __syncthreads();
+    pose_frame_epilogue(sm[0], f, ff, pose, max_trans, max_rot, grad_pose, grad_feat, g_delta);
+    return;
+  }
   float acc[12 + NOF_VIEW_COLS];
 #pragma unroll
   for (int k = 0; k < 12 + NOF_VIEW_COLS; ++k) acc[k] = 0.0f;
@@ -268,16 +315,7 @@ __global__ __launch_bounds__(256) void k_pose_reduce_bwd(const float* __restrict
     sm[0][k] = (sm[0][k] + sm[1][k]) + (sm[2][k] + sm[3][k]);
   }
   __syncthreads();
-  if (threadIdx.x < ff && grad_feat) grad_feat[(size_t)f * ff + threadIdx.x] += sm[0][12 + threadIdx.x];
-  if (threadIdx.x < 12 && g_delta) g_delta[(size_t)f * 12 + threadIdx.x] = sm[0][threadIdx.x];
-  if (threadIdx.x == 0 && pose && grad_pose && f != 0) {
-    float G[12], gp[6];
-#pragma unroll
-    for (int k = 0; k < 12; ++k) G[k] = sm[0][k];
-    se3_backward(pose + (size_t)f * 6, G, max_trans, max_rot, gp);
-#pragma unroll
-    for (int k = 0; k < 6; ++k) grad_pose[(size_t)f * 6 + k] += gp[k];
-  }
+  pose_frame_epilogue(sm[0], f, ff, pose, max_trans, max_rot, grad_pose, grad_feat, g_delta);
 }
 
 extern "C" int nof_pose_fwd(const float* pose_data, const float* c2w, float max_trans, float max_rot_rad, float* tf,
@@ -300,26 +338,33 @@ extern "C" int nof_pose_bwd(const float* pose_data, const float* g_delta, float 
   return 0;
 }
 
-extern "C" int nof_pose_grad_accum(const float* dpts, const float* dview, const float* batch, const float* z_vals,
+extern "C" int nof_pose_grad_accum(const float* dpts, float* dview, const float* batch, const float* z_vals,
                                     const float* c2w, const float* tf, int32_t ff, int32_t sh_degree, int64_t R, int32_t S,
-                                    float* g_ray, void* stream) {
+                                    float* g_ray, float* frame_slots, void* stream) {
   NOF_ARG(batch && z_vals && c2w && tf && g_ray && R >= 0 && S >= 1 && ff >= 0 && ff <= NOF_VIEW_COLS);
-  NOF_ARG(sh_degree >= 1 && sh_degree <= 3);
+  NOF_ARG(sh_degree >= 1 && sh_degree <= 3 && (frame_slots == nullptr || dview != nullptr));
+  static_assert(NOF_POSE_SLOT_W == 12 + NOF_VIEW_COLS && (NOF_POSE_SLOTS & (NOF_POSE_SLOTS - 1)) == 0, "slot layout");
   if (R == 0) return 0;
   hipLaunchKernelGGL(k_pose_grad_accum, dim3((unsigned)R), dim3(64), 0, (hipStream_t)stream, dpts, dview, batch, z_vals,
-                     c2w, tf, ff, sh_degree, R, S, g_ray);
+                     c2w, tf, ff, sh_degree, R, S, g_ray, frame_slots);
   NOF_LAUNCH_OK();
   return 0;
 }
 
 extern "C" int nof_pose_reduce_bwd(const float* pose_data, const float* g_ray, float* dview, const float* batch,
                                     int64_t R, int32_t ff, float max_trans, float max_rot_rad, float* grad_pose,
-                                    float* grad_feat, float* g_delta, int32_t F, int32_t zero_dview, void* stream) {
-  NOF_ARG(batch && R >= 0 && F >= 0 && ff >= 0 && ff <= NOF_VIEW_COLS && (!zero_dview || dview));
-  NOF_ARG((ff == 0 || grad_feat == nullptr || dview != nullptr) && (grad_pose == nullptr || (pose_data && g_ray)));
+                                    float* grad_feat, float* g_delta, int32_t F, int32_t zero_dview, float* frame_slots,
+                                    void* stream) {
+  NOF_ARG(R >= 0 && F >= 0 && ff >= 0 && ff <= NOF_VIEW_COLS);
+  if (frame_slots == nullptr) {
+    NOF_ARG(batch && (!zero_dview || dview));
+    NOF_ARG((ff == 0 || grad_feat == nullptr || dview != nullptr) && (grad_pose == nullptr || (pose_data && g_ray)));
+  } else {
+    NOF_ARG(grad_pose == nullptr || pose_data);
+  }
   if (F == 0) return 0;
   hipLaunchKernelGGL(k_pose_reduce_bwd, dim3((unsigned)F), dim3(256), 0, (hipStream_t)stream, pose_data, g_ray, dview,
-                     batch, R, ff, max_trans, max_rot_rad, grad_pose, grad_feat, g_delta, (int)zero_dview);
+                     batch, R, ff, max_trans, max_rot_rad, grad_pose, grad_feat, g_delta, (int)zero_dview, frame_slots);
   NOF_LAUNCH_OK();
   return 0;
 }

@@ -72,6 +72,7 @@ class NeuralObjectField:
         # gradients: a few floats of headroom in FRONT of the flat buffer, so that the data-parallel step can put a copy of the tail
         # [frame features | poses] next to the coarse table levels and reduce both in one collective (train_step, `bucketed`)
         self._st, self._sh, self._events = None, None, {}     # the step's stream (torch object, raw handle), fork / join events
+        self.pose_slots = torch.zeros(max(self.F, 1) * 16 * 28, device=dev)      # [F, NOF_POSE_SLOTS, NOF_POSE_SLOT_W], kept zero between steps
         self._n_tail = self.n_feat + self.n_pose
         self._head = (self._n_tail + 63) // 64 * 64
         self._grads_store = torch.zeros(self._head + self.n_total, device=dev)
@@ -450,15 +451,19 @@ class NeuralObjectField:
                            dpts, lo, hi, tiles, parts, self.scatter_wgs_per_cu, B, tag=tag)
 
         def pose_kernels():
-            if self.optimize_poses or self.ff > 0:
-                if self.optimize_poses:
-                    self._call('nof_pose_grad_accum', b['dpts'], b['dview'], b['batch'], b['z_vals'], self.c2w, self.tf, self.ff,
-                               self.sh_degree, R, S, b['g_ray'])
-                self._call('nof_pose_reduce_bwd', self.pose if self.optimize_poses else None,
-                           b['g_ray'] if self.optimize_poses else None, b['dview'], b['batch'], R, self.ff,
-                           C.c_float(self.max_trans), C.c_float(self.max_rot),
-                           self._seg(self.grads, 'pose') if self.optimize_poses else None,
-                           self._seg(self.grads, 'feat') if self.ff > 0 else None, None, self.F, 1)   # (zeroes dview for the next step's atomics)
+            if self.optimize_poses:
+                # per-ray rows, added on the fly to 16 partial sums per frame (one atomic instruction per ray; dview rows zeroed
+                # for the next step's atomics); the per-frame kernel adds a frame's partial sums instead of searching the batch
+                # for the frame's rays (25 -> 8 us on the step's second chain)
+                self._call('nof_pose_grad_accum', b['dpts'], b['dview'], b['batch'], b['z_vals'], self.c2w, self.tf, self.ff,
+                           self.sh_degree, R, S, b['g_ray'], self.pose_slots)
+                self._call('nof_pose_reduce_bwd', self.pose, None, None, None, R, self.ff, C.c_float(self.max_trans),
+                           C.c_float(self.max_rot), self._seg(self.grads, 'pose'),
+                           self._seg(self.grads, 'feat') if self.ff > 0 else None, None, self.F, 0, self.pose_slots)
+            elif self.ff > 0:
+                self._call('nof_pose_reduce_bwd', None, None, b['dview'], b['batch'], R, self.ff,
+                           C.c_float(self.max_trans), C.c_float(self.max_rot), None, self._seg(self.grads, 'feat'), None, self.F, 1,
+                           None)                                       # (zeroes dview for the next step's atomics)
             else:
                 with torch.cuda.stream(self._st):
                     b['dview'].zero_()

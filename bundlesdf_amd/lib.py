@@ -83,8 +83,8 @@ _SIGNATURES = {
     'nof_reduce_partials': ([_P, _I32, _I32, _P, _P, _P], C.c_int),
     'nof_mlp_sdf': ([C.POINTER(NofMlpDesc), _P, _P, _I32, _P, _I64, _P], C.c_int),
     'nof_composite_loss': ([C.POINTER(NofLossCfg), _P, _P, _P, _P, _I64, _I32, _P, _P, _P, _P, _P, _P], C.c_int),
-    'nof_pose_grad_accum': ([_P, _P, _P, _P, _P, _P, _I32, _I32, _I64, _I32, _P, _P], C.c_int),
-    'nof_pose_reduce_bwd': ([_P, _P, _P, _P, _I64, _I32, _F, _F, _P, _P, _P, _I32, _I32, _P], C.c_int),
+    'nof_pose_grad_accum': ([_P, _P, _P, _P, _P, _P, _I32, _I32, _I64, _I32, _P, _P, _P], C.c_int),
+    'nof_pose_reduce_bwd': ([_P, _P, _P, _P, _I64, _I32, _F, _F, _P, _P, _P, _I32, _I32, _P, _P], C.c_int),
     'nof_pose_reg': ([_P, _P, _I32, _F, _F, _P, _P], C.c_int),
     'nof_small_regs': ([_P, _P, _I32, _F, _F, _P], C.c_int),
     'nof_adam_step': ([_P, _P, _P, _P, _I64, _I64, _F, _F, _F, _F, _F, _I32, _P], C.c_int),

@@ -359,17 +359,26 @@ int nof_composite_loss_fwd_bwd(const NofLossCfg* h_cfg, const float* raw, const 
 
 /* ---- pose / feature gradients of a batch ---------------------------------------------------------- */
 /* dpts [R*S,3] (from nof_hash_encode_bwd, may be NULL), dview [R,16] (from nof_mlp_bwd), batch, z_vals, c2w [F,16], tf [F,12]
- * -> g_ray [R,12] = this ray's contribution to dL/dDelta_frame (rows of frame-0 rays are 0).  No atomics. */
-int nof_pose_grad_accum(const float* dpts, const float* dview, const float* batch, const float* z_vals,
+ * -> g_ray [R,12] = this ray's contribution to dL/dDelta_frame (rows of frame-0 rays are 0).
+ * frame_slots (may be NULL): [F, NOF_POSE_SLOTS, NOF_POSE_SLOT_W] floats, all zero on entry.  When given, the ray's 12 values and
+ * its dview[:ff] are ALSO added (one fp32 atomic instruction per ray) to slot (frame, ray % NOF_POSE_SLOTS), and the ray's dview
+ * row is set to 0 (this is then its last reader in a step) -- nof_pose_reduce_bwd sums a frame's slots instead of searching the
+ * batch for the frame's rays. */
+#define NOF_POSE_SLOTS 16
+#define NOF_POSE_SLOT_W 28                  /* 12 + NOF_VIEW_COLS */
+int nof_pose_grad_accum(const float* dpts, float* dview, const float* batch, const float* z_vals,
                         const float* c2w, const float* tf, int32_t ff, int32_t sh_degree, int64_t R, int32_t S,
-                        float* g_ray, void* stream);
+                        float* g_ray, float* frame_slots, void* stream);
 /* one workgroup per frame: g_delta[f] = sum of its rays' rows (written when non-NULL), grad_pose [F,6] += se3 backward,
- * grad_feat [F,ff] += sum of its rays' dview[:, :ff] (either gradient pointer may be NULL).  zero_dview != 0: the rows of dview
- * are set to 0 once read (this is their last reader in a step; every ray's frame must lie in [0, F)): ready for the next step's
- * nof_mlp_bwd, which accumulates into them. */
+ * grad_feat [F,ff] += sum of its rays' dview[:, :ff] (either gradient pointer may be NULL).
+ * frame_slots == NULL: the frame's rays are found in `batch` and their rows of g_ray / dview summed in a fixed order;
+ * zero_dview != 0: the rows of dview are set to 0 once read (this is their last reader in a step; every ray's frame must lie in
+ * [0, F)): ready for the next step's nof_mlp_bwd, which accumulates into them.
+ * frame_slots != NULL (filled by nof_pose_grad_accum): the frame's NOF_POSE_SLOTS partial sums are added in slot order and set
+ * back to 0; g_ray / dview / batch are not read. */
 int nof_pose_reduce_bwd(const float* pose_data, const float* g_ray, float* dview, const float* batch, int64_t R,
                         int32_t ff, float max_trans, float max_rot_rad, float* grad_pose, float* grad_feat,
-                        float* g_delta, int32_t F, int32_t zero_dview, void* stream);
+                        float* g_delta, int32_t F, int32_t zero_dview, float* frame_slots, void* stream);
 /* grad += 2*w*data/numel  (feature_reg, nerf_runner.py:745-747) and pose_reg (:749-752) */
 int nof_small_regs(const float* feat_data, float* grad_feat, int32_t n_feat, float feature_reg_weight,
                    float grad_scale, void* stream);
