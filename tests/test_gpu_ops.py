@@ -613,3 +613,57 @@ def test_adam_ranges_are_bit_identical(nof, off, n, nb):
         assert torch.equal(x[off:off + n], y[k:k + n]), k
         assert torch.equal(x[:off], z[:off]) and torch.equal(x[off + n:], z[off + n:]), k
     assert (a[1][off:off + n] == 0).all()
+
+
+@pytest.mark.parametrize('R,S,F,ff', [(4096, 192, 64, 0), (1000, 64, 7, 2), (33, 32, 3, 16), (257, 96, 300, 1)])
+def test_pose_gradients_slot_sums_equal_batch_search(nof, R, S, F, ff):
+    """nof_pose_grad_accum + nof_pose_reduce_bwd in their two forms: per-ray rows searched by frame (no atomics, fixed order) and
+    the rows added on the fly to 16 partial sums per frame (what the step uses).  Same per-ray rows bit for bit; per-frame sums,
+    pose and frame-feature gradients equal up to fp32 summation order; dview rows and the slots come back zeroed."""
+    rng = np.random.default_rng(R + F)
+    B = R * S
+    batch = rng.normal(size=(R, 12)).astype(np.float32)
+    batch[:, 8] = rng.integers(0, F, size=R)
+    batch[:5, 8] = 0                                                   # frame 0: no pose correction, but frame features
+    pose = (rng.normal(size=(F, 6)) * 0.1).astype(np.float32)
+    c2w = np.tile(np.eye(4, dtype=np.float32), (F, 1, 1)) + rng.normal(size=(F, 4, 4)).astype(np.float32) * 0.1
+    mt, mr = 0.02, np.float32(np.deg2rad(5.0))
+    tf = torch.empty(F, 12, device='cuda')
+    nof.call('nof_pose_fwd', U.dev(pose), U.dev(c2w.reshape(F, 16)), C.c_float(mt), C.c_float(mr), tf, F)
+    dpts = U.dev(rng.normal(size=(B, 3)).astype(np.float32) * 1e-3)
+    dview0 = rng.normal(size=(R, 16)).astype(np.float32)
+    z = U.dev(rng.random((R, S)).astype(np.float32) + 0.2)
+    out = {}
+    for mode in ('search', 'slots'):
+        dview = U.dev(dview0)
+        g_ray = torch.full((R, 12), 7.0, device='cuda')
+        gp, gf, gd = torch.zeros(F, 6, device='cuda'), torch.zeros(F, max(ff, 1), device='cuda'), torch.zeros(F, 12, device='cuda')
+        slots = torch.zeros(F * 16 * 28, device='cuda') if mode == 'slots' else None
+        nof.call('nof_pose_grad_accum', dpts, dview, U.dev(batch), z, U.dev(c2w.reshape(F, 16)), tf, ff, 3 if ff <= 7 else 1, R, S,
+                 g_ray, slots)                                     # (view row = [ff features | SH]: 9 SH coefficients need ff <= 7)
+        if mode == 'slots':
+            nof.call('nof_pose_reduce_bwd', U.dev(pose), None, None, None, R, ff, C.c_float(mt), C.c_float(mr), gp,
+                     gf if ff else None, gd, F, 0, slots)
+        else:
+            nof.call('nof_pose_reduce_bwd', U.dev(pose), g_ray, dview, U.dev(batch), R, ff, C.c_float(mt), C.c_float(mr), gp,
+                     gf if ff else None, gd, F, 1, None)
+        torch.cuda.synchronize()
+        assert (dview == 0).all()
+        if slots is not None:
+            assert (slots == 0).all()
+        out[mode] = [cpu(x) for x in (g_ray, gd, gp, gf)]
+    a, b = out['search'], out['slots']
+    assert np.array_equal(a[0], b[0])                                  # the per-ray rows do not depend on the mode
+    assert (a[0][:5] == 0).all()
+    # reference for the per-frame sums: float64 over the rows
+    want = np.zeros((F, 12))
+    np.add.at(want, batch[:, 8].astype(int), a[0].astype(np.float64))
+    scale = np.abs(want).max() + 1e-12
+    for k, name in ((1, 'g_delta'), (2, 'grad_pose'), (3, 'grad_feat')):
+        s = max(np.abs(a[k]).max(), 1e-12)
+        assert np.abs(a[k] - b[k]).max() <= 2e-5 * s, name
+    assert np.abs(a[1] - want).max() <= 2e-5 * scale and np.abs(b[1] - want).max() <= 2e-5 * scale
+    if ff:
+        wf = np.zeros((F, ff))
+        np.add.at(wf, batch[:, 8].astype(int), dview0[:, :ff].astype(np.float64))
+        assert np.abs(b[3] - wf).max() <= 2e-5 * (np.abs(wf).max() + 1e-12)
