@@ -72,7 +72,9 @@ def build_runner(args, rank, world, device):
     # bucketed step, exercised on the one GPU a test box has)
     if dist.is_initialized() and (world > 1 or os.environ.get('NOF_DP_FORCE') == '1'):
         from bundlesdf_amd.dist import GradSync
-        sync = GradSync()                   # bucketed: the fine hash levels' slice is reduced beside the rest of the backward
+        # bucketed: the fine hash levels' slice is reduced beside the rest of the backward; NOF_DP_PAYLOAD=bf16: that slice travels
+        # as bfloat16 (opt-in: it changes the gradient by 2^-8 relative per entry; fp32, the default, changes nothing)
+        sync = GradSync(payload=os.environ.get('NOF_DP_PAYLOAD', 'fp32'))
         if os.environ.get('NOF_DP_OVERLAP', '1') == '0':
             sync = sync.__call__            # one blocking all-reduce of the whole buffer
     ns, nc, hidden = MLP_SHAPES[args.mlp]
@@ -463,7 +465,7 @@ def main():
             # step's stream waited for them after the backward (events around GradSync.finish: what did not hide)
             "allreduce_bytes_per_step": (sync.bytes_step if sync is not None else (fld.n_total * 4 if runner.grad_sync is not None else 0)),
             "collectives_per_step": (sync.collectives_step if sync is not None else (1 if runner.grad_sync is not None else 0)),
-            "exposed_comm_ms": exposed_comm_ms,
+            "exposed_comm_ms": exposed_comm_ms, "dp_payload": getattr(sync, 'payload', None),
             "roofline": roof,
         }
         if not args.no_cpu_baseline and world == 1:          # the CPU leg is timed on rank 0 at N = 1 only

@@ -45,11 +45,14 @@ class GradSync:
     slice's share of Adam.  Sums are
     element-wise, so bucketing does not change a single bit of the result."""
 
-    def __init__(self):
-        self.pending = []
+    def __init__(self, payload='fp32'):
+        assert payload in ('fp32', 'bf16')
+        self.payload = payload       # 'bf16': slices started with compressed=True travel as bfloat16 (half the bytes on the wire)
+        self.pending = []            # [(work, fp32 slice to refill from its staging buffer or None, staging buffer)]
         self.bytes_step = 0          # payload bytes handed to all-reduce in the last step (per rank)
         self.collectives_step = 0
         self._bytes = self._n = 0
+        self._staging = None
         self.timing = None           # list of (event before a wait, event after it): bench.py's exposed-communication time
         self.timed_steps = 0
 
@@ -57,19 +60,35 @@ class GradSync:
         dist.all_reduce(flat, op=dist.ReduceOp.SUM)
         self.bytes_step, self.collectives_step = flat.numel() * flat.element_size(), 1
 
-    def start(self, part):
-        if part.numel():
-            self.pending.append(dist.all_reduce(part, op=dist.ReduceOp.SUM, async_op=True))
+    def start(self, part, compressed=False):
+        """asynchronous all-reduce of a slice of the flat fp32 gradient buffer.  compressed (and payload 'bf16'): the slice is
+        rounded to bfloat16 into a staging buffer, summed in bfloat16 -- every rank receives the same bits, so replicas stay
+        identical -- and written back to the slice when the collective is waited for.  Meant for the table slice only: Adam
+        divides a gradient by its own running magnitude, so a 2^-8 relative error per entry moves no parameter by more than that
+        fraction of a step (tests/test_gpu_dp.py measures the loss drift over 50 steps)."""
+        if not part.numel():
+            return
+        if compressed and self.payload == 'bf16':
+            if self._staging is None or self._staging.numel() < part.numel() or self._staging.device != part.device:
+                self._staging = torch.empty(part.numel(), dtype=torch.bfloat16, device=part.device)
+            st = self._staging[:part.numel()]
+            st.copy_(part)
+            self.pending.append((dist.all_reduce(st, op=dist.ReduceOp.SUM, async_op=True), part, st))
+            self._bytes += st.numel() * st.element_size()
+        else:
+            self.pending.append((dist.all_reduce(part, op=dist.ReduceOp.SUM, async_op=True), None, None))
             self._bytes += part.numel() * part.element_size()
-            self._n += 1
+        self._n += 1
 
     def _wait(self, works):
         ev = None
         if self.timing is not None and torch.cuda.is_available():
             ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             ev[0].record()
-        for w in works:
+        for w, part, st in works:
             w.wait()
+            if part is not None:
+                part.copy_(st)
         if ev is not None:
             ev[1].record()
             self.timing.append(ev)
@@ -90,11 +109,11 @@ class GradSync:
         self.bytes_step, self.collectives_step, self._bytes, self._n = self._bytes, self._n, 0, 0
 
 
-def make_grad_sync(overlap=True):
+def make_grad_sync(overlap=True, payload='fp32'):
     """GradSync when a process group with more than one rank exists, else None."""
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return None
-    g = GradSync()
+    g = GradSync(payload)
     return g if overlap else g.__call__
 
 

@@ -69,12 +69,13 @@ class NeuralObjectField:
         self.max_rot = float(cfg['max_rot'] / 180.0 * np.pi)
         dev = self.device
         self.params = torch.zeros(self.n_total, device=dev)
-        # gradients: a few floats of headroom in FRONT of the flat buffer, so that the data-parallel step can put a copy of the tail
-        # [frame features | poses] next to the coarse table levels and reduce both in one collective (train_step, `bucketed`)
         self._st, self._sh, self._events = None, None, {}     # the step's stream (torch object, raw handle), fork / join events
         self.pose_slots = torch.zeros(max(self.F, 1) * 16 * 28, device=dev)      # [F, NOF_POSE_SLOTS, NOF_POSE_SLOT_W], kept zero between steps
+        # gradients: some headroom in FRONT of the flat buffer, so that the data-parallel step can put a copy of what lies behind
+        # the table ([MLP | frame features | poses]: tens of KB) next to the coarse table levels and reduce both in one collective
+        # (train_step, `bucketed`)
         self._n_tail = self.n_feat + self.n_pose
-        self._head = (self._n_tail + 63) // 64 * 64
+        self._head = (self._n_tail + self.n_mlp + 63) // 64 * 64
         self._grads_store = torch.zeros(self._head + self.n_total, device=dev)
         self.grads = self._grads_store[self._head:]
         self.exp_avg = torch.zeros(self.n_total, device=dev)
@@ -482,13 +483,17 @@ class NeuralObjectField:
             self._after(side, main, 'fork')
             if bucketed:
                 # data parallel: the fine (hashed) levels first; their slice [rows of level `split` .., MLP] of the flat gradient
-                # buffer (80 % of its bytes at cfg2) is all-reduced while the coarse levels, dL/dx and the pose kernels still run
+                # buffer (80 % of its bytes at cfg2) is all-reduced while the coarse levels, dL/dx and the pose kernels still run.
+                # With a bf16 payload (GradSync.payload) that slice is the table rows alone, rounded to bfloat16 on their way out,
+                # and the MLP rows travel in fp32 with the trailing collective.
                 a = 2 * int(self.offsets[split])
+                compressed = getattr(grad_sync, 'payload', 'fp32') == 'bf16'
+                first_hi = self.n_table if compressed else self.n_table + self.n_mlp
                 reduce_mlp()
                 hash_bwd(BIG | SMALL, split, self.L)
-                if wide_aux is not None:                             # the MLP gradient is part of the slice that goes out next
+                if wide_aux is not None:                             # the MLP gradient is part of what goes out
                     self._after(main, wide_aux, 'aux_dp')
-                grad_sync.start(self.grads[a:self.n_table + self.n_mlp])
+                grad_sync.start(self.grads[a:first_hi], compressed=compressed)
                 with self._on(side):
                     hash_bwd(INPUT, 0, self.L)
                     pose_kernels()
@@ -514,21 +519,22 @@ class NeuralObjectField:
             self._call('nof_small_regs', self.feat, self._seg(self.grads, 'feat'), self.n_feat,
                        C.c_float(cfg['feature_reg_weight']), C.c_float(1.0 / self.world_size))
         if bucketed:
-            # ONE more collective: everything that is not in flight yet.  [0, a) and the tail behind the MLP are not contiguous
-            # in the flat buffer, so a copy of the tail (frame features + poses: a few KB) rides in the headroom in front of it
-            nt, h = self._n_tail, self._head
-            tail = self.grads[self.n_table + self.n_mlp:]
-            if nt:
-                self._grads_store[h - nt:h].copy_(tail)
-            grad_sync.start(self._grads_store[h - nt:h + a])
+            # ONE more collective: everything that is not in flight yet.  [0, a) and what lies behind the first slice are not
+            # contiguous in the flat buffer, so a copy of the latter (tens of KB) rides in the headroom in front of it
+            h = self._head
+            rest = self.grads[first_hi:]
+            nr = rest.numel()
+            if nr:
+                self._grads_store[h - nr:h].copy_(rest)
+            grad_sync.start(self._grads_store[h - nr:h + a])
             if do_step and not dyn and hasattr(grad_sync, 'finish_first'):
                 # Adam is element-wise: the first slice's share of it runs while the trailing collective is on the wire
                 grad_sync.finish_first()
-                self.adam_step(False, a, self.n_table + self.n_mlp, advance=False)
-                adam_done = (a, self.n_table + self.n_mlp)
+                self.adam_step(False, a, first_hi, advance=False)
+                adam_done = (a, first_hi)
             grad_sync.finish()
-            if nt:
-                tail.copy_(self._grads_store[h - nt:h])
+            if nr:
+                rest.copy_(self._grads_store[h - nr:h])
         elif grad_sync is not None:
             grad_sync(self.grads)
         if do_step:

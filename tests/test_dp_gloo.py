@@ -79,6 +79,27 @@ def _worker(rank, world, port, R, out):
     view[b:] = store[:nt]
     assert not sync.pending and torch.equal(view, flat)
     assert sync.collectives_step == 2 and sync.bytes_step == 4 * (b - a + nt + a) and sync.timed_steps == 1
+    # bf16 payload: the slice is rounded to bfloat16, summed in bfloat16 and written back -- the same bits on every rank
+    n = 4099
+    mine = [((torch.arange(n) % 97).float() - 48.0) * (1e-3 * (r + 1)) + 1e-5 * (r + 1) for r in range(world)]
+    buf = mine[rank].clone()
+    sb = D.GradSync(payload='bf16')
+    sb.start(buf[3:], compressed=True)
+    sb.start(buf[:3])                                    # (uncompressed slices of the same step stay fp32)
+    assert len(sb.pending) == 2
+    sb.finish_first()
+    want = mine[0][3:].bfloat16()
+    for r in range(1, world):
+        want = want + mine[r][3:].bfloat16()
+    assert torch.equal(buf[3:], want.float())
+    sb.finish()
+    assert torch.equal(buf[:3], sum(m[:3] for m in mine)) and sb.bytes_step == 2 * (n - 3) + 4 * 3 and sb.collectives_step == 2
+    assert (buf[3:] - sum(m[3:] for m in mine)).abs().max() <= 2.0 ** -7 * sum(m[3:] for m in mine).abs().max()
+    plain = mine[rank].clone()
+    sp = D.GradSync()                                    # payload fp32: compressed=True changes nothing
+    sp.start(plain[3:], compressed=True)
+    sp.finish()
+    assert torch.equal(plain[3:], sum(m[3:] for m in mine)) and sp.bytes_step == 4 * (n - 3)
     if rank == 0:
         out.put(flat.numpy())
     dist.barrier()

@@ -14,10 +14,11 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run(overlap, port, backend='gloo', ranks=2, force='0'):
-    env = dict(os.environ, NOF_DIST_BACKEND=backend, HSA_ENABLE_IPC_MODE_LEGACY='0', NOF_DP_OVERLAP=overlap, NOF_DP_FORCE=force)
+def _run(overlap, port, backend='gloo', ranks=2, force='0', steps=6, payload='fp32'):
+    env = dict(os.environ, NOF_DIST_BACKEND=backend, HSA_ENABLE_IPC_MODE_LEGACY='0', NOF_DP_OVERLAP=overlap, NOF_DP_FORCE=force,
+               NOF_DP_PAYLOAD=payload)
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(ranks), '--master-addr', '127.0.0.1',
-           '--master-port', str(port), os.path.join(ROOT, 'bench.py'), '--gpus', str(ranks), '--steps', '6', '--warmup', '2',
+           '--master-port', str(port), os.path.join(ROOT, 'bench.py'), '--gpus', str(ranks), '--steps', str(steps), '--warmup', '2',
            '--keyframes', '3', '--no-cpu-baseline', '--settle', '0']
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-3000:]
@@ -41,6 +42,22 @@ def test_bench_two_ranks_one_gpu_gloo(nof):
     # the trailing one carries a copy of the [features | poses] tail in the headroom in front of the gradient buffer
     assert d['collectives_per_step'] == 2 and d0['collectives_per_step'] == 1
     assert d['allreduce_bytes_per_step'] >= d0['allreduce_bytes_per_step'] > 4 * 9_000_000
+
+
+def test_bf16_payload_loss_drift_over_50_steps(nof):
+    """GradSync(payload='bf16'): the fine hash levels' slice of the gradient travels as bfloat16 (opt-in).  Two ranks, 52 steps
+    each way: the replicas stay bit-identical (every rank receives the same rounded sum), half the table bytes go out, and the
+    loss after the run is the fp32 run's within a few per cent."""
+    d = _run('1', 29541, steps=50, payload='bf16')
+    d0 = _run('1', 29542, steps=50)
+    assert d['dp_payload'] == 'bf16' and d0['dp_payload'] == 'fp32'
+    assert d['dp_param_checksum_spread'] == 0.0 and d['flags'] == 0
+    assert d['collectives_per_step'] == 2 and d0['collectives_per_step'] == 2
+    assert d['allreduce_bytes_per_step'] < 0.65 * d0['allreduce_bytes_per_step']
+    print(f"loss after 52 steps on 2 ranks: bf16 payload {d['loss']:.6f}, fp32 {d0['loss']:.6f}; "
+          f"bytes per step {d['allreduce_bytes_per_step']} vs {d0['allreduce_bytes_per_step']}")
+    assert abs(d['loss'] - d0['loss']) <= 0.03 * abs(d0['loss'])
+    assert abs(d['param_checksum'] - d0['param_checksum']) <= 2e-3 * d0['param_checksum']
 
 
 def test_rccl_calls_of_the_bucketed_step_one_rank(nof):
