@@ -130,12 +130,19 @@ __device__ __forceinline__ int trace_one(const uint32_t* __restrict__ bits, int 
         }
       }
     }
-    int a = 0;                                                        // leave through the nearest exit plane (ties: x, y, z)
-    if (tmax[1] < tmax[a]) a = 1;
-    if (tmax[2] < tmax[a]) a = 2;
-    if (ax[a].zero) break;
-    c[a] += ax[a].step;
-    if (c[a] < 0 || c[a] >= n) break;
+    // leave through the nearest exit plane (ties: x, y, z).  The axis is picked with selects, not by indexing ax[] / c[] with it:
+    // a run-time index sends both arrays to scratch memory, and this loop then waits for a scratch round trip per step
+    const bool y_first = tmax[1] < tmax[0];
+    const float t01 = y_first ? tmax[1] : tmax[0];
+    const bool z_first = tmax[2] < t01;
+    const bool zero_a = z_first ? ax[2].zero : (y_first ? ax[1].zero : ax[0].zero);
+    const int step_a = z_first ? ax[2].step : (y_first ? ax[1].step : ax[0].step);
+    if (zero_a) break;
+    c[0] += (!z_first && !y_first) ? step_a : 0;
+    c[1] += (!z_first && y_first) ? step_a : 0;
+    c[2] += z_first ? step_a : 0;
+    const int ca = z_first ? c[2] : (y_first ? c[1] : c[0]);
+    if (ca < 0 || ca >= n) break;
   }
   return nh;
 }

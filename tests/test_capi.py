@@ -152,3 +152,80 @@ def test_nerf_runner_plugin_surface():
         from bundlesdf_amd import lib
         with pytest.raises(lib.NofError):
             nr.NerfRunner({}, None, None, None, None, None, np.eye(3))
+
+
+def _kernel_metadata():
+    """(demangled name, metadata dict) of every gfx950 kernel in libnof_hip.so, read from the code objects bundled in the library
+    (clang offload bundles, uncompressed) with llvm-readelf: what the COMPILER decided, no GPU needed."""
+    import re
+    import struct
+    import subprocess
+    import tempfile
+    readelf = '/opt/rocm/lib/llvm/bin/llvm-readelf'
+    if not os.path.exists(readelf):
+        pytest.skip('llvm-readelf not found')
+    from bundlesdf_amd import lib
+    d = open(lib.LIB_PATH, 'rb').read()
+    magic, pos, rows = b'__CLANG_OFFLOAD_BUNDLE__', 0, []
+    with tempfile.TemporaryDirectory() as tmp:
+        while True:
+            i = d.find(magic, pos)
+            if i < 0:
+                break
+            pos = i + len(magic)
+            n, p = struct.unpack_from('<Q', d, i + 24)[0], i + 32
+            for _ in range(n):
+                off, size, tl = struct.unpack_from('<QQQ', d, p)
+                triple = d[p + 24:p + 24 + tl].decode()
+                p += 24 + tl
+                if 'gfx950' not in triple or not size:
+                    continue
+                co = os.path.join(tmp, 'k.co')
+                open(co, 'wb').write(d[i + off:i + off + size])
+                notes = subprocess.run([readelf, '--notes', co], capture_output=True, text=True, check=True).stdout
+                for blk in notes.split('  - .agpr_count:')[1:]:
+                    md = {k: v for k, v in re.findall(r'\.(\w+):\s+(\S+)\n', blk)}
+                    md['agpr_count'] = blk.split('\n')[0].strip()
+                    rows.append(md)
+    assert rows, 'no gfx950 code object found in the library'
+    names = subprocess.run(['c++filt'] + [r['name'] for r in rows], capture_output=True, text=True).stdout.splitlines()
+    return [(n.replace('void ', ''), r) for n, r in zip(names, rows)]
+
+
+def test_hot_kernels_have_no_scratch():
+    """Spills in the step's kernels cost time twice (the memory round trip, and a spilled address register is reloaded behind
+    s_waitcnt vmcnt(0)), and a run-time index into a small local array does the same silently (the ray marcher's DDA loop did,
+    until round 3).  The compiler's own metadata says which kernels use private memory: none of the kernels a default step or a
+    wide-network step launches may.  Known exceptions, listed so that a new one is noticed: the one-kernel MLP backward
+    (`k_mlp_bwd`: fp32 mode and the entry point without a split workspace; 512 registers + AGPRs by design), the colour backward
+    with THREE colour layers, the bf16 colour backward at hidden 128 (2 registers = 12 bytes; the fp16 variant, cfg5's,
+    is clean), and the mesh extractors' emit kernels (renderer side: the case table indexes the cell's corner values at run time)."""
+    import re
+    allowed = (r'^k_mlp_bwd<', r'^k_mlp_bwd_color<\w+, \d, 3>', r'^k_wide_bwd_color<PrecBF16, 4>', r'^k_m[ct]_emit$')
+    bad = []
+    seen = set()
+    for name, md in _kernel_metadata():
+        short = name.split('(')[0]
+        seen.add(re.sub(r'<.*', '', short))
+        if any(re.match(a, short) for a in allowed):
+            continue
+        if int(md['private_segment_fixed_size']) or int(md['vgpr_spill_count']):
+            bad.append((short, md['private_segment_fixed_size'], md['vgpr_spill_count']))
+    assert not bad, bad
+    for k in ('k_hash_fwd', 'k_hash_bwd_agg', 'k_hash_bwd_lds', 'k_hash_dx', 'k_batch_trace', 'k_sample_points', 'k_mlp_fwd',
+              'k_mlp_bwd_sigma', 'k_mlp_bwd_color', 'k_composite_loss', 'k_loss_reduce', 'k_adam', 'k_wide_dw', 'k_wide_fwd_sigma',
+              'k_pose_grad_accum', 'k_pose_reduce_bwd', 'k_reduce_partials', 'k_sdf_grid', 'k_mc_emit'):
+        assert k in seen, k                                            # (the metadata reader really saw the library's kernels)
+
+
+def test_forward_mlp_fits_four_waves_per_simd():
+    """k_mlp_fwd in the 16-bit precisions is launched with 8 waves per workgroup, two workgroups per CU (one LDS image of the
+    weight fragments per 8 waves): that needs <= 128 registers per lane -- the launch bound asks for it, this checks the compiler
+    delivered it without spilling (covered above) in every shape."""
+    n = 0
+    for name, md in _kernel_metadata():
+        if name.startswith('k_mlp_fwd<PrecF16') or name.startswith('k_mlp_fwd<PrecBF16'):
+            assert int(md['vgpr_count']) + int(md['agpr_count']) <= 128, (name, md['vgpr_count'])
+            assert int(md['max_flat_workgroup_size']) == 512, name
+            n += 1
+    assert n == 32                                                     # 2 types x 4 shapes x {raw, sdf only} x {plain, split}
