@@ -155,41 +155,15 @@ def test_nerf_runner_plugin_surface():
 
 
 def _kernel_metadata():
-    """(demangled name, metadata dict) of every gfx950 kernel in libnof_hip.so, read from the code objects bundled in the library
-    (clang offload bundles, uncompressed) with llvm-readelf: what the COMPILER decided, no GPU needed."""
-    import re
-    import struct
-    import subprocess
-    import tempfile
-    readelf = '/opt/rocm/lib/llvm/bin/llvm-readelf'
-    if not os.path.exists(readelf):
-        pytest.skip('llvm-readelf not found')
+    """(demangled name, metadata dict) of every gfx950 kernel in libnof_hip.so (tools/kernel_metadata.py): what the COMPILER
+    decided, read from the code objects bundled in the library; no GPU needed."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, 'tools'))
+    import kernel_metadata as KM
     from bundlesdf_amd import lib
-    d = open(lib.LIB_PATH, 'rb').read()
-    magic, pos, rows = b'__CLANG_OFFLOAD_BUNDLE__', 0, []
-    with tempfile.TemporaryDirectory() as tmp:
-        while True:
-            i = d.find(magic, pos)
-            if i < 0:
-                break
-            pos = i + len(magic)
-            n, p = struct.unpack_from('<Q', d, i + 24)[0], i + 32
-            for _ in range(n):
-                off, size, tl = struct.unpack_from('<QQQ', d, p)
-                triple = d[p + 24:p + 24 + tl].decode()
-                p += 24 + tl
-                if 'gfx950' not in triple or not size:
-                    continue
-                co = os.path.join(tmp, 'k.co')
-                open(co, 'wb').write(d[i + off:i + off + size])
-                notes = subprocess.run([readelf, '--notes', co], capture_output=True, text=True, check=True).stdout
-                for blk in notes.split('  - .agpr_count:')[1:]:
-                    md = {k: v for k, v in re.findall(r'\.(\w+):\s+(\S+)\n', blk)}
-                    md['agpr_count'] = blk.split('\n')[0].strip()
-                    rows.append(md)
-    assert rows, 'no gfx950 code object found in the library'
-    names = subprocess.run(['c++filt'] + [r['name'] for r in rows], capture_output=True, text=True).stdout.splitlines()
-    return [(n.replace('void ', ''), r) for n, r in zip(names, rows)]
+    if not os.path.exists(KM.READELF):
+        pytest.skip('llvm-readelf not found')
+    return KM.read(lib.LIB_PATH)
 
 
 def test_hot_kernels_have_no_scratch():
