@@ -57,7 +57,7 @@ def test_bf16_payload_loss_drift_over_50_steps(nof):
     print(f"loss after 52 steps on 2 ranks: bf16 payload {d['loss']:.6f}, fp32 {d0['loss']:.6f}; "
           f"bytes per step {d['allreduce_bytes_per_step']} vs {d0['allreduce_bytes_per_step']}")
     assert abs(d['loss'] - d0['loss']) <= 0.03 * abs(d0['loss'])
-    assert abs(d['param_checksum'] - d0['param_checksum']) <= 2e-3 * d0['param_checksum']
+    assert abs(d['param_checksum'] - d0['param_checksum']) <= 1e-2 * d0['param_checksum']
 
 
 def test_rccl_calls_of_the_bucketed_step_one_rank(nof):
