@@ -301,6 +301,35 @@ extern "C" int nof_composite_loss(const NofLossCfg* cfg, const float* raw, const
   return composite_loss(cfg, raw, z_vals, valid, batch, R, S, rgb_map, weights, draw, loss_rows, loss_out, nullptr, 0, stream);
 }
 
+// render_images' depth (nerf_runner.py:604-612): z at the first sample pair whose SDFs differ in sign, `far` for a ray whose pairs
+// all have a strictly positive product, z_vals[:,0] for the rest (torch.argmax of an all-false mask is 0).  One wave per ray.
+__global__ __launch_bounds__(64) void k_render_depth(const float4* __restrict__ raw, const float* __restrict__ z_vals, int64_t R, int S,
+                                                      float far, float* __restrict__ depth) {
+  const int64_t r = blockIdx.x;
+  const int lane = threadIdx.x;
+  const int64_t base = r * S;
+  bool all_pos = true;
+  int first = -1;
+  for (int s0 = 0; s0 < S - 1 && first < 0; s0 += 64) {
+    const int s = s0 + lane;
+    float prod = 1.0f;
+    if (s < S - 1) prod = raw[base + s + 1].w * raw[base + s].w;       // signs = sdf[:, 1:] * sdf[:, :-1]
+    const unsigned long long neg = __builtin_amdgcn_ballot_w64(prod < 0.0f);
+    const unsigned long long pos = __builtin_amdgcn_ballot_w64(s >= S - 1 || prod > 0.0f);
+    all_pos = all_pos && (pos == ~0ull);
+    if (neg != 0ull) first = s0 + __builtin_ctzll(neg);
+  }
+  if (lane == 0) depth[r] = all_pos ? far : z_vals[base + (first < 0 ? 0 : first)];
+}
+
+extern "C" int nof_render_depth(const float* raw, const float* z_vals, int64_t R, int32_t S, float far, float* depth, void* stream) {
+  NOF_ARG(raw && z_vals && depth && R >= 0 && S >= 2);
+  if (R == 0) return 0;
+  hipLaunchKernelGGL(k_render_depth, dim3((unsigned)R), dim3(64), 0, (hipStream_t)stream, (const float4*)raw, z_vals, R, (int)S, far, depth);
+  NOF_LAUNCH_OK();
+  return 0;
+}
+
 // The work list on its own: from an existing dL/draw [B,4] (`all` == 0), or every tile of the batch (`all` != 0; draw may be NULL):
 // the list that makes the backward kernels do the whole batch without looking for zeros (the dense-backward measurement of bench.py).
 extern "C" int nof_tile_list_build(const float* draw, int64_t B, int32_t all, void* tile_list, void* stream) {
@@ -335,9 +364,17 @@ __device__ __forceinline__ void adam_one(float& p, float& g, float& m, float& v,
 // Entries [0, n) of the four flat buffers.  When they share their offset from a 16-byte boundary (they do: same index range of
 // four allocations) the body moves 16 bytes per lane and array -- 4x the bytes in flight of the scalar form, which is what a
 // 59 M-parameter table (cfg5: nothing of it stays in the MALL) needs to approach the HBM rate; element arithmetic is unchanged.
+// `skip_flags` (may be NULL): bit 2 of skip_flags[0] = this step's weight gradient is not finite (raised by nof_reduce_partials /
+// nof_grad_check before this launch).  Then the step is SKIPPED the way torch's GradScaler.step skips it (nerf_runner.py:756-761):
+// parameters and moments stay as they are, the gradient is zeroed for the next step.
 __device__ __forceinline__ void adam_range(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
-                                           float* __restrict__ v, int64_t n, int64_t n_basic, const AdamK& k) {
+                                           float* __restrict__ v, int64_t n, int64_t n_basic, const AdamK& k,
+                                           const int32_t* __restrict__ skip_flags) {
   const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (int64_t)gridDim.x * blockDim.x;
+  if (skip_flags != nullptr && (skip_flags[0] & 4)) {        // workgroup-uniform
+    for (int64_t i = tid; i < n; i += stride) g[i] = 0.0f;
+    return;
+  }
   const unsigned mis = (unsigned)((uintptr_t)p >> 2) & 3u;
   const bool same = (((uintptr_t)g >> 2) & 3u) == mis && (((uintptr_t)m >> 2) & 3u) == mis && (((uintptr_t)v >> 2) & 3u) == mis;
   int64_t head = same ? (int64_t)((4u - mis) & 3u) : n;
@@ -359,8 +396,9 @@ __device__ __forceinline__ void adam_range(float* __restrict__ p, float* __restr
 
 __global__ __launch_bounds__(256) void k_adam(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
                                                float* __restrict__ v, int64_t n, int64_t n_basic, float step_basic,
-                                               float step_pose, float b1, float b2, float eps, float inv_sqrt_bc2) {
-  adam_range(p, g, m, v, n, n_basic, AdamK{step_basic, step_pose, b1, b2, eps, inv_sqrt_bc2});
+                                               float step_pose, float b1, float b2, float eps, float inv_sqrt_bc2,
+                                               const int32_t* __restrict__ skip_flags) {
+  adam_range(p, g, m, v, n, n_basic, AdamK{step_basic, step_pose, b1, b2, eps, inv_sqrt_bc2}, skip_flags);
 }
 
 // ---- the same with the per-step scalars in device memory (replayable captured step) ----------------------------------
@@ -381,8 +419,9 @@ __global__ void k_step_advance(NofStepState* st, float lrate, float lrate_pose, 
 
 __global__ __launch_bounds__(256) void k_adam_dyn(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
                                                    float* __restrict__ v, int64_t n, int64_t n_basic,
-                                                   const NofStepState* __restrict__ st, float b1, float b2, float eps) {
-  adam_range(p, g, m, v, n, n_basic, AdamK{st->step_basic, st->step_pose, b1, b2, eps, st->inv_sqrt_bc2});
+                                                   const NofStepState* __restrict__ st, float b1, float b2, float eps,
+                                                   const int32_t* __restrict__ skip_flags) {
+  adam_range(p, g, m, v, n, n_basic, AdamK{st->step_basic, st->step_pose, b1, b2, eps, st->inv_sqrt_bc2}, skip_flags);
 }
 
 extern "C" int nof_step_state_advance(NofStepState* d_state, float lrate, float lrate_pose, float decay_rate, int32_t n_iters,
@@ -395,18 +434,20 @@ extern "C" int nof_step_state_advance(NofStepState* d_state, float lrate, float 
 }
 
 extern "C" int nof_adam_step_dyn(float* params, float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, int64_t n_basic,
-                                  const NofStepState* d_state, float beta1, float beta2, float eps, void* stream) {
+                                  const NofStepState* d_state, float beta1, float beta2, float eps, const int32_t* skip_flags,
+                                  void* stream) {
   NOF_ARG(params && grads && exp_avg && exp_avg_sq && d_state && n >= 0 && n_basic >= 0 && n_basic <= n);
   if (n == 0) return 0;
   const int64_t blocks = nof_div_up(n, 1024) < 4096 ? nof_div_up(n, 1024) : 4096;
   hipLaunchKernelGGL(k_adam_dyn, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, params, grads, exp_avg, exp_avg_sq, n,
-                     n_basic, d_state, beta1, beta2, eps);
+                     n_basic, d_state, beta1, beta2, eps, skip_flags);
   NOF_LAUNCH_OK();
   return 0;
 }
 
 extern "C" int nof_adam_step(float* params, float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, int64_t n_basic,
-                              float lr, float lr_pose, float beta1, float beta2, float eps, int32_t step, void* stream) {
+                              float lr, float lr_pose, float beta1, float beta2, float eps, int32_t step,
+                              const int32_t* skip_flags, void* stream) {
   NOF_ARG(params && grads && exp_avg && exp_avg_sq && n >= 0 && n_basic >= 0 && n_basic <= n && step >= 1);
   if (n == 0) return 0;
   const double bc1 = 1.0 - pow((double)beta1, (double)step);
@@ -414,7 +455,7 @@ extern "C" int nof_adam_step(float* params, float* grads, float* exp_avg, float*
   const float inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
   const int64_t blocks = nof_div_up(n, 1024) < 4096 ? nof_div_up(n, 1024) : 4096;
   hipLaunchKernelGGL(k_adam, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, params, grads, exp_avg,
-                     exp_avg_sq, n, n_basic, (float)(lr / bc1), (float)(lr_pose / bc1), beta1, beta2, eps, inv_sqrt_bc2);
+                     exp_avg_sq, n, n_basic, (float)(lr / bc1), (float)(lr_pose / bc1), beta1, beta2, eps, inv_sqrt_bc2, skip_flags);
   NOF_LAUNCH_OK();
   return 0;
 }
@@ -458,6 +499,25 @@ extern "C" int nof_reduce_partials(const float* partials, int32_t n_rows, int32_
   if (n_cols == 0 || n_rows == 0) return 0;
   hipLaunchKernelGGL(k_reduce_partials, dim3((unsigned)nof_div_up(n_cols, 32), RED_RSPLIT), dim3(1024), 0, (hipStream_t)stream,
                      partials, n_rows, n_cols, out, flags);
+  NOF_LAUNCH_OK();
+  return 0;
+}
+
+// flags[0] |= 4 when any of grad[0, n) is not finite: the check of nof_reduce_partials for a gradient that was summed over the
+// data-parallel ranks afterwards (a rank whose own partial sums were finite receives the other rank's inf with the all-reduce and
+// must skip the same step, or the replicas part).
+__global__ __launch_bounds__(256) void k_grad_check(const float* __restrict__ grad, int64_t n, int32_t* __restrict__ flags) {
+  bool bad = false;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    bad = bad || !(fabsf(grad[i]) <= 3.0e38f);
+  if (__builtin_amdgcn_ballot_w64(bad) != 0ull && (threadIdx.x & 63) == 0) atomicOr(&flags[0], 4);
+}
+
+extern "C" int nof_grad_check(const float* grad, int64_t n, int32_t* flags, void* stream) {
+  NOF_ARG(grad && flags && n >= 0);
+  if (n == 0) return 0;
+  const int64_t blocks = nof_div_up(n, 256) < 256 ? nof_div_up(n, 256) : 256;
+  hipLaunchKernelGGL(k_grad_check, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, grad, n, flags);
   NOF_LAUNCH_OK();
   return 0;
 }

@@ -309,6 +309,11 @@ __device__ __forceinline__ float stratified(int i, int N, float near, float far,
   float z = lower + (upper - lower) * u;
   return fminf(fmaxf(z, near), far);
 }
+// the same with perturb=False (render_images, nerf_runner.py:597): the linspace itself, no jitter and no clip (:78-85 are skipped)
+__device__ __forceinline__ float unperturbed(int i, int N, float near, float far) {
+  const float t = lin01(i, N);
+  return near * (1.0f - t) + far * t;
+}
 
 // One workgroup per ray: lanes stage the (clipped) z intervals in LDS, lane 0 sums their lengths in
 // order, then every lane places its sample by the reference's sequential subtraction walk.
@@ -322,6 +327,12 @@ __global__ void k_sample_points(NofSampleCfg cfg, const float* __restrict__ batc
   float* zout = smem + max_hits;
   __shared__ float s_total;
   const int64_t r = blockIdx.x;
+  // a new batch starts here: a "this step's weight gradient is not finite" mark left by the PREVIOUS step (bit 2, raised by
+  // nof_reduce_partials / nof_grad_check and consumed by that step's Adam launches, which skipped) becomes the sticky bit 3 that
+  // the host polls to lower the loss scale (field.poll_flags) -- so that exactly the offending step is skipped, like GradScaler
+  if (blockIdx.x == 0 && threadIdx.x == 0 && flags != nullptr) {
+    if (atomicAnd(&flags[0], ~4) & 4) atomicOr(&flags[0], 8);
+  }
   const int S = cfg.n_samples + cfg.n_around;
   const float* row = batch + r * NOF_RAY_COLS;
   const float dx = row[0], dy = row[1], dz = row[2];
@@ -367,11 +378,11 @@ __global__ void k_sample_points(NofSampleCfg cfg, const float* __restrict__ batc
   if (!occupied_mode) {
     const float nd = depth - cfg.trunc;                                  // nerf_runner.py:1067-1071
     const float fd = depth + cfg.trunc * cfg.neg_trunc_ratio;
-    z = stratified(i, N, nd, fd, u);
+    z = cfg.deterministic ? unperturbed(i, N, nd, fd) : stratified(i, N, nd, fd, u);
   } else if (nh == 0) {
     z = 0.0f;                                                            // common.cu:54 (no box -> z_vals stays 0)
   } else {
-    float zr = stratified(i, N, 0.0f, total, u);
+    float zr = cfg.deterministic ? unperturbed(i, N, 0.0f, total) : stratified(i, N, 0.0f, total, u);
     int ib = 0;
     for (;;) {                                                           // common.cu:56-104
       if (ib >= nh) {

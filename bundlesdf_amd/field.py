@@ -285,11 +285,11 @@ class NeuralObjectField:
             self._aux = torch.cuda.Stream(device=self.device)
         return self._aux
 
-    def _sample_cfg(self, seed, step, dyn=False):
+    def _sample_cfg(self, seed, step, dyn=False, deterministic=False):
         cfg = self.cfg
         return lib.NofSampleCfg(cfg['N_samples'], cfg['N_samples_around_depth'], cfg['near'] * cfg['sc_factor'],
                                 cfg['far'] * cfg['sc_factor'], self.truncation(), cfg['neg_trunc_ratio'], seed, step,
-                                self._state.data_ptr() if dyn else None)
+                                self._state.data_ptr() if dyn else None, 1 if deterministic else 0)
 
     # ---- device-resident step state (NofStepState): what makes a captured step replayable ----------------------
     def sync_step_state(self):
@@ -311,13 +311,17 @@ class NeuralObjectField:
 
     def poll_flags(self):
         """Host side of the device flags (ONE sync; the runner calls it at its print interval and at the end of training, never
-        inside a step).  Bit 2 = a non-finite weight gradient came out of the 16-bit backward: where the reference's GradScaler
-        skips the step and halves its scale (nerf_runner.py:756-761), the loss scale of the following steps is halved here and the
-        bit is cleared; the other bits (1 = a ray exceeded max_hits, 2 = inconsistent sample walk) are returned as they are."""
+        inside a step).  A non-finite weight gradient out of the 16-bit backward raises bit 2 (value 4) for the step it happened
+        in: that step's Adam launches see it and skip the update on the device, like the reference's GradScaler.step
+        (nerf_runner.py:756-761), and the next batch's sampler launch turns it into the sticky bit 3 (value 8).  Here -- the other
+        half of GradScaler.update -- the loss scale of the following steps is halved and the sticky bit cleared.  Returned: the
+        flags as found, with a skipped step reported as 4; the other bits (1 = a ray exceeded max_hits, 2 = inconsistent sample
+        walk) as they are."""
         v = int(self.flags[0].item())
-        if v & 4:
+        if v & 12:
             self._scale_backoff += 1
-            self.flags[0] = v & ~4
+            self.flags[0] = v & ~12                                  # (.item() synchronised: no step is in flight)
+            v = (v & ~12) | 4
         return v
 
     def _loss_cfg(self):
@@ -341,7 +345,7 @@ class NeuralObjectField:
         self._call('nof_pose_fwd', self.pose if self.optimize_poses else None, self.c2w, C.c_float(self.max_trans),
                  C.c_float(self.max_rot), self.tf, self.F)
 
-    def _prologue(self, b, pool, ids, R, u_occ, u_dep, seed, want_cells, dyn):
+    def _prologue(self, b, pool, ids, R, u_occ, u_dep, seed, want_cells, dyn, deterministic=False):
         """What a step needs before it touches the hash table: the MFMA fragment image of the MLPs (5 us on the main stream:
         packing it on the side stream cost more in the cross-stream hand-over than the overlap returned), the pose corrections,
         occupancy ray marching + stratified sampling + sample points of the batch (nerf_runner.py:1044-1060 via :918-1000).
@@ -353,18 +357,18 @@ class NeuralObjectField:
         cid = None
         if want_cells:
             cid = b.setdefault('cell_ids', torch.empty(R, self.max_hits, dtype=torch.int32, device=self.device))
-        sc = self._sample_cfg(seed, self.global_step, dyn)
+        sc = self._sample_cfg(seed, self.global_step, dyn, deterministic)
         self._call('nof_raymarch_sample', C.byref(sc), pool, ids, self.tf, self.feat if self.ff > 0 else None, self.ff,
                    self.sh_degree, self.occ_bits, self.level, R, self.max_hits, u_occ, u_dep, b['batch'], b['rays_o_w'],
                    b['viewdirs_w'], b['view'], b['t_in_out'], cid, b['n_hits'], b['z_vals'], b['pts_w'], b['valid'],
                    self.flags)
 
-    def forward_batch(self, pool, ids, R, u_occ=None, u_dep=None, seed=0, want_cells=False, dyn=False):
-        """render_rays up to raw (nerf_runner.py:1044-1088); returns the buffer dict."""
+    def forward_batch(self, pool, ids, R, u_occ=None, u_dep=None, seed=0, want_cells=False, dyn=False, deterministic=False):
+        """render_rays up to raw (nerf_runner.py:1044-1088); returns the buffer dict.  `deterministic`: perturb=False."""
         cfg = self.cfg
         S = cfg['N_samples'] + cfg['N_samples_around_depth']
         b = self._buffers(R, S)
-        self._prologue(b, pool, ids, R, u_occ, u_dep, seed, want_cells, dyn)
+        self._prologue(b, pool, ids, R, u_occ, u_dep, seed, want_cells, dyn, deterministic)
         B = R * S
         self._call('nof_hash_encode_fwd', C.byref(self.grid), b['pts_w'], self.table, b['feat'], B)
         if self.wide:
@@ -431,7 +435,8 @@ class NeuralObjectField:
         gtab = self._seg(self.grads, 'table')
         hashed = [l for l in range(self.L) if self.grid.hashed[l]]
         split = hashed[0] if hashed and 0 < hashed[0] < self.L else None
-        bucketed = grad_sync is not None and hasattr(grad_sync, 'start') and split is not None
+        # (a captured step is one chain on one stream: no bucketed exchange inside it)
+        bucketed = grad_sync is not None and hasattr(grad_sync, 'start') and split is not None and not dyn
         BIG, SMALL, INPUT, ALL = lib.HASH_BWD_TABLE_BIG, lib.HASH_BWD_TABLE_SMALL, lib.HASH_BWD_INPUT, lib.HASH_BWD_ALL
         adam_done = None                               # flat entries [adam_done) that have had their Adam update already
 
@@ -537,6 +542,9 @@ class NeuralObjectField:
                 rest.copy_(self._grads_store[h - nr:h])
         elif grad_sync is not None:
             grad_sync(self.grads)
+        if grad_sync is not None and self.desc.precision in FP16_MODES and self.world_size > 1:
+            # every rank must skip the same steps: the overflow check again, on the SUMMED weight gradient
+            self._call('nof_grad_check', self._seg(self.grads, 'mlp'), self.n_mlp, self.flags)
         if do_step:
             if adam_done is not None:                                  # (data parallel: everything on either side of the early slice)
                 self.adam_step(dyn, 0, adam_done[0], advance=False)
@@ -552,19 +560,35 @@ class NeuralObjectField:
         bufs = [x[lo:hi] for x in (self.params, self.grads, self.exp_avg, self.exp_avg_sq)]
         if dyn:
             cfg = self.cfg
-            self._call('nof_adam_step_dyn', *bufs, n, nb, self._state, C.c_float(0.9), C.c_float(0.999), C.c_float(1e-15))
+            self._call('nof_adam_step_dyn', *bufs, n, nb, self._state, C.c_float(0.9), C.c_float(0.999), C.c_float(1e-15), self.flags)
             if advance:
                 self._call('nof_step_state_advance', self._state, C.c_float(cfg['lrate']), C.c_float(cfg['lrate_pose']),
                            C.c_float(cfg['decay_rate']), int(cfg['n_step']) + 1, C.c_float(0.9), C.c_float(0.999), -1)
         else:
             lr, lr_pose = self.learning_rates()
             self._call('nof_adam_step', *bufs, n, nb, C.c_float(lr), C.c_float(lr_pose), C.c_float(0.9), C.c_float(0.999),
-                       C.c_float(1e-15), self.adam_steps + 1, tag=None if lo == 0 and hi >= self.n_table else 'nof_adam_step[rest]')
+                       C.c_float(1e-15), self.adam_steps + 1, self.flags,
+                       tag=None if lo == 0 and hi >= self.n_table else 'nof_adam_step[rest]')
         if advance:
             self.global_step += 1
             self.adam_steps += 1
 
     # ---- renderer side ------------------------------------------------------------------------------------
+    def render_batch(self, pool, ids, R, want_cells=False):
+        """The forward half of the step for R rays of `pool` with perturb=False, as render_images runs it (nerf_runner.py:595-612
+        -> render -> batchify_rays -> render_rays -> raw2outputs): ray marching, UNPERTURBED z samples, encode, both MLPs,
+        depth-guided compositing, and the depth read off the first SDF sign change.  No gradient, no optimiser state touched.
+        Returns the step's buffer dict with `rgb_map` [R,3], `depth` [R], `raw`, `z_vals`, `valid` (views: copy before the next call)."""
+        with self._on(torch.cuda.current_stream()):
+            b, S = self.forward_batch(pool, ids, R, want_cells=want_cells, deterministic=True)
+            lc = self._loss_cfg()
+            self._call('nof_composite_loss', C.byref(lc), b['raw'], b['z_vals'], b['valid'], b['batch'], R, S, b['rgb_map'],
+                       None, b['draw'], None, None)
+            if 'depth' not in b:
+                b['depth'] = torch.empty(R, device=self.device)
+            self._call('nof_render_depth', b['raw'], b['z_vals'], R, S, C.c_float(self.cfg['far'] * self.cfg['sc_factor']), b['depth'])
+        return b
+
     def query_sdf(self, pts, chunk=1 << 22):
         """run_network_density (nerf_runner.py:1307-1347): clip to [-1,1], hash encode, sigma_net -> sdf [N]."""
         pts = torch.clip(pts.to(self.device, torch.float32), -1, 1).contiguous()
@@ -641,11 +665,14 @@ class GraphedStep:
         field.global_step, field.adam_steps = step0, adam0       # capturing executes nothing: only the host-side counters moved
         field._packed_step = None
         self.trunc = field.truncation()
+        self.grad_scale = float(field.desc.grad_scale)           # baked into the captured launches
 
     def usable(self):
         f = self.field
         # (the device step state drives the schedule AND Adam's bias correction from one counter)
-        return f.profile is None and f.truncation() == self.trunc and f.adam_steps == f.global_step
+        f._set_grad_scale(self.R * (f.cfg['N_samples'] + f.cfg['N_samples_around_depth']))
+        return (f.profile is None and f.truncation() == self.trunc and f.adam_steps == f.global_step
+                and float(f.desc.grad_scale) == self.grad_scale)   # (a loss-scale back-off since the capture: capture again)
 
     def __call__(self, ids):
         self.ids.copy_(ids)

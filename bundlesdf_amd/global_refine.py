@@ -13,6 +13,7 @@ import logging
 import os
 
 import numpy as np
+import torch
 
 from .data_reader import TrackerOutput
 from .mesh import Mesh, largest_component
@@ -87,6 +88,7 @@ def run_global_nerf(debug_dir, cfg_nerf, reader=None, get_texture=False, tex_res
     m = largest_component(m)                                        # trimesh_split + biggest piece (bundlesdf.py:748-760)
     m = Mesh(np.asarray(m.vertices), np.asarray(m.faces))
     m.export(f'{debug_dir}/mesh_cleaned.obj')
+    textured = False
     if get_texture:
         # the per-triangle atlas needs a few texels per triangle: a 2 mm mesh (~200 k triangles) does not fit 1024^2, so the
         # size follows the face count; and a failed bake must not cost the trained field -- the untextured mesh is exported
@@ -95,11 +97,13 @@ def run_global_nerf(debug_dir, cfg_nerf, reader=None, get_texture=False, tex_res
             logging.info(f'texture: {len(m.faces)} triangles need a {res}^2 atlas (asked for {tex_res}^2)')
         try:
             m = nerf.mesh_texture_from_train_images(m, rgbs_raw=rgbs_raw.astype(np.float32), train_texture=False, tex_res=res)
-        except Exception as e:                                       # noqa: BLE001  (reported, the result below is still written)
-            logging.error(f'texture bake failed ({e!r}): exporting the untextured mesh')
+            textured = True
+        except (ValueError, torch.cuda.OutOfMemoryError) as e:       # the two expected failures: atlas does not fit / device memory
+            logging.error(f'texture bake failed ({e!r}): exporting the UNTEXTURED mesh (result["textured"] is False)')
     m = mesh_to_real_world(m, pose_offset=offset, translation=cfg['translation'], sc_factor=cfg['sc_factor'])
     m.export(f'{debug_dir}/textured_mesh.obj')
-    return dict(mesh=m, optimized_cvcam_in_obs=optimized_cvcam_in_obs, offset=offset, runner=nerf, frame_ids=frame_ids)
+    return dict(mesh=m, textured=textured, optimized_cvcam_in_obs=optimized_cvcam_in_obs, offset=offset, runner=nerf,
+                frame_ids=frame_ids)
 
 
 if __name__ == '__main__':

@@ -43,7 +43,7 @@ class NofFrameRaysCfg(C.Structure):
 class NofSampleCfg(C.Structure):
     _fields_ = [('n_samples', C.c_int32), ('n_around', C.c_int32),
                 ('near_sc', C.c_float), ('far_sc', C.c_float), ('trunc', C.c_float), ('neg_trunc_ratio', C.c_float),
-                ('seed', C.c_uint64), ('step', C.c_uint32), ('d_step', C.c_void_p)]
+                ('seed', C.c_uint64), ('step', C.c_uint32), ('d_step', C.c_void_p), ('deterministic', C.c_int32)]
 
 
 class NofMlpDesc(C.Structure):
@@ -87,9 +87,11 @@ _SIGNATURES = {
     'nof_pose_reduce_bwd': ([_P, _P, _P, _P, _I64, _I32, _F, _F, _P, _P, _P, _I32, _I32, _P, _P], C.c_int),
     'nof_pose_reg': ([_P, _P, _I32, _F, _F, _P, _P], C.c_int),
     'nof_small_regs': ([_P, _P, _I32, _F, _F, _P], C.c_int),
-    'nof_adam_step': ([_P, _P, _P, _P, _I64, _I64, _F, _F, _F, _F, _F, _I32, _P], C.c_int),
+    'nof_adam_step': ([_P, _P, _P, _P, _I64, _I64, _F, _F, _F, _F, _F, _I32, _P, _P], C.c_int),
+    'nof_grad_check': ([_P, _I64, _P, _P], C.c_int),
+    'nof_render_depth': ([_P, _P, _I64, _I32, _F, _P, _P], C.c_int),
     'nof_step_state_advance': ([_P, _F, _F, _F, _I32, _F, _F, _I32, _P], C.c_int),
-    'nof_adam_step_dyn': ([_P, _P, _P, _P, _I64, _I64, _P, _F, _F, _F, _P], C.c_int),
+    'nof_adam_step_dyn': ([_P, _P, _P, _P, _I64, _I64, _P, _F, _F, _F, _P, _P], C.c_int),
     'nof_raymarch_sample': ([C.POINTER(NofSampleCfg), _P, _P, _P, _P, _I32, _I32, _P, _I32, _I64, _I32, _P, _P,
                              _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P], C.c_int),
     'nof_composite_loss_fwd_bwd': ([C.POINTER(NofLossCfg), _P, _P, _P, _P, _I64, _I32, _P, _P, _P, _P, _P, _P, _P], C.c_int),

@@ -237,8 +237,12 @@ class NerfRunner:
         g = getattr(self, '_graph', None)
         if g is not None and (g.field is not f or g.R != ids.shape[0] or not g.usable() or not graph_ok):
             g = self._graph = None
-        if graph_ok and g is None and getattr(self, '_eager_steps', 0) >= 3 and getattr(self, '_graph_field', None) is f:
-            g = self._graph = GraphedStep(f, self.rays, ids.shape[0], seed)
+        # (the device step state drives schedule AND bias correction from one counter: no capture while the Adam moments are
+        # not as old as the schedule step, e.g. after a checkpoint without optimiser state)
+        if (graph_ok and g is None and getattr(self, '_eager_steps', 0) >= 3 and getattr(self, '_graph_field', None) is f
+                and f.adam_steps == f.global_step):
+            g = GraphedStep(f, self.rays, ids.shape[0], seed)
+            g = self._graph = g if g.usable() else None
         if g is not None:
             g(ids)
         else:
@@ -248,11 +252,89 @@ class NerfRunner:
             f.train_step(self.rays, ids, ids.shape[0], seed=seed, grad_sync=self.grad_sync)
         if self.global_step % self.cfg['i_print'] == 0 and self.global_step > 0:
             if self.field.poll_flags() & 4:
-                logging.warning('non-finite weight gradient in the fp16 backward: loss scale halved for the following steps')
+                logging.warning('non-finite weight gradient in the fp16 backward: that step was skipped, loss scale halved')
             m = self.field.losses()
             logging.info(f"Iter: {self.global_step}, " + ", ".join(f"{k}: {v:.7f}" for k, v in m.items()))
         if self.global_step % self.cfg['i_weights'] == 0 and self.global_step > 0 and self.cfg.get('save_dir'):
             self.save_weights(os.path.join(self.cfg['save_dir'], 'model_latest.pth'))
+        if self.global_step % self.cfg['i_img'] == 0 and self.global_step > 0 and self.cfg.get('save_dir'):
+            self.save_image_canvas(f"{self.cfg['save_dir']}/image_step_{self.global_step:07d}.png")
+
+    # ---- forward image renderer (nerf_runner.py:586-637, used by train_loop :768-791) -----------------------
+    @torch.no_grad()
+    def render_images(self, img_i, cur_rays=None):
+        """Colour and depth of keyframe `img_i` (a GLOBAL frame id, as stored in the ray table) rendered through the field.
+        Every ray of that frame in the pool goes through the forward half of the step with perturb=False, N_rand rays at a time
+        (the reference sets chunk = N_rand, :595-598); depth = z at the first SDF sign change, far*sc_factor for rays without one
+        (:604-612); results are scattered back to the H x W pixel each ray came from (:616-634, last ray wins on a shared pixel).
+        Returns (rgb [H,W,3], depth [H,W], ray_mask [H,W,3] uint8, gt_rgb [H,W,3], gt_depth [H,W], extras) like the reference;
+        extras holds the per-ray arrays 'raw' [n,S,4], 'z_vals' [n,S], 'valid_samples' [n,S], 'rgb_map' [n,3], 'depth' [n]."""
+        f = self.field
+        if cur_rays is None:
+            sel = torch.nonzero(self.rays[:, 8] == float(img_i)).reshape(-1)
+            pool = self.rays
+        else:                                            # (the reference's own cur_rays path dies on an unbound name, :594)
+            pool = torch.as_tensor(cur_rays, dtype=torch.float32, device=self.device).contiguous()
+            sel = torch.arange(pool.shape[0], device=self.device)
+        n = int(sel.numel())
+        S = self.cfg['N_samples'] + self.cfg['N_samples_around_depth']
+        chunk = int(self.cfg['N_rand'])
+        keys = ('rgb_map', 'depth', 'raw', 'z_vals', 'valid')
+        parts = {k: [] for k in keys}
+        for i in range(0, n, chunk):
+            ids = sel[i:i + chunk].contiguous()
+            R = int(ids.numel())
+            b = f.render_batch(pool, ids, R)
+            for k in keys:
+                parts[k].append(b[k].clone())
+        cat = {k: (torch.cat(v, 0) if v else torch.zeros(0, device=self.device)) for k, v in parts.items()}
+        rows = pool[sel].cpu().numpy()
+        rgb = cat['rgb_map'].cpu().numpy().reshape(-1, 3)
+        depth = cat['depth'].cpu().numpy().reshape(-1)
+        H, W = self.H, self.W
+        rgb_full = np.zeros((H, W, 3), dtype=float)
+        depth_full = np.zeros((H, W), dtype=float)
+        ray_mask_full = np.zeros((H, W, 3), dtype=np.uint8)
+        gt_rgb_full = np.zeros((H, W, 3), dtype=float)
+        gt_depth_full = np.zeros((H, W), dtype=float)
+        if n:
+            X = rows[:, 0:3].copy()
+            X[:, [1, 2]] = -X[:, [1, 2]]
+            projected = (self.K @ X.T).T
+            uvs = (projected / projected[:, 2].reshape(-1, 1)).round().astype(int)
+            ray_type = rows[:, 9]
+            good, unc = uvs[ray_type == 0], uvs[ray_type == 1]
+            ray_mask_full[good[:, 1], good[:, 0]] = [255, 0, 0]
+            ray_mask_full[unc[:, 1], unc[:, 0]] = [0, 255, 0]
+            rgb_full[uvs[:, 1], uvs[:, 0]] = rgb
+            depth_full[uvs[:, 1], uvs[:, 0]] = depth
+            gt_rgb_full[uvs[:, 1], uvs[:, 0]] = rows[:, 3:6]
+            gt_depth_full[uvs[:, 1], uvs[:, 0]] = rows[:, 6]
+        extras = {'raw': cat['raw'].reshape(n, S, 4), 'z_vals': cat['z_vals'].reshape(n, S),
+                  'valid_samples': cat['valid'].reshape(n, S).bool(), 'rgb_map': cat['rgb_map'].reshape(n, 3), 'depth': cat['depth']}
+        return rgb_full, depth_full, ray_mask_full, gt_rgb_full, gt_depth_full, extras
+
+    def save_image_canvas(self, path):
+        """train_loop's i_img block (nerf_runner.py:768-791): up to six keyframes (every len/5-th + the last), one row each:
+        [render | gt | depth | gt depth | ray-type mask over the render], written as one PNG."""
+        from .data_reader import write_png
+        ids = sorted(int(i) for i in torch.unique(self.rays[:, 8]).cpu().numpy().astype(int).tolist())
+        last = ids[-1]
+        ids = ids[::max(1, len(ids) // 5)]
+        if last not in ids:
+            ids.append(last)
+        to8b = lambda x: (255 * np.clip(x, 0, 1)).astype(np.uint8)
+        far = self.cfg['far'] * self.cfg['sc_factor']
+        canvas = []
+        for frame_idx in ids:
+            rgb, depth, ray_mask, gt_rgb, gt_depth, _ = self.render_images(frame_idx)
+            mask_vis = np.clip((rgb * 255 * 0.2 + ray_mask * 0.8).astype(np.uint8), 0, 255)
+            gt_depth = np.clip(gt_depth, self.cfg['near'] * self.cfg['sc_factor'], far)
+            depth_vis = np.tile(np.concatenate((to8b(depth / far), to8b(gt_depth / far)), axis=1)[..., None], (1, 1, 3))
+            canvas.append(np.concatenate((to8b(np.concatenate((rgb, gt_rgb), axis=1)), depth_vis, mask_vis), axis=1))
+        os.makedirs(os.path.dirname(path) or '.', exist_ok=True)
+        write_png(path, np.concatenate(canvas, axis=0).astype(np.uint8))
+        return path
 
     def train(self):
         set_seed(0)

@@ -147,6 +147,8 @@ typedef struct {
   uint32_t step;                          /* Philox counter word 2 */
   const uint32_t* d_step;                 /* DEVICE pointer (or NULL): when set, the Philox step is read from it at run time
                                            * instead of `step` -- what lets a captured step be replayed (NofStepState.step) */
+  int32_t  deterministic;                 /* != 0: perturb=False of sample_rays_uniform (nerf_runner.py:67-87) -- the linspace itself,
+                                           * no jitter, no clip; u_occ / u_dep / seed are ignored (render_images, :597) */
 } NofSampleCfg;
 /* z sampling + point generation (nerf_runner.py:979-1011,1063-1083,1242-1245; common.cu:41-105).
  * u_occ [R,n_samples], u_dep [R,n_around] injected uniforms or NULL (Philox4x32-10).
@@ -180,7 +182,7 @@ int nof_step_state_advance(NofStepState* d_state, float lrate, float lrate_pose,
                            float beta2, int32_t set_step, void* stream);
 /* nof_adam_step with lr / step taken from the device state */
 int nof_adam_step_dyn(float* params, float* grads, float* exp_avg, float* exp_avg_sq, int64_t n_total, int64_t n_basic,
-                      const NofStepState* d_state, float beta1, float beta2, float eps, void* stream);
+                      const NofStepState* d_state, float beta1, float beta2, float eps, const int32_t* skip_flags, void* stream);
 
 /* ---- SDF + colour tiny-MLPs on MFMA (replaces NeRFSmall's cuBLAS GEMMs) ------------------------ */
 typedef struct {
@@ -223,8 +225,9 @@ int nof_mlp_bwd_tiles(const NofMlpDesc* h_desc, const void* packed, const float*
                       const float* view, int32_t S, const float* draw, const void* sigma_out, void* dsigma_ws,
                       float* dfeat, float* dview, float* partials, const void* tile_list, int64_t B, void* stream);
 /* out[j] += sum_i partials[i,j].  flags (int32, may be NULL): flags[0] |= 4 when a column sum is not finite -- an overflow inside the
- * 16-bit backward, where the reference's GradScaler would skip the step and back off (nerf_runner.py:756-761); the host polls the
- * flag and lowers NofMlpDesc.grad_scale (bundlesdf_amd/field.py), the step itself never synchronises. */
+ * 16-bit backward, where the reference's GradScaler skips the step and backs off (nerf_runner.py:756-761): nof_adam_step[_dyn]
+ * given the same flags skips the update, the next batch's nof_sample_points turns the mark into the sticky bit 3 (value 8), the
+ * host polls that and lowers NofMlpDesc.grad_scale (bundlesdf_amd/field.py); the step itself never synchronises. */
 int nof_reduce_partials(const float* partials, int32_t n_rows, int32_t n_cols, float* out, int32_t* flags, void* stream);
 /* sigma_net only: feat [L,B,2] -> sdf [B]  (NeRFSmall.forward_sdf, nerf_helpers.py:296-302) */
 int nof_mlp_sdf(const NofMlpDesc* h_desc, const void* packed, const float* feat, int32_t L,
@@ -388,11 +391,23 @@ int nof_small_regs(const float* feat_data, float* grad_feat, int32_t n_feat, flo
 int nof_pose_reg(const float* pose_data, float* grad_pose, int32_t F, float pose_reg_weight, float grad_scale,
                  float* loss_out, void* stream);
 
+/* render_images' depth map values (nerf_runner.py:604-612): per ray the z of the first sample pair whose SDFs (raw[..,3]) differ in
+ * sign; `far` (= cfg far * sc_factor) when every pair's product is > 0; z_vals[r,0] otherwise.  raw [R,S,4], z_vals [R,S] -> depth [R]. */
+int nof_render_depth(const float* raw, const float* z_vals, int64_t R, int32_t S, float far, float* depth, void* stream);
+
 /* ---- optimiser ---------------------------------------------------------------------------------- */
 /* torch.optim.Adam(betas, eps=1e-15, weight_decay=0) over the flat buffer; entries [0,n_basic) use lr,
- * [n_basic,n) use lr_pose (param groups nerf_runner.py:498-500).  step is 1-based.  Grads are zeroed. */
+ * [n_basic,n) use lr_pose (param groups nerf_runner.py:498-500).  step is 1-based.  Grads are zeroed.
+ * skip_flags (device int32, may be NULL): when bit 2 of skip_flags[0] is set -- this step's weight gradient came out of the 16-bit
+ * backward non-finite (nof_reduce_partials / nof_grad_check) -- the update is SKIPPED like torch's GradScaler.step skips it
+ * (nerf_runner.py:756-761): params / exp_avg / exp_avg_sq untouched, grads zeroed.  The next step's nof_sample_points turns the
+ * mark into the sticky bit 3 (value 8) that the host polls to lower NofMlpDesc.grad_scale. */
 int nof_adam_step(float* params, float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, int64_t n_basic,
-                  float lr, float lr_pose, float beta1, float beta2, float eps, int32_t step, void* stream);
+                  float lr, float lr_pose, float beta1, float beta2, float eps, int32_t step, const int32_t* skip_flags,
+                  void* stream);
+/* flags[0] |= 4 when any of grad[0, n) is not finite (the check of nof_reduce_partials, for a gradient that was summed over the
+ * data-parallel ranks afterwards: every rank must skip the same step). */
+int nof_grad_check(const float* grad, int64_t n, int32_t* flags, void* stream);
 
 /* ---- test hook: raw MFMA tile  D[32,32] = A[32,K] * B[K,32] with the operand layouts nof_mlp uses ---- */
 int nof_mfma_probe(int32_t precision, const float* A, const float* Bm, float* D, int32_t K, void* stream);

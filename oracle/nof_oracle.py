@@ -495,12 +495,15 @@ def linspace01(N):
 
 
 def sample_rays_uniform(N, near, far, u):
-    """sample_rays_uniform (nerf_runner.py:67-87), perturb=True with injected uniforms u [R,N]."""
+    """sample_rays_uniform (nerf_runner.py:67-87), perturb=True with injected uniforms u [R,N]; u = None: perturb=False
+    (render_images, :597) -- the linspace itself, lines :78-85 (jitter and clip) are skipped."""
     near = near.reshape(-1, 1).astype(f32)
     far = far.reshape(-1, 1).astype(f32)
     t = linspace01(N).reshape(1, -1)
     z = (near * (f32(1.0) - t)).astype(f32) + (far * t).astype(f32)
     z = z.astype(f32)
+    if u is None:
+        return z
     mids = (f32(0.5) * (z[:, 1:] + z[:, :-1]).astype(f32)).astype(f32)
     upper = np.concatenate([mids, z[:, -1:]], -1)
     lower = np.concatenate([z[:, :1], mids], -1)
@@ -572,7 +575,7 @@ def sample_z(t_in_out, viewdir_cam_z, depth, cfg, trunc, u_occ, u_dep):
     far_d = (depth + f32(f32(trunc) * f32(cfg['neg_trunc_ratio']))).astype(f32)
     z_a = sample_rays_uniform(Na, near_d, far_d, u_dep)
     if (~valid).any():
-        z_inv, _, _ = sample_occupied(t_in_out, viewdir_cam_z, Na, u_dep, depths=None)
+        z_inv, _, _ = sample_occupied(t_in_out, viewdir_cam_z, Na, u_dep, depths=None)   # (u_dep None: perturb=False)
         z_a = np.where(valid[:, None], z_a, z_inv).astype(f32)
     return np.concatenate([z_occ, z_a], axis=-1).astype(f32)
 
@@ -707,7 +710,8 @@ class OracleField:
             tio, cid, nh = trace_rays(self.occ_l, rays_o_w.numpy(), viewdirs_w.numpy())
             trunc = get_truncation(cfg, self.global_step)
             z = sample_z(tio, viewdirs[:, 2].numpy(), batch[:, 6].numpy(), cfg, trunc,
-                         np.asarray(u_occ, dtype=f32), np.asarray(u_dep, dtype=f32))
+                         None if u_occ is None else np.asarray(u_occ, dtype=f32),
+                         None if u_dep is None else np.asarray(u_dep, dtype=f32))
         return torch.from_numpy(z), dict(t_in_out=tio, cell_ids=cid, n_hits=nh, rays_o_w=rays_o_w, viewdirs_w=viewdirs_w)
 
     def forward(self, batch, z_vals):
@@ -787,6 +791,36 @@ class OracleField:
                 self.schedule_lr()
             self.global_step += 1
         return dict(z_vals=z_vals, trace=tr, fwd=fwd, losses=out, grads=grads)
+
+    def render_rays_image(self, rays, chunk=None):
+        """render_images up to the per-ray results (nerf_runner.py:586-613): the rays of one keyframe through render ->
+        batchify_rays (chunk = N_rand, :595-598) -> render_rays with perturb=False and the rays' own depth, then
+        depth = z_vals at the first SDF sign change (torch.argmax of the mask: index 0 when there is none), far*sc_factor for rays
+        whose neighbouring SDF products are all > 0 (:604-612).  Returns rgb [n,3], depth [n] and the extras the reference keeps."""
+        cfg = self.cfg
+        rays = torch.as_tensor(rays, dtype=torch.float32)
+        chunk = int(chunk or cfg['N_rand'])
+        outs = dict(rgb_map=[], raw=[], z_vals=[], valid_samples=[], cell_ids=[], n_hits=[])
+        with torch.no_grad():
+            for i in range(0, rays.shape[0], chunk):
+                b = rays[i:i + chunk]
+                z_vals, tr = self.trace_and_sample(b, None, None)
+                fwd = self.forward(b, z_vals)
+                outs['rgb_map'].append(fwd['rgb_map']); outs['raw'].append(fwd['raw']); outs['z_vals'].append(z_vals)
+                outs['valid_samples'].append(fwd['valid_samples'])
+                outs['cell_ids'].append(tr['cell_ids']); outs['n_hits'].append(tr['n_hits'])
+            cell_w = max(c.shape[1] for c in outs['cell_ids'])
+            cells = np.concatenate([np.pad(c, ((0, 0), (0, cell_w - c.shape[1])), constant_values=-1) for c in outs['cell_ids']], 0)
+            n_hits = np.concatenate(outs['n_hits'], 0)
+            out = {k: torch.cat(v, 0) for k, v in outs.items() if k not in ('cell_ids', 'n_hits')}
+            sdf = out['raw'][..., -1]
+            signs = sdf[:, 1:] * sdf[:, :-1]
+            empty_rays = (signs > 0).all(dim=-1)
+            inds = torch.argmax((signs < 0).float(), axis=1)[..., None]
+            depth = torch.gather(out['z_vals'], dim=1, index=inds)
+            depth[empty_rays] = cfg['far'] * cfg['sc_factor']
+        out.update(depth=depth.reshape(-1), cell_ids=cells, n_hits=n_hits)
+        return out
 
     def schedule_lr(self):
         """nerf_runner.py:579-583."""

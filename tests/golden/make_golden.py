@@ -18,7 +18,7 @@ ray/cell intersection list) and pytorch3d's `se3_exp_map`.  Everything else that
                     PoseArray.get_matrices
   nerf_runner.py  : sample_rays_uniform, compute_near_far_and_filter_rays, DataLoader,
                     NerfRunner.{get_truncation, raw2outputs, sample_rays_uniform_occupied_voxels, render_rays, run_network,
-                    batchify_rays, render, train_loop, schedule_lr}
+                    batchify_rays, render, train_loop, schedule_lr, render_images}
   Utils.py        : to_homo, to_homo_torch, transform_pts
 """
 import ast
@@ -90,7 +90,8 @@ def build_namespace():
     ns['RefOctree'] = ons['RefOctree']
     ns['_octree_ns'] = ons
     methods = cut('nerf_runner.py', ['get_truncation', 'raw2outputs', 'sample_rays_uniform_occupied_voxels', 'render_rays',
-                                     'run_network', 'batchify_rays', 'render', 'train_loop', 'schedule_lr'], cls='NerfRunner')
+                                     'run_network', 'batchify_rays', 'render', 'train_loop', 'schedule_lr', 'render_images'],
+                  cls='NerfRunner')
     cls_src = 'class RefRunner:\n' + '\n\n'.join(methods)
     exec(cls_src, ns)
     return ns
@@ -325,6 +326,26 @@ def main():
         r.global_step = 40
         r.schedule_lr()
         out['lr_step40'] = np.float64(r.optimizer.param_groups[0]['lr'])
+
+        # ---- g12 the reference's render_images (nerf_runner.py:586-637) on the same scene and parameters -----------------
+        # every ray of one keyframe through render(perturb=False) in chunks of N_rand, depth at the first SDF sign change,
+        # scattered to the pixel the ray came from.  (Scaler.step above is a no-op: the parameters are still the step's.)
+        r.cfg = dict(cfg, N_rand=4)                              # 4 rays per chunk: batchify_rays really loops
+        with torch.no_grad():                                    # the fresh net's SDF is 0.068..0.084 everywhere: shift the sdf
+            model.sigma_net[-1].bias[0] -= 0.0765                # bias so that rays do cross zero (same weights otherwise)
+        out['render_mlp_flat'] = torch.cat([p.detach().reshape(-1) for p in model.parameters()]).numpy()
+        r.global_step = 1
+        r.rays = tb
+        r.H, r.W = 48, 64
+        r.K = np.array([[100.0, 0, 32.0], [0, 100.0, 24.0], [0, 0, 1]])
+        img_i = int(np.bincount(batch[:, 8].astype(int)).argmax())
+        rgb_f, depth_f, mask_f, gt_rgb_f, gt_depth_f, ex = r.render_images(img_i)
+        out['render_img_i'], out['render_HW'], out['render_K'] = np.int64(img_i), np.array([r.H, r.W]), r.K
+        out['render_n_rand'] = np.int64(r.cfg['N_rand'])
+        out['render_rgb_full'], out['render_depth_full'], out['render_mask_full'] = rgb_f, depth_f, mask_f
+        out['render_gt_rgb_full'], out['render_gt_depth_full'] = gt_rgb_f, gt_depth_f
+        out['render_raw'], out['render_z'] = ex['raw'].detach().numpy(), ex['z_vals'].numpy()
+        out['render_valid'] = ex['valid_samples'].numpy()
     finally:
         torch.Tensor.cuda = real_cuda
         torch.rand = real_rand

@@ -161,23 +161,54 @@ def test_full_size_step_properties(nof):
 # conservation.
 #   cfg2  4096 rays x 192 samples, L = 16, T = 2^19, finest 256, SDF 3x64 + colour 2x64            (~20 s of oracle per case)
 #   cfg4  8192 rays, finest 512 (the float32 resolution quirk of levels 12 / 15: 257 / 513), same network   (~45 s)
-#   cfg5  T = 2^22 (237 MB table), finest 512, SDF 4x128 + colour 4x128, fp16 operands: the table and the network are the point,
-#         4096 of the configuration's 16 384 rays keep the oracle at ~1 min (the rays are independent)
+#   cfg5  T = 2^22 (237 MB table), finest 512, SDF 4x128 + colour 4x128, fp16 operands, all 16 384 rays of the configuration: the
+#         oracle runs them as four chunks of 4096 (rays are independent; every loss term is a mean over the batch, so the
+#         chunks' losses and gradients add up with weight R_chunk / R)                                     (~3 min of oracle)
 CASES = {
     'cfg2': dict(R=4096, T=19, finest=256, ns=3, nc=2, hidden=64),
     'cfg4': dict(R=8192, T=19, finest=512, ns=3, nc=2, hidden=64),
-    'cfg5': dict(R=4096, T=22, finest=512, ns=4, nc=4, hidden=128),
+    'cfg5': dict(R=16384, T=22, finest=512, ns=4, nc=4, hidden=128),         # ALL of the configuration's rays (oracle in 4 chunks)
+    'cfg5_quarter': dict(R=4096, T=22, finest=512, ns=4, nc=4, hidden=128),
 }
+ORACLE_CHUNK = 4096          # rays per oracle call: rays are independent and every loss term is a mean over the batch
 
 
-@pytest.mark.parametrize("case,precision", [('cfg2', 'fp32'), ('cfg2', 'fp16x3'), ('cfg4', 'fp16x3'), ('cfg5', 'fp16'),
-                                            ('cfg5', 'fp16x3')])
+def _oracle_step_chunked(orc, batch, u_occ, u_dep):
+    """OracleField.train_step(do_step=False) over the batch in chunks of ORACLE_CHUNK rays: per-ray results concatenated, losses and
+    gradients combined with weight R_chunk / R (every term is a .mean() over R or R*S: nerf_runner.py:700, nerf_helpers.py:389-395)."""
+    R = batch.shape[0]
+    if R <= ORACLE_CHUNK:
+        return orc.train_step(batch, u_occ, u_dep, do_step=False)
+    parts = []
+    for i in range(0, R, ORACLE_CHUNK):
+        sl = slice(i, i + ORACLE_CHUNK)
+        p = orc.train_step(batch[sl], u_occ[sl], u_dep[sl], do_step=False)
+        w = batch[sl].shape[0] / R
+        parts.append(dict(
+            z_vals=p['z_vals'], trace={k: p['trace'][k] for k in ('n_hits', 'cell_ids')},
+            fwd={k: p['fwd'][k].detach() for k in ('raw', 'valid_samples')},
+            losses={k: float(v) * w for k, v in p['losses'].items() if k in ('loss', 'rgb_loss', 'fs_loss', 'sdf_loss')},
+            grads=[None if g is None else g * w for g in p['grads']]))
+        del p
+    Hc = max(q['trace']['cell_ids'].shape[1] for q in parts)
+    pad = lambda c: np.pad(c, ((0, 0), (0, Hc - c.shape[1])), constant_values=-1)
+    return dict(
+        z_vals=torch.cat([q['z_vals'] for q in parts], 0),
+        trace=dict(n_hits=np.concatenate([q['trace']['n_hits'] for q in parts]),
+                   cell_ids=np.concatenate([pad(q['trace']['cell_ids']) for q in parts], 0)),
+        fwd={k: torch.cat([q['fwd'][k] for q in parts], 0) for k in ('raw', 'valid_samples')},
+        losses={k: sum(q['losses'][k] for q in parts) for k in parts[0]['losses']},
+        grads=[None if g[0] is None else sum(g) for g in zip(*[q['grads'] for q in parts])])
+
+
+@pytest.mark.parametrize("case,precision", [('cfg2', 'fp32'), ('cfg2', 'fp16x3'), ('cfg2', 'bf16x3'), ('cfg4', 'fp16x3'),
+                                            ('cfg5', 'fp16'), ('cfg5_quarter', 'fp16x3')])
 def test_fullsize_step_matches_oracle(nof, case, precision):
     from bundlesdf_amd import synthetic
     from bundlesdf_amd.config import default_cfg
     from bundlesdf_amd.nerf_runner import NerfRunner
     from oracle import nof_oracle as O
-    from tests.test_gpu_ops import rel_l2, rel_max, ODT
+    from tests.test_gpu_ops import rel_l2, rel_max, worst_elementwise, ODT
     from bundlesdf_amd.field import PRECISIONS
     c = CASES[case]
     R, T, ns, nc, hidden = c['R'], c['T'], c['ns'], c['nc'], c['hidden']
@@ -214,7 +245,7 @@ def test_fullsize_step_matches_oracle(nof, case, precision):
     plain16 = precision in ('fp16', 'bf16')
     orc = O.OracleField(cfg, geo, shape, F, pool['poses'], occ_l, table=table0, mlp=mlp, pose=pose0,
                         operand_dtype=ODT[PRECISIONS[precision]] if plain16 else None)
-    ref = orc.train_step(batch, u_occ, u_dep, do_step=False)
+    ref = _oracle_step_chunked(orc, batch, u_occ, u_dep)
 
     cpu = lambda t: t.detach().cpu().numpy()
     # ---- index work: ray-hit cell lists (bit-identical except for rays whose fp32 pose transform grazes a cell face) ----
@@ -234,12 +265,19 @@ def test_fullsize_step_matches_oracle(nof, case, precision):
     raw_ref = ref['fwd']['raw'].detach().numpy()
     raw = cpu(b['raw']).reshape(R, S, 4)
     err_rgb, err_sdf = rel_max(raw[both][:, :3], raw_ref[both][:, :3]), rel_max(raw[both][:, 3], raw_ref[both][:, 3])
-    print(f'fullsize {case} {precision}: colour rel-max {err_rgb:.2e}, sdf rel-max {err_sdf:.2e}, valid fraction {both.mean():.3f}')
+    # ... and per element: |err| <= 1e-3 |ref| + 1e-5 for EVERY colour / SDF value (a plain 16-bit forward is measured against
+    # the oracle with the same operand rounding: what it can be held to per element is that rounding's own noise floor)
+    ew_rgb, ew_sdf = worst_elementwise(raw[both][:, :3], raw_ref[both][:, :3]), worst_elementwise(raw[both][:, 3], raw_ref[both][:, 3])
+    print(f'fullsize {case} {precision}: colour rel-max {err_rgb:.2e}, sdf rel-max {err_sdf:.2e}, valid fraction {both.mean():.3f}; '
+          f'per element (|err| / (1e-3 |ref| + 1e-5)) colour {ew_rgb:.3f}, sdf {ew_sdf:.3f}')
     assert err_rgb < 1e-3 and err_sdf < 1e-3
+    if not plain16 and not fld.wide:                 # (the wide path has no operand split: its 'x3' forward is a plain 16-bit one)
+        assert ew_rgb <= 1.0 and ew_sdf <= 1.0, (ew_rgb, ew_sdf)
     if plain16:
         with torch.no_grad():
             orc32 = O.OracleField(cfg, geo, shape, F, pool['poses'], occ_l, table=table0, mlp=mlp, pose=pose0)
-            raw32 = orc32.forward(torch.from_numpy(batch), ref['z_vals'])['raw'].numpy()
+            raw32 = np.concatenate([orc32.forward(torch.from_numpy(batch[i:i + ORACLE_CHUNK]), ref['z_vals'][i:i + ORACLE_CHUNK])['raw'].numpy()
+                                    for i in range(0, R, ORACLE_CHUNK)], 0)
         print(f'fullsize {case} {precision}: vs the PURE fp32 oracle colour {rel_max(raw[both][:, :3], raw32[both][:, :3]):.2e}, '
               f'sdf {rel_max(raw[both][:, 3], raw32[both][:, 3]):.2e}')
     Lo = fld.losses()
@@ -249,20 +287,21 @@ def test_fullsize_step_matches_oracle(nof, case, precision):
     # ---- gradients: table (201 M scattered contributions at cfg2), MLP layers, poses.  fp32: against the oracle as is; 16-bit
     #      backward (the reference's autocast): looser, the backward rounds its operands to the 16-bit type ----
     tight = precision == 'fp32'
+    bf = 2.0 if precision.startswith('bf16') else 1.0             # bfloat16 backward: 8 mantissa bits
     names = ['table'] + [f'mlp{i}' for i in range(2 * (ns + nc))] + ['pose']
     g_ref = dict(zip(names, ref['grads']))
     gt = cpu(fld._seg(fld.grads, 'table')).reshape(-1, 2)
     gt_ref = g_ref['table'].numpy()
     e_tab = rel_l2(gt, gt_ref)
     print(f'fullsize {case} {precision}: table-gradient rel-L2 {e_tab:.2e}, touched rows {int((gt_ref != 0).any(1).sum())}')
-    assert e_tab < (1e-3 if tight else 3e-2)
+    assert e_tab < (1e-3 if tight else 3e-2 * bf)
     for lvl in range(L):                                           # per level, so that a coarse level cannot hide a fine one
         lo, hi = int(fld.offsets[lvl]), int(fld.offsets[lvl + 1])
-        assert rel_l2(gt[lo:hi], gt_ref[lo:hi]) < (2e-3 if tight else 5e-2), lvl
+        assert rel_l2(gt[lo:hi], gt_ref[lo:hi]) < (2e-3 if tight else 5e-2 * bf), lvl
     gm = cpu(fld._seg(fld.grads, 'mlp'))
     gm_ref = torch.cat([g.reshape(-1) for n, g in g_ref.items() if n.startswith('mlp')]).numpy()
     for l in range(ns + nc):
         lo, hi = fld.desc.w_off[l], fld.desc.b_off[l] + fld.desc.out_dim[l]
-        assert rel_l2(gm[lo:hi], gm_ref[lo:hi]) < (2e-3 if tight else 5e-2), (l, rel_l2(gm[lo:hi], gm_ref[lo:hi]))
+        assert rel_l2(gm[lo:hi], gm_ref[lo:hi]) < (2e-3 if tight else 5e-2 * bf), (l, rel_l2(gm[lo:hi], gm_ref[lo:hi]))
     gp = cpu(fld._seg(fld.grads, 'pose')).reshape(-1, 6)
-    assert rel_l2(gp, g_ref['pose'].numpy()) < (1e-2 if tight else 5e-2), rel_l2(gp, g_ref['pose'].numpy())
+    assert rel_l2(gp, g_ref['pose'].numpy()) < (1e-2 if tight else 5e-2 * bf), rel_l2(gp, g_ref['pose'].numpy())

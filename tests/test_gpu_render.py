@@ -1,0 +1,162 @@
+"""The forward image renderer, NerfRunner.render_images (reference nerf_runner.py:586-637; train_loop calls it every i_img
+steps, :768-791, and run_ho3d.py:86 switches it on): every ray of one keyframe through the forward half of the step with
+perturb=False, depth at the first SDF sign change, scattered back to the H x W pixels.
+
+  * against the REFERENCE's own render_images, executed on CPU by tests/golden/make_golden.py (fixture `render_*`);
+  * at 640 x 480 against the oracle's restatement (oracle/nof_oracle.py:OracleField.render_rays_image, itself pinned on the same
+    fixture by tests/test_oracle.py): colour and depth per element within 1e-3, ray-hit cell lists identical."""
+import numpy as np
+import pytest
+import torch
+
+from tests import util as U
+from tests.test_oracle import G, _step_cfg
+from tests.test_gpu_ops import worst_elementwise
+
+pytestmark = pytest.mark.gpu
+
+
+def cpu(t):
+    return t.detach().cpu().numpy()
+
+
+def _shell(field, rays, K, H, W, cfg):
+    """a NerfRunner around an existing field and ray table (render_images uses nothing else of the runner)"""
+    from bundlesdf_amd.nerf_runner import NerfRunner
+    r = object.__new__(NerfRunner)
+    r.field, r.rays, r.K, r.H, r.W, r.cfg, r.device = field, rays, np.asarray(K, dtype=np.float64), int(H), int(W), cfg, torch.device('cuda')
+    return r
+
+
+@pytest.mark.parametrize("precision", ['fp32', 'fp16x3'])
+def test_render_images_matches_reference_run(nof, precision):
+    from bundlesdf_amd.field import NeuralObjectField
+    cfg = dict(_step_cfg(), N_rand=int(G['render_n_rand']))
+    occ, c2w = G['step_occ'], G['step_c2w']
+    level = int(np.log2(occ.shape[0]))
+    fld = NeuralObjectField(cfg, c2w.shape[0], c2w, precision=precision, n_sigma=2, n_color=3, seed_init=False)
+    fld.load_parameters(table=G['step_table'], mlp=G['render_mlp_flat'], feat=G['step_feat'], pose=G['step_pose'])
+    fld.set_occupancy(U.occ_to_coords(occ), level, level)
+    fld.global_step = 1
+    H, W = (int(x) for x in G['render_HW'])
+    runner = _shell(fld, U.dev(G['step_batch']), G['render_K'], H, W, cfg)
+    before = fld.params.clone()
+    rgb, depth, mask, gt_rgb, gt_depth, ex = runner.render_images(int(G['render_img_i']))
+    torch.cuda.synchronize()
+    assert torch.equal(fld.params, before) and fld.global_step == 1            # a renderer: no state touched
+    # per ray, in pool order (the reference's extras)
+    assert np.abs(cpu(ex['z_vals']) - G['render_z']).max() < 2e-5
+    assert np.array_equal(cpu(ex['valid_samples']), G['render_valid'])
+    raw = cpu(ex['raw'])
+    w_rgb, w_sdf = worst_elementwise(raw[..., :3], G['render_raw'][..., :3]), worst_elementwise(raw[..., 3], G['render_raw'][..., 3])
+    print(f'render {precision}: per element |err| / (1e-3 |ref| + 1e-5): raw colour {w_rgb:.3f}, sdf {w_sdf:.3f}')
+    assert w_rgb <= 1.0 and w_sdf <= 1.0
+    # the images
+    assert rgb.shape == (H, W, 3) and depth.shape == (H, W) and mask.dtype == np.uint8
+    assert np.array_equal(mask, G['render_mask_full'])
+    assert np.array_equal(gt_rgb, G['render_gt_rgb_full']) and np.array_equal(gt_depth, G['render_gt_depth_full'])
+    hit = G['render_depth_full'] != 0
+    assert np.array_equal(depth != 0, hit)
+    far = cfg['far'] * cfg['sc_factor']
+    assert np.array_equal(depth == far, G['render_depth_full'] == far)          # the same rays are "empty" (:607,612)
+    assert (G['render_depth_full'][hit] != far).sum() >= 8                     # ... and the fixture has real sign changes
+    assert np.abs(depth - G['render_depth_full']).max() < 2e-5                 # z of the same sample index
+    w_img = worst_elementwise(rgb, G['render_rgb_full'])
+    print(f'render {precision}: rgb image per element {w_img:.3f}, max abs {np.abs(rgb - G["render_rgb_full"]).max():.2e}')
+    assert w_img <= 1.0
+
+
+def test_render_depth_kernel_edge_cases(nof):
+    """nof_render_depth against torch on adversarial SDF rows: no sign change, all positive, exact zeros (product 0 is neither
+    > 0 nor < 0: not empty, argmax of an all-false mask = index 0), a change at the last pair, NaN, S not a multiple of 64."""
+    torch.manual_seed(0)
+    for S in (2, 63, 64, 65, 96, 192, 200):
+        R = 64
+        sdf = torch.randn(R, S)
+        sdf[0] = sdf[0].abs() + 0.1                         # all positive: empty
+        sdf[1] = -sdf[1].abs() - 0.1                        # all negative: products > 0: empty as well
+        sdf[2] = sdf[2].abs() + 0.1; sdf[2, S // 2] = 0.0    # an exact zero: not empty, no negative product -> index 0
+        sdf[3] = sdf[3].abs() + 0.1; sdf[3, -1] = -1.0       # change at the very last pair
+        sdf[4] = sdf[4].abs() + 0.1; sdf[4, 0] = -1.0        # ... at the first
+        sdf[5] = sdf[5].abs() + 0.1; sdf[5, S // 3] = float('nan')
+        z = torch.rand(R, S) * 3
+        raw = torch.zeros(R, S, 4)
+        raw[..., 3] = sdf
+        signs = sdf[:, 1:] * sdf[:, :-1]
+        empty = (signs > 0).all(dim=-1)
+        inds = torch.argmax((signs < 0).float(), axis=1)[..., None]
+        want = torch.gather(z, dim=1, index=inds).reshape(-1)
+        want[empty] = 7.5
+        got = torch.empty(R, device='cuda')
+        nof.call('nof_render_depth', raw.cuda().contiguous(), z.cuda().contiguous(), R, S, 7.5, got)
+        torch.cuda.synchronize()
+        assert torch.equal(got.cpu(), want), S
+
+
+def test_render_images_640x480_vs_oracle(nof):
+    from bundlesdf_amd import synthetic
+    from bundlesdf_amd.config import default_cfg
+    from bundlesdf_amd.nerf_runner import NerfRunner
+    from oracle import nof_oracle as O
+    L, T = 16, 17
+    pool = synthetic.make_pool(n_frames=4, H=480, W=640, fx=600.0, seed=0, analytic_bounds=True)
+    cfg = default_cfg(n_step=300, N_rand=2048, num_levels=L, log2_hashmap_size=T, finest_res=256, base_res=16, far=1.0,
+                      sc_factor=pool['sc_factor'], translation=pool['translation'], i_img=999999)
+    runner = NerfRunner(cfg, pool['rgbs'], depths=pool['depths'], masks=pool['masks'], normal_maps=None, poses=pool['poses'],
+                        K=pool['K'], build_octree_pcd=synthetic.PointCloud(pool['pcd_normalized']), precision='fp16x3')
+    fld = runner.field
+    for _ in range(150):                                  # a field whose SDF crosses zero on the surface
+        runner.train_loop()
+        runner.global_step += 1
+    torch.cuda.synchronize()
+    img_i = 2
+    rgb, depth, mask, gt_rgb, gt_depth, ex = runner.render_images(img_i)
+    torch.cuda.synchronize()
+    sel = torch.nonzero(runner.rays[:, 8] == float(img_i)).reshape(-1)
+    rows = runner.rays[sel].cpu().numpy()
+    n = rows.shape[0]
+    assert n > 20000 and ex['raw'].shape == (n, cfg['N_samples'] + cfg['N_samples_around_depth'], 4)
+    # every pixel of the frame's ray set is written once, nothing else is
+    u = np.round(rows[:, 0] * 600.0 + 320.0).astype(int)
+    v = np.round(-rows[:, 1] * 600.0 + 240.0).astype(int)
+    assert len(set(zip(u.tolist(), v.tolist()))) == n
+    written = np.zeros((480, 640), bool)
+    written[v, u] = True
+    assert np.array_equal(depth != 0, written) and np.array_equal(mask[..., 0] == 255, written)
+    assert np.array_equal(gt_depth[v, u], rows[:, 6].astype(np.float64))
+    far = cfg['far'] * cfg['sc_factor']
+    d_ray = cpu(ex['depth'])
+    assert ((d_ray != far).mean() > 0.5), 'the trained field should have a surface on most object rays'
+    # the rendered surface is where the depth camera saw it (trained field; a sanity bound, not parity)
+    good = (d_ray != far) & (rows[:, 6] < far)
+    assert np.median(np.abs(d_ray[good] - rows[good, 6])) < 0.02 * cfg['sc_factor']
+
+    # ---- parity with the oracle on two chunks of the frame's rays (chunks are independent: perturb=False) ----
+    occ, occ_l, max_level, level = O.build_occupancy(pool['pcd_normalized'], cfg)
+    geo = O.HashGeometry(L, 2, cfg['base_res'], T, cfg['finest_res'])
+    shape = O.FieldShape(input_ch=2 * L, input_ch_views=9, num_layers=2, num_layers_color=3, hidden_dim=64, hidden_dim_color=64)
+    mlp = [[W.clone(), b.clone()] for W, b in fld.mlp_state()]
+    orc = O.OracleField(cfg, geo, shape, fld.F, pool['poses'], occ_l, table=cpu(fld.table).reshape(-1, 2), mlp=mlp,
+                        pose=cpu(fld.pose).reshape(-1, 6))
+    orc.global_step = fld.global_step
+    for lo in (0, (n // 2048 // 2) * 2048):
+        sl = slice(lo, lo + 2048)
+        ref = orc.render_rays_image(rows[sl], chunk=2048)
+        b = fld.render_batch(runner.rays, sel[sl].contiguous(), 2048, want_cells=True)
+        torch.cuda.synchronize()
+        Hc = ref['cell_ids'].shape[1]
+        same = (cpu(b['n_hits']) == ref['n_hits']) & (cpu(b['cell_ids'])[:, :Hc] == ref['cell_ids']).all(axis=1)
+        assert same.mean() > 0.999, same.mean()             # (rays that graze a cell face after the fp32 pose transform)
+        z_ref = ref['z_vals'].numpy()
+        assert np.abs(cpu(ex['z_vals'])[sl] - z_ref)[same].max() < 2e-5
+        raw, raw_ref = cpu(ex['raw'])[sl][same], ref['raw'].numpy()[same]
+        w_rgb, w_sdf = worst_elementwise(raw[..., :3], raw_ref[..., :3]), worst_elementwise(raw[..., 3], raw_ref[..., 3])
+        w_map = worst_elementwise(cpu(ex['rgb_map'])[sl][same], ref['rgb_map'].numpy()[same])
+        # depth: the same sample index wherever the SDF pair products are not within rounding of zero
+        d_ref = ref['depth'].numpy()[same]
+        d_got = d_ray[sl][same]
+        agree = np.abs(d_got - d_ref) <= 1e-3 * np.abs(d_ref) + 1e-5
+        print(f'render 640x480 rays {lo}..: identical hit lists {same.mean():.4f}, per element raw colour {w_rgb:.3f} sdf {w_sdf:.3f} '
+              f'rgb_map {w_map:.3f}, depth agrees on {agree.mean():.5f}')
+        assert w_rgb <= 1.0 and w_sdf <= 1.0 and w_map <= 1.0
+        assert agree.mean() > 0.999

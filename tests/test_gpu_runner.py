@@ -221,6 +221,7 @@ def test_global_refine_from_a_tracker_directory(nof, tmp_path):
     cfg = default_cfg(n_step=500, N_rand=2048, num_levels=16, log2_hashmap_size=17, finest_res=256, far=1.0, frame_features=2,
                       mesh_resolution=0.004, n_train_image=500)
     out = run_global_nerf(dd, cfg, get_texture=True, tex_res=1024)
+    assert out['textured'] is True
     mesh = out['mesh']
     import os
     for f in ('final/nerf/config.yml', 'final/nerf/normalization.yml', 'final/nerf/naive_fusion_biggest_cluster.ply',

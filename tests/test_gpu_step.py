@@ -391,3 +391,62 @@ def test_pose_regulariser_matches_oracle(nof):
     rp = np.asarray(ref['grads'][-1].detach() if hasattr(ref['grads'][-1], 'detach') else ref['grads'][-1]).reshape(-1, 6)
     assert rel_l2(gp, rp) < 5e-4, rel_l2(gp, rp)
     assert np.abs(gp[0]).max() == 0                      # the anchor frame takes no part
+
+
+def test_fp16_overflow_skips_the_step_on_the_device(nof):
+    """The reference's GradScaler skips an optimiser step whose (scaled) gradients are not finite and halves its scale
+    (nerf_runner.py:756-761).  Here: a loss scale 2^30 too large makes the fp16 backward overflow for real; nof_reduce_partials
+    raises bit 2 of the device flags, the step's Adam launches skip (parameters and moments bit-equal, gradients zeroed), the next
+    batch's sampler turns the mark into the sticky bit 3, poll_flags reports it once and halves the scale; a captured step notices
+    the changed scale (GraphedStep.usable)."""
+    from bundlesdf_amd.field import GraphedStep
+    cfg, fld, orc, batch, rng = _pair(nof, 'fp16x3', R=256)
+    pool = U.dev(batch)
+    R = batch.shape[0]
+    ids = torch.arange(R, device='cuda')
+    for _ in range(2):
+        fld.train_step(pool, ids, R, seed=3)
+    torch.cuda.synchronize()
+    assert cpu(fld.flags)[0] == 0
+    p0, m0, v0 = fld.params.clone(), fld.exp_avg.clone(), fld.exp_avg_sq.clone()
+    g = GraphedStep(fld, pool, R, seed=3)
+    assert g.usable()
+    fld._scale_backoff = -30                                           # loss scale x 2^30: binary16 overflows
+    assert not g.usable()                                              # the captured launches carry the old scale
+    fld.train_step(pool, ids, R, seed=3)
+    torch.cuda.synchronize()
+    assert cpu(fld.flags)[0] & 4, 'the overflow was not noticed'
+    assert torch.equal(fld.params, p0) and torch.equal(fld.exp_avg, m0) and torch.equal(fld.exp_avg_sq, v0), 'the step was applied'
+    assert (fld.grads == 0).all()
+    fld._scale_backoff = 0                                             # a sane scale again: this step goes through
+    fld.train_step(pool, ids, R, seed=3)
+    torch.cuda.synchronize()
+    assert cpu(fld.flags)[0] & 12 == 8, 'the mark of the skipped step should be sticky now'
+    assert not torch.equal(fld.params, p0) and torch.isfinite(fld.params).all() and torch.isfinite(fld.exp_avg_sq).all()
+    assert fld.poll_flags() & 4 and fld._scale_backoff == 1
+    assert fld.poll_flags() == 0 and fld._scale_backoff == 1           # reported once
+    s_before = float(fld.desc.grad_scale)
+    fld.train_step(pool, ids, R, seed=3)
+    assert float(fld.desc.grad_scale) == s_before / 2
+
+
+def test_dyn_step_with_grad_sync_hook(nof):
+    """train_step(dyn=True, grad_sync=...) is a public combination: the captured-step form takes a blocking hook,
+    never the bucketed exchange."""
+    cfg, fld, orc, batch, rng = _pair(nof, 'fp16x3', R=128)
+    pool = U.dev(batch)
+    R = batch.shape[0]
+
+    class Sync:
+        calls = 0
+
+        def __call__(self, g):
+            Sync.calls += 1
+
+        def start(self, *a, **k):
+            raise AssertionError('bucketed exchange inside a dyn step')
+
+    fld.sync_step_state()
+    fld.train_step(pool, torch.arange(R, device='cuda'), R, seed=1, grad_sync=Sync(), dyn=True)
+    torch.cuda.synchronize()
+    assert Sync.calls == 1

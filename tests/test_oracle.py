@@ -114,6 +114,49 @@ def test_full_step_matches_reference_driven_run():
         assert np.abs(got - ref).max() < 1e-4 * max(np.abs(ref).max(), 1e-6) + 1e-7, i
 
 
+def test_render_images_matches_reference_driven_run():
+    """OracleField.render_rays_image == the reference's own render_images (nerf_runner.py:586-637: render -> batchify_rays in
+    chunks of N_rand -> render_rays with perturb=False; depth = z at the first SDF sign change, far*sc for rays without one)
+    executed on CPU by tests/golden/make_golden.py on the step fixture's scene, with the sdf bias shifted so that rays cross zero."""
+    cfg = dict(_step_cfg(), N_rand=int(G['render_n_rand']))
+    occ, c2w, batch = G['step_occ'], G['step_c2w'], G['step_batch']
+    geo = O.HashGeometry(cfg['num_levels'], 2, cfg['base_res'], cfg['log2_hashmap_size'], cfg['finest_res'])
+    shape = O.FieldShape(input_ch=geo.out_dim, input_ch_views=9 + cfg['frame_features'])
+    fld = O.OracleField(cfg, geo, shape, c2w.shape[0], c2w, occ, table=G['step_table'], mlp=_unflatten(shape, G['render_mlp_flat']),
+                        pose=G['step_pose'], feat=G['step_feat'])
+    fld.global_step = 1
+    img_i = int(G['render_img_i'])
+    rows = batch[batch[:, 8] == img_i]
+    out = fld.render_rays_image(rows)
+    assert out['raw'].shape == G['render_raw'].shape and cfg['N_rand'] < rows.shape[0]      # several chunks
+    assert np.abs(out['z_vals'].numpy() - G['render_z']).max() < 2e-6
+    assert np.array_equal(out['valid_samples'].numpy(), G['render_valid'])
+    assert np.abs(out['raw'].numpy() - G['render_raw']).max() < 2e-5
+    # scatter like the reference (:616-634) and compare the images
+    H, W = (int(x) for x in G['render_HW'])
+    X = rows[:, 0:3].astype(np.float64).copy()
+    X[:, [1, 2]] = -X[:, [1, 2]]
+    proj = (G['render_K'] @ X.T).T
+    uvs = (proj / proj[:, 2].reshape(-1, 1)).round().astype(int)
+    rgb_full, depth_full = np.zeros((H, W, 3)), np.zeros((H, W))
+    rgb_full[uvs[:, 1], uvs[:, 0]] = out['rgb_map'].numpy()
+    depth_full[uvs[:, 1], uvs[:, 0]] = out['depth'].numpy()
+    far = cfg['far'] * cfg['sc_factor']
+    assert np.array_equal(depth_full == far, G['render_depth_full'] == far) and (G['render_depth_full'] == far).any()
+    assert np.abs(depth_full - G['render_depth_full']).max() < 2e-6
+    assert np.abs(rgb_full - G['render_rgb_full']).max() < 1e-6
+
+
+def test_unperturbed_sampler_is_the_linspace():
+    """perturb=False (nerf_runner.py:78 is not entered): z = near (1 - t) + far t with torch's own linspace, no clip."""
+    near = np.array([[0.5], [1.0], [2.0]], np.float32)
+    far = np.array([[0.5], [3.0], [2.5]], np.float32)
+    for N in (2, 32, 64, 128):
+        t = torch.linspace(0., 1., steps=N).reshape(1, -1)
+        want = (torch.from_numpy(near) * (1. - t) + torch.from_numpy(far) * t).numpy()
+        assert np.array_equal(O.sample_rays_uniform(N, near, far, None), want)
+
+
 def test_raw_at_invalid_samples_is_mlp_of_zero_features():
     """invalid samples still run through both MLPs with zero hash features (nerf_runner.py:1247,1289-1294)."""
     v = G['step_valid']

@@ -3,7 +3,7 @@ sys.path.insert(0, '.')
 from bundlesdf_amd import lib
 for n in (12_700_000, 59_000_000):
     bufs = [torch.randn(n + 8, device='cuda').abs_() for _ in range(4)]
-    args = (C.c_float(0.01), C.c_float(0.003), C.c_float(0.9), C.c_float(0.999), C.c_float(1e-15), 7)
+    args = (C.c_float(0.01), C.c_float(0.003), C.c_float(0.9), C.c_float(0.999), C.c_float(1e-15), 7, None)
     for name, views in (('float4', [x[:n] for x in bufs]), ('scalar', [x[k:k + n] for k, x in enumerate(bufs)])):
         for _ in range(3): lib.call('nof_adam_step', *views, n, n, *args)
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
