@@ -90,8 +90,12 @@ __device__ __forceinline__ int inmap(const NofMlpDesc& d, int l, int q, int hi, 
       const int o = nloc(hi, r);                                      // sigma output o: 0 = sdf, 1..geo = geo_feat
       return (o >= 1 && o <= d.geo) ? d.n_view + o - 1 : -1;
     }
-    const int u = 16 * hi + r;
-    return u < d.n_view ? u : -1;
+    // view block: column u sits in slot (hi, r) = (u >> 3, u & 7), registers r >= 8 unused.  Both lane halves then hold eight
+    // columns in their first eight registers, and in the TRANSPOSED weight-gradient block of this layer (dW^T[slot][neuron], see
+    // dw_block) the slot rows nloc(hi, r), r < 8, are the only non-zero ones: 8 accumulator registers per block instead of 16,
+    // like the sigma-out block beside it (o = nloc(hi, r) <= 15 <=> r < 8).
+    const int u = 8 * hi + r;
+    return (r < 8 && u < d.n_view) ? u : -1;
   }
   const int c = 32 * q + nloc(hi, r);
   return c < d.in_dim[l] ? c : -1;
@@ -169,7 +173,9 @@ struct Shp {                                       // compile-time layer table (
   static constexpr __host__ __device__ int pn(int l) { return (l == NS - 1 || l == NL - 1) ? 1 : 2; }
   static constexpr __host__ __device__ int qn(int l) { return l == 0 ? 1 : 2; }
   // rows of a dW accumulator that can be non-zero: sigma head has 16 outputs (regs 0..7), colour head 3 (regs 0..3)
-  static constexpr __host__ __device__ int nacc(int l) { return l == NS - 1 ? 8 : (l == NL - 1 ? 4 : 16); }
+  // colour layer 0 (l == NS) accumulates the TRANSPOSED block dW^T[input slot][neuron]: both its input blocks use slots r < 8 only
+  static constexpr __host__ __device__ int nacc(int l) { return (l == NS - 1 || l == NS) ? 8 : (l == NL - 1 ? 4 : 16); }
+  static constexpr __host__ __device__ bool tr(int l) { return l == NS; }
   static constexpr __host__ __device__ int pair_base(int l) { int s = 0; for (int k = 0; k < l; ++k) s += pn(k) * qn(k); return s; }
   static constexpr __host__ __device__ int oblk_base(int l) { int s = 0; for (int k = 0; k < l; ++k) s += pn(k); return s; }
 };
@@ -315,17 +321,21 @@ __device__ __forceinline__ void store_dfeat_o1(float2* __restrict__ dfeat, int L
 }
 __device__ __forceinline__ void load_view_o1(const float* __restrict__ view, int S, int64_t B, int64_t b, int hi,
                                              float (&x)[16]) {
-  if (hi == 0 && b < B) {
-    const float4* v = (const float4*)(view + (b / S) * NOF_VIEW_COLS);
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
+  for (int r = 0; r < 16; ++r) x[r] = 0.0f;
+  if (b < B) {                                          // slot (hi, r < 8) = view column 8 hi + r (inmap)
+    const float4* v = (const float4*)(view + (b / S) * NOF_VIEW_COLS + 8 * hi);
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
       const float4 t = v[g];
       x[4 * g] = t.x; x[4 * g + 1] = t.y; x[4 * g + 2] = t.z; x[4 * g + 3] = t.w;
     }
-  } else {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) x[r] = 0.0f;
   }
+}
+// view column held by lane j of a slot-per-lane (transposed) view block, -1 for the unused slots: lane j = slot (hi_j, r_j)
+__device__ __forceinline__ int view_col_of_lane(int j) {
+  const int hi_j = (j >> 2) & 1, r_j = (j & 3) + 4 * (j >> 3);
+  return r_j < 8 ? 8 * hi_j + r_j : -1;
 }
 
 // The sigma head's 16 outputs (sdf + geo_feat) of a sample in operand precision: [B][hi][8] elements; lane (j, hi) holds
@@ -610,14 +620,34 @@ struct Ident {
   }
 };
 
+// The same fragments kept in LDS ([step][lane], written once per workgroup by build()) and read where they are used: eight
+// registers less across the persistent loop of a kernel that runs at its register cap (three colour layers).
 template <class P>
-__device__ __forceinline__ void transpose32(const Ident<P>& I, const float (&x)[16], float (&y)[16]) {
+struct IdentLds {
+  const typename P::frag* base;                                      // + lane
+  __device__ __forceinline__ void build(char* smem_at, int lane) {
+    Ident<P> I;
+    I.init(lane);
+    typename P::frag* w = reinterpret_cast<typename P::frag*>(smem_at) + lane;
+    if (threadIdx.x < 64) {
+#pragma unroll
+      for (int s = 0; s < 16 / P::KR; ++s) w[s * 64] = I.f[s];
+    }
+    base = w;
+  }
+  __device__ __forceinline__ typename P::frag get(int s) const { return base[s * 64]; }
+};
+template <class P> __device__ __forceinline__ typename P::frag ident_frag(const Ident<P>& I, int s) { return I.f[s]; }
+template <class P> __device__ __forceinline__ typename P::frag ident_frag(const IdentLds<P>& I, int s) { return I.get(s); }
+
+template <class P, class ID>
+__device__ __forceinline__ void transpose32(const ID& I, const float (&x)[16], float (&y)[16]) {
   constexpr int KR = P::KR, NSTEP = 16 / KR;
   f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
 #pragma unroll
-  for (int s = 0; s < NSTEP; ++s) acc = P::mma(P::pack(&x[KR * s]), I.f[s], acc);
+  for (int s = 0; s < NSTEP; ++s) acc = P::mma(P::pack(&x[KR * s]), ident_frag<P>(I, s), acc);
 #pragma unroll
   for (int r = 0; r < 16; ++r) y[r] = acc[r];
 }
@@ -642,8 +672,8 @@ struct In2Store<P, NSLOT, false> {
 };
 
 // transpose one sample-per-lane block and park it as MFMA operands in slot `slot`
-template <class P, class ST>
-__device__ __forceinline__ void park_o2(ST& st, const Ident<P>& I, int slot, const float (&x)[16]) {
+template <class P, class ST, class ID>
+__device__ __forceinline__ void park_o2(ST& st, const ID& I, int slot, const float (&x)[16]) {
   float y[16];
   transpose32<P>(I, x, y);
 #pragma unroll
@@ -651,8 +681,10 @@ __device__ __forceinline__ void park_o2(ST& st, const Ident<P>& I, int slot, con
 }
 
 // one output block p of layer l:  g2 = T(g1[p]);  db += sum_samples g2;  dW[p][q] += g2 (x) in2(l,q)
-template <class P, int QN, int NACC, class ST>
-__device__ __forceinline__ void dw_block(float (&dw)[2][16], float* db_lane, const Ident<P>& I, const float (&g1p)[16],
+// TR: the operands swapped -- dW^T[slot of block q][neuron of block p], registers = input slots (used where only the first NACC
+// slot rows of every input block can be non-zero: colour layer 0)
+template <class P, int QN, int NACC, class ST, bool TR = false, class ID = Ident<P>>
+__device__ __forceinline__ void dw_block(float (&dw)[2][16], float* db_lane, const ID& I, const float (&g1p)[16],
                                          const ST& st, int slot0) {
   constexpr int KR = P::KR, NSTEP = 16 / KR;
   float g2[16];
@@ -670,7 +702,7 @@ __device__ __forceinline__ void dw_block(float (&dw)[2][16], float* db_lane, con
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = r < NACC ? dw[q][r] : 0.0f;
 #pragma unroll
-    for (int s = 0; s < NSTEP; ++s) acc = P::mma(ga[s], st.get(slot0 + q, s), acc);
+    for (int s = 0; s < NSTEP; ++s) acc = TR ? P::mma(st.get(slot0 + q, s), ga[s], acc) : P::mma(ga[s], st.get(slot0 + q, s), acc);
 #pragma unroll
     for (int r = 0; r < NACC; ++r) dw[q][r] = acc[r];
   }
@@ -683,14 +715,26 @@ __device__ __forceinline__ void dw_block(float (&dw)[2][16], float* db_lane, con
 // lane owns a distinct (row, column) and the (lane, register) pairs cover every parameter exactly once, so no zero-fill and no
 // global atomics are needed.  One row per workgroup instead of one per wave is a quarter of the bytes nof_reduce_partials reads
 // (cfg2: 75 MB -> 19 MB per step).  `db_stride`: floats between two waves' lane-private bias sums.  Deterministic: ((w0+w1)+w2)+w3.
+// floats of LDS flush_dw's reduction needs per group of four waves (x 256 bytes): must end below the lane-private bias sums
 template <class SH, int LA, int LB>
+constexpr int flush_dw_accs() {
+  int a = 0;
+  for (int l = LA; l < LB; ++l) a += SH::pn(l) * SH::qn(l) * SH::nacc(l);
+  return a;
+}
+// NW waves per workgroup (4 or 8): every GROUP of four consecutive waves is reduced on its own (its own LDS region, the same
+// barriers) and writes its own row, 4 groups' worth of rows per launch being what the host sized `partials` for.
+template <class SH, int LA, int LB, int NW = 4>
 __device__ __forceinline__ void flush_dw(const NofMlpDesc& d, float (&dw)[SH::NL][2][2][16], const float* dbw, int db_stride,
-                                         char* smem, float* __restrict__ partials, float unscale) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+                                         char* smem, float* __restrict__ partials, float unscale, int wave_s) {
+  static_assert(NW % 4 == 0, "waves are reduced in groups of four");
+  // lane id from mbcnt, not from threadIdx.x: the work-item id register is long overwritten by the end of the persistent loop
+  // and a copy kept for this epilogue was the one value the three-colour-layer kernel spilled
+  const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
   const int hi = lane >> 5, j = lane & 31;
   const int hi_j = (j >> 2) & 1, r_j = (j & 3) + 4 * (j >> 3);      // dW column lane j = input slot (hi_j, r_j)
-  float* red = reinterpret_cast<float*>(smem) + lane;
-  const int wv = __builtin_amdgcn_readfirstlane(wave);              // scalar: the phases below are whole-wave branches
+  const int grp = wave_s >> 2, wv = wave_s & 3;                     // wave_s: SCALAR wave index (the phases below are whole-wave branches)
+  float* red = reinterpret_cast<float*>(smem) + grp * (flush_dw_accs<SH, LA, LB>() * 64) + lane;
   // phase W: 0 = store, 1 / 2 = add into LDS, 3 = add LDS into the registers (the last wave keeps the totals).  Straight-line per
   // phase, so that a wave's 70-110 LDS reads are all in flight together (one branch per element serialised their latencies: 30 us)
   auto phase = [&](auto W) {
@@ -720,8 +764,8 @@ __device__ __forceinline__ void flush_dw(const NofMlpDesc& d, float (&dw)[SH::NL
   __syncthreads();
   if (wv == 3) phase(std::integral_constant<int, 3>());
   if (wv != 3) return;
-  float* __restrict__ dst = partials + (size_t)blockIdx.x * d.n_params;
-  const float* db0 = dbw - 3 * db_stride;                          // wave 0's lane-private sums (this is wave 3)
+  float* __restrict__ dst = partials + ((size_t)blockIdx.x * (NW / 4) + grp) * d.n_params;
+  const float* db0 = dbw - 3 * db_stride;                          // the group's first wave's lane-private sums (this is its fourth)
 #pragma unroll
   for (int l = LA; l < LB; ++l) {
     const int in_dim = d.in_dim[l], out_dim = d.out_dim[l];
@@ -731,11 +775,13 @@ __device__ __forceinline__ void flush_dw(const NofMlpDesc& d, float (&dw)[SH::NL
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
           if (q < SH::qn(l)) {
-            const int col = inmap(d, l, q, hi_j, r_j);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
               if (r < SH::nacc(l)) {
-                const int row = 32 * p + nloc(hi, r);
+                // normal block: lane = input slot (hi_j, r_j), register = neuron row nloc(hi, r); transposed block (SH::tr): lane =
+                // neuron row j, register = input slot (hi, r)
+                const int col = SH::tr(l) ? inmap(d, l, q, hi, r) : inmap(d, l, q, hi_j, r_j);
+                const int row = 32 * p + (SH::tr(l) ? j : nloc(hi, r));
                 if (col >= 0 && row < out_dim) dst[d.w_off[l] + row * in_dim + col] = dw[l][p][q][r] * unscale;
               }
             }
@@ -749,13 +795,6 @@ __device__ __forceinline__ void flush_dw(const NofMlpDesc& d, float (&dw)[SH::NL
       }
     }
   }
-}
-// floats of LDS flush_dw's reduction needs (x 256 bytes): must end below the lane-private bias sums
-template <class SH, int LA, int LB>
-constexpr int flush_dw_accs() {
-  int a = 0;
-  for (int l = LA; l < LB; ++l) a += SH::pn(l) * SH::qn(l) * SH::nacc(l);
-  return a;
 }
 
 template <class P, int NS, int NC>
@@ -899,8 +938,8 @@ __global__ __launch_bounds__(256) void k_mlp_bwd(NofMlpDesc d, const char* __res
     }
     // ---- colour layer 0: inputs = [sigma-out block | view block] ----
     {
-      dw_block<P, 2, 16>(dw[NS][0], dbw + (2 * NS) * 64, I, g1[0], st, 2 * NS);
-      dw_block<P, 2, 16>(dw[NS][1], dbw + (2 * NS + 1) * 64, I, g1[1], st, 2 * NS);
+      dw_block<P, 2, 8, Store, true>(dw[NS][0], dbw + (2 * NS) * 64, I, g1[0], st, 2 * NS);
+      dw_block<P, 2, 8, Store, true>(dw[NS][1], dbw + (2 * NS + 1) * 64, I, g1[1], st, 2 * NS);
       float ds1[16], dv1[16], dv2[16];
       bwd_data<P, 2>(smem, BW_OFF(NS), 0, g1, ds1, lane);
       bwd_data<P, 2>(smem, BW_OFF(NS), 1, g1, dv1, lane);
@@ -918,8 +957,8 @@ __global__ __launch_bounds__(256) void k_mlp_bwd(NofMlpDesc d, const char* __res
         }
         sa += __shfl_xor(sa, 32, 64);
         sb += __shfl_xor(sb, 32, 64);
-        const int hi_j = (j >> 2) & 1, u = (j & 3) + 4 * (j >> 3);   // lane j holds slot (hi_j, r_j) -> view column 16 hi_j + r_j
-        if (hi == 0 && hi_j == 0 && u < d.n_view) {
+        const int u = view_col_of_lane(j);
+        if (hi == 0 && u >= 0 && u < d.n_view) {
           if (sa != 0.0f) atomicAdd(&dview[ray0 * NOF_VIEW_COLS + u], sa * gunscale);
           if (sb != 0.0f) atomicAdd(&dview[(ray0 + 1) * NOF_VIEW_COLS + u], sb * gunscale);
         }
@@ -964,7 +1003,7 @@ __global__ __launch_bounds__(256) void k_mlp_bwd(NofMlpDesc d, const char* __res
 
   // ---------------- reduce the workgroup's dW/db and write its row of `partials` ----------------
   static_assert(flush_dw_accs<SH, 0, NL>() * 256 <= DB_BASE, "flush_dw's LDS reduction would overwrite the bias sums");
-  flush_dw<SH, 0, NL>(d, dw, dbw, NSLOT * 64, smem, partials, gunscale);
+  flush_dw<SH, 0, NL>(d, dw, dbw, NSLOT * 64, smem, partials, gunscale, __builtin_amdgcn_readfirstlane(wave));
 }
 
 // =====================================================================================================
@@ -976,8 +1015,20 @@ __global__ __launch_bounds__(256) void k_mlp_bwd(NofMlpDesc d, const char* __res
 // output (written by the forward kernel) and its gradient -- 64 B/sample of extra traffic against ~300 B/sample saved
 // instructions' worth of time.  Numerically identical to the fused kernel (same operand roundings, same MFMA chains).
 // =====================================================================================================
+// Waves per workgroup of the two split-backward kernels.  Three colour layers (the reference's own shape, nerf_runner.py:221): the
+// fragments (40 KB) + four waves' parked operands (48 KB) + bias sums are 95 KB, i.e. ONE 4-wave workgroup per CU = one wave per
+// SIMD; eight waves around ONE copy of the fragments are 148 KB: one workgroup per CU, two waves per SIMD.
+#ifndef NOF_BWD_WAVES_C2
+#define NOF_BWD_WAVES_C2 4
+#endif
+#ifndef NOF_BWD_WAVES_S
+#define NOF_BWD_WAVES_S 4
+#endif
+template <int NC> struct ColorWaves { static constexpr int value = NC >= 3 ? 8 : NOF_BWD_WAVES_C2; };
+template <int NS> struct SigmaWaves { static constexpr int value = NOF_BWD_WAVES_S; };
+
 template <class P, int NS, int NC>
-__global__ __launch_bounds__(256, 2) void k_mlp_bwd_color(NofMlpDesc d, const char* __restrict__ image,
+__global__ __launch_bounds__(64 * ColorWaves<NC>::value, 2) void k_mlp_bwd_color(NofMlpDesc d, const char* __restrict__ image,
                                                            const typename P::elem* __restrict__ sig,
                                                            const float* __restrict__ view, int S,
                                                            const float4* __restrict__ draw, typename P::elem* __restrict__ dsig,
@@ -994,10 +1045,17 @@ __global__ __launch_bounds__(256, 2) void k_mlp_bwd_color(NofMlpDesc d, const ch
   constexpr int IN2_BASE = BIASB + (OB - OA) * 128;
   constexpr int NSLOT = 2 * NC;                                                     // slot(l, q) = 2 (l - NS) + q
   constexpr int IN2_WAVE = NSLOT * NSTEP * 64 * (int)sizeof(frag);
-  constexpr int DB_BASE = IN2_BASE + 4 * IN2_WAVE;
+  constexpr int NW = ColorWaves<NC>::value;
+  constexpr int DB_BASE = IN2_BASE + NW * IN2_WAVE;
   copy16(smem, image + (size_t)PA * PAIR_BYTES, (size_t)NP * PAIR_BYTES);
   copy16(smem + BWB, image + (size_t)(PB + PA) * PAIR_BYTES, (size_t)NP * PAIR_BYTES);
   copy16(smem + BIASB, image + 2 * (size_t)PB * PAIR_BYTES + OA * 128, (size_t)(OB - OA) * 128);
+  // identity fragments of the MFMA transposes: in LDS where the registers are all taken (three colour layers), else in registers
+  constexpr int ID_BASE = DB_BASE + NW * (2 * NC) * 64 * 4;
+  typedef typename std::conditional<(NC >= 3), IdentLds<P>, Ident<P>>::type IdT;
+  IdT I;
+  if constexpr (NC >= 3) I.build(smem + ID_BASE, threadIdx.x & 63);
+  else I.init(threadIdx.x & 63);
   __syncthreads();
 #define CFW(l) ((SH::pair_base(l) - PA) * PAIR_BYTES)
 #define CBW(l) (BWB + (SH::pair_base(l) - PA) * PAIR_BYTES)
@@ -1011,8 +1069,6 @@ __global__ __launch_bounds__(256, 2) void k_mlp_bwd_color(NofMlpDesc d, const ch
 #pragma unroll
   for (int k = 0; k < 2 * NC; ++k) dbl[k * 64] = 0.0f;
   float* dbw = dbl - (2 * NS) * 64;                                                 // so that [2 l + p] addresses it (never dereferenced below 2 NS)
-  Ident<P> I;
-  I.init(lane);
   // loss scaling of the 16-bit backward (the reference's GradScaler, nerf_runner.py:159,758): the loss gradient is multiplied
   // by a power of two where it enters and every fp32 output is divided by it where it leaves -- exact in fp32, and it keeps
   // the ~1e-7 gradients of a 1/(R*S)-normalised loss out of binary16's subnormal range inside the MFMA operands
@@ -1029,12 +1085,13 @@ __global__ __launch_bounds__(256, 2) void k_mlp_bwd_color(NofMlpDesc d, const ch
           if (p < SH::pn(l) && q < SH::qn(l) && r < SH::nacc(l)) dw[l][p][q][r] = 0.0f;
 
   const int64_t ntiles = (B + 31) / 32;
-  const int64_t tstride = (int64_t)gridDim.x * 4;
+  const int64_t tstride = (int64_t)gridDim.x * NW;
   // the NEXT tile's inputs are loaded a whole tile ahead (latency hidden behind this tile's MFMA chain) where the 20 registers
   // cost no heavy spilling (two colour layers; with three: 244 B of scratch per lane), draw at the top of the tile
   constexpr bool AHEAD = NC == 2;
   const TileWork work(tile_list, ntiles);
-  const int64_t w0 = (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(wave);
+  const int wave_s = __builtin_amdgcn_readfirstlane(wave);
+  const int64_t w0 = (int64_t)blockIdx.x * NW + wave_s;
   int64_t tile_n = work.at(w0);                       // the tile whose inputs are in flight
   typename P::frag sign = load_sig_raw<P>(sig, B, AHEAD ? tile_n * 32 + j : B, hi);
   float viewn[16];
@@ -1051,9 +1108,14 @@ __global__ __launch_bounds__(256, 2) void k_mlp_bwd_color(NofMlpDesc d, const ch
     uint32_t m1[NL];
     float h[2][16];
     float4 dr = drn;
-    asm volatile("" : "+v"(dr.x), "+v"(dr.y), "+v"(dr.z), "+v"(dr.w));
-    drn = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (hi == 0 && tile_n * 32 + j < B) drn = draw[tile_n * 32 + j];
+    if constexpr (AHEAD) {
+      asm volatile("" : "+v"(dr.x), "+v"(dr.y), "+v"(dr.z), "+v"(dr.w));
+      drn = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (hi == 0 && tile_n * 32 + j < B) drn = draw[tile_n * 32 + j];
+    } else {                                           // (three colour layers: no register to carry it across a tile)
+      dr = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (hi == 0 && b < B) dr = draw[b];
+    }
     float cin[2][16];
     if constexpr (AHEAD) {
       sig_to_o1<P>(sign, cin[0]);
@@ -1133,8 +1195,8 @@ __global__ __launch_bounds__(256, 2) void k_mlp_bwd_color(NofMlpDesc d, const ch
         for (int r = 0; r < 16; ++r) g1[p][r] = d1[p][r];
     }
     {
-      dw_block<P, 2, 16>(dw[NS][0], dbw + (2 * NS) * 64, I, g1[0], st, 0);
-      dw_block<P, 2, 16>(dw[NS][1], dbw + (2 * NS + 1) * 64, I, g1[1], st, 0);
+      dw_block<P, 2, 8, Store, true>(dw[NS][0], dbw + (2 * NS) * 64, I, g1[0], st, 0);
+      dw_block<P, 2, 8, Store, true>(dw[NS][1], dbw + (2 * NS + 1) * 64, I, g1[1], st, 0);
       float dv1[16], dv2[16];
       bwd_data<P, 2>(smem, CBW(NS), 0, g1, ds1, lane);
       bwd_data<P, 2>(smem, CBW(NS), 1, g1, dv1, lane);
@@ -1151,8 +1213,8 @@ __global__ __launch_bounds__(256, 2) void k_mlp_bwd_color(NofMlpDesc d, const ch
         }
         sa += __shfl_xor(sa, 32, 64);
         sb += __shfl_xor(sb, 32, 64);
-        const int hi_j = (j >> 2) & 1, u = (j & 3) + 4 * (j >> 3);
-        if (hi == 0 && hi_j == 0 && u < d.n_view) {
+        const int u = view_col_of_lane(j);
+        if (hi == 0 && u >= 0 && u < d.n_view) {
           if (sa != 0.0f) atomicAdd(&dview[ray0 * NOF_VIEW_COLS + u], sa * gunscale);
           if (sb != 0.0f) atomicAdd(&dview[(ray0 + 1) * NOF_VIEW_COLS + u], sb * gunscale);
         }
@@ -1162,15 +1224,15 @@ __global__ __launch_bounds__(256, 2) void k_mlp_bwd_color(NofMlpDesc d, const ch
     }                                                    // if (!skip)
     store_sig_o1<P>(dsig, B, b, hi, ds1);                // zeros for a skipped tile
   }
-  static_assert(flush_dw_accs<SH, NS, NL>() * 256 <= DB_BASE, "flush_dw's LDS reduction would overwrite the bias sums");
-  flush_dw<SH, NS, NL>(d, dw, dbw, (2 * NC) * 64, smem, partials, gunscale);
+  static_assert(flush_dw_accs<SH, NS, NL>() * 256 * (NW / 4) <= DB_BASE, "flush_dw's LDS reduction would overwrite the bias sums");
+  flush_dw<SH, NS, NL, NW>(d, dw, dbw, (2 * NC) * 64, smem, partials, gunscale, wave_s);
 #undef CFW
 #undef CBW
 #undef CBIAS
 }
 
 template <class P, int NS, int NC>
-__global__ __launch_bounds__(256, 2) void k_mlp_bwd_sigma(NofMlpDesc d, const char* __restrict__ image,
+__global__ __launch_bounds__(64 * SigmaWaves<NS>::value, 2) void k_mlp_bwd_sigma(NofMlpDesc d, const char* __restrict__ image,
                                                            const float2* __restrict__ feat, int L,
                                                            const typename P::elem* __restrict__ dsig, float2* __restrict__ dfeat,
                                                            float* __restrict__ partials, int64_t B,
@@ -1185,7 +1247,8 @@ __global__ __launch_bounds__(256, 2) void k_mlp_bwd_sigma(NofMlpDesc d, const ch
   constexpr int IN2_BASE = BIASB + SH::oblk_base(NS - 1) * 128;
   constexpr int NSLOT = 2 * NS - 1;                                                 // slot(0, 0) = 0, slot(l, q) = 2 l + q - 1
   constexpr int IN2_WAVE = NSLOT * NSTEP * 64 * (int)sizeof(frag);
-  constexpr int DB_BASE = IN2_BASE + 4 * IN2_WAVE;
+  constexpr int NW = SigmaWaves<NS>::value;
+  constexpr int DB_BASE = IN2_BASE + NW * IN2_WAVE;
   copy16(smem, image, (size_t)FWN * PAIR_BYTES);
   copy16(smem + BWB, image + (size_t)SH::pair_base(NL) * PAIR_BYTES, (size_t)NP * PAIR_BYTES);
   copy16(smem + BIASB, image + 2 * (size_t)SH::pair_base(NL) * PAIR_BYTES, (size_t)SH::oblk_base(NS - 1) * 128);
@@ -1219,12 +1282,13 @@ __global__ __launch_bounds__(256, 2) void k_mlp_bwd_sigma(NofMlpDesc d, const ch
           if (p < SH::pn(l) && q < SH::qn(l) && r < SH::nacc(l)) dw[l][p][q][r] = 0.0f;
 
   const int64_t ntiles = (B + 31) / 32;
-  const int64_t tstride = (int64_t)gridDim.x * 4;
+  const int64_t tstride = (int64_t)gridDim.x * NW;
   // 64 % of this kernel's wave cycles used to be s_waitcnt on global memory (SQ_WAIT_ANY): the tile's feature loads queued
   // behind the previous tile's dfeat stores (vmcnt retires in order) and were waited for where they were issued, like the dsig
   // load.  Now the NEXT tile's features are requested a whole tile ahead and dsig at the top of the tile: 111 -> 82 us at cfg2.
   const TileWork work(tile_list, ntiles);
-  const int64_t w0 = (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(wave);
+  const int wave_s = __builtin_amdgcn_readfirstlane(wave);
+  const int64_t w0 = (int64_t)blockIdx.x * NW + wave_s;
   int64_t tile_n = work.at(w0);
   float xn[1][16];
   load_feat_o1(feat, L, B, tile_n * 32 + j, hi, xn);
@@ -1308,8 +1372,8 @@ __global__ __launch_bounds__(256, 2) void k_mlp_bwd_sigma(NofMlpDesc d, const ch
     }                                                                    // if (!skip)
     store_dfeat_o1(dfeat, L, B, b, hi, df1, gunscale);                   // zeros for a skipped tile
   }
-  static_assert(flush_dw_accs<SH, 0, NS>() * 256 <= DB_BASE, "flush_dw's LDS reduction would overwrite the bias sums");
-  flush_dw<SH, 0, NS>(d, dw, dbw, (2 * NS) * 64, smem, partials, gunscale);
+  static_assert(flush_dw_accs<SH, 0, NS>() * 256 * (NW / 4) <= DB_BASE, "flush_dw's LDS reduction would overwrite the bias sums");
+  flush_dw<SH, 0, NS, NW>(d, dw, dbw, (2 * NS) * 64, smem, partials, gunscale, wave_s);
 #undef SFW
 #undef SBW
 #undef SBIAS
@@ -1521,7 +1585,7 @@ __global__ __launch_bounds__(256) void k_eikonal(NofMlpDesc d, const char* __res
     }
   }
   static_assert(flush_dw_accs<SH, 0, NS>() * 256 <= DB_BASE, "flush_dw's LDS reduction would overwrite the bias sums");
-  flush_dw<SH, 0, NS>(d, dw, dbz, (2 * NS + 1) * 64, smem, partials, 1.0f);
+  flush_dw<SH, 0, NS>(d, dw, dbz, (2 * NS + 1) * 64, smem, partials, 1.0f, __builtin_amdgcn_readfirstlane(wave));
   // loss: one atomic pair per wave
   loss_acc += __shfl_xor(loss_acc, 1, 64);  loss_acc += __shfl_xor(loss_acc, 2, 64);  loss_acc += __shfl_xor(loss_acc, 4, 64);
   loss_acc += __shfl_xor(loss_acc, 8, 64);  loss_acc += __shfl_xor(loss_acc, 16, 64); loss_acc += __shfl_xor(loss_acc, 32, 64);
@@ -1708,21 +1772,23 @@ extern "C" int nof_mlp_bwd_tiles(const NofMlpDesc* d, const void* packed, const 
   const unsigned rows = (unsigned)nof_mlp_bwd_blocks();
   if (d->precision != 0 && sigma_out != nullptr && dsigma_ws != nullptr) {
     // split path: colour net, then sigma net; 2 workgroups per CU each, one partial row per wave
+    // `rows` partial rows = one per group of four waves (flush_dw): rows * 4 / waves-per-workgroup workgroups
+    const size_t wc = d->n_color >= 3 ? 8 : NOF_BWD_WAVES_C2, ws = NOF_BWD_WAVES_S;
     const size_t shm_c = 2 * (size_t)(n_pairs(*d, nl) - n_pairs(*d, ns)) * pair_bytes + (size_t)(n_oblk(*d, nl) - n_oblk(*d, ns)) * 128 +
-                         (size_t)4 * (2 * d->n_color) * 2 * 64 * 16 + (size_t)4 * (2 * d->n_color) * 64 * 4;
+                         wc * (2 * d->n_color) * 2 * 64 * 16 + wc * (2 * d->n_color) * 64 * 4 + 2048;   // (+ identity fragments)
     const size_t shm_s = (size_t)(n_pairs(*d, ns - 1) + n_pairs(*d, ns)) * pair_bytes + (size_t)n_oblk(*d, ns - 1) * 128 +
-                         (size_t)4 * (2 * ns - 1) * 2 * 64 * 16 + (size_t)4 * (2 * ns) * 64 * 4;
-    const unsigned blocks = rows;
+                         ws * (2 * ns - 1) * 2 * 64 * 16 + ws * (2 * ns) * 64 * 4;
+    const unsigned blocks_c = rows * 4 / (unsigned)wc, blocks_s = rows * 4 / (unsigned)ws;
 #define LAUNCH_SPLIT(P, NS_, NC_, dummy)                                                                  \
   {                                                                                                       \
     auto kc = k_mlp_bwd_color<P, NS_, NC_>;                                                               \
     auto ks = k_mlp_bwd_sigma<P, NS_, NC_>;                                                               \
     if (int e = set_smem(kc, shm_c)) return e;                                                            \
     if (int e = set_smem(ks, shm_s)) return e;                                                            \
-    hipLaunchKernelGGL(kc, dim3(blocks), dim3(256), shm_c, (hipStream_t)stream, *d, (const char*)packed,  \
+    hipLaunchKernelGGL(kc, dim3(blocks_c), dim3(64 * (unsigned)wc), shm_c, (hipStream_t)stream, *d, (const char*)packed,  \
                        (const typename P::elem*)sigma_out, view, (int)S, (const float4*)draw,             \
                        (typename P::elem*)dsigma_ws, dview, partials, B, tile_list);                      \
-    hipLaunchKernelGGL(ks, dim3(blocks), dim3(256), shm_s, (hipStream_t)stream, *d, (const char*)packed,  \
+    hipLaunchKernelGGL(ks, dim3(blocks_s), dim3(64 * (unsigned)ws), shm_s, (hipStream_t)stream, *d, (const char*)packed,  \
                        (const float2*)feat, (int)L, (const typename P::elem*)dsigma_ws, (float2*)dfeat,   \
                        partials, B, tile_list);                                                           \
   }

@@ -327,8 +327,8 @@ __global__ __launch_bounds__(768) void k_wide_bwd_color(NofMlpDesc d, const char
       }
       sa += __shfl_xor(sa, 32, 64);
       sb += __shfl_xor(sb, 32, 64);
-      const int hi_j = (j >> 2) & 1, u = (j & 3) + 4 * (j >> 3);
-      if (hi == 0 && hi_j == 0 && u < d.n_view) {
+      const int u = view_col_of_lane(j);
+      if (hi == 0 && u >= 0 && u < d.n_view) {
         if (sa != 0.0f) atomicAdd(&dview[ray0 * NOF_VIEW_COLS + u], sa * gunscale);
         if (sb != 0.0f) atomicAdd(&dview[(ray0 + 1) * NOF_VIEW_COLS + u], sb * gunscale);
       }
