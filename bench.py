@@ -37,6 +37,7 @@ PRECISION_NOTE = {
 # (num_layers, num_layers_color, hidden): BASELINE cfg2's network, the reference's own (nerf_runner.py:221), BASELINE cfg5's
 MLP_SHAPES = {'baseline': (3, 2, 64), 'reference': (2, 3, 64), 'cfg5': (4, 4, 128)}
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+L2_PEAK_GBS = 34500.0          # MI355X_MICROARCH.md "L2 (per XCD)": ~34.5 TB/s aggregate over the 8 XCDs' 4 MiB L2s
 MFMA_BF16_PEAK_TF = 2500.0     # dense bf16 MFMA
 
 
@@ -170,6 +171,25 @@ def self_launch(args):
     raise SystemExit(subprocess.call(cmd, env=env))
 
 
+def extra_configs():
+    """BASELINE.json configs[4] (cfg5: 1280x720, T = 2^22, MLP 4x128 + 4x128, fp16, 16 384 rays per step) as a sub-record of the
+    one line, so that the driver's run carries it: a short run of this same script in a child process (16 keyframes: the step
+    does not depend on how many rows the ray table has; building 64 frames of 1280x720 would take longer than the run)."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), '--mlp', 'cfg5', '--rays', '16384', '--log2_T', '22', '--finest', '512',
+           '--width', '1280', '--height', '720', '--precision', 'fp16', '--keyframes', '16', '--steps', '20', '--warmup', '10',
+           '--settle', '0', '--round-steps', '0', '--no-cpu-baseline', '--no-extra-configs']
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+        d = json.loads(r.stdout.strip().splitlines()[-1])
+        keep = ('value', 'unit', 'ms_per_step', 'steps', 'warmup', 'dtype', 'ms_per_step_dense_backward', 'zero_grad_sample_fraction',
+                'train_iters_per_sec', 'loss', 'flags', 'step_ms_spread')
+        return [{"name": "cfg5", **{k: d.get(k) for k in keep}, "workload": d['config']['workload'].split(';')[0],
+                 "roofline": {k: d['roofline'].get(k) for k in ('kernel', 'bound', 'frac', 'avg_ms')} if d.get('roofline') else None}]
+    except Exception as ex:                       # a sub-record must never cost the main line
+        return [{"name": "cfg5", "error": repr(ex)[:300]}]
+
+
 ATOMIC_PEAK_G = 20.8        # G line requests/s: tools/atomic_probe.py on MI355X (profiles/r02_d_atomic_probe.txt)
 
 
@@ -213,7 +233,10 @@ def main():
                          'cfg5: SDF 4x128 + colour 4x128 (BASELINE.json cfg5, with --rays 16384 --log2_T 22 --width 1280 --height 720 '
                          '--precision fp16)')
     ap.add_argument('--finest', type=int, default=256, help='finest hash resolution (256: cfg1-3; 512: cfg4/5)')
-    ap.add_argument('--settle', type=int, default=200, help='untimed steps between the warm-up and the timed region (the zero-gradient fraction settles; 0: time right after the warm-up)')
+    ap.add_argument('--settle', type=int, default=200, help='steps into the run at which the K steps are timed AGAIN for ms_per_step_settled (the zero-gradient fraction has settled by then); 0: skip.  `value` is always the K steps right after the W warm-up steps')
+    ap.add_argument('--round-steps', type=int, default=501, help='steps of the whole-round measurement from a fresh field (the reference\'s N_iters = n_step + 1 = 501); 0: skip')
+    ap.add_argument('--unfused', action='store_true', help='training forward as nof_hash_encode_fwd + nof_mlp_fwd (fp32 embedding in HBM) instead of the fused nof_encode_mlp_fwd')
+    ap.add_argument('--no-extra-configs', action='store_true', help='skip the BASELINE cfg5 sub-record (N = 1 default run only)')
     ap.add_argument('--scatter-wgs', type=int, default=0, help='persistent workgroups per CU of the table scatter (0 = library default)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-seconds', type=float, default=25.0)
@@ -248,6 +271,10 @@ def main():
     R, S = args.rays, cfg['N_samples'] + cfg['N_samples_around_depth']
     B = R * S
 
+    if args.unfused:
+        fld.fused_forward = False
+    fwd_name = 'nof_encode_mlp_fwd' if fld.fused_forward else 'nof_hash_encode_fwd'     # the launch that holds the hash lookup
+
     def zero_fraction():
         """ray-samples of the last batch whose loss gradient is exactly zero (one device reduction + host sync: outside timing)"""
         return float((fld._buffers(R, S)['draw'] == 0).all(-1).float().mean().item())
@@ -272,8 +299,8 @@ def main():
     fld.profile = {dominant: []} if dominant else None          # timed region: only the dominant kernel keeps its events
     fld.profile_only = dominant
     # the hash lookup (north_star: ">= 40 % HBM roofline for hash lookup") is timed as well: two more events per step
-    if dominant != 'nof_hash_encode_fwd':
-        fld.profile_also = 'nof_hash_encode_fwd'
+    if dominant != fwd_name:
+        fld.profile_also = fwd_name
     if sync is not None:
         sync.timing, sync.timed_steps = [], 0
 
@@ -295,40 +322,48 @@ def main():
             dt = float(t.item())
         return dt
 
-    # The step's cost depends on how many ray-samples carry a loss gradient (the backward runs over their tiles only), and that
-    # fraction moves during the first few hundred steps of a run (0.49 -> 0.67 at cfg2) before it stays put for the thousands
-    # that follow.  So: the K steps right after the W warm-up steps are timed for the record (`ms_per_step_first_steps`), then
-    # `--settle` more untimed steps bring the field to the regime a run spends its time in, and the K steps that make `value`
-    # are timed there.  Both figures, the fractions at both ends and the sparsity-independent dense figure are in the line.
-    early_ms, zero_early = None, None
-    if args.settle > 0:
-        zero_early = zero_fraction() if args.warmup > 0 else None
-        early_ms = timed(args.steps) / args.steps * 1e3
-        keep = fld.profile, fld.profile_only, fld.profile_also
-        fld.profile = None                            # (no events for the settling steps)
-        for _ in range(args.settle):
-            step()
-        torch.cuda.synchronize()
-        fld.profile, fld.profile_only, fld.profile_also = {k: [] for k in keep[0]} if keep[0] is not None else None, keep[1], keep[2]
-        if sync is not None:
-            sync.timing, sync.timed_steps = [], 0
-        log(f'first {args.steps} steps after the warm-up: {early_ms:.3f} ms/step (zero-gradient fraction {zero_early}); {args.settle} settling steps done')
-    zero_first = zero_fraction() if args.warmup + args.settle > 0 else None
+    # ---- THE timed region: exactly K steps right after the W warm-up steps (the contract) ----------------------------------
+    # The step's cost depends on how many ray-samples carry a loss gradient (the backward runs over their tiles only); that
+    # fraction moves over the first few hundred steps of a run (0.49 -> 0.67 at cfg2).  `value` is what these K steps deliver;
+    # the same K steps once the fraction has settled, with every tile listed, and the mean over a whole reference round
+    # (501 steps from a fresh field, config.yml:2) are reported beside it under their own names.
+    zero_first = zero_fraction() if args.warmup > 0 else None
     dt = timed(args.steps)
     log(f'timed region done: {dt / args.steps * 1e3:.3f} ms/step')
     zero_last = zero_fraction()
     kt = fld.kernel_times_ms()
     dom_ms = kt.get(dominant) if dominant else None
-    hash_fwd_ms = kt.get('nof_hash_encode_fwd')
+    hash_fwd_ms = kt.get(fwd_name)
     exposed_comm_ms = None
     if sync is not None and sync.timing:
         torch.cuda.synchronize()
         exposed_comm_ms = float(np.sum([a.elapsed_time(b) for a, b in sync.timing])) / max(sync.timed_steps, 1)
         sync.timing = None
     fld.profile, fld.profile_only, fld.profile_also = None, None, None
+    # ---- spread of the step time: K more steps with one event after each (device-side durations, no host sync in between) ----
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    barrier()
+    evs[0].record()
+    for i in range(args.steps):
+        step()
+        evs[i + 1].record()
+    barrier()
+    per_step = np.array([evs[i].elapsed_time(evs[i + 1]) for i in range(args.steps)])
+    # (the events are recorded when the step's last launch retires; a step that found the queue empty shows its host time instead)
+    spread = {"p10": float(np.percentile(per_step, 10)), "p50": float(np.percentile(per_step, 50)),
+              "p90": float(np.percentile(per_step, 90)), "n": int(args.steps)} if args.steps >= 5 else None
+    # ---- the same K steps once the zero-gradient fraction has settled (>= --settle steps into the run) ----
+    settled_ms, zero_settled, settled_after = None, None, None
+    if args.settle > 0:
+        more = max(0, args.settle - fld.global_step)
+        for _ in range(more):
+            step()
+        settled_after = fld.global_step
+        zero_settled = zero_fraction()
+        settled_ms = timed(args.steps) / args.steps * 1e3
+        log(f'settled ({settled_after} steps into the run, zero-gradient fraction {zero_settled:.3f}): {settled_ms:.3f} ms/step')
     # The same K steps with EVERY tile in the backward's work list (nothing skipped, same kernels): what the step costs when no
-    # loss gradient is zero.  The headline depends on the data-dependent sparsity reported in zero_grad_sample_fraction; this
-    # figure does not.
+    # loss gradient is zero -- the sparsity-independent figure.
     fld.backward_tiles = 'all'
     timed(2)
     dense_ms = timed(args.steps) / args.steps * 1e3
@@ -349,6 +384,8 @@ def main():
             torch.cuda.synchronize()
             graph_ms = (time.perf_counter() - t1) / args.steps * 1e3
             log(f'captured-step mode: {graph_ms:.3f} ms/step')
+        runner.cfg['hip_graph'] = False
+        runner._graph = None
     flags = int(fld.flags[0].item())
     losses = fld.losses()
     dp_spread, checksum = None, float(fld.params.double().abs().sum().item())
@@ -358,6 +395,33 @@ def main():
         dist.all_gather(allc, chk)
         allc = torch.stack(allc)
         dp_spread = float((allc.max(0).values - allc.min(0).values).abs().max().item())
+    # ---- one whole round of the reference: N_iters = n_step + 1 = 501 steps from a FRESH field (config.yml:2, nerf_runner.py:160,
+    #      855-863) with its learning-rate schedule; mean step time over the round, early (denser) steps included ----
+    round_ms, round_zero = None, None
+    if args.round_steps > 0:
+        keep_step = runner.cfg['n_step']
+        runner.cfg['n_step'] = args.round_steps - 1
+        runner.N_iters = args.round_steps
+        runner.create_nerf()
+        runner.create_optimizer()
+        runner.global_step = 0
+        fld_r = runner.field
+        fld_r.scatter_wgs_per_cu = args.scatter_wgs
+        fld_r.fused_forward = fld.fused_forward
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.round_steps):
+            step()
+        barrier()
+        dt_r = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt_r], device=device, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt_r = float(t.item())
+        round_ms = dt_r / args.round_steps * 1e3
+        round_zero = float((fld_r._buffers(R, S)['draw'] == 0).all(-1).float().mean().item())
+        runner.cfg['n_step'] = keep_step
+        log(f'reference round ({args.round_steps} steps from a fresh field): {round_ms:.3f} ms/step, final loss {fld_r.losses()["loss"]:.5f}')
 
     if rank == 0:
         ms = dt / args.steps * 1e3
@@ -368,15 +432,20 @@ def main():
         n_mlp = fld.n_mlp
         fl_fwd = 2.0 * (n_mlp - sum(o for o, _ in fld.layer_dims))      # 2*MAC per sample
         fl_net = [2.0 * sum(o * i for o, i in fld.layer_dims[:fld.n_sigma]), 2.0 * sum(o * i for o, i in fld.layer_dims[fld.n_sigma:])]
-        hash_fwd_bytes = B * (16 * 8 * 2 * 4 + 12 + 16 * 2 * 4)
+        gather_bytes = B * (16 * 8 * 2 * 4 + 12)                          # L * 2^D * C * 4 table bytes + the point
+        hash_fwd_bytes = gather_bytes + B * 16 * 2 * 4                    # + the fp32 embedding written by the stand-alone encoder
+        # the fused forward writes raw (16 B), the sigma hand-off (32 B) and the operand-precision feature copy (64 B) per sample
+        fused_bytes = gather_bytes + B * (16 + 32 + 64)
         work = {
             'nof_hash_encode_fwd': ('hbm', hash_fwd_bytes),
-            # dfeat read (L*C*4) + atomic read-modify-write of 8 corners x 2 channels per level (2*L*8*2*4) = 2112 B/sample,
-            # both only for the samples the work list keeps: the others are not read and would add 0 -- pricing them would credit
-            # work that is not done (frac > 1).  This is the table scatter (the run-merged global atomics of the large levels + the
+            'nof_encode_mlp_fwd': ('hbm', fused_bytes),
+            # dfeat read (L*C*4 = 64 B at the reference's fp16 gradient... 128 B for this fp32 dfeat; 8d prices 64) +
+            # atomic read-modify-write of 8 corners x 2 channels per level (2*L*8*2*4 = 2048 B) = 2112 B per sample, both only
+            # for the samples the work list keeps: the others are not read and would add 0 -- pricing them would credit work that
+            # is not done (frac > 1).  This is the table scatter (the run-merged global atomics of the large levels + the
             # LDS-accumulated small level behind them); dL/dx (k_hash_dx, 1048 B/sample) runs beside it on the step's second
             # stream and is its own entry.
-            'hash_bwd[table+table_lds]': ('hbm', B * (1.0 - zero_frac) * (16 * 2 * 4 + 2 * 16 * 8 * 2 * 4)),
+            'hash_bwd[table+table_lds]': ('hbm', B * (1.0 - zero_frac) * 2112.0),
             'hash_bwd[input]': ('hbm', B * (1.0 - zero_frac) * (16 * 2 * 4 + 16 * 8 * 2 * 4 + 12) + B * 12),
             'nof_mlp_fwd': ('mfma', B * fl_fwd),
             'nof_mlp_bwd_tiles': ('mfma', B * (1.0 - zero_frac) * 3.0 * fl_fwd),
@@ -394,7 +463,7 @@ def main():
             if args.mlp == 'baseline' and R == 4096 and args.log2_T == 19:
                 pm = json.load(open(os.path.join(ROOT, 'profiles', 'pmc_traffic.json')))
                 traffic = pm.get(dominant, {}).get('traffic_bytes')
-                hash_fwd_traffic = pm.get('nof_hash_encode_fwd', {}).get('traffic_bytes')
+                hash_fwd_traffic = pm.get(fwd_name, {}).get('traffic_bytes')
         except Exception:
             traffic = None
         src = ("profiles/pmc_traffic.json (rocprofv3 --pmc passes of this workload, committed; not re-measured in this run)")
@@ -422,14 +491,21 @@ def main():
             roof = {"kernel": dominant, "bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None,
                     "traffic": None, "avg_ms": dom_ms}
         if roof is not None and hash_fwd_ms:
-            # The hash lookup, both ways: SURVEY 8d's algorithmic bytes count every corner read as memory traffic (L2 hits
-            # included: this fraction can exceed 1), the memory-side figure is what the PMC counters saw leave / enter HBM.
-            ach = hash_fwd_bytes / (hash_fwd_ms * 1e-3) / 1e9
-            roof["hash_fwd"] = {"kernel": "nof_hash_encode_fwd", "avg_ms": hash_fwd_ms, "algorithmic_bytes": hash_fwd_bytes,
-                                "achieved_algorithmic": ach, "frac_algorithmic": ach / HBM_PEAK_GBS, "traffic": hash_fwd_traffic,
+            # The hash lookup, three ways: SURVEY 8d's algorithmic bytes count every corner read as memory traffic (L2 hits
+            # included: against HBM this fraction can exceed 1, so it is also put against the L2's own rate, where the 36 MB table
+            # mostly lives), and the memory-side figure is what the PMC counters saw leave / enter HBM.
+            fwd_bytes = fused_bytes if fld.fused_forward else hash_fwd_bytes
+            ach = fwd_bytes / (hash_fwd_ms * 1e-3) / 1e9
+            roof["hash_fwd"] = {"kernel": fwd_name, "avg_ms": hash_fwd_ms, "algorithmic_bytes": fwd_bytes,
+                                "achieved_algorithmic": ach, "frac_algorithmic": ach / HBM_PEAK_GBS,
+                                "frac_of_l2_peak": ach / L2_PEAK_GBS, "l2_peak": L2_PEAK_GBS,
+                                "traffic": hash_fwd_traffic,
                                 "frac_memory_side": (hash_fwd_traffic / (hash_fwd_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if hash_fwd_traffic else None,
                                 "traffic_source": src if hash_fwd_traffic else None, "unit": "GB/s", "peak": HBM_PEAK_GBS,
-                                "note": "bound by the vector-memory instruction rate (8 gathers x 16 levels per sample), not by HBM"}
+                                "note": "bound by the vector-memory instruction rate (92 gather instructions per 64 samples), not by HBM"}
+            if fld.fused_forward:                       # the same launch holds both MLPs: its matrix-core side
+                roof["hash_fwd"]["mlp_tflops_useful"] = B * fl_fwd / (hash_fwd_ms * 1e-3) / 1e12
+                roof["hash_fwd"]["mlp_frac_of_mfma_peak"] = roof["hash_fwd"]["mlp_tflops_useful"] / MFMA_BF16_PEAK_TF
         shape_key = (args.keyframes, R, args.log2_T, args.mlp, args.width, args.height)
         cfg_name = {(64, 4096, 19, 'baseline', 640, 480): 'cfg2' if world == 1 else 'cfg3',
                     (4, 1024, 14, 'reference', 640, 480): 'cfg1 shapes',
@@ -446,13 +522,22 @@ def main():
                                    f"the forward and the loss, the backward runs over the work list of the 32-sample tiles that hold a "
                                    f"non-zero loss gradient (the others add exactly nothing: same sums; fraction of zero samples in "
                                    f"zero_grad_sample_fraction, the step with every tile listed in ms_per_step_dense_backward); "
-                                   f"timed after {args.warmup} warm-up + {args.settle} settling steps (the steps right after the "
-                                   f"warm-up: ms_per_step_first_steps)",
+                                   f"`value` = the {args.steps} steps right after the {args.warmup} warm-up steps of a fresh field; the "
+                                   f"same steps later in the run: ms_per_step_settled; a whole {args.round_steps}-step reference "
+                                   f"round from a fresh field: round_ms_per_step",
                        "rays_per_step": R, "samples_per_ray": S, "keyframes_per_gpu": args.keyframes,
-                       "pool_rays": int(runner.rays.shape[0]), "parallelism": f"dp{world}"},
+                       "pool_rays": int(runner.rays.shape[0]), "parallelism": f"dp{world}",
+                       "forward": "fused encode+MLP (nof_encode_mlp_fwd)" if fld.fused_forward else "nof_hash_encode_fwd + nof_mlp_fwd"},
             "train_iters_per_sec": it_s * 1.0, "captured_step_ms_per_step": graph_ms,
+            # device-side duration of single steps (K more steps, one event after each): p10 / p50 / p90
+            "step_ms_spread": spread,
+            # the reference's unit of work: one round = N_iters steps from a fresh field (config.yml:2); mean over the whole round
+            "round_steps": args.round_steps, "round_ms_per_step": round_ms,
+            "round_ray_samples_per_sec": (world * B / (round_ms * 1e-3)) if round_ms else None,
+            "round_zero_grad_sample_fraction_last_step": round_zero,
+            # the same K steps `settled_after_steps` steps into the run, where the zero-gradient fraction has stopped moving
+            "ms_per_step_settled": settled_ms, "settled_after_steps": settled_after, "zero_grad_sample_fraction_settled": zero_settled,
             # same run, same kernels, every tile of the batch in the backward's work list (no sparsity): DESIGN 2.9
-            "settle_steps": args.settle, "ms_per_step_first_steps": early_ms, "zero_grad_sample_fraction_after_warmup": zero_early,
             "ms_per_step_dense_backward": dense_ms, "value_dense_backward": world * B / (dense_ms * 1e-3),
             "kernel_ms_warmup": {k: round(v, 4) for k, v in sorted(ktimes.items(), key=lambda kv: -kv[1])},
             "valid_sample_fraction": losses['n_valid_samples'] / B,     # samples inside [-1,1]^3 (the rest still run the MLPs)
@@ -468,6 +553,9 @@ def main():
             "exposed_comm_ms": exposed_comm_ms, "dp_payload": getattr(sync, 'payload', None),
             "roofline": roof,
         }
+        default_workload = shape_key == (64, 4096, 19, 'baseline', 640, 480)
+        if world == 1 and default_workload and not args.no_extra_configs and not dist.is_initialized():
+            out["extra_configs"] = extra_configs()
         if not args.no_cpu_baseline and world == 1:          # the CPU leg is timed on rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline(args.cpu_seconds, R, args.log2_T, args.mlp, args.finest)
         print(json.dumps(out), flush=True)

@@ -86,5 +86,30 @@ def build_perturb(force=False, verbose=True):
     return PERTURB_LIB
 
 
+def build_variant(name, defines, sources=('nof_mlp.hip',), verbose=True):
+    """Development aid for A/B runs on the GPU box: the library with `sources` recompiled under extra -D flags, linked with the
+    regular objects of everything else, as bundlesdf_amd/ab_<name>.so (git-ignored; travels with the gpurun snapshot).  Loaded
+    instead of libnof_hip.so when the environment names it (NOF_LIB, read by lib.py -- the Python host, not the C library)."""
+    build(verbose=verbose)
+    cc = hipcc()
+    objs = []
+    for src in SOURCES:
+        o = os.path.join(OBJ, src.replace('.hip', '.o'))
+        if src in sources:
+            o = os.path.join(OBJ, f'ab_{name}_' + src.replace('.hip', '.o'))
+            cmd = [cc] + FLAGS + EXTRA.get(src, []) + [f'-D{d}' for d in defines] + ['-x', 'hip', '-c', os.path.join(CSRC, src), '-o', o]
+            if verbose:
+                print(' '.join(cmd), flush=True)
+            subprocess.check_call(cmd)
+        objs.append(o)
+    out = os.path.join(HERE, f'ab_{name}.so')
+    subprocess.check_call([cc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', out] + objs)
+    return out
+
+
 if __name__ == '__main__':
-    print(build(force='--force' in sys.argv))
+    if '--variant' in sys.argv:                      # python -m bundlesdf_amd.build --variant NAME DEFINE[=V] ...
+        i = sys.argv.index('--variant')
+        print(build_variant(sys.argv[i + 1], sys.argv[i + 2:]))
+    else:
+        print(build(force='--force' in sys.argv))

@@ -307,6 +307,21 @@ __device__ __forceinline__ void load_feat_o1(const float2* __restrict__ feat, in
     x[0][2 * k + 1] = v.y;
   }
 }
+// the same 16 features from the operand-precision copy the fused forward leaves (k_enc_mlp_fwd: [B][hi][16] elements): two 16-byte
+// loads per lane instead of eight 8-byte ones; exact (the backward rounds the fp32 features to the operand type first thing)
+template <class P>
+__device__ __forceinline__ void load_featq_o1(const typename P::elem* __restrict__ featq, int64_t B, int64_t b, int hi, float (&x)[1][16]) {
+#pragma unroll
+  for (int r = 0; r < 16; ++r) x[0][r] = 0.0f;
+  if constexpr (P::KR == 8) {
+    if (b < B) {
+      const typename P::frag* q = reinterpret_cast<const typename P::frag*>(featq + (b * 2 + hi) * 16);
+      const typename P::frag q0 = q[0], q1 = q[1];
+#pragma unroll
+      for (int t = 0; t < 8; ++t) { x[0][t] = (float)q0[t]; x[0][8 + t] = (float)q1[t]; }
+    }
+  }
+}
 // dfeat[level 8hi + k][b] = (df[2k], df[2k+1]) * scale, same addressing
 __device__ __forceinline__ void store_dfeat_o1(float2* __restrict__ dfeat, int L, int64_t B, int64_t b, int hi,
                                                const float (&df)[16], float scale) {
@@ -489,6 +504,243 @@ NofMlpDesc d, const char* __restrict__ image,
       dense_o1<P, 2, 1, SPLIT>(smem, FW_OFF(NS + NC - 1), BIAS_OFF(NS + NC - 1), h, co, lane, LO_OFF(NS + NC - 1));
       if (hi == 0 && b < B) ((float4*)out)[b] = make_float4(co[0][0], co[0][1], co[0][2], so[0][0]);
     }
+  }
+}
+
+// =====================================================================================================
+// forward with the hash encode fused in ("LDS-staged features": the encoded features never leave the CU).
+//   pts_w [B,3] -> multiresolution encode (gridencoder.cu:107-200) -> both MLPs -> raw [B,4]
+// The reference materialises the [B,32] embedding (nerf_runner.py:1255-1267) and so did k_hash_fwd + k_mlp_fwd: 100.7 MB written
+// and read back per cfg2 step.  Here a wave owns 64 consecutive samples = TWO 32-sample tiles:
+//   * encode with one SAMPLE per lane and the level uniform over the wave -- the form the stand-alone encoder is fastest in: level
+//     constants in SGPRs, no divergence between dense and hashed levels, the x-neighbour pair of a dense level in one 16-byte load
+//     (level_pairs), 92 gather instructions per 64 samples at cfg2.  (k_sdf_grid's lane = (sample, half of the levels) form issues
+//     128 and reads its level constants through vector loads.)  The levels are encoded in groups of four: 32 gathers in flight per
+//     lane before the first blend;
+//   * lane s then holds all 32 features of sample s, while the first layer's B operand wants lane (j, hi) to hold features
+//     16 hi .. 16 hi + 15 of sample j: ONE v_permlane32_swap per register pair (gfx950) exchanges the upper half's low features with
+//     the lower half's high features and leaves both tiles' operands in place: 16 instructions per 64 samples, no LDS;
+//   * the two tiles go through the MLP chain one after the other (dense_o1, the same fragments in LDS as k_mlp_fwd).
+// `featq` (may be NULL): the features in MFMA operand precision and operand order, [B][hi][16] elements = 64 B per sample -- what
+// the split backward's sigma kernel needs of them (it rounds them to the operand type first thing): half the bytes of the fp32
+// level-major array, written with two 16-byte stores per lane.  NULL: nothing but raw (and the sigma hand-off) is written.
+// Same values as k_hash_fwd + k_mlp_fwd: the encode is encode_level() itself, the chain is dense_o1().
+// =====================================================================================================
+#ifndef NOF_ENC_WAVES
+#define NOF_ENC_WAVES 12                                  // waves per workgroup, ONE workgroup per CU = 3 waves per SIMD (168 registers) around one fragment image
+#endif
+#ifndef NOF_ENC_GROUP
+#define NOF_ENC_GROUP 2                                   // levels whose gathers are in flight together
+#endif
+
+// indices and fractions of one level for one point; the loads and the blend are separate steps so that a GROUP of levels has all
+// its gathers in flight before the first one is waited for
+struct EncCell {
+  uint32_t idx[8];
+  float f[3];
+  bool oob;
+};
+// The rows are grid_index()'s (gridencoder.cu:66-83) with the terms the eight corners share computed once and every decision taken
+// per LEVEL (wave-uniform here), so that the lanes run straight-line code: grid_index() per corner tests `index >= size` per lane,
+// which costs a branch per corner.  (The same rule as make_scatter in nof_hash.hip, whose rows the scatter tests pin.)
+__device__ __forceinline__ EncCell enc_prep(const HashLevel& lv, const float (&p)[3]) {
+  const CellPos c = locate3(p, lv.scale);
+  EncCell e;
+  e.oob = c.oob;
+#pragma unroll
+  for (int d = 0; d < 3; ++d) e.f[d] = c.f[d];
+  if (lv.hashed) {
+    const uint32_t hy0 = c.g[1] * 2654435761u, hy1 = hy0 + 2654435761u, hz0 = c.g[2] * 805459861u, hz1 = hz0 + 805459861u;
+    const uint32_t yz[4] = {hy0 ^ hz0, hy1 ^ hz0, hy0 ^ hz1, hy1 ^ hz1};
+#pragma unroll
+    for (int k = 0; k < 8; ++k) e.idx[k] = (c.g[0] + (k & 1)) ^ yz[k >> 1];
+    if ((lv.size & (lv.size - 1u)) == 0u) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) e.idx[k] &= lv.size - 1u;
+    } else {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) e.idx[k] %= lv.size;
+    }
+  } else {
+    const uint32_t r1 = lv.res + 1u, r2 = r1 * r1;
+    const uint32_t base = c.g[0] + c.g[1] * r1 + c.g[2] * r2;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) e.idx[k] = base + (k & 1) + ((k >> 1) & 1) * r1 + (k >> 2) * r2;
+    if (!level_pairs(lv)) {                                  // a dense level whose linear index can reach the modulo wrap
+#pragma unroll
+      for (int k = 0; k < 8; ++k) e.idx[k] %= lv.size;
+    }
+  }
+  return e;
+}
+template <bool PAIRS>
+__device__ __forceinline__ void enc_load(const HashLevel& lv, const float2* __restrict__ table, const EncCell& e, float2 (&v)[8]) {
+  // (an out-of-range point still loads: grid_index wraps every row into the level, and enc_blend returns zeros for it)
+  const float2* __restrict__ tl = table + lv.offset;
+  if constexpr (PAIRS) {
+#pragma unroll
+    for (int k = 0; k < 8; k += 2) {
+      const RowPair t = *reinterpret_cast<const RowPair*>(tl + e.idx[k]);
+      v[k] = make_float2(t.x, t.y);
+      v[k + 1] = make_float2(t.z, t.w);
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = tl[e.idx[k]];
+  }
+}
+__device__ __forceinline__ float2 enc_blend(const EncCell& e, const float2 (&v)[8]) {   // encode_level's own weights and order
+  float2 acc = make_float2(0.f, 0.f);
+  if (e.oob) return acc;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    float wk = 1.0f;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) wk *= (k & (1 << d)) ? e.f[d] : 1.0f - e.f[d];
+    acc.x += wk * v[k].x;
+    acc.y += wk * v[k].y;
+  }
+  return acc;
+}
+
+// one 32-sample tile through both networks: x = the first layer's B operand (lane (j, hi): features 16 hi .. 16 hi + 15 of sample b)
+template <class P, int NS, int NC, bool SPLIT>
+__device__ __forceinline__ void enc_chain_tile(const NofMlpDesc& d, const char* smem, const float (&xin)[16], int64_t b,
+                                               const float* __restrict__ view, int S, float* __restrict__ out,
+                                               typename P::elem* __restrict__ sig, typename P::elem* __restrict__ featq, int64_t B,
+                                               int lane) {
+  typedef Shp<NS, NC> SH;
+  constexpr int NL = NS + NC;
+  constexpr int BIAS_BASE = SH::pair_base(NL) * PAIR_BYTES;
+  constexpr int LO_BASE = BIAS_BASE + SH::oblk_base(NL) * 32 * 4;
+  const int hi = lane >> 5;
+  float x[1][16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) x[0][r] = xin[r];
+  if (featq != nullptr && b < B) {
+    typename P::frag* q = reinterpret_cast<typename P::frag*>(featq + (b * 2 + hi) * 16);
+#pragma unroll
+    for (int s2 = 0; s2 < 16 / P::KR; ++s2) q[s2] = P::pack(&x[0][P::KR * s2]);
+  }
+  float h[2][16], so[1][16];
+  dense_o1<P, 1, 2, SPLIT>(smem, FW_OFF(0), BIAS_OFF(0), x, h, lane, LO_OFF(0));
+  relu_mask<2>(h);
+#pragma unroll
+  for (int l = 1; l < NS - 1; ++l) {
+    float h2[2][16];
+    dense_o1<P, 2, 2, SPLIT>(smem, FW_OFF(l), BIAS_OFF(l), h, h2, lane, LO_OFF(l));
+    relu_mask<2>(h2);
+#pragma unroll
+    for (int pp = 0; pp < 2; ++pp)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) h[pp][r] = h2[pp][r];
+  }
+  dense_o1<P, 2, 1, SPLIT>(smem, FW_OFF(NS - 1), BIAS_OFF(NS - 1), h, so, lane, LO_OFF(NS - 1));
+  float cin[2][16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) cin[0][r] = so[0][r];
+  if (sig != nullptr) store_sig_o1<P>(sig, B, b, hi, so[0]);
+  load_view_o1(view, S, B, b, hi, cin[1]);
+  dense_o1<P, 2, 2, SPLIT>(smem, FW_OFF(NS), BIAS_OFF(NS), cin, h, lane, LO_OFF(NS));
+  relu_mask<2>(h);
+#pragma unroll
+  for (int l = NS + 1; l < NS + NC - 1; ++l) {
+    float h2[2][16];
+    dense_o1<P, 2, 2, SPLIT>(smem, FW_OFF(l), BIAS_OFF(l), h, h2, lane, LO_OFF(l));
+    relu_mask<2>(h2);
+#pragma unroll
+    for (int pp = 0; pp < 2; ++pp)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) h[pp][r] = h2[pp][r];
+  }
+  float co[1][16];
+  dense_o1<P, 2, 1, SPLIT>(smem, FW_OFF(NS + NC - 1), BIAS_OFF(NS + NC - 1), h, co, lane, LO_OFF(NS + NC - 1));
+  if (hi == 0 && b < B) ((float4*)out)[b] = make_float4(co[0][0], co[0][1], co[0][2], so[0][0]);
+}
+
+template <class P, int NS, int NC, bool SPLIT>
+__global__ __launch_bounds__(64 * NOF_ENC_WAVES, (NOF_ENC_WAVES + 3) / 4) void k_enc_mlp_fwd(
+    NofMlpDesc d, const char* __restrict__ image, NofHashGrid g, const float2* __restrict__ table, const float* __restrict__ pts_w,
+    const float* __restrict__ view, int S, float* __restrict__ out, typename P::elem* __restrict__ sig,
+    typename P::elem* __restrict__ featq, int64_t B) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  typedef Shp<NS, NC> SH;
+  constexpr int NL = NS + NC;
+  constexpr int BIAS_BASE = SH::pair_base(NL) * PAIR_BYTES;
+  constexpr int LO_BASE = BIAS_BASE + SH::oblk_base(NL) * 32 * 4;
+  constexpr int PARK_BASE = LO_BASE + (SPLIT ? BIAS_BASE : 0);        // [wave][4][64] float4: tile B's operand (see below)
+  copy16(smem, image, (size_t)BIAS_BASE);
+  copy16(smem + BIAS_BASE, image + 2 * (size_t)SH::pair_base(NL) * PAIR_BYTES, (size_t)SH::oblk_base(NL) * 32 * 4);
+  if constexpr (SPLIT)
+    copy16(smem + LO_BASE, image + 2 * (size_t)SH::pair_base(NL) * PAIR_BYTES + (size_t)SH::oblk_base(NL) * 32 * 4, (size_t)BIAS_BASE);
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int hi = lane >> 5, j = lane & 31;
+  constexpr int NW = NOF_ENC_WAVES, GR = NOF_ENC_GROUP;
+  const int64_t npairs = (B + 63) / 64;
+  for (int64_t tp = (int64_t)blockIdx.x * NW + wave; tp < npairs; tp += (int64_t)gridDim.x * NW) {
+    asm volatile("" ::: "memory");                    // keep the weight fragments in LDS (no hoisting into VGPRs)
+    // ---------------- encode: lane = sample tp*64 + lane, all levels ----------------
+    const int64_t bs = tp * 64 + lane;
+    const int64_t bb = bs < B ? bs : B - 1;           // (a lane past the end encodes the last sample: nothing of it is stored)
+    const float p[3] = {pts_w[bb * 3], pts_w[bb * 3 + 1], pts_w[bb * 3 + 2]};
+    float f[32];
+#pragma unroll
+    for (int r = 0; r < 32; ++r) f[r] = 0.0f;
+#pragma unroll
+    for (int l0 = 0; l0 < NOF_MAX_LEVELS; l0 += GR) {
+      if (l0 < g.L) {                                 // (uniform)
+        EncCell e[GR];
+        float2 v[GR][8];
+#pragma unroll
+        for (int u = 0; u < GR; ++u) {
+          if (l0 + u < g.L) {
+            const HashLevel lv = load_level(g, l0 + u);               // compile-time level index: scalar loads of the kernel argument
+            e[u] = enc_prep(lv, p);
+            if (level_pairs(lv)) enc_load<true>(lv, table, e[u], v[u]);
+            else enc_load<false>(lv, table, e[u], v[u]);
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < GR; ++u) {
+          if (l0 + u < g.L) {
+            const float2 a = enc_blend(e[u], v[u]);
+            f[2 * (l0 + u)] = a.x;
+            f[2 * (l0 + u) + 1] = a.y;
+          }
+        }
+      }
+    }
+    // ---------------- lane s holds f[0..31] of sample s  ->  operand layout of the two tiles ----------------
+    // v_permlane32_swap a, b: lanes 32..63 of a <-> lanes 0..31 of b.  With a = f[r], b = f[16 + r]:
+    //   a' = { lanes j: f_j[r],        lanes 32 + j: f_j[16 + r] }        = tile A (samples tp*64 + j), slot (hi, r)
+    //   b' = { lanes j: f_{32+j}[r],   lanes 32 + j: f_{32+j}[16 + r] }   = tile B (samples tp*64 + 32 + j)
+    // Tile B's operand waits in a lane-private LDS slot (64 B per lane) while tile A goes through the chain: 16 registers that
+    // the chain at its widest (split operands, three sigma layers) does not have at 3 waves per SIMD.
+    float xa[16];
+    float4* park = reinterpret_cast<float4*>(smem + PARK_BASE + wave * 4096) + lane;      // [4][64 lanes] float4, conflict-free
+#pragma unroll
+    for (int r4 = 0; r4 < 4; ++r4) {
+      float xb[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int r = 4 * r4 + c;
+        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(f[r]), __float_as_uint(f[16 + r]), false, false);
+        xa[r] = __uint_as_float(sw[0]);
+        xb[c] = __uint_as_float(sw[1]);
+      }
+      park[r4 * 64] = make_float4(xb[0], xb[1], xb[2], xb[3]);
+    }
+    // ---------------- the two tiles through the chain (two inlined copies: no selects, tile B's operand is the only extra
+    //                  live state while tile A runs) ----------------
+    enc_chain_tile<P, NS, NC, SPLIT>(d, smem, xa, tp * 64 + j, view, S, out, sig, featq, B, lane);
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int r4 = 0; r4 < 4; ++r4) {
+      const float4 t = park[r4 * 64];
+      xa[4 * r4] = t.x; xa[4 * r4 + 1] = t.y; xa[4 * r4 + 2] = t.z; xa[4 * r4 + 3] = t.w;
+    }
+    enc_chain_tile<P, NS, NC, SPLIT>(d, smem, xa, tp * 64 + 32 + j, view, S, out, sig, featq, B, lane);
   }
 }
 
@@ -1236,7 +1488,8 @@ __global__ __launch_bounds__(64 * SigmaWaves<NS>::value, 2) void k_mlp_bwd_sigma
                                                            const float2* __restrict__ feat, int L,
                                                            const typename P::elem* __restrict__ dsig, float2* __restrict__ dfeat,
                                                            float* __restrict__ partials, int64_t B,
-                                                           const void* __restrict__ tile_list) {
+                                                           const void* __restrict__ tile_list,
+                                                           const typename P::elem* __restrict__ featq) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   typedef Shp<NS, NC> SH;
   constexpr int NL = NS + NC;
@@ -1291,7 +1544,9 @@ __global__ __launch_bounds__(64 * SigmaWaves<NS>::value, 2) void k_mlp_bwd_sigma
   const int64_t w0 = (int64_t)blockIdx.x * NW + wave_s;
   int64_t tile_n = work.at(w0);
   float xn[1][16];
-  load_feat_o1(feat, L, B, tile_n * 32 + j, hi, xn);
+  // features: the fp32 level-major array of nof_hash_encode_fwd, or (featq != NULL, uniform) the operand-precision copy of the fused forward
+  if (featq != nullptr) load_featq_o1<P>(featq, B, tile_n * 32 + j, hi, xn);
+  else load_feat_o1(feat, L, B, tile_n * 32 + j, hi, xn);
   typename P::frag dsn = load_sig_raw<P>(dsig, B, tile_n * 32 + j, hi);
   for (int64_t wi = w0; wi < work.n; wi += tstride) {
     asm volatile("" ::: "memory");
@@ -1306,7 +1561,8 @@ __global__ __launch_bounds__(64 * SigmaWaves<NS>::value, 2) void k_mlp_bwd_sigma
 #pragma unroll
     for (int r = 0; r < 16; ++r) x[0][r] = xn[0][r];
     pin16(x[0]);
-    load_feat_o1(feat, L, B, tile_n * 32 + j, hi, xn);
+    if (featq != nullptr) load_featq_o1<P>(featq, B, tile_n * 32 + j, hi, xn);
+    else load_feat_o1(feat, L, B, tile_n * 32 + j, hi, xn);
     bool skip;
     {
       // all 32 x 16 gradients exactly zero (the colour kernel skipped the tile, see there): dfeat = 0, nothing else to do
@@ -1753,6 +2009,41 @@ extern "C" int nof_mlp_sdf(const NofMlpDesc* d, const void* packed, const float*
   return 0;
 }
 
+// Hash encode + both MLPs in ONE launch (16-bit operand types): pts_w [B,3] -> raw [B,4]; the [B,32] embedding stays on chip.
+// sigma_out: as in nof_mlp_fwd.  featq (may be NULL): [B][2][16] operand-type elements, the features as the sigma backward wants
+// them (nof_mlp_bwd_featq).
+extern "C" int nof_encode_mlp_fwd(const NofHashGrid* g, const NofMlpDesc* d, const void* packed, const float* table,
+                                   const float* pts_w, const float* view, int32_t S, float* raw, void* sigma_out, void* featq,
+                                   int64_t B, void* stream) {
+  if (int e = check_narrow(d)) return e;
+  NOF_ARG(g && g->C == 2 && g->L >= 1 && g->L <= NOF_MAX_LEVELS && g->L * 2 == d->in_feat);
+  NOF_ARG(packed && table && pts_w && view && raw && B >= 0 && S >= 1);
+  if (d->precision == 0) return nof_set_error(-1, "nof_encode_mlp_fwd: 16-bit operand types only (fp32: nof_hash_encode_fwd + nof_mlp_fwd)");
+  if (B == 0) return 0;
+  const int nl = d->n_sigma + d->n_color;
+  const size_t shm = (is_split(d->precision) ? 2 : 1) * (size_t)n_pairs(*d, nl) * 16 * 64 * elem_size(d->precision) +
+                     (size_t)n_oblk(*d, nl) * 32 * 4 + (size_t)NOF_ENC_WAVES * 4096;
+  const int64_t npairs = (B + 63) / 64;
+  const int64_t want = nof_div_up(npairs, NOF_ENC_WAVES);
+  const int64_t cap = (int64_t)nof_mlp_bwd_blocks() / 2 * (NOF_ENC_WAVES >= 12 ? 1 : 2);   // workgroups resident at once: 1 or 2 per CU
+  const unsigned blocks = (unsigned)(want < cap ? want : cap);
+#define LAUNCH_ENC(P, NS_, NC_, SPLIT_)                                                                   \
+  {                                                                                                       \
+    auto kern = k_enc_mlp_fwd<P, NS_, NC_, SPLIT_>;                                                       \
+    if (int e = set_smem(kern, shm)) return e;                                                            \
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(64 * NOF_ENC_WAVES), shm, (hipStream_t)stream, *d, (const char*)packed, *g, \
+                       (const float2*)table, pts_w, view, (int)S, raw, (typename P::elem*)sigma_out,      \
+                       (typename P::elem*)featq, B);                                                      \
+  }
+  if (d->precision == 1) { DISPATCH_SHAPE(PrecBF16, LAUNCH_ENC, false) }
+  else if (d->precision == 2) { DISPATCH_SHAPE(PrecF16, LAUNCH_ENC, false) }
+  else if (d->precision == 3) { DISPATCH_SHAPE(PrecF16, LAUNCH_ENC, true) }
+  else { DISPATCH_SHAPE(PrecBF16, LAUNCH_ENC, true) }
+#undef LAUNCH_ENC
+  NOF_LAUNCH_OK();
+  return 0;
+}
+
 extern "C" int nof_mlp_bwd(const NofMlpDesc* d, const void* packed, const float* feat, int32_t L, const float* view,
                             int32_t S, const float* draw, const void* sigma_out, void* dsigma_ws, float* dfeat, float* dview,
                             float* partials, int64_t B, void* stream) {
@@ -1761,11 +2052,28 @@ extern "C" int nof_mlp_bwd(const NofMlpDesc* d, const void* packed, const float*
 
 // The same over a work list (NofTileList): only the listed 32-sample tiles are computed, dealt evenly to the persistent waves.
 // dfeat (and the dsigma workspace) of unlisted tiles is NOT written -- the consumers of the same step take the same list.
+static int mlp_bwd_tiles(const NofMlpDesc* d, const void* packed, const float* feat, const void* featq, int32_t L, const float* view,
+                         int32_t S, const float* draw, const void* sigma_out, void* dsigma_ws, float* dfeat, float* dview,
+                         float* partials, const void* tile_list, int64_t B, void* stream);
 extern "C" int nof_mlp_bwd_tiles(const NofMlpDesc* d, const void* packed, const float* feat, int32_t L, const float* view,
                                   int32_t S, const float* draw, const void* sigma_out, void* dsigma_ws, float* dfeat, float* dview,
                                   float* partials, const void* tile_list, int64_t B, void* stream) {
+  NOF_ARG(feat);
+  return mlp_bwd_tiles(d, packed, feat, nullptr, L, view, S, draw, sigma_out, dsigma_ws, dfeat, dview, partials, tile_list, B, stream);
+}
+// The same with the features taken from `featq`, the operand-precision copy nof_encode_mlp_fwd leaves ([B][2][16] elements): the
+// backward of the fused forward.  16-bit operand types, split workspace required.
+extern "C" int nof_mlp_bwd_featq(const NofMlpDesc* d, const void* packed, const void* featq, int32_t L, const float* view,
+                                  int32_t S, const float* draw, const void* sigma_out, void* dsigma_ws, float* dfeat, float* dview,
+                                  float* partials, const void* tile_list, int64_t B, void* stream) {
+  NOF_ARG(featq && d && d->precision != 0 && sigma_out && dsigma_ws);
+  return mlp_bwd_tiles(d, packed, nullptr, featq, L, view, S, draw, sigma_out, dsigma_ws, dfeat, dview, partials, tile_list, B, stream);
+}
+static int mlp_bwd_tiles(const NofMlpDesc* d, const void* packed, const float* feat, const void* featq, int32_t L, const float* view,
+                         int32_t S, const float* draw, const void* sigma_out, void* dsigma_ws, float* dfeat, float* dview,
+                         float* partials, const void* tile_list, int64_t B, void* stream) {
   if (int e = check_narrow(d)) return e;
-  NOF_ARG(packed && feat && view && draw && dfeat && dview && partials && B >= 0 && S >= 32 && L * 2 == d->in_feat);
+  NOF_ARG(packed && (feat || featq) && view && draw && dfeat && dview && partials && B >= 0 && S >= 32 && L * 2 == d->in_feat);
   NOF_ARG((int64_t)L * B * 8 < (1ll << 32));                   // level-major arrays are addressed with 32-bit lane offsets
   const int nl = d->n_sigma + d->n_color, ns = d->n_sigma;
   const size_t es = elem_size(d->precision), pair_bytes = 16 * 64 * es;
@@ -1790,7 +2098,7 @@ extern "C" int nof_mlp_bwd_tiles(const NofMlpDesc* d, const void* packed, const 
                        (typename P::elem*)dsigma_ws, dview, partials, B, tile_list);                      \
     hipLaunchKernelGGL(ks, dim3(blocks_s), dim3(64 * (unsigned)ws), shm_s, (hipStream_t)stream, *d, (const char*)packed,  \
                        (const float2*)feat, (int)L, (const typename P::elem*)dsigma_ws, (float2*)dfeat,   \
-                       partials, B, tile_list);                                                           \
+                       partials, B, tile_list, (const typename P::elem*)featq);                           \
   }
     if (is_bf16(d->precision)) { DISPATCH_SHAPE(PrecBF16, LAUNCH_SPLIT, 0) }
     else { DISPATCH_SHAPE(PrecF16, LAUNCH_SPLIT, 0) }

@@ -103,6 +103,9 @@ class NeuralObjectField:
         # backward over the work list of non-zero tiles ('list'), over every tile through the same code path ('all': what the
         # dense-backward figure of bench.py measures), or without a list ('off': every tile, zero tiles skipped in place)
         self.backward_tiles = 'list'
+        # the training forward as ONE launch with the embedding kept on chip (nof_encode_mlp_fwd; 64-wide networks, 16-bit operand
+        # types); False: the two launches nof_hash_encode_fwd + nof_mlp_fwd with the fp32 [L,B,2] embedding in HBM between them
+        self.fused_forward = not self.wide and self.desc.precision != 0
         self.scatter_wgs_per_cu = 0                  # persistent workgroups per CU of the table scatter (0 = the library's default)
         self._state = None           # NofStepState on the device (captured-step mode): see sync_step_state / GraphedStep
         if seed_init:
@@ -263,7 +266,8 @@ class NeuralObjectField:
             self._bufs[key] = dict(
                 batch=e(R, 12), rays_o_w=e(R, 3), viewdirs_w=e(R, 3), view=e(R, 16), t_in_out=e(R, self.max_hits, 2),
                 n_hits=e(R, dt=torch.int32), z_vals=e(R, S), pts_w=e(B, 3), valid=e(B, dt=torch.uint8),
-                feat=e(self.L, B, 2), raw=e(B, 4), draw=e(B, 4), dfeat=e(self.L, B, 2), dview=torch.zeros(R, 16, device=d), dpts=e(B, 3),
+                feat=None, featq=None,                  # the embedding: fp32 [L,B,2], or the fused forward's operand-precision copy [B,32]
+                raw=e(B, 4), draw=e(B, 4), dfeat=e(self.L, B, 2), dview=torch.zeros(R, 16, device=d), dpts=e(B, 3),
                 rgb_map=e(R, 3), partials=e(self.nblk, self.n_mlp), loss_rows=e(R, 8), g_ray=e(R, 12),
                 # sigma-head output / its gradient in MFMA operand precision: the hand-off of the split MLP backward
                 sig=e(B, 16, dt=torch.int16) if self.desc.precision != 0 and not self.wide else None,
@@ -370,6 +374,14 @@ class NeuralObjectField:
         b = self._buffers(R, S)
         self._prologue(b, pool, ids, R, u_occ, u_dep, seed, want_cells, dyn, deterministic)
         B = R * S
+        if self.fused_forward:
+            if b['featq'] is None:
+                b['featq'] = torch.empty(B, 32, dtype=torch.int16, device=self.device)
+            self._call('nof_encode_mlp_fwd', C.byref(self.grid), C.byref(self.desc), self.packed, self.table, b['pts_w'], b['view'], S,
+                       b['raw'], b['sig'], b['featq'], B)
+            return b, S
+        if b['feat'] is None:
+            b['feat'] = torch.empty(self.L, B, 2, device=self.device)
         self._call('nof_hash_encode_fwd', C.byref(self.grid), b['pts_w'], self.table, b['feat'], B)
         if self.wide:
             self._call('nof_mlp_wide_fwd', C.byref(self.desc), self.packed, b['feat'], self.L, b['view'], S, b['raw'], b['wide_ws'], B)
@@ -420,6 +432,9 @@ class NeuralObjectField:
                 with self._on(wide_aux):
                     wide_bwd(8, 'wide_bwd[dW sigma]')
                     self._call('nof_reduce_partials', b['partials'], self.nblk, self.n_mlp, self._seg(self.grads, 'mlp'), self.flags)
+        elif self.fused_forward:
+            self._call('nof_mlp_bwd_featq', C.byref(self.desc), self.packed, b['featq'], self.L, b['view'], S, b['draw'], b['sig'],
+                       b['dsig'], b['dfeat'], b['dview'], b['partials'], tiles, B, tag='nof_mlp_bwd_tiles')
         else:
             self._call('nof_mlp_bwd_tiles', C.byref(self.desc), self.packed, b['feat'], self.L, b['view'], S, b['draw'], b['sig'],
                        b['dsig'], b['dfeat'], b['dview'], b['partials'], tiles, B)

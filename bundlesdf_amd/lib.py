@@ -11,7 +11,8 @@ import numpy as np
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libnof_hip.so')
+# NOF_LIB: a development override for A/B builds of the same C ABI (bundlesdf_amd/build.py:build_variant); unset in every product run
+LIB_PATH = os.environ.get('NOF_LIB') or os.path.join(_HERE, 'libnof_hip.so')
 
 NOF_MAX_LEVELS = 16
 NOF_MAX_LAYERS = 8
@@ -78,6 +79,8 @@ _SIGNATURES = {
     'nof_mlp_packed_bytes': ([C.POINTER(NofMlpDesc)], C.c_int64),
     'nof_mlp_pack': ([C.POINTER(NofMlpDesc), _P, _P, _P], C.c_int),
     'nof_mlp_fwd': ([C.POINTER(NofMlpDesc), _P, _P, _I32, _P, _I32, _P, _P, _I64, _P], C.c_int),
+    'nof_encode_mlp_fwd': ([C.POINTER(NofHashGrid), C.POINTER(NofMlpDesc), _P, _P, _P, _P, _I32, _P, _P, _P, _I64, _P], C.c_int),
+    'nof_mlp_bwd_featq': ([C.POINTER(NofMlpDesc), _P, _P, _I32, _P, _I32, _P, _P, _P, _P, _P, _P, _P, _I64, _P], C.c_int),
     'nof_mlp_bwd_blocks': ([], C.c_int),
     'nof_mlp_bwd': ([C.POINTER(NofMlpDesc), _P, _P, _I32, _P, _I32, _P, _P, _P, _P, _P, _P, _I64, _P], C.c_int),
     'nof_reduce_partials': ([_P, _I32, _I32, _P, _P, _P], C.c_int),

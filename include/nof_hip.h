@@ -224,6 +224,17 @@ int nof_mlp_bwd(const NofMlpDesc* h_desc, const void* packed, const float* feat,
 int nof_mlp_bwd_tiles(const NofMlpDesc* h_desc, const void* packed, const float* feat, int32_t L,
                       const float* view, int32_t S, const float* draw, const void* sigma_out, void* dsigma_ws,
                       float* dfeat, float* dview, float* partials, const void* tile_list, int64_t B, void* stream);
+/* Hash encode + both MLPs in ONE launch, the embedding kept on chip (north_star: "LDS-staged features"; replaces the pair
+ * nof_hash_encode_fwd + nof_mlp_fwd of the training forward, reference nerf_runner.py:1255-1294 which materialises `embedded`).
+ * 16-bit operand precisions.  pts_w [B,3] world points, table [rows,2], view [R,16], raw [B,4]; sigma_out as in nof_mlp_fwd;
+ * featq (may be NULL): [B][2][16] operand-type elements (64 B per sample) -- the features as nof_mlp_bwd_featq reads them. */
+int nof_encode_mlp_fwd(const NofHashGrid* h_grid, const NofMlpDesc* h_desc, const void* packed, const float* table,
+                       const float* pts_w, const float* view, int32_t S, float* raw, void* sigma_out, void* featq,
+                       int64_t B, void* stream);
+/* nof_mlp_bwd_tiles with the features read from featq instead of the fp32 level-major array (split workspace required). */
+int nof_mlp_bwd_featq(const NofMlpDesc* h_desc, const void* packed, const void* featq, int32_t L,
+                      const float* view, int32_t S, const float* draw, const void* sigma_out, void* dsigma_ws,
+                      float* dfeat, float* dview, float* partials, const void* tile_list, int64_t B, void* stream);
 /* out[j] += sum_i partials[i,j].  flags (int32, may be NULL): flags[0] |= 4 when a column sum is not finite -- an overflow inside the
  * 16-bit backward, where the reference's GradScaler skips the step and backs off (nerf_runner.py:756-761): nof_adam_step[_dyn]
  * given the same flags skips the update, the next batch's nof_sample_points turns the mark into the sticky bit 3 (value 8), the

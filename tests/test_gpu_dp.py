@@ -19,7 +19,7 @@ def _run(overlap, port, backend='gloo', ranks=2, force='0', steps=6, payload='fp
                NOF_DP_PAYLOAD=payload)
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(ranks), '--master-addr', '127.0.0.1',
            '--master-port', str(port), os.path.join(ROOT, 'bench.py'), '--gpus', str(ranks), '--steps', str(steps), '--warmup', '2',
-           '--keyframes', '3', '--no-cpu-baseline', '--settle', '0']
+           '--keyframes', '3', '--no-cpu-baseline', '--settle', '0', '--round-steps', '0']
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-3000:]
     line = [l for l in out.stdout.splitlines() if l.startswith('{"metric"')]

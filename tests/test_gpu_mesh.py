@@ -175,3 +175,21 @@ def test_bary_uv_matches_numpy(nof):
     ref = (ww[:, :, None] * uv[F[fid]].astype(np.float64)).sum(1)
     assert np.abs(ww - w).max() < 1e-4                                # the restatement recovers the sampling weights
     assert np.abs(out.cpu().numpy() - ref).max() < 2e-4
+
+
+def test_marching_cubes_gpu_on_hand_checkable_cells_and_vertex_set(nof):
+    """The device extractor against the paper-derived fixture of tests/test_mesh.py (20 classical cells: E vertices on the crossed
+    edges, E - 2 (I + O - 1) triangles) and against the property it shares with skimage's 'lewiner', the extractor the reference
+    calls (nerf_runner.py:1389): the vertex set is exactly the set of grid edges whose end points straddle the iso level."""
+    from bundlesdf_amd.mesh_gpu import marching_cubes_gpu
+    from tests.test_mesh import MC_HAND_CASES, _cell_volume, _crossed_edges, _vertex_edges, _noisy_sdf
+    for name, inside, E, I, O in MC_HAND_CASES:
+        vol = _cell_volume(inside)
+        v, f = marching_cubes_gpu(torch.from_numpy(vol).cuda(), 0.0)
+        assert len(v) == E and len(f) == E - 2 * (I + O - 1), name
+        assert _vertex_edges(v, vol.shape) == _crossed_edges(vol), name
+    for seed, noise in ((0, 0.3), (2, 3.0)):
+        vol = _noisy_sdf(40, seed, noise).astype(np.float32)
+        v, f = marching_cubes_gpu(torch.from_numpy(vol).cuda(), 0.0)
+        edges = _crossed_edges(vol)
+        assert len(v) == len(edges) and _vertex_edges(v, vol.shape) == edges

@@ -675,3 +675,66 @@ def test_pose_gradients_slot_sums_equal_batch_search(nof, R, S, F, ff):
         wf = np.zeros((F, ff))
         np.add.at(wf, batch[:, 8].astype(int), dview0[:, :ff].astype(np.float64))
         assert np.abs(b[3] - wf).max() <= 2e-5 * (np.abs(wf).max() + 1e-12)
+
+
+@pytest.mark.parametrize("ns,nc,ff,L,T,finest", [(3, 2, 0, 16, 19, 256), (2, 3, 2, 16, 14, 256), (2, 2, 0, 8, 12, 128), (3, 3, 0, 16, 19, 512),
+                                                  (2, 3, 0, 4, 14, 64)])
+@pytest.mark.parametrize("precision", [1, 2, 3, 4])
+def test_fused_encode_mlp_forward_equals_the_two_launches(nof, ns, nc, ff, L, T, finest, precision):
+    """nof_encode_mlp_fwd (hash encode in the MLP forward kernel, the embedding never in HBM) against nof_hash_encode_fwd +
+    nof_mlp_fwd on the same points: the encode is the same arithmetic per level and the chain the same MFMA sequence, so raw and
+    the sigma hand-off must be BIT-identical; `featq` must be the fp32 embedding rounded to the operand type in operand order;
+    and the backward fed from featq (nof_mlp_bwd_featq) must give the bits of the backward fed from the fp32 embedding.
+    Geometries: dense + hashed levels, the 257 / 513 resolution quirk (finest 512), L < 8 (upper lane half idle), ragged B."""
+    shape, params, desc, flat = _mlp_setup(nof, ns, nc, ff, L, precision, seed=3)
+    g, geo = U.make_grids(nof, L=L, T=T, finest=finest)
+    R, S = 37, 40                                        # B = 1480: not a multiple of 64 (a ragged tile pair) nor of 32
+    B = R * S
+    rng = np.random.default_rng(7)
+    pts = rng.uniform(-1, 1, size=(B, 3)).astype(np.float32)
+    pts[:6] = U.test_points(6)                           # corners, centre, out of range, an ulp outside
+    pts[100:140] = pts[100] + np.linspace(0, 1e-3, 40, dtype=np.float32)[:, None]    # a run inside one cell, like samples of a ray
+    table = (rng.uniform(-1, 1, size=(geo.n_entries, 2)) * 0.3).astype(np.float32)
+    view = torch.zeros(R, 16)
+    view[:, :9 + ff] = torch.randn(R, 9 + ff)
+    d_pts, d_table, d_view = U.dev(pts), U.dev(table), view.cuda()
+    packed = _pack(nof, desc, flat)
+    feat = torch.empty(L, B, 2, device='cuda')
+    raw_a, raw_b = torch.zeros(B, 4, device='cuda'), torch.ones(B, 4, device='cuda')
+    sig_a, sig_b = torch.zeros(B, 16, dtype=torch.int16, device='cuda'), torch.ones(B, 16, dtype=torch.int16, device='cuda')
+    featq = torch.full((B, 32), 7, dtype=torch.int16, device='cuda')
+    nof.call('nof_hash_encode_fwd', C.byref(g), d_pts, d_table, feat, B)
+    nof.call('nof_mlp_fwd', C.byref(desc), packed, feat, L, d_view, S, raw_a, sig_a, B)
+    nof.call('nof_encode_mlp_fwd', C.byref(g), C.byref(desc), packed, d_table, d_pts, d_view, S, raw_b, sig_b, featq, B)
+    torch.cuda.synchronize()
+    assert torch.isfinite(raw_a).all()
+    assert torch.equal(raw_a, raw_b), (raw_a - raw_b).abs().max().item()
+    assert torch.equal(sig_a, sig_b)
+    # featq[b][hi][r] = operand-type rounding of feature 16 hi + r of sample b
+    odt = torch.bfloat16 if precision in (1, 4) else torch.float16
+    want = feat.permute(1, 0, 2).reshape(B, 32 if L == 16 else 2 * L)
+    if L < 16:
+        want = torch.cat([want, torch.zeros(B, 32 - 2 * L, device='cuda')], 1)
+    assert torch.equal(featq.view(odt), want.to(odt))
+    # without the copy (featq = NULL) the outputs are the same
+    raw_c = torch.zeros(B, 4, device='cuda')
+    nof.call('nof_encode_mlp_fwd', C.byref(g), C.byref(desc), packed, d_table, d_pts, d_view, S, raw_c, None, None, B)
+    torch.cuda.synchronize()
+    assert torch.equal(raw_c, raw_a)
+    # the backward from featq == the backward from the fp32 embedding (S >= 32 is required there)
+    draw = torch.randn(B, 4, device='cuda')
+    draw[64:256] = 0                                     # some all-zero tiles
+    nblk = nof.load().nof_mlp_bwd_blocks()
+    outs = []
+    for use_q in (False, True):
+        dsig = torch.zeros(B, 16, dtype=torch.int16, device='cuda')
+        dfeat = torch.full((L, B, 2), 3.0, device='cuda')
+        dview = torch.zeros(R, 16, device='cuda')
+        partials = torch.full((nblk, desc.n_params), 5.0, device='cuda')
+        if use_q:
+            nof.call('nof_mlp_bwd_featq', C.byref(desc), packed, featq, L, d_view, S, draw, sig_a, dsig, dfeat, dview, partials, None, B)
+        else:
+            nof.call('nof_mlp_bwd_tiles', C.byref(desc), packed, feat, L, d_view, S, draw, sig_a, dsig, dfeat, dview, partials, None, B)
+        torch.cuda.synchronize()
+        outs.append((dfeat, partials, dsig))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[0][2], outs[1][2])

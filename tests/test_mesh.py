@@ -147,3 +147,141 @@ def test_atlas_resolution_follows_the_face_count():
         big.unwrap(1024)
     n = int(np.ceil(np.sqrt((228000 + 1) // 2)))
     assert (r - 1) / n >= 4                                                   # what unwrap() asks for
+
+
+# ---- marching cubes, pinned by hand-checkable volumes -------------------------------------------------------
+# The reference extracts its mesh with skimage.measure.marching_cubes (nerf_runner.py:1388-1394, default 'lewiner'); skimage is
+# absent here and unpinned there, so its output cannot be a fixture.  What CAN be pinned without it:
+#   (1) the vertex SET: every marching-cubes variant, 'lewiner' included, puts exactly one vertex on every grid edge whose end
+#       points lie on different sides of the iso level and nowhere else -- tested below on noisy volumes;
+#   (2) the triangle COUNT of a cell, which follows from its corner signs on paper.  A cell's surface is made of closed loops
+#       over its E crossed edges, a loop of n edges is n - 2 triangles, so T = E - 2 k for k loops; and k = I + O - 1, where I is
+#       the number of connected groups of inside corners and O of outside corners (the cube's surface is a sphere: every loop
+#       separates one inside group from one outside group).  Corners are connected along cube edges; on an AMBIGUOUS face (its
+#       corners alternate inside / outside) this table cuts off the inside corners, i.e. the two OUTSIDE corners of such a face are
+#       connected across it and the two inside corners are not (oracle/marching_cubes.py, bundlesdf_amd/mesh.py: the rule looks at
+#       the face only, so both cells sharing it agree and the surface is watertight).  'lewiner' decides ambiguous faces by an
+#       interior test instead: in the cases marked * a cell's triangle count may differ from skimage's, the vertices may not.
+# The fixture: the 14 classical sign configurations (Lorensen & Cline's cases 1-14; corner c = x + 2 y + 4 z) and, for the six that
+# have an ambiguous face, the complementary configuration as well (inside <-> outside: E stays, I and O swap roles WITH the
+# connection rule, so the count can change) = 20 volumes.  Columns: inside corners, E, I, O as counted by hand.
+MC_HAND_CASES = [
+    # name                                  inside corners   E   I  O
+    ('1 one corner',                         [0],             3,  1, 1),
+    ('2 one edge',                           [0, 1],          4,  1, 1),
+    ('3* two corners across a face',         [0, 3],          6,  2, 1),   # face z=0 is ambiguous: 0 | 3 not connected
+    ('3* complement',                        [1, 2, 4, 5, 6, 7], 6, 1, 1),  # outside 0, 3 ARE connected across that face: one loop of 6
+    ('4 two corners across the cube',        [0, 7],          6,  2, 1),   # no face holds both: no ambiguous face
+    ('5 three corners of a face',            [0, 1, 2],       5,  1, 1),
+    ('6* an edge and the far corner',        [0, 1, 6],       7,  2, 1),   # face x=0 (0,2,6,4) is ambiguous: 0 | 6 separate
+    ('6* complement',                        [2, 3, 4, 5, 7], 7,  1, 1),   # outside {0,1} and {6} joined across it: one loop of 7
+    ('7* three corners, pairwise across a face', [1, 2, 4],   9,  3, 1),   # three ambiguous faces, outside all connected anyway
+    ('7* complement',                        [0, 3, 5, 6, 7], 9,  2, 1),   # inside {3,5,6,7} + {0}; outside 1,2,4 joined across the faces
+    ('8 a whole face',                       [0, 1, 2, 3],    4,  1, 1),
+    ('9 a corner and its three neighbours',  [0, 1, 2, 4],    6,  1, 1),   # the hexagon
+    ('10* two opposite parallel edges',      [0, 1, 6, 7],    8,  2, 1),   # faces x=0, x=1 ambiguous: outside {2,3},{4,5} joined
+    ('10* complement',                       [2, 3, 4, 5],    8,  2, 1),   # the same picture turned by 90 degrees
+    ('11 a bent chain of four',              [0, 1, 3, 7],    6,  1, 1),
+    ('12* three corners of a face and the far corner', [0, 1, 2, 7], 8, 2, 1),
+    ('12* complement',                       [3, 4, 5, 6],    8,  2, 1),   # inside {3} + {4,5,6}; outside {0,1,2} ~ {7} across an ambiguous face
+    ('13* four corners, no two adjacent',    [0, 3, 5, 6],    12, 4, 1),   # all six faces ambiguous: four separate triangles
+    ('13* complement',                       [1, 2, 4, 7],    12, 4, 1),
+    ('14 the mirrored chain',                [1, 0, 2, 6],    6,  1, 1),
+]
+
+
+def _cell_volume(inside):
+    vol = np.ones((2, 2, 2), np.float32)
+    for c in inside:
+        vol[c & 1, (c >> 1) & 1, c >> 2] = -1.0
+    return vol
+
+
+def _crossed_edges(vol, iso=0.0):
+    """set of (lo, hi) linear indices of the grid edges whose end points lie on different sides of iso"""
+    nx, ny, nz = vol.shape
+    idx = np.arange(vol.size).reshape(vol.shape)
+    ins = vol < iso
+    out = set()
+    for ax in range(3):
+        a = [slice(None)] * 3
+        b = [slice(None)] * 3
+        a[ax], b[ax] = slice(0, -1), slice(1, None)
+        m = ins[tuple(a)] != ins[tuple(b)]
+        out |= set(zip(idx[tuple(a)][m].tolist(), idx[tuple(b)][m].tolist()))
+    return out
+
+
+def _vertex_edges(verts, shape):
+    """the grid edge each vertex lies on, from its coordinates (one coordinate is fractional, or all are integral: t = 0)"""
+    nx, ny, nz = shape
+    lo = np.floor(verts + 1e-12).astype(np.int64)
+    frac = verts - lo
+    ax = np.argmax(frac, axis=1)
+    hi = lo.copy()
+    hi[np.arange(len(hi)), ax] += 1
+    lin = lambda p: (p[:, 0] * ny + p[:, 1]) * nz + p[:, 2]
+    return set(zip(lin(lo).tolist(), lin(hi).tolist()))
+
+
+def test_hand_table_is_self_consistent():
+    """the hand-counted columns against a direct count (so that a typo in the fixture cannot hide behind a matching bug): E =
+    crossed cube edges; I = inside groups along cube edges; O = outside groups along cube edges + across ambiguous faces"""
+    from oracle import marching_cubes as MC
+    assert len(MC_HAND_CASES) == 20 and len({tuple(sorted(c[1])) for c in MC_HAND_CASES}) == 20
+    for name, inside, E, I, O in MC_HAND_CASES:
+        s = [c in inside for c in range(8)]
+        assert sum(s[a] != s[b] for a, b in MC._EDGES) == E, name
+
+        def groups(sel, extra):
+            left, n = set(c for c in range(8) if s[c] == sel), 0
+            while left:
+                n += 1
+                todo = [left.pop()]
+                while todo:
+                    c = todo.pop()
+                    for a, b in list(MC._EDGES) + extra:
+                        for p, q in ((a, b), (b, a)):
+                            if p == c and q in left:
+                                left.discard(q)
+                                todo.append(q)
+            return n
+        amb = [f for f in MC._FACES if [s[c] for c in f] in ([True, False, True, False], [False, True, False, True])]
+        diag = [(f[k], f[k + 2]) for f in amb for k in (0, 1) if not s[f[k]]]       # outside corners of an ambiguous face
+        assert groups(True, []) == I and groups(False, diag) == O, name
+        assert ('*' in name) == bool(amb), name
+
+
+@pytest.mark.parametrize("row", MC_HAND_CASES, ids=[c[0] for c in MC_HAND_CASES])
+def test_marching_cubes_on_hand_checkable_cells(row):
+    """one cell per classical configuration: vertices exactly on the crossed edges (at their midpoints: values -1 / +1), and
+    E - 2 (I + O - 1) triangles -- oracle table, product table and the oracle extractor"""
+    from bundlesdf_amd.mesh import mc_case_table
+    from oracle import marching_cubes as MC
+    name, inside, E, I, O = row
+    want_tris = E - 2 * (I + O - 1)
+    case = sum(1 << c for c in inside)
+    assert len(MC._TABLE[case]) == want_tris, name
+    t = mc_case_table()
+    assert int(t[case, 0]) == want_tris, name
+    vol = _cell_volume(inside)
+    v, f = MC.marching_cubes(vol, 0.0)
+    assert len(v) == E and len(f) == want_tris
+    assert _vertex_edges(v, vol.shape) == _crossed_edges(vol)
+    assert np.allclose(np.sort(v - np.floor(v), axis=1)[:, -1], 0.5)                 # midpoints of the crossed edges
+    # every triangle of the table uses three DIFFERENT crossed edges of this cell
+    crossed = {i for i, (a, b) in enumerate(MC._EDGES) if (a in inside) != (b in inside)}
+    used = set(int(e) for e in MC._TABLE[case].reshape(-1))
+    assert used == crossed and all(len(set(tri)) == 3 for tri in MC._TABLE[case].tolist())
+
+
+@pytest.mark.parametrize("seed,noise", [(0, 0.3), (1, 1.0), (2, 3.0)])
+def test_vertex_set_is_the_set_of_sign_changing_grid_edges(seed, noise):
+    """The property every marching-cubes variant shares with skimage's 'lewiner' (nerf_runner.py:1389): one vertex per grid edge
+    whose end points straddle the iso level, none elsewhere -- whatever the ambiguous cases do to the triangles."""
+    from oracle import marching_cubes as MC
+    vol = _noisy_sdf(24, seed, noise)
+    v, f = MC.marching_cubes(vol, 0.0)
+    edges = _crossed_edges(vol)
+    assert len(v) == len(edges) and _vertex_edges(v, vol.shape) == edges
+    assert set(np.unique(f).tolist()) == set(range(len(v)))                          # every vertex is used by a triangle

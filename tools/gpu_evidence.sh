@@ -11,8 +11,8 @@
 cd "$GRAFT_REPO_ROOT" || exit 1
 R=$GRAFT_REPO_ROOT; mkdir -p gpurun_out; export TMPDIR=/tmp
 T=${1:-r03}; LEGS=${2:-"bench trace mfma traffic cfg5"}
-SETTLED="--steps 60 --warmup 200 --settle 0 --no-cpu-baseline --keyframes 16"
-CFG5="--mlp cfg5 --rays 16384 --log2_T 22 --finest 512 --width 1280 --height 720 --precision fp16 --no-cpu-baseline --settle 0"
+SETTLED="--steps 60 --warmup 200 --settle 0 --round-steps 0 --no-cpu-baseline --no-extra-configs --keyframes 16"
+CFG5="--mlp cfg5 --rays 16384 --log2_T 22 --finest 512 --width 1280 --height 720 --precision fp16 --no-cpu-baseline --settle 0 --round-steps 0"
 has() { [[ " $LEGS " == *" $1 "* ]]; }
 db() { find "$1" -name "*.db" | head -1; }
 if has bench; then
@@ -25,19 +25,19 @@ if has trace; then
   python $R/tools/step_timeline.py $(db $R/gpurun_out/prof_t) 240 > $R/gpurun_out/${T}_timeline.txt 2>&1
 fi
 if has mfma; then
-  rm -rf $R/gpurun_out/pmc_mfma; timeout 400 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVES GRBM_GUI_ACTIVE --kernel-trace -d $R/gpurun_out/pmc_mfma -o b -- python $R/bench.py --steps 10 --warmup 200 --settle 0 --no-cpu-baseline --keyframes 16 > $R/gpurun_out/pmc_mfma.log 2>&1
+  rm -rf $R/gpurun_out/pmc_mfma; timeout 400 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVES GRBM_GUI_ACTIVE --kernel-trace -d $R/gpurun_out/pmc_mfma -o b -- python $R/bench.py --steps 10 --warmup 200 --settle 0 --round-steps 0 --no-cpu-baseline --keyframes 16 > $R/gpurun_out/pmc_mfma.log 2>&1
   python $R/tools/pmc_summary.py $R/gpurun_out/pmc_mfma > $R/gpurun_out/${T}_pmc_mfma.txt 2>&1; grep "k_mlp" $R/gpurun_out/${T}_pmc_mfma.txt | grep "MFMA\|GRBM" | cut -c1-120
 fi
 if has traffic; then
   for c in FETCH_SIZE WRITE_SIZE; do
     d=$R/gpurun_out/pmc_$(echo $c | tr A-Z a-z | cut -d_ -f1); rm -rf $d
-    timeout 400 rocprofv3 --pmc $c --kernel-trace -d $d -o b -- python $R/bench.py --steps 10 --warmup 200 --settle 0 --no-cpu-baseline --keyframes 16 > $d.log 2>&1
+    timeout 400 rocprofv3 --pmc $c --kernel-trace -d $d -o b -- python $R/bench.py --steps 10 --warmup 200 --settle 0 --round-steps 0 --no-cpu-baseline --keyframes 16 > $d.log 2>&1
   done
-  rm -rf $R/gpurun_out/pmc_atomic; timeout 400 rocprofv3 --pmc TCC_ATOMIC_sum TCC_EA0_ATOMIC_sum --kernel-trace -d $R/gpurun_out/pmc_atomic -o b -- python $R/bench.py --steps 10 --warmup 200 --settle 0 --no-cpu-baseline --keyframes 16 > $R/gpurun_out/pmc_atomic.log 2>&1
+  rm -rf $R/gpurun_out/pmc_atomic; timeout 400 rocprofv3 --pmc TCC_ATOMIC_sum TCC_EA0_ATOMIC_sum --kernel-trace -d $R/gpurun_out/pmc_atomic -o b -- python $R/bench.py --steps 10 --warmup 200 --settle 0 --round-steps 0 --no-cpu-baseline --keyframes 16 > $R/gpurun_out/pmc_atomic.log 2>&1
   (cd $R && python tools/pmc_summary.py gpurun_out/pmc_fetch gpurun_out/pmc_write gpurun_out/pmc_atomic > gpurun_out/${T}_pmc_fetch_write.txt 2>&1; python tools/pmc_traffic.py gpurun_out/${T}_pmc_traffic.json ${T}_pmc_fetch_write.txt | cut -c1-400)
 fi
 if has sq; then
-  rm -rf $R/gpurun_out/pmc_sq; timeout 400 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES SQ_WAVES SQ_INSTS_VALU SQ_WAIT_INST_LDS --kernel-trace -d $R/gpurun_out/pmc_sq -o b -- python $R/bench.py --steps 6 --warmup 200 --settle 0 --no-cpu-baseline --keyframes 16 > $R/gpurun_out/pmc_sq.log 2>&1
+  rm -rf $R/gpurun_out/pmc_sq; timeout 400 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES SQ_WAVES SQ_INSTS_VALU SQ_WAIT_INST_LDS --kernel-trace -d $R/gpurun_out/pmc_sq -o b -- python $R/bench.py --steps 6 --warmup 200 --settle 0 --round-steps 0 --no-cpu-baseline --keyframes 16 > $R/gpurun_out/pmc_sq.log 2>&1
   python $R/tools/pmc_summary.py $R/gpurun_out/pmc_sq > $R/gpurun_out/${T}_pmc_sq.txt 2>&1
 fi
 if has cfg5; then
