@@ -75,8 +75,9 @@ def build_runner(args, rank, world, device):
         from bundlesdf_amd.dist import GradSync
         # bucketed: the fine hash levels' slice is reduced beside the rest of the backward; NOF_DP_PAYLOAD=bf16: that slice travels
         # as bfloat16 (opt-in: it changes the gradient by 2^-8 relative per entry; fp32, the default, changes nothing)
-        sync = GradSync(payload=os.environ.get('NOF_DP_PAYLOAD', 'fp32'))
-        if os.environ.get('NOF_DP_OVERLAP', '1') == '0':
+        # NOF_DP_MODE=zero1: reduce-scatter -> Adam on 1/world of the flat buffers -> all-gather of the parameters (opt-in)
+        sync = GradSync(payload=os.environ.get('NOF_DP_PAYLOAD', 'fp32'), mode=os.environ.get('NOF_DP_MODE', 'allreduce'))
+        if os.environ.get('NOF_DP_OVERLAP', '1') == '0' and sync.mode == 'allreduce':
             sync = sync.__call__            # one blocking all-reduce of the whole buffer
     ns, nc, hidden = MLP_SHAPES[args.mlp]
     precision = args.precision
@@ -287,6 +288,7 @@ def main():
     # ---- warm-up with every launch bracketed by events: finds the dominant kernel --------------------------------
     fld.profile = {}
     sync = runner.grad_sync if hasattr(runner.grad_sync, 'finish') else None
+    dp_mode = getattr(runner.grad_sync, 'mode', None) if runner.grad_sync is not None else None
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
@@ -550,7 +552,7 @@ def main():
             # step's stream waited for them after the backward (events around GradSync.finish: what did not hide)
             "allreduce_bytes_per_step": (sync.bytes_step if sync is not None else (fld.n_total * 4 if runner.grad_sync is not None else 0)),
             "collectives_per_step": (sync.collectives_step if sync is not None else (1 if runner.grad_sync is not None else 0)),
-            "exposed_comm_ms": exposed_comm_ms, "dp_payload": getattr(sync, 'payload', None),
+            "exposed_comm_ms": exposed_comm_ms, "dp_payload": getattr(sync, 'payload', None), "dp_mode": dp_mode,
             "roofline": roof,
         }
         default_workload = shape_key == (64, 4096, 19, 'baseline', 640, 480)

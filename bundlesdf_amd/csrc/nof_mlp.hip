@@ -527,10 +527,13 @@ NofMlpDesc d, const char* __restrict__ image,
 // Same values as k_hash_fwd + k_mlp_fwd: the encode is encode_level() itself, the chain is dense_o1().
 // =====================================================================================================
 #ifndef NOF_ENC_WAVES
-#define NOF_ENC_WAVES 12                                  // waves per workgroup, ONE workgroup per CU = 3 waves per SIMD (168 registers) around one fragment image
+#define NOF_ENC_WAVES 12                                  // most waves per workgroup, ONE workgroup per CU = 3 waves per SIMD (168 registers) around one fragment image
 #endif
 #ifndef NOF_ENC_GROUP
-#define NOF_ENC_GROUP 2                                   // levels whose gathers are in flight together
+#define NOF_ENC_GROUP 4                                   // levels whose gathers are in flight together
+#endif
+#ifndef NOF_ENC_GROUP_SPLIT
+#define NOF_ENC_GROUP_SPLIT 3                             // ... in the operand-split variants (their chain leaves fewer registers)
 #endif
 
 // indices and fractions of one level for one point; the loads and the blend are separate steps so that a GROUP of levels has all
@@ -668,7 +671,7 @@ __global__ __launch_bounds__(64 * NOF_ENC_WAVES, (NOF_ENC_WAVES + 3) / 4) void k
   constexpr int NL = NS + NC;
   constexpr int BIAS_BASE = SH::pair_base(NL) * PAIR_BYTES;
   constexpr int LO_BASE = BIAS_BASE + SH::oblk_base(NL) * 32 * 4;
-  constexpr int PARK_BASE = LO_BASE + (SPLIT ? BIAS_BASE : 0);        // [wave][4][64] float4: tile B's operand (see below)
+  constexpr int PARK_BASE = LO_BASE + (SPLIT ? BIAS_BASE : 0);        // [wave][32][64] floats: the wave's feature stage (see below)
   copy16(smem, image, (size_t)BIAS_BASE);
   copy16(smem + BIAS_BASE, image + 2 * (size_t)SH::pair_base(NL) * PAIR_BYTES, (size_t)SH::oblk_base(NL) * 32 * 4);
   if constexpr (SPLIT)
@@ -676,17 +679,19 @@ __global__ __launch_bounds__(64 * NOF_ENC_WAVES, (NOF_ENC_WAVES + 3) / 4) void k
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int hi = lane >> 5, j = lane & 31;
-  constexpr int NW = NOF_ENC_WAVES, GR = NOF_ENC_GROUP;
+  constexpr int GR = SPLIT ? (NS >= 3 ? 2 : NOF_ENC_GROUP_SPLIT) : NOF_ENC_GROUP;     // (what each variant's chain leaves room for at 168 registers)
+  const int NW = blockDim.x >> 6;                     // (the host sizes the workgroup by what LDS admits: 8 KB of stage per wave)
   const int64_t npairs = (B + 63) / 64;
   for (int64_t tp = (int64_t)blockIdx.x * NW + wave; tp < npairs; tp += (int64_t)gridDim.x * NW) {
     asm volatile("" ::: "memory");                    // keep the weight fragments in LDS (no hoisting into VGPRs)
-    // ---------------- encode: lane = sample tp*64 + lane, all levels ----------------
+    // ---------------- encode: lane = sample tp*64 + lane, all levels, GR levels' gathers in flight together ----------------
+    // The features go to a wave-private LDS stage as they are produced, feature-major: stage[feature][sample] -- one conflict-free
+    // ds_write_b32 per feature -- so that no register holds them while the next group's gathers are in flight (32 accumulated
+    // features + four levels in flight did not fit 168 registers), and the chain reads them back in operand order below.
     const int64_t bs = tp * 64 + lane;
     const int64_t bb = bs < B ? bs : B - 1;           // (a lane past the end encodes the last sample: nothing of it is stored)
     const float p[3] = {pts_w[bb * 3], pts_w[bb * 3 + 1], pts_w[bb * 3 + 2]};
-    float f[32];
-#pragma unroll
-    for (int r = 0; r < 32; ++r) f[r] = 0.0f;
+    float* stage = reinterpret_cast<float*>(smem + PARK_BASE + wave * 8192);              // [32][64] floats
 #pragma unroll
     for (int l0 = 0; l0 < NOF_MAX_LEVELS; l0 += GR) {
       if (l0 < g.L) {                                 // (uniform)
@@ -694,53 +699,39 @@ __global__ __launch_bounds__(64 * NOF_ENC_WAVES, (NOF_ENC_WAVES + 3) / 4) void k
         float2 v[GR][8];
 #pragma unroll
         for (int u = 0; u < GR; ++u) {
-          if (l0 + u < g.L) {
+          if (l0 + u < NOF_MAX_LEVELS && l0 + u < g.L) {
             const HashLevel lv = load_level(g, l0 + u);               // compile-time level index: scalar loads of the kernel argument
             e[u] = enc_prep(lv, p);
             if (level_pairs(lv)) enc_load<true>(lv, table, e[u], v[u]);
             else enc_load<false>(lv, table, e[u], v[u]);
-          }
+            asm volatile("" ::: "memory");            // this level's gathers are issued before the next level's rows are computed
+          }                                           // (the scheduler otherwise computes all 32 rows first: 32 more live registers)
         }
 #pragma unroll
         for (int u = 0; u < GR; ++u) {
-          if (l0 + u < g.L) {
-            const float2 a = enc_blend(e[u], v[u]);
-            f[2 * (l0 + u)] = a.x;
-            f[2 * (l0 + u) + 1] = a.y;
+          float2 a = make_float2(0.f, 0.f);
+          if (l0 + u < NOF_MAX_LEVELS && l0 + u < g.L) a = enc_blend(e[u], v[u]);
+          if (l0 + u < NOF_MAX_LEVELS) {
+            stage[(2 * (l0 + u)) * 64 + lane] = a.x;
+            stage[(2 * (l0 + u) + 1) * 64 + lane] = a.y;
           }
         }
+      } else {
+#pragma unroll
+        for (int u = 0; u < 2 * GR; ++u)
+          if (2 * l0 + u < 32) stage[(2 * l0 + u) * 64 + lane] = 0.0f;                     // levels the grid does not have
       }
     }
-    // ---------------- lane s holds f[0..31] of sample s  ->  operand layout of the two tiles ----------------
-    // v_permlane32_swap a, b: lanes 32..63 of a <-> lanes 0..31 of b.  With a = f[r], b = f[16 + r]:
-    //   a' = { lanes j: f_j[r],        lanes 32 + j: f_j[16 + r] }        = tile A (samples tp*64 + j), slot (hi, r)
-    //   b' = { lanes j: f_{32+j}[r],   lanes 32 + j: f_{32+j}[16 + r] }   = tile B (samples tp*64 + 32 + j)
-    // Tile B's operand waits in a lane-private LDS slot (64 B per lane) while tile A goes through the chain: 16 registers that
-    // the chain at its widest (split operands, three sigma layers) does not have at 3 waves per SIMD.
-    float xa[16];
-    float4* park = reinterpret_cast<float4*>(smem + PARK_BASE + wave * 4096) + lane;      // [4][64 lanes] float4, conflict-free
+    // ---------------- the two tiles through the chain: lane (j, hi) of tile t reads features 16 hi .. 16 hi + 15 of sample
+    //                  32 t + j = stage[16 hi + r][32 t + j] (conflict-free: a half-wave reads 32 consecutive words) ----------------
 #pragma unroll
-    for (int r4 = 0; r4 < 4; ++r4) {
-      float xb[4];
+    for (int t = 0; t < 2; ++t) {                     // (two inlined copies: as a rolled loop the split variants spilled)
+      asm volatile("" ::: "memory");
+      float xa[16];
 #pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        const int r = 4 * r4 + c;
-        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(f[r]), __float_as_uint(f[16 + r]), false, false);
-        xa[r] = __uint_as_float(sw[0]);
-        xb[c] = __uint_as_float(sw[1]);
-      }
-      park[r4 * 64] = make_float4(xb[0], xb[1], xb[2], xb[3]);
+      for (int r = 0; r < 16; ++r) xa[r] = stage[(16 * hi + r) * 64 + 32 * t + j];
+      enc_chain_tile<P, NS, NC, SPLIT>(d, smem, xa, tp * 64 + 32 * t + j, view, S, out, sig, featq, B, lane);
     }
-    // ---------------- the two tiles through the chain (two inlined copies: no selects, tile B's operand is the only extra
-    //                  live state while tile A runs) ----------------
-    enc_chain_tile<P, NS, NC, SPLIT>(d, smem, xa, tp * 64 + j, view, S, out, sig, featq, B, lane);
-    asm volatile("" ::: "memory");
-#pragma unroll
-    for (int r4 = 0; r4 < 4; ++r4) {
-      const float4 t = park[r4 * 64];
-      xa[4 * r4] = t.x; xa[4 * r4 + 1] = t.y; xa[4 * r4 + 2] = t.z; xa[4 * r4 + 3] = t.w;
-    }
-    enc_chain_tile<P, NS, NC, SPLIT>(d, smem, xa, tp * 64 + 32 + j, view, S, out, sig, featq, B, lane);
   }
 }
 
@@ -2021,17 +2012,21 @@ extern "C" int nof_encode_mlp_fwd(const NofHashGrid* g, const NofMlpDesc* d, con
   if (d->precision == 0) return nof_set_error(-1, "nof_encode_mlp_fwd: 16-bit operand types only (fp32: nof_hash_encode_fwd + nof_mlp_fwd)");
   if (B == 0) return 0;
   const int nl = d->n_sigma + d->n_color;
-  const size_t shm = (is_split(d->precision) ? 2 : 1) * (size_t)n_pairs(*d, nl) * 16 * 64 * elem_size(d->precision) +
-                     (size_t)n_oblk(*d, nl) * 32 * 4 + (size_t)NOF_ENC_WAVES * 4096;
+  const size_t img = (is_split(d->precision) ? 2 : 1) * (size_t)n_pairs(*d, nl) * 16 * 64 * elem_size(d->precision) +
+                     (size_t)n_oblk(*d, nl) * 32 * 4;
+  int waves = (int)((160 * 1024 - img) / 8192);                         // one workgroup per CU: the image + 8 KB of stage per wave
+  if (waves > NOF_ENC_WAVES) waves = NOF_ENC_WAVES;
+  NOF_ARG(waves >= 4);
+  const size_t shm = img + (size_t)waves * 8192;
   const int64_t npairs = (B + 63) / 64;
-  const int64_t want = nof_div_up(npairs, NOF_ENC_WAVES);
-  const int64_t cap = (int64_t)nof_mlp_bwd_blocks() / 2 * (NOF_ENC_WAVES >= 12 ? 1 : 2);   // workgroups resident at once: 1 or 2 per CU
+  const int64_t want = nof_div_up(npairs, waves);
+  const int64_t cap = (int64_t)nof_mlp_bwd_blocks() / 2;               // one resident workgroup per CU
   const unsigned blocks = (unsigned)(want < cap ? want : cap);
 #define LAUNCH_ENC(P, NS_, NC_, SPLIT_)                                                                   \
   {                                                                                                       \
     auto kern = k_enc_mlp_fwd<P, NS_, NC_, SPLIT_>;                                                       \
     if (int e = set_smem(kern, shm)) return e;                                                            \
-    hipLaunchKernelGGL(kern, dim3(blocks), dim3(64 * NOF_ENC_WAVES), shm, (hipStream_t)stream, *d, (const char*)packed, *g, \
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(64 * waves), shm, (hipStream_t)stream, *d, (const char*)packed, *g, \
                        (const float2*)table, pts_w, view, (int)S, raw, (typename P::elem*)sigma_out,      \
                        (typename P::elem*)featq, B);                                                      \
   }

@@ -45,8 +45,13 @@ class GradSync:
     slice's share of Adam.  Sums are
     element-wise, so bucketing does not change a single bit of the result."""
 
-    def __init__(self, payload='fp32'):
-        assert payload in ('fp32', 'bf16')
+    def __init__(self, payload='fp32', mode='allreduce'):
+        assert payload in ('fp32', 'bf16') and mode in ('allreduce', 'zero1')
+        # 'zero1' (SURVEY 8e): reduce-scatter of the flat gradient -> every rank runs Adam on ITS 1/world of the flat buffers ->
+        # all-gather of the parameters.  The same bytes on the wire as the all-reduce (which is a reduce-scatter + an all-gather
+        # of GRADIENTS), the optimiser pass cut to 1/world per rank; the exchange sits between the backward and the next forward
+        # with nothing to hide behind, which is why it is opt-in (DESIGN 6 has the cost model).  field.py drives it.
+        self.mode = mode
         self.payload = payload       # 'bf16': slices started with compressed=True travel as bfloat16 (half the bytes on the wire)
         self.pending = []            # [(work, fp32 slice to refill from its staging buffer or None, staging buffer)]
         self.bytes_step = 0          # payload bytes handed to all-reduce in the last step (per rank)
@@ -59,6 +64,59 @@ class GradSync:
     def __call__(self, flat):
         dist.all_reduce(flat, op=dist.ReduceOp.SUM)
         self.bytes_step, self.collectives_step = flat.numel() * flat.element_size(), 1
+
+    # ---- 'zero1' ------------------------------------------------------------------------------------------------------
+    @staticmethod
+    def shard_range(n_total, rank=None, world=None):
+        """(n_padded, shard, lo, hi): the flat buffers are padded to a multiple of 4 * world floats (Adam moves 16 bytes per lane);
+        rank r owns entries [r * shard, (r + 1) * shard) of the padded buffer = [lo, hi) of the real one."""
+        world = dist.get_world_size() if world is None else world
+        rank = dist.get_rank() if rank is None else rank
+        q = 4 * world
+        n_pad = (n_total + q - 1) // q * q
+        shard = n_pad // world
+        lo = min(rank * shard, n_total)
+        return n_pad, shard, lo, min(lo + shard, n_total)
+
+    def reduce_scatter_(self, padded):
+        """in place: this rank's shard of `padded` [n_pad] becomes the sum over the ranks (the rest of the buffer is left as it is)"""
+        world, rank = dist.get_world_size(), dist.get_rank()
+        shard = padded.numel() // world
+        ev = self._ev0()
+        dist.reduce_scatter_tensor(padded[rank * shard:(rank + 1) * shard], padded, op=dist.ReduceOp.SUM)
+        self._ev1(ev)
+        self._bytes += padded.numel() * padded.element_size()
+        self._n += 1
+
+    def all_gather_(self, padded):
+        """in place: every rank's shard of `padded` is distributed to all ranks"""
+        world, rank = dist.get_world_size(), dist.get_rank()
+        shard = padded.numel() // world
+        ev = self._ev0()
+        dist.all_gather_into_tensor(padded, padded[rank * shard:(rank + 1) * shard])
+        self._ev1(ev)
+        self._bytes += padded.numel() * padded.element_size()
+        self._n += 1
+
+    def max_flags_(self, flags):
+        """the ranks agree on the device flags (a skipped step must be skipped by everyone)"""
+        dist.all_reduce(flags, op=dist.ReduceOp.MAX)
+
+    def end_step(self):
+        self.timed_steps += 1
+        self.bytes_step, self.collectives_step, self._bytes, self._n = self._bytes, self._n, 0, 0
+
+    def _ev0(self):
+        if self.timing is not None and torch.cuda.is_available():
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
+            return ev
+        return None
+
+    def _ev1(self, ev):
+        if ev is not None:
+            ev[1].record()
+            self.timing.append(ev)
 
     def start(self, part, compressed=False):
         """asynchronous all-reduce of a slice of the flat fp32 gradient buffer.  compressed (and payload 'bf16'): the slice is
@@ -109,12 +167,12 @@ class GradSync:
         self.bytes_step, self.collectives_step, self._bytes, self._n = self._bytes, self._n, 0, 0
 
 
-def make_grad_sync(overlap=True, payload='fp32'):
+def make_grad_sync(overlap=True, payload='fp32', mode='allreduce'):
     """GradSync when a process group with more than one rank exists, else None."""
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return None
-    g = GradSync(payload)
-    return g if overlap else g.__call__
+    g = GradSync(payload, mode)
+    return g if overlap or mode == 'zero1' else g.__call__
 
 
 def shard_frames(n_total, rank, world):

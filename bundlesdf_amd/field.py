@@ -68,7 +68,11 @@ class NeuralObjectField:
         self.max_trans = float(cfg['max_trans'] * cfg['sc_factor'])
         self.max_rot = float(cfg['max_rot'] / 180.0 * np.pi)
         dev = self.device
-        self.params = torch.zeros(self.n_total, device=dev)
+        # (the flat buffers carry a few floats of padding behind them, so that the sharded-optimiser exchange (GradSync mode
+        # 'zero1') can reduce-scatter / all-gather equal shards in place: a multiple of 4 * world entries)
+        self._pad = (-self.n_total) % (4 * max(int(world_size), 1))
+        self._params_store = torch.zeros(self.n_total + self._pad, device=dev)
+        self.params = self._params_store[:self.n_total]
         self._st, self._sh, self._events = None, None, {}     # the step's stream (torch object, raw handle), fork / join events
         self.pose_slots = torch.zeros(max(self.F, 1) * 16 * 28, device=dev)      # [F, NOF_POSE_SLOTS, NOF_POSE_SLOT_W], kept zero between steps
         # gradients: some headroom in FRONT of the flat buffer, so that the data-parallel step can put a copy of what lies behind
@@ -76,8 +80,8 @@ class NeuralObjectField:
         # (train_step, `bucketed`)
         self._n_tail = self.n_feat + self.n_pose
         self._head = (self._n_tail + self.n_mlp + 63) // 64 * 64
-        self._grads_store = torch.zeros(self._head + self.n_total, device=dev)
-        self.grads = self._grads_store[self._head:]
+        self._grads_store = torch.zeros(self._head + self.n_total + self._pad, device=dev)
+        self.grads = self._grads_store[self._head:self._head + self.n_total]
         self.exp_avg = torch.zeros(self.n_total, device=dev)
         self.exp_avg_sq = torch.zeros(self.n_total, device=dev)
         self.c2w = torch.as_tensor(np.asarray(c2w, dtype=np.float32)).reshape(self.F, 16).to(dev).contiguous()
@@ -451,7 +455,8 @@ class NeuralObjectField:
         hashed = [l for l in range(self.L) if self.grid.hashed[l]]
         split = hashed[0] if hashed and 0 < hashed[0] < self.L else None
         # (a captured step is one chain on one stream: no bucketed exchange inside it)
-        bucketed = grad_sync is not None and hasattr(grad_sync, 'start') and split is not None and not dyn
+        bucketed = (grad_sync is not None and hasattr(grad_sync, 'start') and split is not None and not dyn
+                    and getattr(grad_sync, 'mode', 'allreduce') == 'allreduce')
         BIG, SMALL, INPUT, ALL = lib.HASH_BWD_TABLE_BIG, lib.HASH_BWD_TABLE_SMALL, lib.HASH_BWD_INPUT, lib.HASH_BWD_ALL
         adam_done = None                               # flat entries [adam_done) that have had their Adam update already
 
@@ -538,6 +543,32 @@ class NeuralObjectField:
         if self.ff > 0:
             self._call('nof_small_regs', self.feat, self._seg(self.grads, 'feat'), self.n_feat,
                        C.c_float(cfg['feature_reg_weight']), C.c_float(1.0 / self.world_size))
+        zero1 = grad_sync is not None and getattr(grad_sync, 'mode', '') == 'zero1'
+        if zero1:
+            # sharded optimiser: reduce-scatter the flat gradient, Adam on this rank's 1/world of the flat buffers,
+            # all-gather the parameters.  Every rank ends the step with the same parameter bits (they all receive every shard);
+            # the Adam moments of a rank are current on its own shard only (gather_optimizer_state before a checkpoint).
+            from .dist import GradSync
+            padded_g = self._grads_store[self._head:]
+            n_pad, shard, lo, hi = GradSync.shard_range(self.n_total)
+            assert padded_g.numel() == n_pad == self._params_store.numel(), 'field built for another world size'
+            if self.desc.precision in FP16_MODES:
+                # a non-finite partial sum on any rank: every rank skips (its own shard) -- the flag word is agreed on first
+                self._call('nof_grad_check', self._seg(self.grads, 'mlp'), self.n_mlp, self.flags)
+                grad_sync.max_flags_(self.flags)
+            grad_sync.reduce_scatter_(padded_g)
+            if do_step:
+                if hi > lo:
+                    self.adam_step(dyn, lo, hi, advance=False)                  # (zeroes the gradient of [lo, hi))
+                with torch.cuda.stream(self._st):
+                    padded_g[:lo].zero_()
+                    padded_g[hi:].zero_()
+                grad_sync.all_gather_(self._params_store)
+                self.global_step += 1
+                self.adam_steps += 1
+                self._zero1_shard = (lo, hi)
+            grad_sync.end_step()
+            return b
         if bucketed:
             # ONE more collective: everything that is not in flight yet.  [0, a) and what lies behind the first slice are not
             # contiguous in the flat buffer, so a copy of the latter (tens of KB) rides in the headroom in front of it
@@ -587,6 +618,20 @@ class NeuralObjectField:
         if advance:
             self.global_step += 1
             self.adam_steps += 1
+
+    def gather_optimizer_state(self):
+        """after steps with the sharded optimiser (GradSync mode 'zero1') a rank's Adam moments are current on its own shard only:
+        all-gather them (a checkpoint needs all of them).  No-op otherwise."""
+        import torch.distributed as dist
+        if getattr(self, '_zero1_shard', None) is None or not dist.is_initialized():
+            return
+        from .dist import GradSync
+        n_pad, shard, lo, hi = GradSync.shard_range(self.n_total)
+        for buf in (self.exp_avg, self.exp_avg_sq):
+            full = torch.zeros(n_pad, device=self.device)
+            full[lo:hi] = buf[lo:hi]
+            dist.all_gather_into_tensor(full, full[dist.get_rank() * shard:(dist.get_rank() + 1) * shard].clone())
+            buf.copy_(full[:self.n_total])
 
     # ---- renderer side ------------------------------------------------------------------------------------
     def render_batch(self, pool, ids, R, want_cells=False):

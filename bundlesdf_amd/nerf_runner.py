@@ -437,6 +437,7 @@ class NerfRunner:
         """native: the flat buffers + Adam moments + occupancy bitfield; reference_format=True: the reference's own layout
         (nerf_runner.py:546-566: 'model' / 'embed_fn' / 'pose_array' / 'feature_array' state_dicts), loadable by it"""
         f = self.field
+        f.gather_optimizer_state()               # (sharded optimiser: every rank's Adam moments, not only this rank's shard)
         if reference_format:
             torch.save(to_reference_checkpoint(f, self.global_step), out_file)
         else:

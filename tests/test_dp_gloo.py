@@ -59,6 +59,7 @@ def _worker(rank, world, port, R, out):
     sync = D.make_grad_sync()
     assert sync is not None
     bucketed = flat.clone()
+    bucketed_local = flat.clone()                        # this rank's own (pre-scaled) gradient, for the sharded-optimiser check below
     sync(flat)                                           # one blocking all-reduce of the whole buffer
     # the bucketed asynchronous form the device step uses: TWO collectives -- the middle slice (fine levels + MLP) first, then
     # [copy of the tail | head slice] as one contiguous range (the tail rides in headroom in front of the buffer): same bits
@@ -100,6 +101,33 @@ def _worker(rank, world, port, R, out):
     sp.start(plain[3:], compressed=True)
     sp.finish()
     assert torch.equal(plain[3:], sum(m[3:] for m in mine)) and sp.bytes_step == 4 * (n - 3)
+    # sharded optimiser (GradSync mode 'zero1'): reduce-scatter -> Adam on this rank's 1/world of the flat buffers ->
+    # all-gather of the parameters == all-reduce -> Adam on everything, BIT for bit, on every rank
+    n = flat.numel()
+    n_pad, shard, lo, hi = D.GradSync.shard_range(n)
+    assert n_pad % (4 * world) == 0 and shard * world == n_pad and 0 <= n_pad - n < 4 * world
+    assert D.GradSync.shard_range(10, 1, 2) == (16, 8, 8, 10) and D.GradSync.shard_range(10, 1, 4)[2:] == (4, 8)
+    assert D.GradSync.shard_range(3, 3, 4)[2:] == (3, 3)             # a rank can own nothing but padding
+    p0 = torch.linspace(-1, 1, n)
+    pa, ma, va = O.adam_reference_step(p0.numpy(), flat.numpy(), np.zeros(n, np.float32), np.zeros(n, np.float32), 1, np.float32(0.01))
+    gz, pz = torch.zeros(n_pad), torch.zeros(n_pad)
+    gz[:n], pz[:n] = bucketed_local, p0
+    sz = D.make_grad_sync(mode='zero1')
+    assert sz.mode == 'zero1'
+    sz.reduce_scatter_(gz)
+    assert torch.equal(gz[lo:hi], flat[lo:hi])                      # my shard holds the sum the all-reduce gave
+    ps, ms, vs = O.adam_reference_step(p0[lo:hi].numpy(), gz[lo:hi].numpy(), np.zeros(hi - lo, np.float32), np.zeros(hi - lo, np.float32),
+                                       1, np.float32(0.01))
+    pz[lo:hi] = torch.from_numpy(ps)
+    pz[:lo] = float('nan')                                          # what other ranks own is theirs to deliver
+    pz[hi:n] = float('nan')
+    sz.all_gather_(pz)
+    sz.end_step()
+    assert torch.equal(pz[:n], torch.from_numpy(pa))
+    assert sz.collectives_step == 2 and sz.bytes_step == 2 * 4 * n_pad and sz.timed_steps == 1
+    fl = torch.tensor([4 if rank == 1 else 0, 0, 0, 0], dtype=torch.int32)
+    sz.max_flags_(fl)
+    assert int(fl[0]) == 4                                           # one rank's overflow is everybody's skipped step
     if rank == 0:
         out.put(flat.numpy())
     dist.barrier()

@@ -14,9 +14,9 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run(overlap, port, backend='gloo', ranks=2, force='0', steps=6, payload='fp32'):
+def _run(overlap, port, backend='gloo', ranks=2, force='0', steps=6, payload='fp32', mode='allreduce'):
     env = dict(os.environ, NOF_DIST_BACKEND=backend, HSA_ENABLE_IPC_MODE_LEGACY='0', NOF_DP_OVERLAP=overlap, NOF_DP_FORCE=force,
-               NOF_DP_PAYLOAD=payload)
+               NOF_DP_PAYLOAD=payload, NOF_DP_MODE=mode)
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(ranks), '--master-addr', '127.0.0.1',
            '--master-port', str(port), os.path.join(ROOT, 'bench.py'), '--gpus', str(ranks), '--steps', str(steps), '--warmup', '2',
            '--keyframes', '3', '--no-cpu-baseline', '--settle', '0', '--round-steps', '0']
@@ -25,6 +25,16 @@ def _run(overlap, port, backend='gloo', ranks=2, force='0', steps=6, payload='fp
     line = [l for l in out.stdout.splitlines() if l.startswith('{"metric"')]
     assert len(line) == 1, out.stdout[-2000:]                          # rank 0 only
     return json.loads(line[0])
+
+
+def test_sharded_optimiser_two_ranks_one_gpu_gloo(nof):
+    """GradSync mode 'zero1' through bench.py's own launch path, two ranks sharing the one GPU (gloo transport): the replicas end
+    with bit-identical parameters (every rank receives every shard) that equal the all-reduce form's."""
+    d = _run('1', 29541, mode='zero1')
+    d0 = _run('0', 29542)
+    assert d['dp_mode'] == 'zero1' and d['dp_param_checksum_spread'] == 0.0 and d['flags'] == 0
+    assert abs(d['param_checksum'] - d0['param_checksum']) <= 2e-5 * d0['param_checksum']
+    assert d['collectives_per_step'] == 2
 
 
 def test_bench_two_ranks_one_gpu_gloo(nof):
@@ -73,8 +83,14 @@ def test_rccl_calls_of_the_bucketed_step_one_rank(nof):
     assert d['exposed_comm_ms'] is not None and d['exposed_comm_ms'] >= 0 and d0['exposed_comm_ms'] is None
     assert d['flags'] == 0 and d['loss'] == d['loss']
     assert abs(d['param_checksum'] - d1['param_checksum']) <= 2e-5 * d1['param_checksum']
+    # the sharded optimiser (reduce-scatter -> Adam on the rank's shard -> all-gather of the parameters; at one rank the shard is
+    # everything and both collectives are identities performed by RCCL): same parameters again
+    dz = _run('1', 29540, backend='nccl', ranks=1, force='1', mode='zero1')
+    assert dz['dp_mode'] == 'zero1' and dz['collectives_per_step'] == 2 and dz['flags'] == 0
+    assert dz['allreduce_bytes_per_step'] >= 2 * 4 * 9_000_000
+    assert abs(dz['param_checksum'] - d1['param_checksum']) <= 2e-5 * d1['param_checksum']
     print(f"one-rank RCCL: bucketed {d['ms_per_step']:.3f} ms/step (exposed {d['exposed_comm_ms']:.3f} ms), blocking {d1['ms_per_step']:.3f}, "
-          f"no collectives {d0['ms_per_step']:.3f}")
+          f"sharded optimiser {dz['ms_per_step']:.3f} (exposed {dz['exposed_comm_ms']:.3f}), no collectives {d0['ms_per_step']:.3f}")
 
 
 def test_bench_two_ranks_two_gpus_rccl(nof):

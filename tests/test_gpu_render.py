@@ -149,18 +149,22 @@ def test_render_images_640x480_vs_oracle(nof):
         assert same.mean() > 0.999, same.mean()             # (rays that graze a cell face after the fp32 pose transform)
         z_ref = ref['z_vals'].numpy()
         assert np.abs(cpu(ex['z_vals'])[sl] - z_ref)[same].max() < 2e-5
-        raw, raw_ref = cpu(ex['raw'])[sl][same], ref['raw'].numpy()[same]
-        # colour = sigmoid(raw[..., :3]) as raw2outputs uses it (nerf_runner.py:1165); the logits themselves by max-norm (a trained
-        # field's logits reach +-10: 1e-5 absolute on a logit near zero is far inside 1e-3 of the colour)
-        sg = lambda a: 1.0 / (1.0 + np.exp(-a.astype(np.float64)))
+        # network outputs per element: the oracle evaluated AT THE DEVICE'S sample positions.  (Through its own sampler the
+        # oracle's z differs from the device's in the last float32 bits -- the pose transform is evaluated in a different order --
+        # and a trained colour field moves by 1e-3 within 2e-5 of normalised depth: that is the field's texture, not a kernel's
+        # arithmetic; the full-pipeline comparison of rgb_map and depth follows below.)
+        with torch.no_grad():
+            fw = orc.forward(torch.from_numpy(rows[sl]), torch.from_numpy(cpu(ex['z_vals'])[sl]))
+        raw, raw_ref = cpu(ex['raw'])[sl], fw['raw'].numpy()
+        sg = lambda a: 1.0 / (1.0 + np.exp(-a.astype(np.float64)))       # colour as raw2outputs uses it (nerf_runner.py:1165)
         w_rgb, w_sdf = worst_elementwise(sg(raw[..., :3]), sg(raw_ref[..., :3])), worst_elementwise(raw[..., 3], raw_ref[..., 3])
-        assert np.abs(raw[..., :3] - raw_ref[..., :3]).max() < 1e-3 * np.abs(raw_ref[..., :3]).max()
+        w_logit = worst_elementwise(raw[..., :3], raw_ref[..., :3])
         w_map = worst_elementwise(cpu(ex['rgb_map'])[sl][same], ref['rgb_map'].numpy()[same])
         # depth: the same sample index wherever the SDF pair products are not within rounding of zero
         d_ref = ref['depth'].numpy()[same]
         d_got = d_ray[sl][same]
         agree = np.abs(d_got - d_ref) <= 1e-3 * np.abs(d_ref) + 1e-5
         print(f'render 640x480 rays {lo}..: identical hit lists {same.mean():.4f}, per element raw colour {w_rgb:.3f} sdf {w_sdf:.3f} '
-              f'rgb_map {w_map:.3f}, depth agrees on {agree.mean():.5f}')
-        assert w_rgb <= 1.0 and w_sdf <= 1.0 and w_map <= 1.0
+              f'rgb_map {w_map:.3f} (own sampler), depth agrees on {agree.mean():.5f}; colour logits {w_logit:.3f}')
+        assert w_rgb <= 1.0 and w_sdf <= 1.0 and w_map <= 1.0 and w_logit <= 1.0
         assert agree.mean() > 0.999
