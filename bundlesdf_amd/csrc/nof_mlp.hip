@@ -513,27 +513,43 @@ NofMlpDesc d, const char* __restrict__ image,
 // The reference materialises the [B,32] embedding (nerf_runner.py:1255-1267) and so did k_hash_fwd + k_mlp_fwd: 100.7 MB written
 // and read back per cfg2 step.  Here a wave owns 64 consecutive samples = TWO 32-sample tiles:
 //   * encode with one SAMPLE per lane and the level uniform over the wave -- the form the stand-alone encoder is fastest in: level
-//     constants in SGPRs, no divergence between dense and hashed levels, the x-neighbour pair of a dense level in one 16-byte load
-//     (level_pairs), 92 gather instructions per 64 samples at cfg2.  (k_sdf_grid's lane = (sample, half of the levels) form issues
-//     128 and reads its level constants through vector loads.)  The levels are encoded in groups of four: 32 gathers in flight per
-//     lane before the first blend;
-//   * lane s then holds all 32 features of sample s, while the first layer's B operand wants lane (j, hi) to hold features
-//     16 hi .. 16 hi + 15 of sample j: ONE v_permlane32_swap per register pair (gfx950) exchanges the upper half's low features with
-//     the lower half's high features and leaves both tiles' operands in place: 16 instructions per 64 samples, no LDS;
-//   * the two tiles go through the MLP chain one after the other (dense_o1, the same fragments in LDS as k_mlp_fwd).
+//     constants in SGPRs (staged in LDS once per workgroup, read per level: as plain kernel arguments all 80 of them were held in
+//     SGPRs across the loop and 285 of those were spilled to VGPR lanes), no divergence between dense and hashed levels, the
+//     x-neighbour pair of a dense level in one 16-byte load (level_pairs), 92 gather instructions per 64 samples at cfg2, rows
+//     computed per level without a branch per corner (enc_prep), gathers in global_load's saddr + 32-bit-offset form;
+//   * lane s then holds the features of sample s, while the first layer's B operand wants lane (j, hi) to hold features
+//     16 hi .. 16 hi + 15 of sample j: the features go through a wave-private LDS stage, feature-major [32][64] floats -- one
+//     conflict-free ds_write per feature as it is produced, one conflict-free ds_read per operand register -- which also frees the
+//     registers while the next level's gathers are in flight.  (Round 4's first version exchanged the halves with 16
+//     v_permlane32_swap and parked tile B's operand in LDS: the same time, 32 more live registers.)
+//   * the two tiles go through the MLP chain one after the other (dense_o1, the same fragments in LDS as k_mlp_fwd).  ONE
+//     workgroup of up to 12 waves per CU around one fragment image (3 waves per SIMD; 8 KB of stage per wave bound the count).
 // `featq` (may be NULL): the features in MFMA operand precision and operand order, [B][hi][16] elements = 64 B per sample -- what
 // the split backward's sigma kernel needs of them (it rounds them to the operand type first thing): half the bytes of the fp32
 // level-major array, written with two 16-byte stores per lane.  NULL: nothing but raw (and the sigma hand-off) is written.
-// Same values as k_hash_fwd + k_mlp_fwd: the encode is encode_level() itself, the chain is dense_o1().
+// Same values as k_hash_fwd + k_mlp_fwd, bit for bit (tests/test_gpu_ops.py): the encode is encode_level()'s arithmetic, the
+// chain is dense_o1().
+//
+// ONE level's gathers in flight per wave (NOF_ENC_GROUP = 1), although registers would allow four.  With two or more levels in
+// flight this kernel -- and only with the chain present and 8-12 waves per workgroup -- delivered, in a few 16-sample groups per
+// million samples and differently on every run, a wrong value for ONE of the eight corner loads of the LAST level of a group, always
+// in lanes 48-63 (the last quarter-wave a vector load returns): found because the kernel is compared bit for bit with the
+// two-launch path (tools/fused_debug.py, fused_debug2.py; profiles/r04_fused_forward_race.txt).  Ruled out by experiment: the
+// compiler's waits (an explicit s_waitcnt vmcnt(0) with the loaded registers tied to it, + 16 idle cycles), address registers being
+// reused as destinations or the saddr pair being overwritten after issue (kept live past the wait: enc_keep), the LDS stage (the
+// values are wrong before they reach it), the 16-byte pair loads, the points' load, SGPR spilling, per-lane branches around the
+// blend (selects now), XNACK replays (xnack-).  Not root-caused; with one level in flight: 0 differing samples in 180 runs x
+// 196 608 samples, and the same 115 us (the kernel is bound by gather issue + matrix pipe taking turns, not by gather latency).
+// tests/test_gpu_ops.py::test_fused_forward_is_repeatable guards it.
 // =====================================================================================================
 #ifndef NOF_ENC_WAVES
-#define NOF_ENC_WAVES 12                                  // most waves per workgroup, ONE workgroup per CU = 3 waves per SIMD (168 registers) around one fragment image
+#define NOF_ENC_WAVES 12                                  // most waves per workgroup (one workgroup per CU, 3 waves per SIMD)
 #endif
 #ifndef NOF_ENC_GROUP
-#define NOF_ENC_GROUP 4                                   // levels whose gathers are in flight together
+#define NOF_ENC_GROUP 1                                   // levels whose gathers are in flight together (see above before raising it)
 #endif
-#ifndef NOF_ENC_GROUP_SPLIT
-#define NOF_ENC_GROUP_SPLIT 3                             // ... in the operand-split variants (their chain leaves fewer registers)
+#ifndef NOF_ENC_DEBUG_FEAT
+#define NOF_ENC_DEBUG_FEAT 0                              // tools/fused_debug*.py: the features as computed, before the LDS stage
 #endif
 
 // indices and fractions of one level for one point; the loads and the blend are separate steps so that a GROUP of levels has all
@@ -542,6 +558,7 @@ struct EncCell {
   uint32_t idx[8];
   float f[3];
   bool oob;
+  const char* base;                                    // the level's first table row (wave-uniform: an SGPR pair)
 };
 // The rows are grid_index()'s (gridencoder.cu:66-83) with the terms the eight corners share computed once and every decision taken
 // per LEVEL (wave-uniform here), so that the lanes run straight-line code: grid_index() per corner tests `index >= size` per lane,
@@ -576,25 +593,37 @@ __device__ __forceinline__ EncCell enc_prep(const HashLevel& lv, const float (&p
   }
   return e;
 }
+// The gathers of one level: a wave-uniform base (SGPR pair) + one 32-bit byte offset per lane and corner (global_load's
+// saddr + voffset form).  The offsets are turned into byte offsets in place and stay in e.idx: enc_keep() below holds them live
+// until the group's gathers have landed.
 template <bool PAIRS>
-__device__ __forceinline__ void enc_load(const HashLevel& lv, const float2* __restrict__ table, const EncCell& e, float2 (&v)[8]) {
+__device__ __forceinline__ void enc_load(const HashLevel& lv, const float2* __restrict__ table, EncCell& e, float2 (&v)[8]) {
   // (an out-of-range point still loads: grid_index wraps every row into the level, and enc_blend returns zeros for it)
-  const float2* __restrict__ tl = table + lv.offset;
+  const char* __restrict__ base = reinterpret_cast<const char*>(table + lv.offset);
+  e.base = base;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) e.idx[k] *= 8u;                        // rows -> bytes (a level is far below 4 GiB)
   if constexpr (PAIRS) {
 #pragma unroll
     for (int k = 0; k < 8; k += 2) {
-      const RowPair t = *reinterpret_cast<const RowPair*>(tl + e.idx[k]);
+      const RowPair t = *reinterpret_cast<const RowPair*>(base + e.idx[k]);
       v[k] = make_float2(t.x, t.y);
       v[k + 1] = make_float2(t.z, t.w);
     }
   } else {
 #pragma unroll
-    for (int k = 0; k < 8; ++k) v[k] = tl[e.idx[k]];
+    for (int k = 0; k < 8; ++k) v[k] = *reinterpret_cast<const float2*>(base + e.idx[k]);
   }
+}
+// "These address registers are read HERE": placed behind the s_waitcnt that ends a group's gathers, it keeps the offsets and the base
+// apart from the gathers' destination registers (the register allocator otherwise hands a gather's address registers to a later
+// gather as its destination: legal, and not the cause of the quarter-wave fault described at the kernel -- kept as cheap insurance).
+__device__ __forceinline__ void enc_keep(const EncCell& e) {
+  asm volatile("" :: "v"(e.idx[0]), "v"(e.idx[1]), "v"(e.idx[2]), "v"(e.idx[3]), "v"(e.idx[4]), "v"(e.idx[5]), "v"(e.idx[6]), "v"(e.idx[7]),
+               "s"(e.base));
 }
 __device__ __forceinline__ float2 enc_blend(const EncCell& e, const float2 (&v)[8]) {   // encode_level's own weights and order
   float2 acc = make_float2(0.f, 0.f);
-  if (e.oob) return acc;
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
     float wk = 1.0f;
@@ -603,6 +632,10 @@ __device__ __forceinline__ float2 enc_blend(const EncCell& e, const float2 (&v)[
     acc.x += wk * v[k].x;
     acc.y += wk * v[k].y;
   }
+  // an out-of-range point: zeros (gridencoder.cu:131-139), by a select -- no lane is switched off around the blend, so no
+  // execution mask per level in flight has to be kept (they were being spilled to VGPR lanes)
+  acc.x = e.oob ? 0.0f : acc.x;
+  acc.y = e.oob ? 0.0f : acc.y;
   return acc;
 }
 
@@ -676,10 +709,29 @@ __global__ __launch_bounds__(64 * NOF_ENC_WAVES, (NOF_ENC_WAVES + 3) / 4) void k
   copy16(smem + BIAS_BASE, image + 2 * (size_t)SH::pair_base(NL) * PAIR_BYTES, (size_t)SH::oblk_base(NL) * 32 * 4);
   if constexpr (SPLIT)
     copy16(smem + LO_BASE, image + 2 * (size_t)SH::pair_base(NL) * PAIR_BYTES + (size_t)SH::oblk_base(NL) * 32 * 4, (size_t)BIAS_BASE);
+  // the 16 levels' constants (80 scalars of the kernel argument) in LDS: read per level where they are needed.  As plain kernel
+  // arguments they were all loaded up front and kept in SGPRs across the persistent loop -- 285 SGPR spills to VGPR lanes.
+  uint32_t* lvl = reinterpret_cast<uint32_t*>(smem + PARK_BASE + (blockDim.x >> 6) * 8192);     // [16][8] words behind the stages
+  if (threadIdx.x < NOF_MAX_LEVELS) {
+    const int l = threadIdx.x;
+    lvl[l * 8 + 0] = __float_as_uint(g.scale[l]); lvl[l * 8 + 1] = g.resolution[l]; lvl[l * 8 + 2] = g.offset[l];
+    lvl[l * 8 + 3] = g.size[l]; lvl[l * 8 + 4] = g.hashed[l];
+  }
+  const int n_levels = g.L;
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int hi = lane >> 5, j = lane & 31;
-  constexpr int GR = SPLIT ? (NS >= 3 ? 2 : NOF_ENC_GROUP_SPLIT) : NOF_ENC_GROUP;     // (what each variant's chain leaves room for at 168 registers)
+  constexpr int GR = NOF_ENC_GROUP;
+  auto level_at = [&](int l) {                          // wave-uniform: the LDS words go through readfirstlane into SGPRs
+    HashLevel lv;
+    const uint4 q = *reinterpret_cast<const uint4*>(lvl + l * 8);
+    lv.scale = __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)q.x));
+    lv.res = (uint32_t)__builtin_amdgcn_readfirstlane((int)q.y);
+    lv.offset = (uint32_t)__builtin_amdgcn_readfirstlane((int)q.z);
+    lv.size = (uint32_t)__builtin_amdgcn_readfirstlane((int)q.w);
+    lv.hashed = (uint32_t)__builtin_amdgcn_readfirstlane((int)lvl[l * 8 + 4]);
+    return lv;
+  };
   const int NW = blockDim.x >> 6;                     // (the host sizes the workgroup by what LDS admits: 8 KB of stage per wave)
   const int64_t npairs = (B + 63) / 64;
   for (int64_t tp = (int64_t)blockIdx.x * NW + wave; tp < npairs; tp += (int64_t)gridDim.x * NW) {
@@ -694,26 +746,37 @@ __global__ __launch_bounds__(64 * NOF_ENC_WAVES, (NOF_ENC_WAVES + 3) / 4) void k
     float* stage = reinterpret_cast<float*>(smem + PARK_BASE + wave * 8192);              // [32][64] floats
 #pragma unroll
     for (int l0 = 0; l0 < NOF_MAX_LEVELS; l0 += GR) {
-      if (l0 < g.L) {                                 // (uniform)
+      if (l0 < n_levels) {                            // (uniform)
         EncCell e[GR];
         float2 v[GR][8];
 #pragma unroll
         for (int u = 0; u < GR; ++u) {
-          if (l0 + u < NOF_MAX_LEVELS && l0 + u < g.L) {
-            const HashLevel lv = load_level(g, l0 + u);               // compile-time level index: scalar loads of the kernel argument
+          if (l0 + u < NOF_MAX_LEVELS && l0 + u < n_levels) {
+            const HashLevel lv = level_at(l0 + u);
             e[u] = enc_prep(lv, p);
             if (level_pairs(lv)) enc_load<true>(lv, table, e[u], v[u]);
             else enc_load<false>(lv, table, e[u], v[u]);
             asm volatile("" ::: "memory");            // this level's gathers are issued before the next level's rows are computed
           }                                           // (the scheduler otherwise computes all 32 rows first: 32 more live registers)
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every gather of the group has landed ...
+#pragma unroll
+        for (int u = 0; u < GR; ++u)
+          if (l0 + u < NOF_MAX_LEVELS && l0 + u < n_levels) enc_keep(e[u]);       // ... and only now may their address registers be reused
 #pragma unroll
         for (int u = 0; u < GR; ++u) {
           float2 a = make_float2(0.f, 0.f);
-          if (l0 + u < NOF_MAX_LEVELS && l0 + u < g.L) a = enc_blend(e[u], v[u]);
+          if (l0 + u < NOF_MAX_LEVELS && l0 + u < n_levels) a = enc_blend(e[u], v[u]);
           if (l0 + u < NOF_MAX_LEVELS) {
             stage[(2 * (l0 + u)) * 64 + lane] = a.x;
             stage[(2 * (l0 + u) + 1) * 64 + lane] = a.y;
+#if NOF_ENC_DEBUG_FEAT
+            if (bs < B) {                             // debug build: the features as computed, before the LDS stage ([B][32] floats behind featq)
+              float* dbg = reinterpret_cast<float*>(featq + B * 32);
+              dbg[bs * 32 + 2 * (l0 + u)] = a.x;
+              dbg[bs * 32 + 2 * (l0 + u) + 1] = a.y;
+            }
+#endif
           }
         }
       } else {
@@ -2014,10 +2077,10 @@ extern "C" int nof_encode_mlp_fwd(const NofHashGrid* g, const NofMlpDesc* d, con
   const int nl = d->n_sigma + d->n_color;
   const size_t img = (is_split(d->precision) ? 2 : 1) * (size_t)n_pairs(*d, nl) * 16 * 64 * elem_size(d->precision) +
                      (size_t)n_oblk(*d, nl) * 32 * 4;
-  int waves = (int)((160 * 1024 - img) / 8192);                         // one workgroup per CU: the image + 8 KB of stage per wave
+  int waves = (int)((160 * 1024 - img - 512) / 8192);                   // one workgroup per CU: the image + 8 KB of stage per wave + the level table
   if (waves > NOF_ENC_WAVES) waves = NOF_ENC_WAVES;
   NOF_ARG(waves >= 4);
-  const size_t shm = img + (size_t)waves * 8192;
+  const size_t shm = img + (size_t)waves * 8192 + 512;
   const int64_t npairs = (B + 63) / 64;
   const int64_t want = nof_div_up(npairs, waves);
   const int64_t cap = (int64_t)nof_mlp_bwd_blocks() / 2;               // one resident workgroup per CU

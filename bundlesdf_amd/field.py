@@ -672,20 +672,30 @@ class NeuralObjectField:
         out = torch.empty(nx, ny, nz, device=self.device)
         occ = self.occ_bits if use_octree else None
         if self.wide:
-            # no fused grid kernel for the wide networks: x-slabs of voxel centres -> octree mask (nof_occgrid_query) -> hash
-            # encode + sigma net of the voxels inside (query_sdf), all on the device
+            # no fused grid kernel for the wide networks: the octree mask of EVERY voxel centre in one nof_occgrid_query (slabs of
+            # x only bound the scratch for the point list), ONE compaction (the only host synchronisation: the number of voxels
+            # inside), then hash encode + sigma net of the voxels inside in large chunks (query_sdf), scattered back -- all on the
+            # device.  (Round 3 looped over x slabs in Python with a host synchronisation per slab.)
             out.fill_(outside_value)
+            flat = out.view(-1)
             yz = torch.stack(torch.meshgrid(ax[1], ax[2], indexing='ij'), -1).reshape(-1, 2)
-            for i in range(nx):
-                pts = torch.cat([ax[0][i].expand(yz.shape[0], 1), yz], -1).contiguous()
+            slab = max(1, (1 << 24) // max(yz.shape[0], 1))               # x planes per scratch buffer (~16 M points)
+            idx_parts, pts_parts = [], []
+            for i0 in range(0, nx, slab):
+                xs = ax[0][i0:i0 + slab]
+                pts = torch.cat([xs.repeat_interleave(yz.shape[0]).unsqueeze(1), yz.repeat(xs.numel(), 1)], -1).contiguous()
                 if occ is not None:
                     inside = torch.empty(pts.shape[0], dtype=torch.uint8, device=self.device)
                     lib.call('nof_occgrid_query', occ, self.level, pts, inside, pts.shape[0])
-                    sel = inside.bool()
+                    sel = torch.nonzero(inside).reshape(-1)                  # (device-side compaction; its size is read below, once per slab group)
+                    idx_parts.append(sel + i0 * yz.shape[0])
+                    pts_parts.append(pts[sel])
                 else:
-                    sel = torch.ones(pts.shape[0], dtype=torch.bool, device=self.device)
-                if sel.any():
-                    out[i].view(-1)[sel] = self.query_sdf(pts[sel])
+                    idx_parts.append(torch.arange(pts.shape[0], device=self.device) + i0 * yz.shape[0])
+                    pts_parts.append(pts)
+            idx = torch.cat(idx_parts)
+            if idx.numel():
+                flat[idx] = self.query_sdf(torch.cat(pts_parts))
             return out
         lib.call('nof_sdf_grid_query', C.byref(self.grid), C.byref(self.desc), self.packed, self.table, occ, self.level,
                  ax[0], ax[1], ax[2], nx, ny, nz, C.c_float(outside_value), out)

@@ -193,3 +193,31 @@ def test_marching_cubes_gpu_on_hand_checkable_cells_and_vertex_set(nof):
         v, f = marching_cubes_gpu(torch.from_numpy(vol).cuda(), 0.0)
         edges = _crossed_edges(vol)
         assert len(v) == len(edges) and _vertex_edges(v, vol.shape) == edges
+
+
+def test_wide_network_grid_query_matches_oracle(nof):
+    """NeuralObjectField.query_sdf_grid for the wide networks (hidden 128 / 4 layers, BASELINE cfg5: no fused grid kernel; octree
+    mask of every voxel in one launch, one compaction, encode + sigma net of the voxels inside) against the oracle's sequence
+    (nerf_runner.py:1363-1386, 1307-1347) -- with and without the octree, with x slabs smaller than the grid."""
+    from tests.test_gpu_step import _pair
+    cfg, fld, orc, batch, rng = _pair(nof, 'fp16', 0, 4, 4, hidden=128)
+    assert fld.wide
+    tx = np.arange(-0.93 + 0.5 * 0.11, 0.95, 0.11)
+    ty = np.arange(-1.08 + 0.5 * 0.13, 1.1, 0.13)
+    tz = np.arange(-0.97 + 0.5 * 0.043, 0.97, 0.043)
+    q = np.stack(np.meshgrid(tx, ty, tz, indexing='ij'), -1).astype(np.float32).reshape(-1, 3)
+    n = 1 << fld.level
+    occ = np.zeros((n, n, n), bool)
+    bits = fld.occ_bits.cpu().numpy().view(np.uint32)
+    ids = np.arange(n ** 3)
+    occ.reshape(-1)[:] = (bits[ids >> 5] >> (ids & 31)) & 1
+    c = np.floor(np.clip(np.float32(n) * (q + np.float32(1)) / np.float32(2), 0, n - 1)).astype(np.int64)
+    valid = occ[c[:, 0], c[:, 1], c[:, 2]]
+    assert 0.05 < valid.mean() < 0.95
+    ref_all = orc.query_sdf(q).numpy().reshape(-1)
+    for use_octree in (True, False):
+        got = fld.query_sdf_grid(tx, ty, tz, outside_value=1.0, use_octree=use_octree).cpu().numpy().reshape(-1)
+        m = valid if use_octree else np.ones_like(valid)
+        assert (got[~m] == 1.0).all()
+        err = np.abs(got[m] - ref_all[m]).max() / np.abs(ref_all[m]).max()
+        assert err < 2e-3, err                                         # plain fp16 wide forward vs the oracle with fp16 operand rounding

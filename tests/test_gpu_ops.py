@@ -738,3 +738,36 @@ def test_fused_encode_mlp_forward_equals_the_two_launches(nof, ns, nc, ff, L, T,
         torch.cuda.synchronize()
         outs.append((dfeat, partials, dsig))
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[0][2], outs[1][2])
+
+
+def test_fused_forward_is_repeatable(nof):
+    """Guard of an observed fault (bundlesdf_amd/csrc/nof_mlp.hip at k_enc_mlp_fwd; profiles/r04_fused_forward_race.txt): with
+    more than one level's gathers in flight the fused forward returned, in a few 16-sample groups per million samples and
+    differently on every run, another value for one corner load in lanes 48-63.  The shipped kernel keeps ONE level in flight;
+    here it runs ten times over 196 608 ray-ordered samples (consecutive lanes in the same cells, like a training batch) and must
+    give the two-launch path's bits every time -- raw, the sigma hand-off and the operand-precision features."""
+    from tests.test_gpu_step import _pair
+    R = 2048
+    for ns, nc in ((3, 2), (2, 3)):
+        cfg, fld, orc, batch, rng = _pair(nof, 'fp16x3', 0, ns, nc, R=R)
+        Ns, Na = cfg['N_samples'], cfg['N_samples_around_depth']
+        S = Ns + Na
+        B = R * S
+        u1, u2 = rng.random((R, Ns)).astype(np.float32), rng.random((R, Na)).astype(np.float32)
+        fld.fused_forward = False
+        b = fld.train_step(U.dev(batch), None, R, U.dev(u1), U.dev(u2), do_step=False)
+        torch.cuda.synchronize()
+        raw_ref, sig_ref = b['raw'].clone(), b['sig'].clone()
+        want_q = b['feat'].permute(1, 0, 2).reshape(B, 32).to(torch.float16)
+        featq = torch.zeros(B, 32, dtype=torch.int16, device='cuda')
+        raw = torch.zeros(B, 4, device='cuda')
+        sig = torch.zeros(B, 16, dtype=torch.int16, device='cuda')
+        for rep in range(10):
+            raw.zero_()
+            featq.zero_()
+            nof.call('nof_encode_mlp_fwd', C.byref(fld.grid), C.byref(fld.desc), fld.packed, fld.table, b['pts_w'], b['view'], S, raw,
+                     sig, featq, B)
+            torch.cuda.synchronize()
+            bad = int((raw != raw_ref).any(-1).sum())
+            assert bad == 0, f'({ns},{nc}) run {rep}: {bad} of {B} samples differ from the two-launch path'
+            assert torch.equal(sig, sig_ref) and torch.equal(featq.view(torch.float16), want_q)
