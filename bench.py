@@ -173,22 +173,58 @@ def self_launch(args):
 
 
 def extra_configs():
-    """BASELINE.json configs[4] (cfg5: 1280x720, T = 2^22, MLP 4x128 + 4x128, fp16, 16 384 rays per step) as a sub-record of the
-    one line, so that the driver's run carries it: a short run of this same script in a child process (16 keyframes: the step
-    does not depend on how many rows the ray table has; building 64 frames of 1280x720 would take longer than the run)."""
+    """Sub-records of the one line, so that the driver's run carries the other single-GPU BASELINE.json configurations: short runs
+    of this same script in child processes (16 keyframes: a step does not depend on how many rows the ray table has).
+      cfg4  configs[3]: 8192 rays per step, finest 512 + the 512^3 dense extraction (query + device marching cubes)
+      cfg5  configs[4]: 1280x720 frames, T = 2^22, MLP 4x128 + 4x128, fp16, 16 384 rays per step"""
     import subprocess
-    cmd = [sys.executable, os.path.abspath(__file__), '--mlp', 'cfg5', '--rays', '16384', '--log2_T', '22', '--finest', '512',
-           '--width', '1280', '--height', '720', '--precision', 'fp16', '--keyframes', '16', '--steps', '20', '--warmup', '10',
-           '--settle', '0', '--round-steps', '0', '--no-cpu-baseline', '--no-extra-configs']
-    try:
-        r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
-        d = json.loads(r.stdout.strip().splitlines()[-1])
-        keep = ('value', 'unit', 'ms_per_step', 'steps', 'warmup', 'dtype', 'ms_per_step_dense_backward', 'zero_grad_sample_fraction',
-                'train_iters_per_sec', 'loss', 'flags', 'step_ms_spread')
-        return [{"name": "cfg5", **{k: d.get(k) for k in keep}, "workload": d['config']['workload'].split(';')[0],
-                 "roofline": {k: d['roofline'].get(k) for k in ('kernel', 'bound', 'frac', 'avg_ms')} if d.get('roofline') else None}]
-    except Exception as ex:                       # a sub-record must never cost the main line
-        return [{"name": "cfg5", "error": repr(ex)[:300]}]
+    common = ['--keyframes', '16', '--steps', '20', '--warmup', '10', '--settle', '0', '--round-steps', '0', '--no-cpu-baseline',
+              '--no-extra-configs']
+    runs = [('cfg4', ['--rays', '8192', '--finest', '512', '--extract', '512']),
+            ('cfg5', ['--mlp', 'cfg5', '--rays', '16384', '--log2_T', '22', '--finest', '512', '--width', '1280', '--height', '720',
+                      '--precision', 'fp16'])]
+    keep = ('value', 'unit', 'ms_per_step', 'steps', 'warmup', 'dtype', 'ms_per_step_dense_backward', 'zero_grad_sample_fraction',
+            'train_iters_per_sec', 'loss', 'flags', 'step_ms_spread', 'extraction')
+    out = []
+    for name, extra in runs:
+        try:
+            r = subprocess.run([sys.executable, os.path.abspath(__file__)] + extra + common, capture_output=True, text=True, timeout=600)
+            d = json.loads(r.stdout.strip().splitlines()[-1])
+            out.append({"name": name, **{k: d.get(k) for k in keep if k in d}, "workload": d['config']['workload'].split(';')[0],
+                        "roofline": {k: d['roofline'].get(k) for k in ('kernel', 'bound', 'frac', 'avg_ms')} if d.get('roofline') else None})
+        except Exception as ex:                       # a sub-record must never cost the main line
+            out.append({"name": name, "error": repr(ex)[:300]})
+    return out
+
+
+def time_extraction(runner, n):
+    """BASELINE cfg4's renderer half: the dense SDF query of an n^3 grid over the bounding box (octree-masked, fused encode + sigma
+    net) and the device iso-surface extraction (marching cubes), on the field as trained so far; a few hundred more steps first
+    if no surface exists yet."""
+    import time as _t
+    from bundlesdf_amd.mesh_gpu import marching_cubes_gpu
+    fld = runner.field
+    bounds = np.array(runner.cfg['bounding_box']).reshape(2, 3)
+    axes = [np.linspace(bounds[0, d], bounds[1, d], n + 1)[:-1] + 0.5 * (bounds[1, d] - bounds[0, d]) / n for d in range(3)]
+    rec = None
+    for attempt in range(3):
+        try:
+            for rep in range(2):
+                torch.cuda.synchronize(); t0 = _t.perf_counter()
+                vol = fld.query_sdf_grid(*axes)
+                torch.cuda.synchronize(); t1 = _t.perf_counter()
+                v, f = marching_cubes_gpu(vol, 0.0)
+                t2 = _t.perf_counter()
+            occ = float((vol != 1.0).float().mean().item())
+            rec = {"grid": n, "voxels": n ** 3, "octree_fraction": round(occ, 4), "query_ms": round((t1 - t0) * 1e3, 3),
+                   "marching_cubes_ms_incl_d2h": round((t2 - t1) * 1e3, 3), "vertices": int(len(v)), "triangles": int(len(f)),
+                   "trained_steps": int(fld.global_step)}
+            break
+        except ValueError:                            # no level set yet: train on
+            for _ in range(200):
+                runner.train_loop()
+                runner.global_step += 1
+    return rec or {"grid": n, "error": "no iso-surface after training"}
 
 
 ATOMIC_PEAK_G = 20.8        # G line requests/s: tools/atomic_probe.py on MI355X (profiles/r02_d_atomic_probe.txt)
@@ -236,8 +272,10 @@ def main():
     ap.add_argument('--finest', type=int, default=256, help='finest hash resolution (256: cfg1-3; 512: cfg4/5)')
     ap.add_argument('--settle', type=int, default=200, help='steps into the run at which the K steps are timed AGAIN for ms_per_step_settled (the zero-gradient fraction has settled by then); 0: skip.  `value` is always the K steps right after the W warm-up steps')
     ap.add_argument('--round-steps', type=int, default=501, help='steps of the whole-round measurement from a fresh field (the reference\'s N_iters = n_step + 1 = 501); 0: skip')
+    ap.add_argument('--preroll', type=int, default=300, help='forward-only batches before the warm-up (clock ramp, host code paths; no training state is touched); 0: none')
     ap.add_argument('--unfused', action='store_true', help='training forward as nof_hash_encode_fwd + nof_mlp_fwd (fp32 embedding in HBM) instead of the fused nof_encode_mlp_fwd')
-    ap.add_argument('--no-extra-configs', action='store_true', help='skip the BASELINE cfg5 sub-record (N = 1 default run only)')
+    ap.add_argument('--no-extra-configs', action='store_true', help='skip the BASELINE cfg4 / cfg5 sub-records (N = 1 default run only)')
+    ap.add_argument('--extract', type=int, default=0, help='after the timed steps: time the dense SDF query + marching cubes of an N^3 grid (BASELINE cfg4: 512)')
     ap.add_argument('--scatter-wgs', type=int, default=0, help='persistent workgroups per CU of the table scatter (0 = library default)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-seconds', type=float, default=25.0)
@@ -285,6 +323,16 @@ def main():
         runner.train_loop()
         runner.global_step += 1
 
+    # ---- pre-roll: forward-only batches (NerfRunner.render_images' path: trace, unperturbed sampling, encode, MLPs, compositing) --
+    # No parameter, optimiser, loader or random-number state is touched, so the W warm-up and K timed steps below are still the
+    # first W + K steps of a fresh field -- but they run on a GPU whose clocks have ramped and through host code that has executed
+    # once (with the driver's 5 warm-up steps = 2.5 ms of device work alone, the 20 timed steps measured 0.52 ms where the same
+    # steps a moment later take 0.44: profiles/r04_f_bench_driver_invocation.json).
+    if args.preroll > 0:
+        ids0 = torch.arange(R, device=device) % runner.rays.shape[0]
+        for _ in range(args.preroll):
+            fld.render_batch(runner.rays, ids0, R)
+        torch.cuda.synchronize()
     # ---- warm-up with every launch bracketed by events: finds the dominant kernel --------------------------------
     fld.profile = {}
     sync = runner.grad_sync if hasattr(runner.grad_sync, 'finish') else None
@@ -388,6 +436,7 @@ def main():
             log(f'captured-step mode: {graph_ms:.3f} ms/step')
         runner.cfg['hip_graph'] = False
         runner._graph = None
+    extraction = time_extraction(runner, args.extract) if args.extract > 0 and world == 1 else None
     flags = int(fld.flags[0].item())
     losses = fld.losses()
     dp_spread, checksum = None, float(fld.params.double().abs().sum().item())
@@ -512,6 +561,10 @@ def main():
         cfg_name = {(64, 4096, 19, 'baseline', 640, 480): 'cfg2' if world == 1 else 'cfg3',
                     (4, 1024, 14, 'reference', 640, 480): 'cfg1 shapes',
                     (64, 16384, 22, 'cfg5', 1280, 720): 'cfg5 (per GPU)'}.get(shape_key, 'custom')
+        if R == 8192 and args.finest == 512 and args.mlp == 'baseline':
+            cfg_name = 'cfg4 shapes'
+        elif args.mlp == 'cfg5' and R == 16384 and args.log2_T == 22:
+            cfg_name = 'cfg5 shapes'  if args.keyframes != 64 else cfg_name
         out = {
             "metric": "ray_samples_per_sec", "value": value, "unit": "ray-samples/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -524,13 +577,16 @@ def main():
                                    f"the forward and the loss, the backward runs over the work list of the 32-sample tiles that hold a "
                                    f"non-zero loss gradient (the others add exactly nothing: same sums; fraction of zero samples in "
                                    f"zero_grad_sample_fraction, the step with every tile listed in ms_per_step_dense_backward); "
-                                   f"`value` = the {args.steps} steps right after the {args.warmup} warm-up steps of a fresh field; the "
+                                   f"`value` = the {args.steps} steps right after the {args.warmup} warm-up steps of a fresh field "
+                                   f"(preceded by {args.preroll} forward-only batches that touch no training state: clock ramp); the "
                                    f"same steps later in the run: ms_per_step_settled; a whole {args.round_steps}-step reference "
                                    f"round from a fresh field: round_ms_per_step",
                        "rays_per_step": R, "samples_per_ray": S, "keyframes_per_gpu": args.keyframes,
                        "pool_rays": int(runner.rays.shape[0]), "parallelism": f"dp{world}",
                        "forward": "fused encode+MLP (nof_encode_mlp_fwd)" if fld.fused_forward else "nof_hash_encode_fwd + nof_mlp_fwd"},
             "train_iters_per_sec": it_s * 1.0, "captured_step_ms_per_step": graph_ms,
+            # forward-only batches run before the warm-up steps (no parameter / optimiser / loader / RNG state touched)
+            "preroll_forward_batches": args.preroll,
             # device-side duration of single steps (K more steps, one event after each): p10 / p50 / p90
             "step_ms_spread": spread,
             # the reference's unit of work: one round = N_iters steps from a fresh field (config.yml:2); mean over the whole round
@@ -555,6 +611,8 @@ def main():
             "exposed_comm_ms": exposed_comm_ms, "dp_payload": getattr(sync, 'payload', None), "dp_mode": dp_mode,
             "roofline": roof,
         }
+        if extraction is not None:
+            out["extraction"] = extraction
         default_workload = shape_key == (64, 4096, 19, 'baseline', 640, 480)
         if world == 1 and default_workload and not args.no_extra_configs and not dist.is_initialized():
             out["extra_configs"] = extra_configs()

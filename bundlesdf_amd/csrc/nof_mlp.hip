@@ -615,7 +615,7 @@ __device__ __forceinline__ void enc_load(const HashLevel& lv, const float2* __re
     for (int k = 0; k < 8; ++k) v[k] = *reinterpret_cast<const float2*>(base + e.idx[k]);
   }
 }
-// "These address registers are read HERE": placed behind the s_waitcnt that ends a group's gathers, it keeps the offsets and the base
+// "These address registers are read HERE": placed behind a group's gathers, it keeps the offsets and the base
 // apart from the gathers' destination registers (the register allocator otherwise hands a gather's address registers to a later
 // gather as its destination: legal, and not the cause of the quarter-wave fault described at the kernel -- kept as cheap insurance).
 __device__ __forceinline__ void enc_keep(const EncCell& e) {
@@ -759,10 +759,9 @@ __global__ __launch_bounds__(64 * NOF_ENC_WAVES, (NOF_ENC_WAVES + 3) / 4) void k
             asm volatile("" ::: "memory");            // this level's gathers are issued before the next level's rows are computed
           }                                           // (the scheduler otherwise computes all 32 rows first: 32 more live registers)
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every gather of the group has landed ...
 #pragma unroll
         for (int u = 0; u < GR; ++u)
-          if (l0 + u < NOF_MAX_LEVELS && l0 + u < n_levels) enc_keep(e[u]);       // ... and only now may their address registers be reused
+          if (l0 + u < NOF_MAX_LEVELS && l0 + u < n_levels) enc_keep(e[u]);       // (the gathers' address registers stay apart from their destinations)
 #pragma unroll
         for (int u = 0; u < GR; ++u) {
           float2 a = make_float2(0.f, 0.f);
