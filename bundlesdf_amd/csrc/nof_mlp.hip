@@ -548,6 +548,9 @@ NofMlpDesc d, const char* __restrict__ image,
 #ifndef NOF_ENC_GROUP
 #define NOF_ENC_GROUP 1                                   // levels whose gathers are in flight together (see above before raising it)
 #endif
+#ifndef NOF_ENC_ROLLED
+#define NOF_ENC_ROLLED 1
+#endif
 #ifndef NOF_ENC_DEBUG_FEAT
 #define NOF_ENC_DEBUG_FEAT 0                              // tools/fused_debug*.py: the features as computed, before the LDS stage
 #endif
@@ -744,7 +747,11 @@ __global__ __launch_bounds__(64 * NOF_ENC_WAVES, (NOF_ENC_WAVES + 3) / 4) void k
     const int64_t bb = bs < B ? bs : B - 1;           // (a lane past the end encodes the last sample: nothing of it is stored)
     const float p[3] = {pts_w[bb * 3], pts_w[bb * 3 + 1], pts_w[bb * 3 + 2]};
     float* stage = reinterpret_cast<float*>(smem + PARK_BASE + wave * 8192);              // [32][64] floats
+#if NOF_ENC_ROLLED
+#pragma unroll 1                                      // one copy of the level body: the unrolled kernel is 76 KB of code (> the 64 KB instruction cache)
+#else
 #pragma unroll
+#endif
     for (int l0 = 0; l0 < NOF_MAX_LEVELS; l0 += GR) {
       if (l0 < n_levels) {                            // (uniform)
         EncCell e[GR];

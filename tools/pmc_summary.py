@@ -4,7 +4,7 @@ for d in sys.argv[1:]:
     for db in glob.glob(os.path.join(d, '**', '*.db'), recursive=True):
         con = sqlite3.connect(db)
         rows = con.execute("select name, counter_name, count(*), avg(counter_value), avg(duration) from pmc_events "
-                           "where name like '%k_%' and name not like '%at::native%' group by name, counter_name "
+                           "where (name like '%k_%' or name like '%copy%' or name like '%Copy%') group by name, counter_name "
                            "order by avg(duration) desc").fetchall()
         print(f'== {db}')
         print(f"{'kernel':56s} {'counter':26s} {'n':>4s} {'avg_value':>16s} {'avg_us':>9s}")

@@ -18,7 +18,7 @@ fetch, write = per_kernel('pmc_fetch', 'FETCH_SIZE'), per_kernel('pmc_write', 'W
 # (keys = the tags NeuralObjectField._call times its launches under: what bench.py names as the dominant entry)
 groups = {'hash_bwd[table+table_lds]': ['k_hash_bwd_agg', 'k_hash_bwd_lds'], 'hash_bwd[input]': ['k_hash_dx'],
           'nof_hash_encode_fwd': ['k_hash_fwd'], 'nof_mlp_bwd_tiles': ['k_mlp_bwd_color<', 'k_mlp_bwd_sigma<'],
-          'nof_mlp_fwd': ['k_mlp_fwd<'], 'nof_adam_step': ['k_adam']}
+          'nof_mlp_fwd': ['k_mlp_fwd<'], 'nof_encode_mlp_fwd': ['k_enc_mlp_fwd<'], 'nof_adam_step': ['k_adam']}
 
 
 def total(table, prefixes):
