@@ -135,6 +135,132 @@ __global__ __launch_bounds__(64) void k_composite_loss(NofLossCfg c, const float
   }
 }
 
+// The same with the ray's samples held in registers (S <= 64 * NS, NS <= 4: the reference's 128 + 64 samples are three per lane):
+// ONE round trip to memory instead of three dependent passes over z / valid / raw -- the launch is latency-bound (4096 waves, a
+// few hundred bytes each) -- and four rays per workgroup.  Element arithmetic and summation order are those of the loop form above
+// (per lane s = lane, lane + 64, ...; then the wave reduction), so both give the same bits.
+template <int NS>
+__global__ __launch_bounds__(256) void k_composite_loss_reg(NofLossCfg c, const float4* __restrict__ raw,
+                                                             const float* __restrict__ z_vals, const uint8_t* __restrict__ valid,
+                                                             const float* __restrict__ batch, int64_t R, int S,
+                                                             float* __restrict__ rgb_map, float* __restrict__ weights,
+                                                             float4* __restrict__ draw, float* __restrict__ loss_rows,
+                                                             uint8_t* __restrict__ tile_flags) {
+  const int lane = threadIdx.x & 63;
+  const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= R) return;                                                    // (wave-uniform)
+  const int64_t base = r * S;
+  float z[NS], w[NS];
+  bool in[NS], v[NS];
+  float4 q[NS];
+#pragma unroll
+  for (int k = 0; k < NS; ++k) {
+    const int s = lane + 64 * k;
+    in[k] = s < S;
+    z[k] = in[k] ? z_vals[base + s] : 0.0f;
+    v[k] = in[k] && valid[base + s] != 0;
+    q[k] = in[k] ? raw[base + s] : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  const float* row = batch + r * NOF_RAY_COLS;
+  const float gt[3] = {row[3], row[4], row[5]};
+  const float depth = row[6];
+  const bool first = row[8] == 0.0f;
+  const bool type1 = row[9] == 1.0f;
+  const bool type0 = row[9] == 0.0f;
+  const bool invalid = depth > c.far_sc;
+
+  float wsum = 0.0f, nvalid = 0.0f;
+#pragma unroll
+  for (int k = 0; k < NS; ++k) {
+    w[k] = in[k] ? depth_weight(c, depth, z[k], invalid) : 0.0f;
+    if (in[k]) {
+      wsum += w[k];
+      nvalid += v[k] ? 1.0f : 0.0f;
+    }
+  }
+  wsum = wave_sum(wsum);
+  nvalid = wave_sum(nvalid);
+  const float denom = wsum + 1e-10f;
+
+  float m0 = 0.f, m1 = 0.f, m2 = 0.f;
+  float c0[NS], c1[NS], c2[NS];
+#pragma unroll
+  for (int k = 0; k < NS; ++k) {
+    w[k] = v[k] ? w[k] / denom : 0.0f;                                  // nerf_runner.py:1166
+    c0[k] = sigmoidf_(q[k].x); c1[k] = sigmoidf_(q[k].y); c2[k] = sigmoidf_(q[k].z);
+    if (in[k]) {
+      if (weights) weights[base + lane + 64 * k] = w[k];
+      m0 += w[k] * c0[k];
+      m1 += w[k] * c1[k];
+      m2 += w[k] * c2[k];
+    }
+  }
+  m0 = wave_sum(m0); m1 = wave_sum(m1); m2 = wave_sum(m2);
+  const bool valid_ray = (nvalid > 0.0f) && type0;                     // nerf_runner.py:693
+  const float ray_w = valid_ray ? (first ? c.first_frame_weight : 1.0f) : 0.0f;
+  if (lane == 0) { rgb_map[r * 3] = m0; rgb_map[r * 3 + 1] = m1; rgb_map[r * 3 + 2] = m2; }
+  const float e0 = m0 - gt[0], e1 = m1 - gt[1], e2 = m2 - gt[2];
+  const float inv3R = 1.0f / (3.0f * (float)R);
+  const float invRS = 1.0f / ((float)R * (float)S);
+  const float k_rgb = 2.0f * ray_w * c.rgb_weight * inv3R;
+  const float dm0 = k_rgb * e0, dm1 = k_rgb * e1, dm2 = k_rgb * e2;
+
+  float l_fs = 0.f, l_empty = 0.f, l_sdf = 0.f, l_fsrgb = 0.f;
+  const bool valid_depth = (depth >= c.near_sc) && (depth <= c.far_sc);
+#pragma unroll
+  for (int k = 0; k < NS; ++k) {
+    const float sdf = q[k].w;
+    const float sw = (v[k] && !type1) ? ray_w : 0.0f;                   // nerf_runner.py:699,723
+    float4 g;
+    g.x = dm0 * w[k] * c0[k] * (1.0f - c0[k]);
+    g.y = dm1 * w[k] * c1[k] * (1.0f - c1[k]);
+    g.z = dm2 * w[k] * c2[k] * (1.0f - c2[k]);
+    float gs = 0.0f;
+    const bool front = z[k] < depth - c.trunc;
+    const bool back = z[k] > depth + c.trunc * c.neg_trunc_ratio;
+    if (in[k] && invalid && sdf < c.fs_sdf) {                            // nerf_helpers.py:387-389
+      const float d = sdf - c.fs_sdf;
+      l_fs += d * d * sw;
+      gs += 2.0f * d * sw * 0.5f * c.fs_weight * invRS;
+    }
+    if (in[k] && front && !invalid && sdf < 1.0f) {                      // nerf_helpers.py:391-392
+      l_empty += fabsf(sdf - 1.0f) * sw;
+      gs += -sw * c.empty_weight * c.fs_weight * invRS;
+    }
+    if (in[k] && !front && !back && valid_depth) {                       // nerf_helpers.py:372,395
+      const float d = (z[k] + sdf * c.trunc) - depth;
+      l_sdf += d * d * sw;
+      gs += 2.0f * d * c.trunc * sw * 0.5f * c.trunc_weight * invRS;
+    }
+    if (in[k] && c.fs_rgb_weight > 0.0f && front) {                      // nerf_runner.py:730-732
+      const float kk = 2.0f * sw * c.fs_rgb_weight * invRS / 3.0f;
+      l_fsrgb += ((c0[k] - 1.0f) * (c0[k] - 1.0f) + (c1[k] - 1.0f) * (c1[k] - 1.0f) + (c2[k] - 1.0f) * (c2[k] - 1.0f)) * sw;
+      g.x += kk * (c0[k] - 1.0f) * c0[k] * (1.0f - c0[k]);
+      g.y += kk * (c1[k] - 1.0f) * c1[k] * (1.0f - c1[k]);
+      g.z += kk * (c2[k] - 1.0f) * c2[k] * (1.0f - c2[k]);
+    }
+    g.w = gs;
+    g.x *= c.grad_scale; g.y *= c.grad_scale; g.z *= c.grad_scale; g.w *= c.grad_scale;
+    if (in[k]) draw[base + lane + 64 * k] = g;
+    if (tile_flags != nullptr) {                                         // (S % 32 == 0; see the loop form)
+      const unsigned long long nz = __ballot(in[k] && (g.x != 0.0f || g.y != 0.0f || g.z != 0.0f || g.w != 0.0f));
+      const int64_t t0 = (base + 64 * k) >> 5;
+      if (lane == 0 && in[k]) tile_flags[t0] = (uint32_t)nz != 0u ? 1 : 0;
+      if (lane == 32 && in[k]) tile_flags[t0 + 1] = (uint32_t)(nz >> 32) != 0u ? 1 : 0;
+    }
+  }
+  l_fs = wave_sum(l_fs); l_empty = wave_sum(l_empty); l_sdf = wave_sum(l_sdf); l_fsrgb = wave_sum(l_fsrgb);
+  if (lane == 0 && loss_rows) {
+    const float rgb_loss = c.rgb_weight * (e0 * e0 + e1 * e1 + e2 * e2) * ray_w * inv3R;
+    const float fs_loss = c.fs_weight * (0.5f * l_fs + c.empty_weight * l_empty) * invRS;
+    const float sdf_loss = c.trunc_weight * 0.5f * l_sdf * invRS;
+    const float fsrgb = c.fs_rgb_weight * l_fsrgb * invRS / 3.0f;
+    float4* out = (float4*)(loss_rows + r * 8);
+    out[0] = make_float4(rgb_loss + fs_loss + sdf_loss + fsrgb, rgb_loss, fs_loss, sdf_loss);
+    out[1] = make_float4(fsrgb, nvalid, valid_ray ? 1.0f : 0.0f, 0.0f);
+  }
+}
+
 // ---- work list of the backward (include/nof_hip.h: NofTileList) --------------------------------------------------------------
 // flags of a batch whose S is not a multiple of 32 (tiles straddle rays): one wave per 64 samples = two tiles, straight from draw
 __global__ __launch_bounds__(256) void k_tile_flags(const float4* __restrict__ draw, int64_t B, uint8_t* __restrict__ tile_flags) {
@@ -273,9 +399,19 @@ static int composite_loss(const NofLossCfg* cfg, const float* raw, const float* 
   uint32_t* tiles = head ? head + 4 : nullptr;
   uint8_t* flags = head ? (uint8_t*)(head + nof_tile_list_words(nt)) : nullptr;
   const bool fused_flags = flags != nullptr && S % 32 == 0;
-  hipLaunchKernelGGL(k_composite_loss, dim3((unsigned)R), dim3(64), 0, (hipStream_t)stream, *cfg, (const float4*)raw,
-                     z_vals, valid, batch, R, S, rgb_map, weights, (float4*)draw, loss_out ? loss_rows : nullptr,
-                     fused_flags ? flags : nullptr);
+#define NOF_COMPOSITE_REG(NS)                                                                                                   \
+  hipLaunchKernelGGL(k_composite_loss_reg<NS>, dim3((unsigned)nof_div_up(R, 4)), dim3(256), 0, (hipStream_t)stream, *cfg,        \
+                     (const float4*)raw, z_vals, valid, batch, R, S, rgb_map, weights, (float4*)draw,                            \
+                     loss_out ? loss_rows : nullptr, fused_flags ? flags : nullptr)
+  if (S <= 64) NOF_COMPOSITE_REG(1);
+  else if (S <= 128) NOF_COMPOSITE_REG(2);
+  else if (S <= 192) NOF_COMPOSITE_REG(3);
+  else if (S <= 256) NOF_COMPOSITE_REG(4);
+  else
+    hipLaunchKernelGGL(k_composite_loss, dim3((unsigned)R), dim3(64), 0, (hipStream_t)stream, *cfg, (const float4*)raw,
+                       z_vals, valid, batch, R, S, rgb_map, weights, (float4*)draw, loss_out ? loss_rows : nullptr,
+                       fused_flags ? flags : nullptr);
+#undef NOF_COMPOSITE_REG
   NOF_LAUNCH_OK();
   if (flags != nullptr && !fused_flags) {
     hipLaunchKernelGGL(k_tile_flags, dim3((unsigned)nof_div_up(B, 256)), dim3(256), 0, (hipStream_t)stream, (const float4*)draw, B, flags);

@@ -649,6 +649,49 @@ class NeuralObjectField:
             self._call('nof_render_depth', b['raw'], b['z_vals'], R, S, C.c_float(self.cfg['far'] * self.cfg['sc_factor']), b['depth'])
         return b
 
+    def view_row(self, viewdir=(0.0, 0.0, 0.0), frame_id=0):
+        """[16] = [frame features | SH(viewdir) | 0]: the per-ray row the colour net consumes (nerf_runner.py:1270-1286), for ONE
+        world direction and ONE frame's latent code -- what k_sample_points writes per ray, built here for free-standing queries."""
+        x, y, z = (np.float32(v) for v in viewdir)
+        sh = [np.float32(0.28209479177387814)]
+        if self.sh_degree > 1:
+            c1 = np.float32(0.4886025119029199)
+            sh += [-c1 * y, c1 * z, -c1 * x]
+        if self.sh_degree > 2:
+            c = [np.float32(v) for v in (1.0925484305920792, -1.0925484305920792, 0.31539156525252005, -1.0925484305920792, 0.5462742152960396)]
+            sh += [c[0] * (x * y), c[1] * (y * z), c[2] * (np.float32(2) * z * z - x * x - y * y), c[3] * (x * z), c[4] * (x * x - y * y)]
+        assert self.sh_degree <= 3 and self.ff + len(sh) <= 16
+        row = torch.zeros(16, device=self.device)
+        if self.ff > 0:
+            row[:self.ff] = self.feat.view(self.F, self.ff)[int(frame_id)]
+        row[self.ff:self.ff + len(sh)] = torch.tensor(np.array(sh, dtype=np.float32), device=self.device)
+        return row
+
+    def query_network(self, pts, viewdir=(0.0, 0.0, 0.0), frame_id=0, chunk=1 << 20):
+        """run_network on free-standing points (nerf_runner.py:1226-1294 the way mesh_vertex_color_from_network :1412-1424 calls it:
+        identity transform, one view direction, one frame's latent code): raw [N,4] = (colour logits, sdf).  Points outside [-1,1]^3
+        get a zero embedding like the reference's valid_samples (:1246-1257)."""
+        pts = pts.to(self.device, torch.float32).contiguous()
+        self.pack_weights()
+        N = pts.shape[0]
+        raw = torch.empty(N, 4, device=self.device)
+        view = self.view_row(viewdir, frame_id).view(1, 16).contiguous()
+        for i in range(0, N, chunk):
+            n = min(chunk, N - i)
+            p = pts[i:i + n]
+            if self.fused_forward:
+                lib.call('nof_encode_mlp_fwd', C.byref(self.grid), C.byref(self.desc), self.packed, self.table, p, view, n, raw[i:i + n],
+                         None, None, n)
+                continue
+            feat = torch.empty(self.L, n, 2, device=self.device)
+            lib.call('nof_hash_encode_fwd', C.byref(self.grid), p, self.table, feat, n)
+            if self.wide:
+                ws = torch.empty(int(lib.load().nof_mlp_wide_workspace_bytes(C.byref(self.desc), n)), dtype=torch.uint8, device=self.device)
+                lib.call('nof_mlp_wide_fwd', C.byref(self.desc), self.packed, feat, self.L, view, n, raw[i:i + n], ws, n)
+            else:
+                lib.call('nof_mlp_fwd', C.byref(self.desc), self.packed, feat, self.L, view, n, raw[i:i + n], None, n)
+        return raw
+
     def query_sdf(self, pts, chunk=1 << 22):
         """run_network_density (nerf_runner.py:1307-1347): clip to [-1,1], hash encode, sigma_net -> sdf [N]."""
         pts = torch.clip(pts.to(self.device, torch.float32), -1, 1).contiguous()

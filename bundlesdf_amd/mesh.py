@@ -147,6 +147,7 @@ class Mesh:
         self.faces = np.asarray(faces, dtype=np.int64)
         self.uv = None if uv is None else np.asarray(uv, dtype=np.float64)      # per-vertex texture coordinates in [0,1]
         self.texture = texture                                                   # [H,W,3] uint8, row 0 = top (image order)
+        self.vertex_colors = None                                                # [V,3] uint8 (mesh_vertex_color_from_network)
 
     def apply_transform(self, T):
         T = np.asarray(T, dtype=np.float64)
@@ -214,10 +215,16 @@ class Mesh:
     def export(self, path):
         path = str(path)
         if path.endswith('.ply'):
+            col = self.vertex_colors is not None and len(self.vertex_colors) == len(self.vertices)
             with open(path, 'w') as f:
                 f.write(f'ply\nformat ascii 1.0\nelement vertex {len(self.vertices)}\nproperty float x\nproperty float y\n'
-                        f'property float z\nelement face {len(self.faces)}\nproperty list uchar int vertex_indices\nend_header\n')
-                np.savetxt(f, self.vertices, fmt='%.7f')
+                        f'property float z\n' + ('property uchar red\nproperty uchar green\nproperty uchar blue\n' if col else '') +
+                        f'element face {len(self.faces)}\nproperty list uchar int vertex_indices\nend_header\n')
+                if col:
+                    for v, c in zip(self.vertices, np.asarray(self.vertex_colors, dtype=np.uint8)):
+                        f.write('%.7f %.7f %.7f %d %d %d\n' % (v[0], v[1], v[2], c[0], c[1], c[2]))
+                else:
+                    np.savetxt(f, self.vertices, fmt='%.7f')
                 np.savetxt(f, np.concatenate([np.full((len(self.faces), 1), 3), self.faces], 1), fmt='%d')
         elif self.uv is not None:                                 # textured OBJ: .obj + .mtl + .png, like trimesh's exporter
             base = path[:-4]

@@ -385,6 +385,23 @@ class NerfRunner:
         return mesh
 
     @torch.no_grad()
+    def mesh_vertex_color_from_network(self, mesh):
+        """nerf_runner.py:1412-1429: the colour net at every vertex (normalised space), zero view direction, frame 0's latent code;
+        vertex colours = sigmoid of the logits, truncated to 8 bits.  One fused encode + MLP launch per million vertices."""
+        pts = torch.from_numpy(np.ascontiguousarray(mesh.vertices, dtype=np.float32)).to(self.device)
+        raw = self.field.query_network(pts, viewdir=(0.0, 0.0, 0.0), frame_id=0)
+        colors = (torch.sigmoid(raw[:, :3]) * 255).to(torch.uint8).cpu().numpy()
+        try:
+            import trimesh
+            if isinstance(mesh, trimesh.Trimesh):
+                mesh.visual = trimesh.visual.ColorVisuals(mesh=mesh, face_colors=None, vertex_colors=colors)
+                return mesh
+        except ImportError:
+            pass
+        mesh.vertex_colors = colors
+        return mesh
+
+    @torch.no_grad()
     def mesh_texture_from_train_images(self, mesh, rgbs_raw, train_texture=False, tex_res=1024):
         """nerf_runner.py:1468-1542: project the raw training images onto the (normalised-space) mesh and average them per
         texel.  Per keyframe the reference renders the mesh's depth with pyrender, takes trimesh's closest point / triangle

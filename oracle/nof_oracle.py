@@ -835,6 +835,23 @@ class OracleField:
             return mlp_forward_sdf(self.shape, self.mlp, feat, self.operand_dtype)
 
 
+    def run_network_points(self, pts, viewdir=(0.0, 0.0, 0.0), frame_id=0):
+        """run_network as mesh_vertex_color_from_network calls it (nerf_runner.py:1412-1424 -> :1226-1294): free-standing points,
+        identity transform, ONE view direction (the reference passes the zero vector), the latent code of ONE frame (it passes
+        frame 0).  Points outside [-1,1]^3 keep a zero embedding (:1246-1257).  raw [N,4]."""
+        with torch.no_grad():
+            x = torch.as_tensor(pts, dtype=torch.float32)
+            valid = (torch.abs(x) <= 1).all(dim=-1)
+            emb = torch.zeros(x.shape[0], self.geo.out_dim)
+            emb[valid] = hash_encode((x[valid] + 1) / 2, self.table, self.geo)
+            parts = [emb]
+            if self.feat is not None:
+                parts.append(self.feat[int(frame_id)][None].expand(x.shape[0], -1))
+            sh = sh_encode(torch.tensor([list(viewdir)], dtype=torch.float32), self.cfg['multires_views'])
+            parts.append(sh.expand(x.shape[0], -1))
+            return mlp_forward(self.shape, self.mlp, torch.cat(parts, -1), self.operand_dtype, self.split_forward)
+
+
 def adam_reference_step(p, g, m, v, t, lr, b1=0.9, b2=0.999, eps=1e-15):
     """torch.optim.Adam single-tensor update restated (what the HIP nof_adam_step must equal);
     t is the 1-based step count."""

@@ -148,7 +148,13 @@ def test_render_images_640x480_vs_oracle(nof):
         same = (cpu(b['n_hits']) == ref['n_hits']) & (cpu(b['cell_ids'])[:, :Hc] == ref['cell_ids']).all(axis=1)
         assert same.mean() > 0.999, same.mean()             # (rays that graze a cell face after the fp32 pose transform)
         z_ref = ref['z_vals'].numpy()
-        assert np.abs(cpu(ex['z_vals'])[sl] - z_ref)[same].max() < 2e-5
+        # unperturbed samples sit at fixed fractions of the occupied length, so now and then one lies within rounding of the
+        # boundary between two occupied intervals and lands on the other side of the gap in one of the two implementations
+        # (a different z by the width of the gap): such rays are counted, and left out of the per-ray comparisons below
+        z_close = np.abs(cpu(ex['z_vals'])[sl] - z_ref) < 2e-5
+        assert z_close[same].mean() > 0.9995, z_close[same].mean()
+        same = same & z_close.all(axis=1)
+        assert same.mean() > 0.99, same.mean()
         # network outputs per element: the oracle evaluated AT THE DEVICE'S sample positions.  (Through its own sampler the
         # oracle's z differs from the device's in the last float32 bits -- the pose transform is evaluated in a different order --
         # and a trained colour field moves by 1e-3 within 2e-5 of normalised depth: that is the field's texture, not a kernel's
@@ -157,16 +163,39 @@ def test_render_images_640x480_vs_oracle(nof):
             fw = orc.forward(torch.from_numpy(rows[sl]), torch.from_numpy(cpu(ex['z_vals'])[sl]))
         raw, raw_ref = cpu(ex['raw'])[sl], fw['raw'].numpy()
         sg = lambda a: 1.0 / (1.0 + np.exp(-a.astype(np.float64)))       # colour as raw2outputs uses it (nerf_runner.py:1165)
-        w_rgb, w_sdf = worst_elementwise(sg(raw[..., :3]), sg(raw_ref[..., :3])), worst_elementwise(raw[..., 3], raw_ref[..., 3])
+        # (sdf: absolute floor 1e-4 here instead of the 1e-5 of the initial-field tests.  The oracle rebuilds the sample points from
+        # z in its own operation order; a trained SDF falls by 1 over the truncation distance, so the last bits of a position are
+        # worth ~1e-5 of SDF near the surface, where |sdf| itself is ~0)
+        w_rgb, w_sdf = worst_elementwise(sg(raw[..., :3]), sg(raw_ref[..., :3])), worst_elementwise(raw[..., 3], raw_ref[..., 3], atol=1e-4)
         w_logit = worst_elementwise(raw[..., :3], raw_ref[..., :3])
         w_map = worst_elementwise(cpu(ex['rgb_map'])[sl][same], ref['rgb_map'].numpy()[same])
         # depth: the same sample index wherever the SDF pair products are not within rounding of zero
         d_ref = ref['depth'].numpy()[same]
         d_got = d_ray[sl][same]
         agree = np.abs(d_got - d_ref) <= 1e-3 * np.abs(d_ref) + 1e-5
-        print(f'render 640x480 rays {lo}..: identical hit lists {same.mean():.4f}, per element raw colour {w_rgb:.3f} sdf {w_sdf:.3f} '
+        print(f'render 640x480 rays {lo}..: identical hit lists and z {same.mean():.4f}, per element raw colour {w_rgb:.3f} sdf {w_sdf:.3f} '
               f'rgb_map {w_map:.3f} (own sampler), depth agrees on {agree.mean():.5f}; colour logits {w_logit:.3f}')
         assert w_rgb <= 1.0 and w_sdf <= 1.0 and w_map <= 1.0
         # (the logits themselves by max-norm: a trained field's logits reach +-10, and the per-element figure above is for the record)
         assert np.abs(raw[..., :3] - raw_ref[..., :3]).max() < 1e-3 * np.abs(raw_ref[..., :3]).max()
         assert agree.mean() > 0.999
+
+    # ---- vertex colours from the colour net (nerf_runner.py:1412-1429) on the mesh of this field ----
+    mesh = runner.extract_mesh(voxel_size=0.008, isolevel=0.0)
+    assert mesh is not None and len(mesh.vertices) > 1000
+    runner.mesh_vertex_color_from_network(mesh)
+    col = np.asarray(mesh.visual.vertex_colors)[:, :3] if hasattr(mesh, 'visual') else np.asarray(mesh.vertex_colors)
+    ref_raw = orc.run_network_points(np.asarray(mesh.vertices, dtype=np.float32)).numpy()
+    ref_col = sg(ref_raw[:, :3]) * 255
+    assert col.shape == (len(mesh.vertices), 3) and col.dtype == np.uint8
+    assert np.abs(col.astype(np.float64) - np.floor(ref_col)).max() <= 1           # (truncation to 8 bits: a level where the value sits on an integer)
+    assert (col == np.floor(ref_col)).mean() > 0.99
+    # the raw outputs behind them, including points outside the unit cube (zero embedding, :1246-1257) and another direction / frame
+    g = torch.Generator().manual_seed(5)
+    pts = torch.rand(5000, 3, generator=g) * 2.4 - 1.2
+    for vd, fid in (((0.0, 0.0, 0.0), 0), ((0.6, -0.48, 0.64), 3)):
+        got = cpu(fld.query_network(pts, viewdir=vd, frame_id=fid))
+        want = orc.run_network_points(pts.numpy(), viewdir=vd, frame_id=fid).numpy()
+        w_c, w_s = worst_elementwise(sg(got[:, :3]), sg(want[:, :3])), worst_elementwise(got[:, 3], want[:, 3])
+        print(f'query_network dir {vd} frame {fid}: per element colour {w_c:.3f} sdf {w_s:.3f}; {int((pts.abs() > 1).any(1).sum())} of 5000 points outside')
+        assert w_c <= 1.0 and w_s <= 1.0
