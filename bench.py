@@ -272,7 +272,7 @@ def main():
     ap.add_argument('--finest', type=int, default=256, help='finest hash resolution (256: cfg1-3; 512: cfg4/5)')
     ap.add_argument('--settle', type=int, default=200, help='steps into the run at which the K steps are timed AGAIN for ms_per_step_settled (the zero-gradient fraction has settled by then); 0: skip.  `value` is always the K steps right after the W warm-up steps')
     ap.add_argument('--round-steps', type=int, default=501, help='steps of the whole-round measurement from a fresh field (the reference\'s N_iters = n_step + 1 = 501); 0: skip')
-    ap.add_argument('--preroll', type=int, default=300, help='forward-only batches before the warm-up (clock ramp, host code paths; no training state is touched); 0: none')
+    ap.add_argument('--preroll', type=int, default=0, help='forward-only batches before the warm-up (no training state is touched); measured to change nothing (DESIGN 5), off by default')
     ap.add_argument('--unfused', action='store_true', help='training forward as nof_hash_encode_fwd + nof_mlp_fwd (fp32 embedding in HBM) instead of the fused nof_encode_mlp_fwd')
     ap.add_argument('--no-extra-configs', action='store_true', help='skip the BASELINE cfg4 / cfg5 sub-records (N = 1 default run only)')
     ap.add_argument('--extract', type=int, default=0, help='after the timed steps: time the dense SDF query + marching cubes of an N^3 grid (BASELINE cfg4: 512)')
@@ -323,11 +323,11 @@ def main():
         runner.train_loop()
         runner.global_step += 1
 
-    # ---- pre-roll: forward-only batches (NerfRunner.render_images' path: trace, unperturbed sampling, encode, MLPs, compositing) --
-    # No parameter, optimiser, loader or random-number state is touched, so the W warm-up and K timed steps below are still the
-    # first W + K steps of a fresh field -- but they run on a GPU whose clocks have ramped and through host code that has executed
-    # once (with the driver's 5 warm-up steps = 2.5 ms of device work alone, the 20 timed steps measured 0.52 ms where the same
-    # steps a moment later take 0.44: profiles/r04_f_bench_driver_invocation.json).
+    # ---- optional pre-roll: forward-only batches (NerfRunner.render_images' path), no parameter / optimiser / loader / RNG state touched.
+    # Built on the suspicion that the driver's 20 timed steps after 5 warm-up steps (0.52 ms) ran on a GPU whose clocks had not ramped;
+    # measured, it changes nothing (0.5232 without, 0.5215 / 0.516 with 300 batches): those are the first steps of a fresh field, where
+    # half of the samples still carry a loss gradient (0.50 -> 0.65 zero-gradient fraction over these 20 steps) and the backward kernels
+    # have 1.5x the settled work.  Off by default.
     if args.preroll > 0:
         ids0 = torch.arange(R, device=device) % runner.rays.shape[0]
         for _ in range(args.preroll):
@@ -578,7 +578,7 @@ def main():
                                    f"non-zero loss gradient (the others add exactly nothing: same sums; fraction of zero samples in "
                                    f"zero_grad_sample_fraction, the step with every tile listed in ms_per_step_dense_backward); "
                                    f"`value` = the {args.steps} steps right after the {args.warmup} warm-up steps of a fresh field "
-                                   f"(preceded by {args.preroll} forward-only batches that touch no training state: clock ramp); the "
+                                   f"-- the most expensive steps of a round: half of the samples still carry a loss gradient there; the "
                                    f"same steps later in the run: ms_per_step_settled; a whole {args.round_steps}-step reference "
                                    f"round from a fresh field: round_ms_per_step",
                        "rays_per_step": R, "samples_per_ray": S, "keyframes_per_gpu": args.keyframes,

@@ -520,12 +520,21 @@ __device__ __forceinline__ void adam_range(float* __restrict__ p, float* __restr
   float4* p4 = (float4*)(p + head); float4* g4 = (float4*)(g + head); float4* m4 = (float4*)(m + head); float4* v4 = (float4*)(v + head);
   for (int64_t q = tid; q < nvec; q += stride) {
     float4 pp = p4[q], gg = g4[q], mm = m4[q], vv = v4[q];
+    // Stores that would write back the bits already there are left out (the loads are not: they decide).  A gradient that is
+    // all-zero bits needs no zeroing -- six of seven table rows at cfg2 in any one step -- and an entry whose gradient and moments
+    // are all-zero bits is a fixed point of the update (m = v = +0, p - step * (0 / eps) = p): hash rows no sample has reached yet,
+    // most of the table in the first steps of a run.  Bit patterns, not values: -0 takes the arithmetic path.
+    const bool g_zero = (__float_as_uint(gg.x) | __float_as_uint(gg.y) | __float_as_uint(gg.z) | __float_as_uint(gg.w)) == 0u;
+    const bool idle = g_zero && (__float_as_uint(mm.x) | __float_as_uint(mm.y) | __float_as_uint(mm.z) | __float_as_uint(mm.w) |
+                                 __float_as_uint(vv.x) | __float_as_uint(vv.y) | __float_as_uint(vv.z) | __float_as_uint(vv.w)) == 0u;
+    if (idle) continue;
     const int64_t i = head + (q << 2);
     adam_one(pp.x, gg.x, mm.x, vv.x, i < n_basic ? k.step_basic : k.step_pose, k);
     adam_one(pp.y, gg.y, mm.y, vv.y, i + 1 < n_basic ? k.step_basic : k.step_pose, k);
     adam_one(pp.z, gg.z, mm.z, vv.z, i + 2 < n_basic ? k.step_basic : k.step_pose, k);
     adam_one(pp.w, gg.w, mm.w, vv.w, i + 3 < n_basic ? k.step_basic : k.step_pose, k);
-    p4[q] = pp; m4[q] = mm; v4[q] = vv; g4[q] = gg;
+    p4[q] = pp; m4[q] = mm; v4[q] = vv;
+    if (!g_zero) g4[q] = gg;
   }
   for (int64_t i = tail + tid; i < n; i += stride) adam_one(p[i], g[i], m[i], v[i], i < n_basic ? k.step_basic : k.step_pose, k);
 }

@@ -608,6 +608,18 @@ def test_adam_ranges_are_bit_identical(nof, off, n, nb):
     N = n + 16
     base = [torch.randn(N, device='cuda') for _ in range(4)]
     base[3].abs_()                                               # exp_avg_sq >= 0
+    if n > 1000:
+        # the 16-byte path leaves out stores that would write back the same bits (a zero gradient is not zeroed again; an entry
+        # whose gradient AND moments are all-zero bits is a fixed point).  The scalar path below does the arithmetic and stores
+        # everything: equal bits prove the shortcut, including -0.0 (not all-zero bits: takes the arithmetic path) and NaN
+        base[1][off + 100:off + 400] = 0                         # gradient zero, moments not
+        for k in (1, 2, 3):
+            base[k][off + 500:off + 900] = 0                     # never-touched entries
+        base[2][off + 600] = -0.0
+        base[1][off + 700] = -0.0
+        base[3][off + 800] = -0.0
+        base[0][off + 520] = -0.0                                # a parameter that is -0 stays -0
+        base[0][off + 530] = float('nan')
     a = [x.clone() for x in base]
     args = (C.c_float(0.01), C.c_float(0.003), C.c_float(0.9), C.c_float(0.999), C.c_float(1e-15), 7, None)
     nof.call('nof_adam_step', *[x[off:off + n] for x in a], n, nb, *args)
@@ -618,7 +630,7 @@ def test_adam_ranges_are_bit_identical(nof, off, n, nb):
     nof.call('nof_adam_step', *[x[k:k + n] for k, x in enumerate(b)], n, nb, *args)
     torch.cuda.synchronize()
     for k, (x, y, z) in enumerate(zip(a, b, base)):
-        assert torch.equal(x[off:off + n], y[k:k + n]), k
+        assert torch.equal(x[off:off + n].view(torch.int32), y[k:k + n].view(torch.int32)), k         # bits (NaN, -0 included)
         assert torch.equal(x[:off], z[:off]) and torch.equal(x[off + n:], z[off + n:]), k
     assert (a[1][off:off + n] == 0).all()
 
