@@ -17,6 +17,7 @@
 // Accumulator layout of v_mfma_f32_32x32x*: lane l = (hi = l>>5, j = l&31) holds column j, rows (r&3)+8(r>>2)+4hi.
 #include <type_traits>
 #include "nof_common.h"
+#include "nof_pose_dev.h"
 #include "nof_hash_dev.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -108,9 +109,18 @@ __device__ __forceinline__ int inmap(const NofMlpDesc& d, int l, int q, int hi, 
 //   image = [ fw : npair*1024 elems | bw : npair*1024 elems | bias : nob*32 floats | (fw_lo : npair*1024 elems) ]
 // fw_lo (split-forward precisions only) holds the rounding residual of fw: fw_lo = round(W - float(fw)), so that fw + fw_lo
 // carries twice the operand's mantissa (fp16: 22 bits, bf16: 16 bits).
+// `pack_blocks` workgroups pack; when F > 0 the launch carries ONE more, which updates the pose table tf [F,12] from the pose
+// corrections (pose_fwd_frame, nof_pose_dev.h) -- the two things a step needs before its ray marcher, in one launch instead of two
+// 6-microsecond ones (nof_mlp_pack_pose).
 template <class P>
 __global__ __launch_bounds__(256) void k_mlp_pack(NofMlpDesc d, const float* __restrict__ params, char* __restrict__ image,
-                                                  int with_lo) {
+                                                  int with_lo, int pack_blocks, const float* __restrict__ pose,
+                                                  const float* __restrict__ c2w, float max_trans, float max_rot,
+                                                  float* __restrict__ tf, int F) {
+  if ((int)blockIdx.x >= pack_blocks) {                                  // (workgroup-uniform)
+    for (int f = threadIdx.x; f < F; f += blockDim.x) pose_fwd_frame(f, pose, c2w, max_trans, max_rot, tf);
+    return;
+  }
   constexpr int KR = P::KR;
   typedef typename P::elem elem;
   const int n_layers = d.n_sigma + d.n_color;
@@ -120,7 +130,7 @@ __global__ __launch_bounds__(256) void k_mlp_pack(NofMlpDesc d, const float* __r
   float* bias = (float*)(bw + (size_t)npair * 16 * 64);
   elem* fw_lo = (elem*)(bias + (size_t)oblk_base(d, n_layers) * 32);
   const int total = npair * 16 * 64;
-  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += pack_blocks * blockDim.x) {
     const int lane = e & 63, r = (e >> 6) & 15;
     int pair = e >> 10, l = 0;
     for (;; ++l) {
@@ -149,7 +159,7 @@ __global__ __launch_bounds__(256) void k_mlp_pack(NofMlpDesc d, const float* __r
     }
   }
   const int nob = oblk_base(d, n_layers);
-  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < nob * 32; e += gridDim.x * blockDim.x) {
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < nob * 32; e += pack_blocks * blockDim.x) {
     int ob = e >> 5, l = 0;
     for (;; ++l) {
       const int pn = lay_pn(d, l);
@@ -1990,16 +2000,29 @@ extern "C" int64_t nof_mlp_packed_bytes(const NofMlpDesc* d) {
          (int64_t)n_oblk(*d, nl) * 32 * 4;
 }
 
-extern "C" int nof_mlp_pack(const NofMlpDesc* d, const float* mlp_params, void* packed, void* stream) {
+static int mlp_pack_launch(const NofMlpDesc* d, const float* mlp_params, void* packed, const float* pose, const float* c2w,
+                           float max_trans, float max_rot, float* tf, int F, void* stream) {
   if (int e = check_desc(d)) return e;
   NOF_ARG(mlp_params && packed);
   const int lo = is_split(d->precision) ? 1 : 0;
-  const unsigned pack_blocks = (unsigned)nof_div_up((int64_t)n_pairs(*d, d->n_sigma + d->n_color) * 1024, 256);   // one element per thread
-  if (d->precision == 0) hipLaunchKernelGGL(k_mlp_pack<PrecF32>, dim3(pack_blocks), dim3(256), 0, (hipStream_t)stream, *d, mlp_params, (char*)packed, 0);
-  else if (is_bf16(d->precision)) hipLaunchKernelGGL(k_mlp_pack<PrecBF16>, dim3(pack_blocks), dim3(256), 0, (hipStream_t)stream, *d, mlp_params, (char*)packed, lo);
-  else hipLaunchKernelGGL(k_mlp_pack<PrecF16>, dim3(pack_blocks), dim3(256), 0, (hipStream_t)stream, *d, mlp_params, (char*)packed, lo);
+  const int pack_blocks = (int)nof_div_up((int64_t)n_pairs(*d, d->n_sigma + d->n_color) * 1024, 256);   // one element per thread
+  const dim3 grid((unsigned)(pack_blocks + (F > 0 ? 1 : 0)));
+  if (d->precision == 0) hipLaunchKernelGGL(k_mlp_pack<PrecF32>, grid, dim3(256), 0, (hipStream_t)stream, *d, mlp_params, (char*)packed, 0, pack_blocks, pose, c2w, max_trans, max_rot, tf, F);
+  else if (is_bf16(d->precision)) hipLaunchKernelGGL(k_mlp_pack<PrecBF16>, grid, dim3(256), 0, (hipStream_t)stream, *d, mlp_params, (char*)packed, lo, pack_blocks, pose, c2w, max_trans, max_rot, tf, F);
+  else hipLaunchKernelGGL(k_mlp_pack<PrecF16>, grid, dim3(256), 0, (hipStream_t)stream, *d, mlp_params, (char*)packed, lo, pack_blocks, pose, c2w, max_trans, max_rot, tf, F);
   NOF_LAUNCH_OK();
   return 0;
+}
+
+extern "C" int nof_mlp_pack(const NofMlpDesc* d, const float* mlp_params, void* packed, void* stream) {
+  return mlp_pack_launch(d, mlp_params, packed, nullptr, nullptr, 0.0f, 0.0f, nullptr, 0, stream);
+}
+
+// nof_mlp_pack and nof_pose_fwd (same arguments, same results) as one launch: what a training step calls before its ray marcher
+extern "C" int nof_mlp_pack_pose(const NofMlpDesc* d, const float* mlp_params, void* packed, const float* pose_data, const float* c2w,
+                                 float max_trans, float max_rot_rad, float* tf, int32_t F, void* stream) {
+  NOF_ARG(c2w && tf && F >= 0);
+  return mlp_pack_launch(d, mlp_params, packed, pose_data, c2w, max_trans, max_rot_rad, tf, (int)F, stream);
 }
 
 static int g_bwd_blocks = 0;

@@ -70,8 +70,24 @@ __device__ __forceinline__ void cell_slab(const Axis& a, int i, float cs, float&
   }
 }
 
+// The DDA's occupancy test.  LDS: the bitfield staged by stage_occ, read through the dynamic LDS block ITSELF, i.e. a ds_read.  (A
+// pointer that is "the LDS copy or the global one" is a flat pointer: the test then was a flat load per DDA step -- one vector-memory
+// round trip through the texture path per cell, 47 of them per wave and zero LDS instructions in profiles/r04_z_pmc_vmem.txt -- on a
+// kernel that is nothing but one dependent chain per ray.)
+template <bool LDS>
+__device__ __forceinline__ bool occ_test_t(const uint32_t* __restrict__ bits, int n, int x, int y, int z) {
+  const uint32_t id = ((uint32_t)x * n + y) * n + z;
+  if constexpr (LDS) {
+    extern __shared__ uint32_t occ_lds_words[];
+    return (occ_lds_words[id >> 5] >> (id & 31)) & 1u;
+  } else {
+    return (bits[id >> 5] >> (id & 31)) & 1u;
+  }
+}
+
 // Walks the occupied cells of one ray; writes at most max_hits intervals. Returns the number written.
-__device__ __forceinline__ int trace_one(const uint32_t* __restrict__ bits, int n, const float o[3], const float d[3], int max_hits,
+template <bool LDS>
+__device__ __forceinline__ int trace_one_t(const uint32_t* __restrict__ bits, int n, const float o[3], const float d[3], int max_hits,
                          float* __restrict__ tio, int32_t* __restrict__ cid, int* overflow) {
   const float cs = 2.0f / (float)n;
   Axis ax[3];
@@ -117,7 +133,7 @@ __device__ __forceinline__ int trace_one(const uint32_t* __restrict__ bits, int 
     for (int a = 0; a < 3; ++a) cell_slab(ax[a], c[a], cs, tmin[a], tmax[a]);
     const float tin = fmaxf(fmaxf(fmaxf(tmin[0], tmin[1]), tmin[2]), 0.0f);
     const float tout = fminf(fminf(tmax[0], tmax[1]), tmax[2]);
-    if (tin <= tout && occ_test(bits, n, c[0], c[1], c[2])) {
+    if (tin <= tout && occ_test_t<LDS>(bits, n, c[0], c[1], c[2])) {
       if (tin == 0.0f || tout == 0.0f) break;                       // common.cu:140 (terminator)
       if (!(fabsf(tout - tin) < MIN_LEN)) {                          // common.cu:142
         if (nh < max_hits) {
@@ -162,6 +178,13 @@ __device__ __forceinline__ const uint32_t* stage_occ(const uint32_t* __restrict_
   return lds;
 }
 
+// `occ`: what stage_occ returned (the LDS copy, or `bits` itself for levels that do not fit)
+__device__ __forceinline__ int trace_one(const uint32_t* __restrict__ occ, const uint32_t* __restrict__ bits, int n, const float o[3],
+                                         const float d[3], int max_hits, float* __restrict__ tio, int32_t* __restrict__ cid, int* overflow) {
+  return occ != bits ? trace_one_t<true>(occ, n, o, d, max_hits, tio, cid, overflow)       // (wave-uniform)
+                     : trace_one_t<false>(bits, n, o, d, max_hits, tio, cid, overflow);
+}
+
 __global__ __launch_bounds__(64) void k_trace_rays(const uint32_t* __restrict__ bits, int n, const float* __restrict__ rays_o,
                                                     const float* __restrict__ rays_d, int64_t R, int max_hits,
                                                     float* __restrict__ t_in_out, int32_t* __restrict__ cell_ids,
@@ -175,7 +198,7 @@ __global__ __launch_bounds__(64) void k_trace_rays(const uint32_t* __restrict__ 
   float* tio = t_in_out + r * max_hits * 2;
   int32_t* cid = cell_ids ? cell_ids + r * max_hits : nullptr;
   int overflow = 0;
-  const int nh = trace_one(occ, n, o, d, max_hits, tio, cid, &overflow);
+  const int nh = trace_one(occ, bits, n, o, d, max_hits, tio, cid, &overflow);
   for (int k = nh; k < max_hits; ++k) reinterpret_cast<float2*>(tio)[k] = make_float2(0.f, 0.f);   // zero padding (at::zeros, common.cu:158)
   if (cid)
     for (int k = nh; k < max_hits; ++k) cid[k] = -1;
@@ -256,7 +279,7 @@ __global__ __launch_bounds__(64) void k_batch_trace(const float* __restrict__ po
   float* tio = t_in_out + r * max_hits * 2;
   int32_t* cid = cell_ids ? cell_ids + r * max_hits : nullptr;
   int overflow = 0;
-  const int nh = trace_one(occ, n, o, d, max_hits, tio, cid, &overflow);
+  const int nh = trace_one(occ, bits, n, o, d, max_hits, tio, cid, &overflow);
   // zero padding of the interval list (at::zeros in common.cu:158) by the ray's own lane: a memset launch in front of this kernel
   // cost 8 us of the step
   for (int k = nh; k < max_hits; ++k) reinterpret_cast<float2*>(tio)[k] = make_float2(0.f, 0.f);
@@ -506,10 +529,11 @@ extern "C" int nof_raymarch_sample(const NofSampleCfg* cfg, const float* pool, c
 // restatement the tests compare against), a brute-force nearest-cloud-point test, and a stable compaction.
 // ================================================================================================================
 // does the ray hit any occupied cell (n_hits > 0 of the tracer, with its terminator / minimum-length filters)?
-__device__ __forceinline__ bool trace_hits_any(const uint32_t* __restrict__ occ, int n, const float (&o)[3], const float (&d)[3]) {
+__device__ __forceinline__ bool trace_hits_any(const uint32_t* __restrict__ occ, const uint32_t* __restrict__ bits, int n,
+                                               const float (&o)[3], const float (&d)[3]) {
   float tio[2];
   int overflow = 0;
-  return trace_one(occ, n, o, d, 1, tio, nullptr, &overflow) > 0;
+  return trace_one(occ, bits, n, o, d, 1, tio, nullptr, &overflow) > 0;
 }
 
 // cv2.dilate with a k x k all-ones kernel (anchor k/2): window offsets -k/2 ... k-1-k/2, borders ignored; separable.
@@ -599,7 +623,7 @@ __global__ __launch_bounds__(64) void k_frame_rays(NofFrameRaysCfg c, const floa
       const double wx = (P[0] * ux + P[1] * uy) + P[2] * uz, wy = (P[4] * ux + P[5] * uy) + P[6] * uz,
                    wz = (P[8] * ux + P[9] * uy) + P[10] * uz;
       const float o32[3] = {(float)ow[0], (float)ow[1], (float)ow[2]}, d32v[3] = {(float)wx, (float)wy, (float)wz};
-      ok = trace_hits_any(occ, n, o32, d32v);
+      ok = trace_hits_any(occ, bits, n, o32, d32v);
     }
   }
   r[10] = nearf; r[11] = farf;

@@ -17,6 +17,7 @@ tiles that have any (a third of a settled cfg2 batch).
 """
 import ctypes as C
 import math
+import os
 
 import numpy as np
 import torch
@@ -360,8 +361,16 @@ class NeuralObjectField:
         (Running the NEXT batch's prologue at the end of a step, on the side stream beside Adam -- it needs only the few KB of
         poses / features / MLPs, updated first -- was built and measured: 0.526 vs 0.515 ms/step.  The fork and the join cost what
         the overlap returns, and the ray marcher's dependent loads slow down under Adam's streaming.)"""
-        self.update_poses()
-        self.pack_weights(force=dyn)
+        if dyn or self._packed_step != self.global_step:
+            # pose table + MFMA fragment image in ONE launch (two 6-microsecond kernels before: the pose update is one short
+            # dependent chain per frame and rides as one extra workgroup of the packing launch)
+            self._call('nof_mlp_pack_pose', C.byref(self.desc), self.mlp, self.packed, self.pose if self.optimize_poses else None,
+                       self.c2w, C.c_float(self.max_trans), C.c_float(self.max_rot), self.tf, self.F)
+            if self.eikonal:
+                self._call('nof_mlp_pack', C.byref(self.desc32), self.mlp, self.packed32)
+            self._packed_step = self.global_step
+        else:
+            self.update_poses()
         cid = None
         if want_cells:
             cid = b.setdefault('cell_ids', torch.empty(R, self.max_hits, dtype=torch.int32, device=self.device))
@@ -530,7 +539,8 @@ class NeuralObjectField:
                     hash_bwd(INPUT, 0, self.L)
                     pose_kernels()
                 hash_bwd(BIG | SMALL, 0, self.L)                     # (the LDS levels on a third stream beside both: no gain; the
-                reduce_mlp()                                         #  two chains swapped between the streams: 2 % slower)
+                reduce_mlp()                                         #  two chains swapped between the streams: 2 % slower; the MLP row
+                                                                     #  reduction at the HEAD of the second chain: settled 0.417-0.422 vs 0.411)
                 # (Adam is element-wise and could start per range as soon as a range's gradient is final -- the table's share right
                 # here, the rest at the end of the side stream.  Measured: 0.518 vs 0.521 ms at cfg2 (noise), 4.9-5.0 vs 4.7-4.8 ms
                 # at cfg5, where it takes HBM bandwidth from the weight-gradient passes that are the critical path: not done)

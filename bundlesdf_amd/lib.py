@@ -78,6 +78,7 @@ _SIGNATURES = {
     'nof_sample_points': ([C.POINTER(NofSampleCfg), _P, _P, _P, _P, _I64, _I32, _P, _P, _P, _P, _P, _P, _P], C.c_int),
     'nof_mlp_packed_bytes': ([C.POINTER(NofMlpDesc)], C.c_int64),
     'nof_mlp_pack': ([C.POINTER(NofMlpDesc), _P, _P, _P], C.c_int),
+    'nof_mlp_pack_pose': ([C.POINTER(NofMlpDesc), _P, _P, _P, _P, _F, _F, _P, _I32, _P], C.c_int),
     'nof_mlp_fwd': ([C.POINTER(NofMlpDesc), _P, _P, _I32, _P, _I32, _P, _P, _I64, _P], C.c_int),
     'nof_encode_mlp_fwd': ([C.POINTER(NofHashGrid), C.POINTER(NofMlpDesc), _P, _P, _P, _P, _I32, _P, _P, _P, _I64, _P], C.c_int),
     'nof_mlp_bwd_featq': ([C.POINTER(NofMlpDesc), _P, _P, _I32, _P, _I32, _P, _P, _P, _P, _P, _P, _P, _I64, _P], C.c_int),

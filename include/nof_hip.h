@@ -204,6 +204,11 @@ typedef struct {
  * optimiser step) into `packed` (nof_mlp_packed_bytes() bytes, caller-allocated); fwd / bwd / sdf read only the image. */
 int64_t nof_mlp_packed_bytes(const NofMlpDesc* h_desc);
 int nof_mlp_pack(const NofMlpDesc* h_desc, const float* mlp_params, void* packed, void* stream);
+/* nof_mlp_pack and nof_pose_fwd (above: same arguments, same results) as ONE launch -- the two things a training step needs before
+ * its ray marcher (the reference rebuilds neither explicitly: autograd re-reads the nn.Linear weights, and PoseArray.get_matrices
+ * runs inside render_rays, nerf_runner.py:1051-1053).  F == 0: nof_mlp_pack alone. */
+int nof_mlp_pack_pose(const NofMlpDesc* h_desc, const float* mlp_params, void* packed, const float* pose_data, const float* c2w,
+                      float max_trans, float max_rot_rad, float* tf, int32_t F, void* stream);
 /* feat [L,B,2]; view [R,16]; raw [B,4] = (rgb_raw[3], sdf)  (nerf_helpers.py:319).
  * sigma_out (may be NULL; ignored in fp32 mode): [B,16] elements of the MFMA operand type (2 bytes) = the sigma head's
  * output as the colour net consumes it; nof_mlp_bwd's split path reads it back instead of recomputing the sigma net twice. */
