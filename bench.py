@@ -496,7 +496,9 @@ def main():
             # is not done (frac > 1).  This is the table scatter (the run-merged global atomics of the large levels + the
             # LDS-accumulated small level behind them); dL/dx (k_hash_dx, 1048 B/sample) runs beside it on the step's second
             # stream and is its own entry.
-            'hash_bwd[table+table_lds]': ('hbm', B * (1.0 - zero_frac) * 2112.0),
+            # (+ the MLP backward's partial rows, whose reduction rides inside the LDS levels' launch in the one-GPU step)
+            'hash_bwd[table+table_lds]': ('hbm', B * (1.0 - zero_frac) * 2112.0 +
+                                          (fld.nblk * fld.n_mlp * 4.0 if not fld.wide and not fld.eikonal and runner.grad_sync is None else 0.0)),
             'hash_bwd[input]': ('hbm', B * (1.0 - zero_frac) * (16 * 2 * 4 + 16 * 8 * 2 * 4 + 12) + B * 12),
             'nof_mlp_fwd': ('mfma', B * fl_fwd),
             'nof_mlp_bwd_tiles': ('mfma', B * (1.0 - zero_frac) * 3.0 * fl_fwd),

@@ -18,6 +18,7 @@
 //                      adjacent lanes (cfg2: 3..15 samples per run at the hashed levels).
 #include <type_traits>
 #include "nof_hash_dev.h"
+#include "nof_reduce_dev.h"
 #pragma clang fp contract(off)
 
 struct LevelList {
@@ -364,14 +365,33 @@ __global__ __launch_bounds__(256) void k_hash_bwd_agg(NofHashGrid g, LevelList l
   }
 }
 
+// The MLP backward's row reduction as a passenger of this launch (nof_hash_encode_bwd_parts_reduce): `partials` != NULL puts
+// ncb * RED_RSPLIT workgroups of reduce_partials_block in FRONT of the launch's own.  Both are 1024-thread workgroups; the reduction
+// needs the MLP backward only, which is long done here, and the step's tail loses a launch and the gap in front of it.
+struct RedArgs {
+  const float* partials;
+  float* out;
+  int32_t* flags;
+  int n_rows, n_cols, ncb;
+};
+
 // levels whose slice fits LDS: accumulate privately, flush once
 __global__ __launch_bounds__(1024) void k_hash_bwd_lds(NofHashGrid g, LevelList ll, int chunks, const float* __restrict__ pts_w,
                                                         const float2* __restrict__ dfeat, float* __restrict__ grad_table,
                                                         int64_t B, const float2* __restrict__ geik, const float* __restrict__ dedn,
-                                                        const uint32_t* __restrict__ tile_list) {
+                                                        const uint32_t* __restrict__ tile_list, RedArgs red) {
   extern __shared__ __attribute__((aligned(16))) float acc[];
-  const int level = ll.level[blockIdx.x % ll.n];
-  const int chunk = blockIdx.x / ll.n;
+  int bid = (int)blockIdx.x;
+  if (red.partials != nullptr) {                                       // (workgroup-uniform)
+    const int nred = red.ncb * RED_RSPLIT;
+    if (bid < nred) {
+      reduce_partials_block(red.partials, red.n_rows, red.n_cols, red.out, red.flags, bid % red.ncb, bid / red.ncb);
+      return;
+    }
+    bid -= nred;
+  }
+  const int level = ll.level[bid % ll.n];
+  const int chunk = bid / ll.n;
   const HashLevel lv = load_level(g, level);
   const int n2 = 2 * (int)lv.size;
   for (int e = threadIdx.x; e < n2; e += blockDim.x) acc[e] = 0.0f;
@@ -603,10 +623,10 @@ extern "C" int nof_hash_encode_bwd_eik(const NofHashGrid* g, const float* pts_w,
 //   NOF_HASH_BWD_TABLE_SMALL  the others: accumulated in LDS, flushed once per workgroup (k_hash_bwd_lds)
 //   NOF_HASH_BWD_INPUT        dL/dpts over ALL levels (k_hash_dx; needs dpts)
 // tile_list (NofTileList or NULL): only the listed tiles are read and scattered; dpts of unlisted tiles is written as 0.
-extern "C" int nof_hash_encode_bwd_parts(const NofHashGrid* g, const float* pts_w, const float* table, const float* dfeat,
-                                          const float* geik_, const float* dedn, float* grad_table, float* dpts, int32_t level_lo,
-                                          int32_t level_hi, const void* tile_list, int32_t parts, int32_t wgs_per_cu, int64_t B,
-                                          void* stream) {
+static int hash_bwd_parts(const NofHashGrid* g, const float* pts_w, const float* table, const float* dfeat,
+                          const float* geik_, const float* dedn, float* grad_table, float* dpts, int32_t level_lo,
+                          int32_t level_hi, const void* tile_list, int32_t parts, int32_t wgs_per_cu, int64_t B,
+                          RedArgs red, void* stream) {
   if (int e = check_grid(g)) return e;
   NOF_ARG(pts_w && table && dfeat && grad_table && B >= 0 && level_lo >= 0 && level_lo <= level_hi && level_hi <= g->L);
   NOF_ARG((geik_ == nullptr) == (dedn == nullptr));
@@ -670,11 +690,38 @@ extern "C" int nof_hash_encode_bwd_parts(const NofHashGrid* g, const float* pts_
     const int chunks = 2 * nof_cu_count();
     if (lds_need > 64 * 1024)
       NOF_HIP(hipFuncSetAttribute((const void*)k_hash_bwd_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_need));
-    hipLaunchKernelGGL(k_hash_bwd_lds, dim3((unsigned)(chunks * small.n)), dim3(1024), lds_need, st, *g, small, chunks, pts_w,
-                       (const float2*)dfeat, grad_table, B, geik, dedn, tl);
+    const unsigned nred = red.partials != nullptr ? (unsigned)(red.ncb * RED_RSPLIT) : 0u;
+    hipLaunchKernelGGL(k_hash_bwd_lds, dim3((unsigned)(chunks * small.n) + nred), dim3(1024), lds_need, st, *g, small, chunks, pts_w,
+                       (const float2*)dfeat, grad_table, B, geik, dedn, tl, red);
     NOF_LAUNCH_OK();
+    red.partials = nullptr;                                            // done
   }
+  if (red.partials != nullptr)                                         // no LDS-level launch to ride in: on its own
+    return nof_reduce_partials(red.partials, red.n_rows, red.n_cols, red.out, red.flags, stream);
   return 0;
+}
+
+extern "C" int nof_hash_encode_bwd_parts(const NofHashGrid* g, const float* pts_w, const float* table, const float* dfeat,
+                                          const float* geik_, const float* dedn, float* grad_table, float* dpts, int32_t level_lo,
+                                          int32_t level_hi, const void* tile_list, int32_t parts, int32_t wgs_per_cu, int64_t B,
+                                          void* stream) {
+  return hash_bwd_parts(g, pts_w, table, dfeat, geik_, dedn, grad_table, dpts, level_lo, level_hi, tile_list, parts, wgs_per_cu, B,
+                        RedArgs{nullptr, nullptr, nullptr, 0, 0, 0}, stream);
+}
+
+// nof_hash_encode_bwd_parts followed by nof_reduce_partials(partials, n_rows, n_cols, grad_mlp, flags) -- same results -- with the
+// reduction inside the launch of the LDS-accumulated levels when `parts` has one (else as its own launch).
+extern "C" int nof_hash_encode_bwd_parts_reduce(const NofHashGrid* g, const float* pts_w, const float* table, const float* dfeat,
+                                                 const float* geik_, const float* dedn, float* grad_table, float* dpts,
+                                                 int32_t level_lo, int32_t level_hi, const void* tile_list, int32_t parts,
+                                                 int32_t wgs_per_cu, int64_t B, const float* partials, int32_t n_rows, int32_t n_cols,
+                                                 float* grad_mlp, int32_t* flags, void* stream) {
+  NOF_ARG(partials && grad_mlp && n_rows >= 0 && n_cols >= 0);
+  RedArgs red{partials, grad_mlp, flags, n_rows, n_cols, (int)nof_div_up(n_cols, 32)};
+  if (n_rows == 0 || n_cols == 0) red.partials = nullptr;
+  if (B == 0 && red.partials != nullptr) return nof_reduce_partials(partials, n_rows, n_cols, grad_mlp, flags, stream);
+  return hash_bwd_parts(g, pts_w, table, dfeat, geik_, dedn, grad_table, dpts, level_lo, level_hi, tile_list, parts, wgs_per_cu, B, red,
+                        stream);
 }
 
 extern "C" int nof_hash_corner_indices(const NofHashGrid* g, const float* pts_w, int32_t* idx, int64_t B, void* stream) {

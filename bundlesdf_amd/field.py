@@ -475,15 +475,23 @@ class NeuralObjectField:
             if self.eikonal:
                 self._call('nof_reduce_partials', b['partials_e'], self.nblk, self.n_mlp, self._seg(self.grads, 'mlp'), self.flags)
 
-        def hash_bwd(parts, lo, hi):
+        def hash_bwd(parts, lo, hi, with_reduce=False):
             """the kernels `parts` of the hash backward for the table levels [lo, hi), on the current stream (the library owns no
-            stream: what runs beside what is decided here)"""
+            stream: what runs beside what is decided here).  with_reduce: followed by the MLP backward's row reduction, which then
+            rides inside the launch of the LDS-accumulated levels instead of being the step's next launch."""
             if not self.optimize_poses:
                 parts &= ~INPUT
             if parts:
                 tag = 'hash_bwd[' + '+'.join(n for n, m in (('table', BIG), ('table_lds', SMALL), ('input', INPUT)) if parts & m) + ']'
+                if with_reduce:
+                    self._call('nof_hash_encode_bwd_parts_reduce', C.byref(self.grid), b['pts_w'], self.table, b['dfeat'], geik, dedn,
+                               gtab, dpts, lo, hi, tiles, parts, self.scatter_wgs_per_cu, B, b['partials'], self.nblk, self.n_mlp,
+                               self._seg(self.grads, 'mlp'), self.flags, tag=tag)
+                    return
                 self._call('nof_hash_encode_bwd_parts', C.byref(self.grid), b['pts_w'], self.table, b['dfeat'], geik, dedn, gtab,
                            dpts, lo, hi, tiles, parts, self.scatter_wgs_per_cu, B, tag=tag)
+            elif with_reduce:
+                reduce_mlp()
 
         def pose_kernels():
             if self.optimize_poses:
@@ -538,9 +546,13 @@ class NeuralObjectField:
                 with self._on(side):
                     hash_bwd(INPUT, 0, self.L)
                     pose_kernels()
-                hash_bwd(BIG | SMALL, 0, self.L)                     # (the LDS levels on a third stream beside both: no gain; the
-                reduce_mlp()                                         #  two chains swapped between the streams: 2 % slower; the MLP row
-                                                                     #  reduction at the HEAD of the second chain: settled 0.417-0.422 vs 0.411)
+                # (the LDS levels on a third stream beside both: no gain; the two chains swapped between the streams: 2 % slower; the
+                # MLP row reduction at the HEAD of the second chain: settled 0.417-0.422 vs 0.411)
+                if wide_aux is None and not self.eikonal:
+                    hash_bwd(BIG | SMALL, 0, self.L, with_reduce=True)
+                else:
+                    hash_bwd(BIG | SMALL, 0, self.L)
+                    reduce_mlp()
                 # (Adam is element-wise and could start per range as soon as a range's gradient is final -- the table's share right
                 # here, the rest at the end of the side stream.  Measured: 0.518 vs 0.521 ms at cfg2 (noise), 4.9-5.0 vs 4.7-4.8 ms
                 # at cfg5, where it takes HBM bandwidth from the weight-gradient passes that are the critical path: not done)

@@ -103,6 +103,8 @@ _SIGNATURES = {
     'nof_tile_list_build': ([_P, _I64, _I32, _P, _P], C.c_int),
     'nof_mlp_bwd_tiles': ([C.POINTER(NofMlpDesc), _P, _P, _I32, _P, _I32, _P, _P, _P, _P, _P, _P, _P, _I64, _P], C.c_int),
     'nof_hash_encode_bwd_parts': ([C.POINTER(NofHashGrid), _P, _P, _P, _P, _P, _P, _P, _I32, _I32, _P, _I32, _I32, _I64, _P], C.c_int),
+    'nof_hash_encode_bwd_parts_reduce': ([C.POINTER(NofHashGrid), _P, _P, _P, _P, _P, _P, _P, _I32, _I32, _P, _I32, _I32, _I64,
+                                          _P, _I32, _I32, _P, _P, _P], C.c_int),
     'nof_mlp_bwd_workspace_bytes': ([C.POINTER(NofMlpDesc)], C.c_int64),
     'nof_sdf_grid_query': ([C.POINTER(NofHashGrid), C.POINTER(NofMlpDesc), _P, _P, _P, _I32, _P, _P, _P, _I32, _I32, _I32,
                             _F, _P, _P], C.c_int),

@@ -76,6 +76,13 @@ int nof_hash_encode_bwd_eik(const NofHashGrid* h_grid, const float* pts_w, const
 int nof_hash_encode_bwd_parts(const NofHashGrid* h_grid, const float* pts_w, const float* table, const float* dfeat,
                               const float* geik, const float* dedn, float* grad_table, float* dpts, int32_t level_lo,
                               int32_t level_hi, const void* tile_list, int32_t parts, int32_t wgs_per_cu, int64_t B, void* stream);
+/* The same followed by nof_reduce_partials(partials, n_rows, n_cols, grad_mlp, flags) (below; same results), the row reduction of
+ * the MLP backward riding inside the launch of the LDS-accumulated levels: what the training step calls for its table gradient. */
+int nof_hash_encode_bwd_parts_reduce(const NofHashGrid* h_grid, const float* pts_w, const float* table, const float* dfeat,
+                                     const float* geik, const float* dedn, float* grad_table, float* dpts, int32_t level_lo,
+                                     int32_t level_hi, const void* tile_list, int32_t parts, int32_t workgroups_per_cu, int64_t B,
+                                     const float* partials, int32_t n_rows, int32_t n_cols, float* grad_mlp, int32_t* flags,
+                                     void* stream);
 int nof_hash_corner_indices(const NofHashGrid* h_grid, const float* pts_w, int32_t* idx, int64_t B, void* stream);
 
 /* ---- pose corrections (replaces PoseArray.get_matrices + pytorch3d se3_exp_map) ---------------- */

@@ -251,6 +251,25 @@ def test_hash_backward_over_the_list_equals_whole_batch(nof, T, finest, R, S):
         got = g_l[off[l]:off[l + 1]].double().sum(0)
         want = g_w[off[l]:off[l + 1]].double().sum(0)
         assert ((got - want).abs() / g_w[off[l]:off[l + 1]].double().abs().sum(0).clamp_min(1e-30)).max().item() < 1e-6, l
+    # the table levels with the MLP backward's row reduction riding in the LDS levels' launch (what the step calls): the same table
+    # gradient, and the reduction's own result bit for bit (fixed summation order per column and row range; two atomics per column
+    # onto zeros commute) -- incl. the overflow flag for a non-finite column
+    rows, cols = 512, 10755
+    partials = torch.randn(rows, cols, device='cuda', generator=gen)
+    partials[7, 123] = float('inf')
+    want_mlp = torch.zeros(cols, device='cuda')
+    want_flags = torch.zeros(4, dtype=torch.int32, device='cuda')
+    nof.call('nof_reduce_partials', partials, rows, cols, want_mlp, want_flags)
+    for parts in (nof.HASH_BWD_TABLE_BIG | nof.HASH_BWD_TABLE_SMALL, nof.HASH_BWD_TABLE_BIG):     # (the second: no launch to ride in)
+        g_m = torch.zeros(geo.n_entries, 2, device='cuda')
+        got_mlp = torch.zeros(cols, device='cuda')
+        got_flags = torch.zeros(4, dtype=torch.int32, device='cuda')
+        nof.call('nof_hash_encode_bwd_parts_reduce', C.byref(g), pts, table, dfeat_garbage, None, None, g_m, None, 0, L, tl, parts, 0, B,
+                 partials, rows, cols, got_mlp, got_flags)
+        torch.cuda.synchronize()
+        assert torch.equal(got_mlp.view(torch.int32), want_mlp.view(torch.int32)) and int(got_flags[0]) == int(want_flags[0]) == 4
+        if parts & nof.HASH_BWD_TABLE_SMALL:
+            assert (g_m - g_w).abs().max().item() <= 2e-5 * scale
 
 
 def test_step_over_the_list_equals_step_without(nof):
