@@ -318,10 +318,27 @@ def main():
         """ray-samples of the last batch whose loss gradient is exactly zero (one device reduction + host sync: outside timing)"""
         return float((fld._buffers(R, S)['draw'] == 0).all(-1).float().mean().item())
 
+    trace_steps = os.environ.get('NOF_BENCH_TRACE_STEPS') == '1'     # diagnosis: loss and parameter sums after every step (host syncs)
+
     def step():
         """one iteration of NerfRunner.train()"""
         runner.train_loop()
         runner.global_step += 1
+        if trace_steps:
+            print(f"[step {fld.global_step}] loss {fld.losses()['loss']:.7f} table {float(fld.table.double().abs().sum().item()):.4f} "
+                  f"mlp {float(fld.mlp.double().abs().sum().item()):.5f} tiles {fld.backward_tiles} ids {runner.data_loader.batch_ray_ids[:4].tolist()} "
+                  f"pos {runner.data_loader.pos} lr {fld.learning_rates()} flags {int(fld.flags[0].item())} scale {fld.desc.grad_scale} "
+                  f"trunc {fld.truncation():.6f} pose {float(fld.pose.double().abs().sum().item()):.6f} "
+                  f"m {float(fld.exp_avg.double().abs().sum().item()):.6f} v {float(fld.exp_avg_sq.double().sum().item()):.8f} "
+                  f"g {float(fld.grads.double().abs().sum().item()):.6f} "
+                  + " ".join(f"{k} {float(v.double().abs().sum().item()):.7f}" for k, v in
+                             (('tf', fld.tf), ('packed', fld.packed.view(torch.int16).float()), ('raw', fld._buffers(R, S)['raw']),
+                              ('rgb', fld._buffers(R, S)['rgb_map']), ('z', fld._buffers(R, S)['z_vals']), ('pts', fld._buffers(R, S)['pts_w']),
+                              ('draw', fld._buffers(R, S)['draw']), ('dfeat', fld._buffers(R, S)['dfeat']),
+                              ('dview', fld._buffers(R, S)['dview']), ('gray', fld._buffers(R, S)['g_ray']),
+                              ('lossrows', fld._buffers(R, S)['loss_rows']), ('view', fld._buffers(R, S)['view'])))
+                  + f" ntiles {int(fld._buffers(R, S)['tiles'][:4].view(torch.int32)[0].item())} lossvec {fld.loss_out.tolist()}",
+                  file=sys.stderr, flush=True)
 
     # ---- optional pre-roll: forward-only batches (NerfRunner.render_images' path), no parameter / optimiser / loader / RNG state touched.
     # Built on the suspicion that the driver's 20 timed steps after 5 warm-up steps (0.52 ms) ran on a GPU whose clocks had not ramped;
@@ -380,6 +397,17 @@ def main():
     zero_first = zero_fraction() if args.warmup > 0 else None
     dt = timed(args.steps)
     log(f'timed region done: {dt / args.steps * 1e3:.3f} ms/step')
+    # The parameters after exactly W + K steps: what the tests compare between the forms of the data-parallel step.  Taken HERE and
+    # not at the end of the run: Adam with eps = 1e-15 (the reference's) turns the first rounding-noise gradient of a so far dead
+    # weight into a full +-lr step, and an MLP weight that wakes up that way moves everything downstream -- 3 of 16 otherwise
+    # identical 26-step runs ended 4e-4 away from the other 13 in sum |p| (all 3 in the same place), parting at step 14
+    # (profiles/r04_q_rccl_states.txt); after 8 steps the runs agree to 1e-6.
+    checksum = float(fld.params.double().abs().sum().item())
+    # (per segment of the flat buffer: tells which of table / MLP / frame features / poses two runs disagree on)
+    checksum_parts = {k: float(getattr(fld, k).double().abs().sum().item()) for k in ('table', 'mlp', 'feat', 'pose')}
+    checksum_parts['steps_taken'] = int(fld.global_step)
+    checksum_parts['adam_steps'] = int(fld.adam_steps)
+    checksum_parts['loss_scale_backoff'] = int(fld._scale_backoff)       # > 0: a step overflowed in the 16-bit backward and was skipped
     zero_last = zero_fraction()
     kt = fld.kernel_times_ms()
     dom_ms = kt.get(dominant) if dominant else None
@@ -439,7 +467,7 @@ def main():
     extraction = time_extraction(runner, args.extract) if args.extract > 0 and world == 1 else None
     flags = int(fld.flags[0].item())
     losses = fld.losses()
-    dp_spread, checksum = None, float(fld.params.double().abs().sum().item())
+    dp_spread = None
     if dist.is_initialized():               # replicas must hold bit-identical parameters after K synchronised steps
         chk = torch.stack([fld.params.double().sum(), fld.params.double().abs().sum()]).to(device)
         allc = [torch.empty_like(chk) for _ in range(dist.get_world_size())]
@@ -606,6 +634,7 @@ def main():
             "zero_grad_sample_fraction": zero_frac,
             "zero_grad_sample_fraction_first_timed_step": zero_first, "zero_grad_sample_fraction_last_timed_step": zero_last,
             "loss": losses['loss'], "flags": flags, "dp_param_checksum_spread": dp_spread, "param_checksum": checksum,
+            "param_checksum_parts": checksum_parts,
             # data parallel (N > 1): gradient bytes each rank hands to RCCL per step, in how many collectives, and how long the
             # step's stream waited for them after the backward (events around GradSync.finish: what did not hide)
             "allreduce_bytes_per_step": (sync.bytes_step if sync is not None else (fld.n_total * 4 if runner.grad_sync is not None else 0)),

@@ -42,7 +42,9 @@ def test_bench_two_ranks_one_gpu_gloo(nof):
     d0 = _run('0', 29534)              # one blocking all-reduce of the whole buffer
     assert d0['dp_param_checksum_spread'] == 0.0
     # element-wise sums: bucketing cannot change the result beyond the atomics' summation order inside each rank -- which Adam
-    # (eps 1e-15) turns into +-lr on entries whose gradient is rounding noise: a few dozen of 9 M parameters over the run's 16 steps
+    # (eps 1e-15) turns into +-lr on entries whose gradient is rounding noise: a few dozen of 9 M parameters over the 8 steps the
+    # checksum is taken after (bench.py takes it right after the timed region: over the 26 steps of the whole run one MLP weight
+    # waking up on noise sent 3 of 16 identical runs 4e-4 away from the other 13, profiles/r04_q_rccl_states.txt)
     assert abs(d['param_checksum'] - d0['param_checksum']) <= 2e-5 * d0["param_checksum"]
     assert d['n_gpus'] == 2 and d['scaling'] == 'weak' and d['config']['parallelism'] == 'dp2'
     assert d['flags'] == 0 and d['loss'] == d['loss']                  # finite
@@ -82,7 +84,7 @@ def test_rccl_calls_of_the_bucketed_step_one_rank(nof):
     assert d['allreduce_bytes_per_step'] >= d1['allreduce_bytes_per_step'] > 4 * 9_000_000 and d0['allreduce_bytes_per_step'] == 0
     assert d['exposed_comm_ms'] is not None and d['exposed_comm_ms'] >= 0 and d0['exposed_comm_ms'] is None
     assert d['flags'] == 0 and d['loss'] == d['loss']
-    assert abs(d['param_checksum'] - d1['param_checksum']) <= 2e-5 * d1['param_checksum']
+    assert abs(d['param_checksum'] - d1['param_checksum']) <= 2e-5 * d1['param_checksum'], (d['param_checksum_parts'], d1['param_checksum_parts'], d0['param_checksum_parts'])
     # the sharded optimiser (reduce-scatter -> Adam on the rank's shard -> all-gather of the parameters; at one rank the shard is
     # everything and both collectives are identities performed by RCCL): same parameters again
     dz = _run('1', 29540, backend='nccl', ranks=1, force='1', mode='zero1')
