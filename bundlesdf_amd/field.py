@@ -689,13 +689,14 @@ class NeuralObjectField:
         row[self.ff:self.ff + len(sh)] = torch.tensor(np.array(sh, dtype=np.float32), device=self.device)
         return row
 
-    def query_network(self, pts, viewdir=(0.0, 0.0, 0.0), frame_id=0, chunk=1 << 20):
+    def query_network(self, pts, viewdir=(0.0, 0.0, 0.0), frame_id=0, chunk=None):
         """run_network on free-standing points (nerf_runner.py:1226-1294 the way mesh_vertex_color_from_network :1412-1424 calls it:
         identity transform, one view direction, one frame's latent code): raw [N,4] = (colour logits, sdf).  Points outside [-1,1]^3
         get a zero embedding like the reference's valid_samples (:1246-1257)."""
         pts = pts.to(self.device, torch.float32).contiguous()
         self.pack_weights()
         N = pts.shape[0]
+        chunk = chunk or (1 << 18 if self.wide else 1 << 20)          # (the wide forward stages ~1.5 KB of activations per point)
         raw = torch.empty(N, 4, device=self.device)
         view = self.view_row(viewdir, frame_id).view(1, 16).contiguous()
         for i in range(0, N, chunk):
