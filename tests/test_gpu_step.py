@@ -217,6 +217,19 @@ def test_wide_network_step_matches_oracle(nof):
     assert np.isfinite(last) and last < 0.8 * first, (first, last)
     sdf = fld.query_sdf(b['pts_w'][:1000])
     assert torch.isfinite(sdf).all()
+    # run_network on free-standing points through the wide kernels (NeuralObjectField.query_network: one view row for all points):
+    # against the fp32 oracle on the trained parameters, and its SDF column against query_sdf's on the points inside the cube
+    orc_t = O.OracleField(cfg, orc.geo, orc.shape, fld.F, cpu(fld.c2w).reshape(-1, 4, 4), orc.occ_l, table=cpu(fld.table).reshape(-1, 2),
+                          mlp=[[W.clone(), bb.clone()] for W, bb in fld.mlp_state()], pose=cpu(fld.pose).reshape(-1, 6))
+    pts = torch.rand(3000, 3, generator=torch.Generator().manual_seed(3)) * 2.2 - 1.1
+    got = cpu(fld.query_network(pts, viewdir=(0.0, 0.6, -0.8), frame_id=1))
+    want = orc_t.run_network_points(pts.numpy(), viewdir=(0.0, 0.6, -0.8), frame_id=1).numpy()
+    e_c, e_s = rel_max(got[:, :3], want[:, :3]), rel_max(got[:, 3], want[:, 3])
+    print(f'wide query_network vs the fp32 oracle: colour {e_c:.2e} sdf {e_s:.2e} (max-norm)')
+    assert e_c < 2e-3 and e_s < 2e-3
+    inside = (pts.abs() <= 1).all(1)
+    sdf_q = cpu(fld.query_sdf(pts[inside]))
+    assert np.abs(got[inside.numpy(), 3] - sdf_q).max() <= 1e-3 * max(1.0, np.abs(sdf_q).max())
 
 
 def test_philox_training_reduces_loss(nof):
