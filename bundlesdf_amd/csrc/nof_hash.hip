@@ -228,7 +228,7 @@ template <bool EIK>
 __global__ __launch_bounds__(256) void k_hash_bwd_agg(NofHashGrid g, LevelList ll, const float* __restrict__ pts_w,
                                                        const float2* __restrict__ dfeat, float* __restrict__ grad_table,
                                                        int64_t B, const float2* __restrict__ geik, const float* __restrict__ dedn,
-                                                       const uint32_t* __restrict__ tile_list) {
+                                                       const uint32_t* __restrict__ tile_list, int trim) {
   __shared__ __attribute__((aligned(16))) AggStage st;
   const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   float* val = st.val[w];
@@ -243,7 +243,16 @@ __global__ __launch_bounds__(256) void k_hash_bwd_agg(NofHashGrid g, LevelList l
   // below only ever compares cell ids of neighbouring lanes, so two tiles from different rays in one wave are just a place where
   // a run ends (or, by coincidence, continues -- same cell, same vertices, same sum).  An odd list ends in a tile past the batch.
   const uint32_t n_items = tile_list ? ((uint32_t)__builtin_amdgcn_readfirstlane((int)tile_list[0]) + 1u) / 2u : (uint32_t)((B + 63) / 64);
-  const uint32_t n_lv = (uint32_t)ll.n, n_sb = n_items, n_waves = gridDim.x * 4u;
+  // How many of the launch's persistent workgroups take part is decided HERE, from the list's length (known on the device only):
+  // with most tiles listed the scatter wants 4 workgroups per CU in flight, with half of them or fewer -- a training batch: 37 % of
+  // the tiles once the field has settled, 50 % in the first steps -- 3 (A/B on one box, whole 501-step round 0.425-0.434 vs
+  // 0.436-0.441 ms/step, settled 0.398-0.406 vs 0.410-0.414; every tile listed 0.662 vs 0.616: profiles/r04_s_scatter_wgs.txt).
+  // The host launches the larger grid (default workgroup count only, `trim` != 0); the last quarter leaves at once when the list is short.
+  uint32_t n_blocks = gridDim.x;
+  if (trim != 0 && tile_list != nullptr && 4u * (uint32_t)__builtin_amdgcn_readfirstlane((int)tile_list[0]) < 3u * (uint32_t)__builtin_amdgcn_readfirstlane((int)tile_list[1]))
+    n_blocks = (gridDim.x * 3u) / 4u;
+  if (blockIdx.x >= n_blocks) return;
+  const uint32_t n_lv = (uint32_t)ll.n, n_sb = n_items, n_waves = n_blocks * 4u;
   const uint32_t t0 = blockIdx.x * 4u + (uint32_t)w, dq = n_waves / n_lv, dr = n_waves % n_lv;
   uint32_t sb = t0 / n_lv, slot_l = t0 % n_lv;
   for (; sb < n_sb; sb += dq, slot_l += dr, sb += slot_l >= n_lv ? 1u : 0u, slot_l -= slot_l >= n_lv ? n_lv : 0u) {
@@ -659,12 +668,13 @@ static int hash_bwd_parts(const NofHashGrid* g, const float* pts_w, const float*
       const int64_t need = nof_div_up(nof_div_up(B, 64) * big.n, 4);
       if (blocks > need) blocks = need;
     }
+    const int trim = wgs_per_cu == 0 ? 1 : 0;                          // (an explicit workgroup count is taken literally)
     if (geik != nullptr)
       hipLaunchKernelGGL(k_hash_bwd_agg<true>, dim3((unsigned)blocks), dim3(256), 0, st, *g, big, pts_w, (const float2*)dfeat,
-                         grad_table, B, geik, dedn, tl);
+                         grad_table, B, geik, dedn, tl, trim);
     else
       hipLaunchKernelGGL(k_hash_bwd_agg<false>, dim3((unsigned)blocks), dim3(256), 0, st, *g, big, pts_w, (const float2*)dfeat,
-                         grad_table, B, geik, dedn, tl);
+                         grad_table, B, geik, dedn, tl, trim);
     NOF_LAUNCH_OK();
   }
   if ((parts & NOF_HASH_BWD_INPUT) && dpts) {
