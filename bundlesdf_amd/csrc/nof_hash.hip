@@ -662,7 +662,8 @@ static int hash_bwd_parts(const NofHashGrid* g, const float* pts_w, const float*
     // persistent waves.  With every sample contributing (6.9 M line requests at cfg2) the kernel is bound by the atomic rate of
     // the memory side: two workgroups per CU saturate it and more only take L2 bandwidth from the kernels beside it
     // (whole call 1 -> 646 us, 2 -> 439, 3 -> 474, 4 -> 525, 8 -> 537).  With the zero-gradient tiles gone (two thirds of a settled
-    // cfg2 batch: 1.3 M requests) it wants more waves in flight: 4 is the default.
+    // cfg2 batch: 1.3 M requests) it wants more waves in flight: 4 are launched by default, of which the kernel
+    // itself keeps 3 when fewer than three quarters of the tiles are listed (see there).
     int64_t blocks = (int64_t)(wgs_per_cu > 0 ? wgs_per_cu : 4) * nof_cu_count();
     if (tl == nullptr) {                                                // (the size of a list is only known on the device)
       const int64_t need = nof_div_up(nof_div_up(B, 64) * big.n, 4);
