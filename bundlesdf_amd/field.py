@@ -17,7 +17,6 @@ tiles that have any (a third of a settled cfg2 batch).
 """
 import ctypes as C
 import math
-import os
 
 import numpy as np
 import torch

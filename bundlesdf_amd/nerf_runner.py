@@ -7,13 +7,15 @@ Plugin surface kept (call sites in /root/reference/bundlesdf.py):
     .add_new_frames(rgbs, depths, masks, normal_maps, poses, occ_masks=, new_pcd=, reuse_weights=False)   :223
     .train()                                                                                              :228,726
     .extract_mesh(isolevel=0, voxel_size=, return_sigma=)                                                 :234,747
+    .mesh_texture_from_train_images(mesh, rgbs_raw=, train_texture=False, tex_res=)                       :763
     .models['pose_array'].get_matrices(ids)   (via get_optimized_poses_in_real_world, Utils.py:491)       :231
     .cfg['translation'], .cfg['sc_factor']                                                                :235
 and the names `from nerf_runner import *` must provide (preprocess_data, get_optimized_poses_in_real_world,
 mesh_to_real_world, glcam_in_cvcam, BAD_DEPTH, set_seed).
+Beside them, the methods of the reference class that its own scripts use: render_images / the i_img canvas (nerf_runner.py:586-637,
+768-791), save_weights / load_weights (:528-577), mesh_vertex_color_from_network (:1412-1429).
 There is no CPU fallback: constructing a runner without the HIP library or without a GPU raises.
 """
-import copy
 import logging
 import os
 
