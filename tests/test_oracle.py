@@ -313,6 +313,50 @@ def _dda_numpy(occ, o, d):
     return out
 
 
+@pytest.mark.parametrize("level,fill", [(2, 0.6), (4, 0.25), (6, 0.03)])
+def test_dda_closed_form_enumeration_equals_the_walk(level, fill):
+    """tools/dda_closed_form.py (groundwork for a lane-parallel ray marcher): the cells of a ray enumerated from the three
+    sorted lists of exit times -- one independent computation per crossing -- are the walk's cells, in the walk's order, with the
+    walk's float32 intervals: random rays, and rays built to tie (lattice origins, axis-parallel / face-diagonal / space-diagonal /
+    small-integer-ratio directions through cell corners and edges, rays inside the grid, rays that miss)."""
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools'))
+    from dda_closed_form import enumerate_cells
+    from tests import util as U
+    n = 1 << level
+    occ = U.random_occ(n, fill, seed=40 + level)
+    o, d = U.random_rays(120, seed=50 + level)
+    rng = np.random.default_rng(60 + level)
+    cs = 2.0 / n
+    extra_o, extra_d = [], []
+    dirs = [(1, 0, 0), (0, -1, 0), (0, 0, 1), (1, 1, 0), (1, -1, 0), (0, 1, 1), (1, 1, 1), (-1, 1, -1), (1, 2, 0), (2, 1, 3), (1, 2, 4),
+            (-3, 1, 2), (1, 1, 2), (4, 4, 1)]
+    for dv in dirs:
+        dv = np.array(dv, np.float64)
+        for _ in range(6):
+            lat = rng.integers(0, n + 1, size=3) * cs - 1.0                    # a grid vertex: the ray runs through corners / edges
+            back = rng.integers(1, 3 * n)
+            extra_o.append(lat - dv / np.abs(dv).max() * back * cs)            # start a whole number of cells back (often outside)
+            extra_d.append(dv / np.linalg.norm(dv))
+        extra_o.append(np.array([0.5 * cs - 1.0, 0.5 * cs - 1.0, 0.5 * cs - 1.0]) + rng.integers(0, n, size=3) * cs)   # cell centre, inside
+        extra_d.append(dv / np.linalg.norm(dv))
+    extra_o += [[-3, 5, 0], [0.2, 0.3, -4], [1.0, 1.0, 1.0], [-1.0, -1.0, -1.0]]                                       # misses / corners
+    extra_d += [[1, 0, 0], [0, 0, -1], [-1, -1, -1], [1, 1, 1]]
+    extra_d[-2] = list(np.array(extra_d[-2]) / np.sqrt(3)); extra_d[-1] = list(np.array(extra_d[-1]) / np.sqrt(3))
+    o = np.concatenate([o, np.array(extra_o)]).astype(np.float32)
+    d = np.concatenate([d, np.array(extra_d)]).astype(np.float32)
+    walk = _dda_numpy(occ, o, d)
+    n_hits = n_tied = 0
+    for r in range(len(o)):
+        got = enumerate_cells(occ, o[r], d[r])
+        assert len(got) == len(walk[r]), (r, o[r], d[r], len(got), len(walk[r]))
+        for k, ((c, a, b), (c2, a2, b2)) in enumerate(zip(got, walk[r])):
+            assert c == c2 and np.float32(a) == np.float32(a2) and np.float32(b) == np.float32(b2), (r, k)
+        n_hits += len(got)
+        n_tied += int(r >= 120)
+    assert n_hits > 50 and n_tied > 80
+
+
 @pytest.mark.parametrize("level,fill", [(3, 0.4), (4, 0.2), (5, 0.05)])
 def test_dda_walk_equals_bruteforce_definition(level, fill):
     """the traversal order the HIP kernel uses visits exactly the cells of the brute-force slab definition"""
