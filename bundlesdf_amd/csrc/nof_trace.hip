@@ -290,6 +290,209 @@ __global__ __launch_bounds__(64) void k_batch_trace(const float* __restrict__ po
 }
 
 // ------------------------------------------------------------------------------------------------
+// The same ray marcher with ONE WAVE PER RAY (nof_set_trace_kernel(1); levels <= 6): no walk.  Along axis a the ray leaves cell
+// index i at tmax_a(i) -- cell_slab's closed form, non-decreasing along the direction of travel -- so the walk's sequence of exit
+// axes is the 3-way merge of three sorted lists under the walk's tie rule (x, then y, then z), and crossing j of axis a has the rank
+//     j + sum over the other axes b of #{m : tmax_b(m) < tmax_a(j)}   (b > a: b loses ties)   or   #{... <= ...}   (b < a)
+// -- two binary searches over closed forms.  The cell entered through it is the start cell moved by (j + 1) steps along a and by
+// those counts along the other axes; the walk ends at the first crossing that is the last of its axis.  One lane per crossing
+// computes its cell, the cell's interval and occupancy bit on its own; the cells go to a wave-private LDS table in rank order, a
+// ballot finds the terminator (common.cu:140) and a prefix count compacts the hits.  Same float32 expressions as trace_one_t, hence
+// the same bits: tools/dda_closed_form.py is this algorithm in NumPy, checked against the walk on the CPU
+// (tests/test_oracle.py::test_dda_closed_form_enumeration_equals_the_walk), and tests/test_gpu_ops.py compares the two kernels.
+#define NOF_TW_SLOTS 196                                               // 3 * 64 crossings + the start cell, rounded up
+struct WaveCells {
+  float tin[NOF_TW_SLOTS], tout[NOF_TW_SLOTS];
+  int32_t code[NOF_TW_SLOTS];                                          // cell id of a hit to emit, -2: nothing, -3: the terminator
+};
+
+__device__ __forceinline__ int wave_min_i(int v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// returns the number of hits written (wave-uniform); tio / cid rows are this ray's
+__device__ __forceinline__ int trace_wave(int n, const float o[3], const float d[3], int max_hits, float* __restrict__ tio,
+                                          int32_t* __restrict__ cid, int* overflow, WaveCells* wc, int lane) {
+  const float cs = 2.0f / (float)n;
+  Axis ax[3];
+  float tenter = 0.0f, texit = NOF_INF;
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    ax[a].o = o[a];
+    ax[a].zero = fabsf(d[a]) < ZERO_DIR;
+    ax[a].inv = ax[a].zero ? 0.0f : 1.0f / d[a];
+    ax[a].step = d[a] > 0.0f ? 1 : -1;
+    if (ax[a].zero) {
+      if (!(-1.0f <= o[a] && o[a] < 1.0f)) texit = -NOF_INF;
+    } else {
+      const float t0 = (-1.0f - o[a]) * ax[a].inv, t1 = (1.0f - o[a]) * ax[a].inv;
+      tenter = fmaxf(tenter, fminf(t0, t1));
+      texit = fminf(texit, fmaxf(t0, t1));
+    }
+  }
+  if (!(tenter <= texit)) return 0;
+  int c0[3], m[3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {                                         // the walk's start cell, unchanged
+    const float p = ax[a].zero ? o[a] : (o[a] + tenter * d[a]);
+    int i = (int)floorf((p + 1.0f) / cs);
+    i = min(max(i, 0), n - 1);
+    if (!ax[a].zero) {
+      for (int it = 0; it < 4; ++it) {
+        float tmin, tmax;
+        cell_slab(ax[a], i, cs, tmin, tmax);
+        if (tmax < tenter && i + ax[a].step >= 0 && i + ax[a].step < n) i += ax[a].step;
+        else if (tmin > tenter && i - ax[a].step >= 0 && i - ax[a].step < n) i -= ax[a].step;
+        else break;
+      }
+    }
+    c0[a] = i;
+    m[a] = ax[a].zero ? 0 : (ax[a].step > 0 ? n - i : i + 1);           // crossings of axis a until the ray leaves the grid
+  }
+  const int M = m[0] + m[1] + m[2];
+  int k_end = M == 0 ? 0 : 0x7fffffff;                                  // rank of the first crossing that leaves the grid
+  for (int q0 = 0; q0 <= M; q0 += 64) {
+    const int q = q0 + lane;                                            // 0: the start cell; q >= 1: crossing q - 1
+    const bool live = q <= M;
+    const int e = q - 1;
+    const int a = e < m[0] ? 0 : (e < m[0] + m[1] ? 1 : 2);             // (selects, not indexing: ax[] / c0[] stay in registers)
+    const int j = e - (a == 0 ? 0 : (a == 1 ? m[0] : m[0] + m[1]));
+    float t = 0.0f;
+    if (q >= 1) {
+      float tmin0, tmax0, tmin1, tmax1, tmin2, tmax2;
+      cell_slab(ax[0], c0[0] + j * ax[0].step, cs, tmin0, tmax0);
+      cell_slab(ax[1], c0[1] + j * ax[1].step, cs, tmin1, tmax1);
+      cell_slab(ax[2], c0[2] + j * ax[2].step, cs, tmin2, tmax2);
+      t = a == 0 ? tmax0 : (a == 1 ? tmax1 : tmax2);
+    }
+    int cnt[3];
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+      int lo = 0, hi = m[b];
+      const bool use_le = b < a;                                        // b wins ties against a
+#pragma unroll
+      for (int it = 0; it < 7; ++it) {                                  // m[b] <= 64
+        if (lo < hi) {
+          const int mid = (lo + hi) >> 1;
+          float tmn, tmx;
+          cell_slab(ax[b], c0[b] + mid * ax[b].step, cs, tmn, tmx);
+          const bool before = use_le ? tmx <= t : tmx < t;
+          lo = before ? mid + 1 : lo;
+          hi = before ? hi : mid;
+        }
+      }
+      cnt[b] = q >= 1 ? (b == a ? j : lo) : 0;
+    }
+    const int rank = cnt[0] + cnt[1] + cnt[2];
+    const int m_a = a == 0 ? m[0] : (a == 1 ? m[1] : m[2]);
+    const bool leaves = q >= 1 && live && j == m_a - 1;
+    k_end = min(k_end, wave_min_i(leaves ? rank : 0x7fffffff));
+    if (live && !leaves) {
+      const int k = q >= 1 ? rank + 1 : 0;
+      const int cc0 = c0[0] + (cnt[0] + (q >= 1 && a == 0 ? 1 : 0)) * ax[0].step;
+      const int cc1 = c0[1] + (cnt[1] + (q >= 1 && a == 1 ? 1 : 0)) * ax[1].step;
+      const int cc2 = c0[2] + (cnt[2] + (q >= 1 && a == 2 ? 1 : 0)) * ax[2].step;
+      float tmin[3], tmax[3];
+      cell_slab(ax[0], cc0, cs, tmin[0], tmax[0]);
+      cell_slab(ax[1], cc1, cs, tmin[1], tmax[1]);
+      cell_slab(ax[2], cc2, cs, tmin[2], tmax[2]);
+      const float tin = fmaxf(fmaxf(fmaxf(tmin[0], tmin[1]), tmin[2]), 0.0f);
+      const float tout = fminf(fminf(tmax[0], tmax[1]), tmax[2]);
+      int code = -2;
+      if (tin <= tout && occ_test_t<true>(nullptr, n, cc0, cc1, cc2)) {
+        if (tin == 0.0f || tout == 0.0f) code = -3;                    // common.cu:140 (terminator)
+        else if (!(fabsf(tout - tin) < MIN_LEN)) code = (int32_t)(((uint32_t)cc0 * n + cc1) * n + cc2);   // common.cu:142
+      }
+      wc->tin[k] = tin;
+      wc->tout[k] = tout;
+      wc->code[k] = code;
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");               // (one wave: LDS operations retire in order; nothing to wait for)
+  __builtin_amdgcn_wave_barrier();
+  int nh = 0;
+  for (int k0 = 0; k0 <= k_end; k0 += 64) {
+    const int k = k0 + lane;
+    const bool valid = k <= k_end;
+    const int code = valid ? wc->code[k] : -2;
+    const unsigned long long term = __builtin_amdgcn_ballot_w64(code == -3);
+    const int k_term = term ? k0 + __builtin_ctzll(term) : 0x7fffffff;
+    const bool emit = code >= 0 && k < k_term;
+    const unsigned long long em = __builtin_amdgcn_ballot_w64(emit);
+    const int pos = nh + __builtin_popcountll(em & ((1ull << lane) - 1ull));
+    if (emit) {
+      if (pos < max_hits) {
+        reinterpret_cast<float2*>(tio)[pos] = make_float2(wc->tin[k], wc->tout[k]);
+        if (cid) cid[pos] = code;
+      } else {
+        *overflow = 1;
+      }
+    }
+    nh += __builtin_popcountll(em);
+    if (term) break;
+  }
+  return min(nh, max_hits);
+}
+
+__global__ __launch_bounds__(256) void k_batch_trace_wave(const float* __restrict__ pool, const int64_t* __restrict__ ids,
+                                                           const float* __restrict__ tf, const float* __restrict__ frame_feat, int ff,
+                                                           int sh_degree, const uint32_t* __restrict__ bits, int n, int64_t R,
+                                                           int max_hits, float* __restrict__ batch, float* __restrict__ rays_o_w,
+                                                           float* __restrict__ viewdirs_w, float* __restrict__ view,
+                                                           float* __restrict__ t_in_out, int32_t* __restrict__ cell_ids,
+                                                           int32_t* __restrict__ n_hits, int32_t* __restrict__ flags, int cells_off) {
+  extern __shared__ uint32_t occ_lds[];
+  stage_occ(bits, n, occ_lds);                                           // (levels <= 6 only: the bitfield is in LDS)
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t r = (int64_t)blockIdx.x * 4 + wave;
+  if (r >= R) return;                                                    // (wave-uniform)
+  WaveCells* wc = reinterpret_cast<WaveCells*>(reinterpret_cast<char*>(occ_lds) + cells_off) + wave;
+  // every lane holds the ray (uniform loads); lanes 0..11 / 0..15 / 0..2 write its rows
+  const int64_t src = ids ? ids[r] : r;
+  float row[NOF_RAY_COLS];
+#pragma unroll
+  for (int k = 0; k < NOF_RAY_COLS; ++k) row[k] = pool[src * NOF_RAY_COLS + k];
+  const int f = (int)row[8];
+  const float* T = tf + (int64_t)f * 12;
+  const float nrm = sqrtf(row[0] * row[0] + row[1] * row[1] + row[2] * row[2]);
+  const float v[3] = {row[0] / nrm, row[1] / nrm, row[2] / nrm};
+  float o[3], d[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    o[i] = T[i * 4 + 3];
+    d[i] = (T[i * 4 + 0] * v[0] + T[i * 4 + 1] * v[1]) + T[i * 4 + 2] * v[2];
+  }
+  float vw[NOF_VIEW_COLS];
+#pragma unroll
+  for (int k = 0; k < NOF_VIEW_COLS; ++k) vw[k] = 0.0f;
+  float sh[16];
+  sh_eval(sh_degree, d[0], d[1], d[2], sh);
+  const int nsh = sh_degree * sh_degree;
+  for (int k = 0; k < ff; ++k) vw[k] = frame_feat[(int64_t)f * ff + k];
+  for (int k = 0; k < nsh && ff + k < NOF_VIEW_COLS; ++k) vw[ff + k] = sh[k];
+  if (lane == 0) {
+#pragma unroll
+    for (int k = 0; k < NOF_RAY_COLS; ++k) batch[r * NOF_RAY_COLS + k] = row[k];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { rays_o_w[r * 3 + i] = o[i]; viewdirs_w[r * 3 + i] = d[i]; }
+#pragma unroll
+    for (int k = 0; k < NOF_VIEW_COLS; ++k) view[r * NOF_VIEW_COLS + k] = vw[k];
+  }
+  float* tio = t_in_out + r * max_hits * 2;
+  int32_t* cid = cell_ids ? cell_ids + r * max_hits : nullptr;
+  int overflow = 0;
+  const int nh = trace_wave(n, o, d, max_hits, tio, cid, &overflow, wc, lane);
+  for (int k = nh + lane; k < max_hits; k += 64) {                       // zero padding (at::zeros, common.cu:158), the wave together
+    reinterpret_cast<float2*>(tio)[k] = make_float2(0.f, 0.f);
+    if (cid) cid[k] = -1;
+  }
+  if (lane == 0) n_hits[r] = nh;
+  if (__builtin_amdgcn_ballot_w64(overflow != 0) != 0ull && lane == 0 && flags) atomicOr(&flags[0], 1);
+}
+
+// ------------------------------------------------------------------------------------------------
 // Philox4x32-10 (Salmon et al. 2011) -> one uniform in [0,1)
 __device__ __forceinline__ float philox_uniform(uint64_t seed, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3) {
   uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
@@ -475,6 +678,17 @@ extern "C" int nof_trace_rays(const uint32_t* occ_bits, int32_t level, const flo
   return 0;
 }
 
+// which kernel nof_batch_trace (and through it nof_raymarch_sample) launches: 0 = one lane per ray walking its cells (k_batch_trace),
+// 1 (default) = one wave per ray, no walk (k_batch_trace_wave; levels <= 6, else 0 is used).  Process-wide; both give the same bits
+// (tests/test_gpu_ops.py::test_wave_ray_marcher_equals_the_walk); at cfg2 the launch takes 13 us instead of 25.
+static int g_trace_kernel = 1;
+extern "C" int nof_set_trace_kernel(int32_t kind) {
+  NOF_ARG(kind == 0 || kind == 1);
+  g_trace_kernel = kind;
+  return 0;
+}
+extern "C" int nof_get_trace_kernel(void) { return g_trace_kernel; }
+
 extern "C" int nof_batch_trace(const float* pool, const int64_t* ids, const float* tf, const float* frame_feat, int32_t ff,
                                 int32_t sh_degree, const uint32_t* occ_bits, int32_t level, int64_t R, int32_t max_hits,
                                 float* batch, float* rays_o_w, float* viewdirs_w, float* view, float* t_in_out,
@@ -483,6 +697,14 @@ extern "C" int nof_batch_trace(const float* pool, const int64_t* ids, const floa
   NOF_ARG(level >= 0 && level <= 8 && max_hits >= 1 && R >= 0 && sh_degree >= 1 && sh_degree <= 4);
   NOF_ARG(ff >= 0 && ff + sh_degree * sh_degree <= NOF_VIEW_COLS && (ff == 0 || frame_feat));
   if (R == 0) return 0;
+  if (g_trace_kernel == 1 && level <= 6) {                              // one wave per ray (k_batch_trace_wave)
+    const size_t cells_off = (occ_lds_bytes(level) + 15) & ~(size_t)15;
+    hipLaunchKernelGGL(k_batch_trace_wave, dim3((unsigned)nof_div_up(R, 4)), dim3(256), cells_off + 4 * sizeof(WaveCells),
+                       (hipStream_t)stream, pool, ids, tf, frame_feat, ff, sh_degree, occ_bits, 1 << level, R, max_hits, batch,
+                       rays_o_w, viewdirs_w, view, t_in_out, cell_ids, n_hits, flags, (int)cells_off);
+    NOF_LAUNCH_OK();
+    return 0;
+  }
   hipLaunchKernelGGL(k_batch_trace, dim3((unsigned)nof_div_up(R, 64)), dim3(64), occ_lds_bytes(level), (hipStream_t)stream, pool, ids, tf,
                      frame_feat, ff, sh_degree, occ_bits, 1 << level, R, max_hits, batch, rays_o_w, viewdirs_w, view,
                      t_in_out, cell_ids, n_hits, flags);

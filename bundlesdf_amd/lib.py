@@ -75,6 +75,8 @@ _SIGNATURES = {
     'nof_occgrid_query': ([_P, _I32, _P, _P, _I64, _P], C.c_int),
     'nof_trace_rays': ([_P, _I32, _P, _P, _I64, _I32, _P, _P, _P, _P, _P], C.c_int),
     'nof_batch_trace': ([_P, _P, _P, _P, _I32, _I32, _P, _I32, _I64, _I32, _P, _P, _P, _P, _P, _P, _P, _P, _P], C.c_int),
+    'nof_set_trace_kernel': ([_I32], C.c_int),
+    'nof_get_trace_kernel': ([], C.c_int),
     'nof_sample_points': ([C.POINTER(NofSampleCfg), _P, _P, _P, _P, _I64, _I32, _P, _P, _P, _P, _P, _P, _P], C.c_int),
     'nof_mlp_packed_bytes': ([C.POINTER(NofMlpDesc)], C.c_int64),
     'nof_mlp_pack': ([C.POINTER(NofMlpDesc), _P, _P, _P], C.c_int),

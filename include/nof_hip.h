@@ -144,6 +144,10 @@ int nof_batch_trace(const float* pool, const int64_t* ids, const float* tf, cons
                     int32_t sh_degree, const uint32_t* occ_bits, int32_t level, int64_t R, int32_t max_hits,
                     float* batch, float* rays_o_w, float* viewdirs_w, float* view,
                     float* t_in_out, int32_t* cell_ids, int32_t* n_hits, int32_t* flags, void* stream);
+/* Which kernel nof_batch_trace / nof_raymarch_sample launch (process-wide): 0 = one lane per ray walking its cells, 1 (default) = one
+ * wave per ray with the cells enumerated from the ranks of the ray's plane crossings (levels <= 6; above, 0 is used).  Same results. */
+int nof_set_trace_kernel(int32_t kind);
+int nof_get_trace_kernel(void);
 
 typedef struct {
   int32_t  n_samples, n_around;           /* N_samples, N_samples_around_depth (config.yml:18-19) */

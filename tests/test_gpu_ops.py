@@ -225,6 +225,74 @@ def _scene(nof, R=300, level=4, seed=0, n_frames=5):
     return cfg, occ, c2w, batch
 
 
+@pytest.mark.parametrize("level,fill", [(2, 0.6), (4, 0.2), (5, 0.08), (6, 0.03)])
+def test_wave_ray_marcher_equals_the_walk(nof, level, fill):
+    """nof_set_trace_kernel(1): one wave per ray, the ray's cells from the ranks of its plane crossings instead of a walk
+    (k_batch_trace_wave; NumPy statement of the algorithm: tools/dda_closed_form.py, checked against the walk on the CPU).  Every
+    output of nof_batch_trace -- gathered rows, ray setup, view rows, intervals, cell ids, hit counts, the overflow flag -- must be
+    the walk kernel's, bit for bit: random rays through random poses, rays built to tie (lattice origins, axis-parallel and diagonal
+    directions, identity pose), frame features in the view rows, a hit-list capacity small enough to overflow, no cell ids."""
+    n = 1 << level
+    rng = np.random.default_rng(70 + level)
+    occ = U.random_occ(n, fill, seed=80 + level)
+    bits = _build_occ(nof, occ, level)
+    F, ff = 24, 2
+    cs = 2.0 / n
+    # frames 0..11: random rigid poses around the grid; 12..23: identity rotation, the translation a grid vertex moved a whole number
+    # of cells back along the ray direction of that frame's rays
+    tf = np.zeros((F, 12), np.float32)
+    dirs = [(1, 0, 0), (0, -1, 0), (0, 0, 1), (1, 1, 0), (1, -1, 0), (0, 1, 1), (1, 1, 1), (-1, 1, -1), (1, 2, 0), (2, 1, 3), (1, 2, 4), (4, 4, 1)]
+    for f in range(12):
+        q, _ = np.linalg.qr(rng.normal(size=(3, 3)))
+        tf[f].reshape(3, 4)[:, :3] = q
+        tf[f].reshape(3, 4)[:, 3] = rng.normal(size=3) * 1.2
+    for f in range(12, 24):
+        dv = np.array(dirs[f - 12], np.float64)
+        tf[f].reshape(3, 4)[:, :3] = np.eye(3)
+        tf[f].reshape(3, 4)[:, 3] = rng.integers(0, n + 1, size=3) * cs - 1.0 - dv / np.abs(dv).max() * rng.integers(1, 2 * n) * cs
+    R = 3000
+    batch = rng.normal(size=(R, 12)).astype(np.float32)
+    fid = rng.integers(0, F, size=R)
+    batch[:, 8] = fid
+    for r in range(R):
+        if fid[r] >= 12:
+            batch[r, :3] = np.array(dirs[fid[r] - 12], np.float32) * np.float32(rng.uniform(0.5, 2.0))
+        else:
+            tgt = rng.uniform(-0.9, 0.9, size=3)                    # towards the grid, in the frame's camera coordinates
+            batch[r, :3] = tf[fid[r]].reshape(3, 4)[:, :3].T @ (tgt - tf[fid[r]].reshape(3, 4)[:, 3])
+    feat = rng.normal(size=(F, ff)).astype(np.float32)
+    ids = torch.from_numpy(rng.permutation(R)).cuda()
+    outs = {}
+    default_kind = int(nof.load().nof_get_trace_kernel())
+    assert default_kind == 1
+    for kind in (0, 1):
+        for H, want_cells in ((3 * n + 2, True), (5, False)):
+            nof.load().nof_set_trace_kernel(kind)
+            try:
+                o = dict(batch=torch.full((R, 12), 7.0, device='cuda'), o_w=torch.empty(R, 3, device='cuda'), d_w=torch.empty(R, 3, device='cuda'),
+                         view=torch.empty(R, 16, device='cuda'), tio=torch.full((R, H, 2), 7.0, device='cuda'),
+                         cid=torch.full((R, H), 7, dtype=torch.int32, device='cuda') if want_cells else None,
+                         nh=torch.empty(R, dtype=torch.int32, device='cuda'), flags=torch.zeros(4, dtype=torch.int32, device='cuda'))
+                nof.call('nof_batch_trace', U.dev(batch), ids, U.dev(tf), U.dev(feat), ff, 3, bits, level, R, H, o['batch'], o['o_w'], o['d_w'],
+                         o['view'], o['tio'], o['cid'], o['nh'], o['flags'])
+                torch.cuda.synchronize()
+            finally:
+                nof.load().nof_set_trace_kernel(default_kind)
+            outs[(kind, H)] = o
+    for H in (3 * n + 2, 5):
+        a, b = outs[(0, H)], outs[(1, H)]
+        for k in ('batch', 'o_w', 'd_w', 'view', 'tio', 'nh', 'flags'):
+            assert torch.equal(a[k].view(torch.int32) if a[k].dtype == torch.float32 else a[k],
+                               b[k].view(torch.int32) if b[k].dtype == torch.float32 else b[k]), (H, k)
+        if a['cid'] is not None:
+            assert torch.equal(a['cid'], b['cid'])
+    full = outs[(1, 3 * n + 2)]
+    assert int(full['flags'][0]) == 0 and int(outs[(1, 5)]['flags'][0]) == (1 if int(full['nh'].max()) > 5 else 0)
+    assert int(full['nh'].sum()) > R // 2, 'the rays should hit something'
+    tied = torch.from_numpy(fid >= 12).cuda()[ids]
+    assert int(full['nh'][tied].sum()) > 0
+
+
 def test_sample_points_bit_identical(nof):
     level = 4
     cfg, occ, c2w, batch = _scene(nof, level=level)
