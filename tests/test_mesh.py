@@ -60,6 +60,18 @@ def test_largest_component_and_mesh_container(tmp_path):
     txt = open(out).read().splitlines()
     assert sum(l.startswith('v ') for l in txt) == len(big.vertices) and sum(l.startswith('f ') for l in txt) == len(big.faces)
     assert make_mesh(v, f) is not None
+    # vertex colours (NerfRunner.mesh_vertex_color_from_network on the trimesh-less container): a coloured ASCII .ply
+    small = Mesh(np.asarray(big.vertices)[:50], np.asarray(big.faces)[:0])
+    small.vertex_colors = (np.arange(150).reshape(50, 3) % 256).astype(np.uint8)
+    ply = open(small.export(str(tmp_path / 'c.ply'))).read().splitlines()
+    head = ply[:ply.index('end_header') + 1]
+    assert 'property uchar red' in head and 'property uchar green' in head and 'property uchar blue' in head and 'element vertex 50' in head
+    rows = [l.split() for l in ply[len(head):len(head) + 50]]
+    assert all(len(r) == 6 for r in rows)
+    assert np.array_equal(np.array([[int(x) for x in r[3:]] for r in rows]), small.vertex_colors)
+    assert np.allclose(np.array([[float(x) for x in r[:3]] for r in rows]), small.vertices, atol=1e-6)
+    small.vertex_colors = None                                   # ... and without colours the plain header
+    assert 'property uchar red' not in open(small.export(str(tmp_path / 'p.ply'))).read()
 
 
 # ------------------------------------------------------------------------------------------------------------------------
