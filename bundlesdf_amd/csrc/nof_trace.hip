@@ -290,6 +290,160 @@ __global__ __launch_bounds__(64) void k_batch_trace(const float* __restrict__ po
 }
 
 // ------------------------------------------------------------------------------------------------
+// Philox4x32-10 (Salmon et al. 2011) -> one uniform in [0,1)
+__device__ __forceinline__ float philox_uniform(uint64_t seed, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3) {
+  uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+  uint32_t x0 = c0, x1 = c1, x2 = c2, x3 = c3;
+#pragma unroll
+  for (int i = 0; i < 10; ++i) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * x0;
+    const uint64_t p1 = (uint64_t)0xCD9E8D57u * x2;
+    const uint32_t y0 = (uint32_t)(p1 >> 32) ^ x1 ^ k0;
+    const uint32_t y1 = (uint32_t)p1;
+    const uint32_t y2 = (uint32_t)(p0 >> 32) ^ x3 ^ k1;
+    const uint32_t y3 = (uint32_t)p0;
+    x0 = y0; x1 = y1; x2 = y2; x3 = y3;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  return (float)(x0 >> 8) * (1.0f / 16777216.0f);
+}
+
+__device__ __forceinline__ float lin01(int i, int N) {               // torch.linspace(0,1,N)[i] in float32
+  const float step = 1.0f / (float)(N - 1);                          // upper half: one rounding (fused), as ATen computes it
+  return (i < N / 2) ? (float)i * step : __builtin_fmaf(-step, (float)(N - 1 - i), 1.0f);
+}
+
+// sample_rays_uniform (nerf_runner.py:67-87) for one sample index
+__device__ __forceinline__ float stratified(int i, int N, float near, float far, float u) {
+  const float t = lin01(i, N);
+  const float zi = near * (1.0f - t) + far * t;
+  float lower = zi, upper = zi;
+  if (i > 0) {
+    const float tp = lin01(i - 1, N);
+    const float zp = near * (1.0f - tp) + far * tp;
+    lower = 0.5f * (zi + zp);
+  }
+  if (i < N - 1) {
+    const float tn = lin01(i + 1, N);
+    const float zn = near * (1.0f - tn) + far * tn;
+    upper = 0.5f * (zn + zi);
+  }
+  float z = lower + (upper - lower) * u;
+  return fminf(fmaxf(z, near), far);
+}
+// the same with perturb=False (render_images, nerf_runner.py:597): the linspace itself, no jitter and no clip (:78-85 are skipped)
+__device__ __forceinline__ float unperturbed(int i, int N, float near, float far) {
+  const float t = lin01(i, N);
+  return near * (1.0f - t) + far * t;
+}
+
+// sample s of ray r: its z by the reference's sequential subtraction walk over the ray's clipped intervals (zin / zout, `total` their
+// summed length), the sample point in world coordinates and its validity.  Shared by k_sample_points (a workgroup per ray) and the
+// fused wave-per-ray kernel (k_raymarch_wave<true>): the same code, the same bits.
+__device__ __forceinline__ void sample_place(const NofSampleCfg& cfg, int64_t r, int s, int S, int nh, float total,
+                                             const float* zin, const float* zout, bool valid_depth, float depth, float dx, float dy,
+                                             float dz, int f, const float* __restrict__ tf, const float* __restrict__ u_occ,
+                                             const float* __restrict__ u_dep, float* __restrict__ z_vals, float* __restrict__ pts_w,
+                                             uint8_t* __restrict__ valid, int32_t* __restrict__ flags) {
+  float z;
+  bool occupied_mode;
+  int N, i;
+  float u;
+  if (s < cfg.n_samples) {
+    occupied_mode = true; N = cfg.n_samples; i = s;
+    u = u_occ ? u_occ[r * cfg.n_samples + i] : philox_uniform(cfg.seed, (uint32_t)r, (uint32_t)s, cfg.d_step ? *cfg.d_step : cfg.step, 0u);
+  } else {
+    N = cfg.n_around; i = s - cfg.n_samples;
+    occupied_mode = !valid_depth;                                       // nerf_runner.py:1072-1076
+    u = u_dep ? u_dep[r * cfg.n_around + i] : philox_uniform(cfg.seed, (uint32_t)r, (uint32_t)s, cfg.d_step ? *cfg.d_step : cfg.step, 0u);
+  }
+  if (!occupied_mode) {
+    const float nd = depth - cfg.trunc;                                  // nerf_runner.py:1067-1071
+    const float fd = depth + cfg.trunc * cfg.neg_trunc_ratio;
+    z = cfg.deterministic ? unperturbed(i, N, nd, fd) : stratified(i, N, nd, fd, u);
+  } else if (nh == 0) {
+    z = 0.0f;                                                            // common.cu:54 (no box -> z_vals stays 0)
+  } else {
+    float zr = cfg.deterministic ? unperturbed(i, N, 0.0f, total) : stratified(i, N, 0.0f, total, u);
+    int ib = 0;
+    for (;;) {                                                           // common.cu:56-104
+      if (ib >= nh) {
+        z = zout[nh - 1];
+        if (zr > 1e-4f && flags) atomicOr(&flags[0], 2);                // the reference would print + spin here
+        break;
+      }
+      const float bl = zout[ib] - zin[ib];
+      if (zr <= bl) { z = zin[ib] + zr; break; }
+      zr -= bl;
+      ++ib;
+    }
+  }
+  const int64_t b = r * S + s;
+  z_vals[b] = z;
+  const float px = dx * z, py = dy * z, pz = dz * z;                     // pts = rays_d * z (nerf_runner.py:1083)
+  const float* T = tf + (int64_t)f * 12;
+  bool ok = true;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {                                           // transform_pts (Utils.py:253-257)
+    const float x = ((T[k * 4 + 0] * px + T[k * 4 + 1] * py) + T[k * 4 + 2] * pz) + T[k * 4 + 3];
+    pts_w[b * 3 + k] = x;
+    ok = ok && (fabsf(x) <= 1.0f);                                         // nerf_runner.py:1245
+  }
+  valid[b] = ok ? 1 : 0;
+}
+
+// One workgroup per ray: lanes stage the (clipped) z intervals in LDS, lane 0 sums their lengths in
+// order, then every lane places its sample by the reference's sequential subtraction walk.
+__global__ void k_sample_points(NofSampleCfg cfg, const float* __restrict__ batch, const float* __restrict__ tf,
+                                const float* __restrict__ t_in_out, const int32_t* __restrict__ n_hits, int max_hits,
+                                const float* __restrict__ u_occ, const float* __restrict__ u_dep,
+                                float* __restrict__ z_vals, float* __restrict__ pts_w, uint8_t* __restrict__ valid,
+                                int32_t* __restrict__ flags) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* zin = smem;
+  float* zout = smem + max_hits;
+  __shared__ float s_total;
+  const int64_t r = blockIdx.x;
+  // a new batch starts here: a "this step's weight gradient is not finite" mark left by the PREVIOUS step (bit 2, raised by
+  // nof_reduce_partials / nof_grad_check and consumed by that step's Adam launches, which skipped) becomes the sticky bit 3 that
+  // the host polls to lower the loss scale (field.poll_flags) -- so that exactly the offending step is skipped, like GradScaler
+  if (blockIdx.x == 0 && threadIdx.x == 0 && flags != nullptr) {
+    if (atomicAnd(&flags[0], ~4) & 4) atomicOr(&flags[0], 8);
+  }
+  const int S = cfg.n_samples + cfg.n_around;
+  const float* row = batch + r * NOF_RAY_COLS;
+  const float dx = row[0], dy = row[1], dz = row[2];
+  const float depth = row[6];
+  const int f = (int)row[8];
+  const float nrm = sqrtf(dx * dx + dy * dy + dz * dz);
+  const float vz = fabsf(dz / nrm);                                   // |viewdirs_z| (nerf_runner.py:987-990)
+  const bool valid_depth = (depth >= cfg.near_sc) && (depth <= cfg.far_sc);
+  const int nh = n_hits[r];
+  for (int h = threadIdx.x; h < nh; h += blockDim.x) {
+    float zi = t_in_out[(r * max_hits + h) * 2] * vz;
+    float zo = t_in_out[(r * max_hits + h) * 2 + 1] * vz;
+    if (valid_depth && zi > 0.0f && zo > 0.0f) {                       // nerf_runner.py:995-999
+      const float cap = depth + cfg.trunc;
+      zi = fminf(fmaxf(zi, 0.0f), cap);
+      zo = fminf(fmaxf(zo, 0.0f), cap);
+    }
+    zin[h] = zi;
+    zout[h] = zo;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float tot = 0.0f;
+    for (int h = 0; h < nh; ++h) tot += zout[h] - zin[h];              // depths_lens.sum (:1002-1003), in order
+    s_total = tot;
+  }
+  __syncthreads();
+  const int s = threadIdx.x;
+  if (s >= S) return;
+  sample_place(cfg, r, s, S, nh, s_total, zin, zout, valid_depth, depth, dx, dy, dz, f, tf, u_occ, u_dep, z_vals, pts_w, valid, flags);
+}
+
+// ------------------------------------------------------------------------------------------------
 // The same ray marcher with ONE WAVE PER RAY (nof_set_trace_kernel(1); levels <= 6): no walk.  Along axis a the ray leaves cell
 // index i at tmax_a(i) -- cell_slab's closed form, non-decreasing along the direction of travel -- so the walk's sequence of exit
 // axes is the 3-way merge of three sorted lists under the walk's tie rule (x, then y, then z), and crossing j of axis a has the rank
@@ -304,6 +458,7 @@ __global__ __launch_bounds__(64) void k_batch_trace(const float* __restrict__ po
 struct WaveCells {
   float tin[NOF_TW_SLOTS], tout[NOF_TW_SLOTS];
   int32_t code[NOF_TW_SLOTS];                                          // cell id of a hit to emit, -2: nothing, -3: the terminator
+  float zin[NOF_TW_SLOTS], zout[NOF_TW_SLOTS];                         // the sampler's clipped intervals, in hit order (k_raymarch_wave<true>)
 };
 
 __device__ __forceinline__ int wave_min_i(int v) {
@@ -424,8 +579,10 @@ __device__ __forceinline__ int trace_wave(int n, const float o[3], const float d
     const int pos = nh + __builtin_popcountll(em & ((1ull << lane) - 1ull));
     if (emit) {
       if (pos < max_hits) {
-        reinterpret_cast<float2*>(tio)[pos] = make_float2(wc->tin[k], wc->tout[k]);
+        const float2 io = make_float2(wc->tin[k], wc->tout[k]);
+        reinterpret_cast<float2*>(tio)[pos] = io;
         if (cid) cid[pos] = code;
+        if (pos < NOF_TW_SLOTS) { wc->zin[pos] = io.x; wc->zout[pos] = io.y; }      // (raw; the sampler half scales and clips them)
       } else {
         *overflow = 1;
       }
@@ -436,14 +593,23 @@ __device__ __forceinline__ int trace_wave(int n, const float o[3], const float d
   return min(nh, max_hits);
 }
 
-__global__ __launch_bounds__(256) void k_batch_trace_wave(const float* __restrict__ pool, const int64_t* __restrict__ ids,
+// SAMPLE: followed, in the same wave, by the sampler (k_sample_points' arithmetic through sample_place, the intervals taken from the
+// LDS table instead of being read back): nof_raymarch_sample as ONE launch.
+template <bool SAMPLE>
+__global__ __launch_bounds__(256) void k_raymarch_wave(const float* __restrict__ pool, const int64_t* __restrict__ ids,
                                                            const float* __restrict__ tf, const float* __restrict__ frame_feat, int ff,
                                                            int sh_degree, const uint32_t* __restrict__ bits, int n, int64_t R,
                                                            int max_hits, float* __restrict__ batch, float* __restrict__ rays_o_w,
                                                            float* __restrict__ viewdirs_w, float* __restrict__ view,
                                                            float* __restrict__ t_in_out, int32_t* __restrict__ cell_ids,
-                                                           int32_t* __restrict__ n_hits, int32_t* __restrict__ flags, int cells_off) {
+                                                           int32_t* __restrict__ n_hits, int32_t* __restrict__ flags, int cells_off,
+                                                           NofSampleCfg cfg, const float* __restrict__ u_occ,
+                                                           const float* __restrict__ u_dep, float* __restrict__ z_vals,
+                                                           float* __restrict__ pts_w, uint8_t* __restrict__ valid) {
   extern __shared__ uint32_t occ_lds[];
+  if (SAMPLE && blockIdx.x == 0 && threadIdx.x == 0 && flags != nullptr) {   // a new batch starts here: see k_sample_points
+    if (atomicAnd(&flags[0], ~4) & 4) atomicOr(&flags[0], 8);
+  }
   stage_occ(bits, n, occ_lds);                                           // (levels <= 6 only: the bitfield is in LDS)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t r = (int64_t)blockIdx.x * 4 + wave;
@@ -490,150 +656,35 @@ __global__ __launch_bounds__(256) void k_batch_trace_wave(const float* __restric
   }
   if (lane == 0) n_hits[r] = nh;
   if (__builtin_amdgcn_ballot_w64(overflow != 0) != 0ull && lane == 0 && flags) atomicOr(&flags[0], 1);
-}
-
-// ------------------------------------------------------------------------------------------------
-// Philox4x32-10 (Salmon et al. 2011) -> one uniform in [0,1)
-__device__ __forceinline__ float philox_uniform(uint64_t seed, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3) {
-  uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
-  uint32_t x0 = c0, x1 = c1, x2 = c2, x3 = c3;
-#pragma unroll
-  for (int i = 0; i < 10; ++i) {
-    const uint64_t p0 = (uint64_t)0xD2511F53u * x0;
-    const uint64_t p1 = (uint64_t)0xCD9E8D57u * x2;
-    const uint32_t y0 = (uint32_t)(p1 >> 32) ^ x1 ^ k0;
-    const uint32_t y1 = (uint32_t)p1;
-    const uint32_t y2 = (uint32_t)(p0 >> 32) ^ x3 ^ k1;
-    const uint32_t y3 = (uint32_t)p0;
-    x0 = y0; x1 = y1; x2 = y2; x3 = y3;
-    k0 += 0x9E3779B9u;
-    k1 += 0xBB67AE85u;
-  }
-  return (float)(x0 >> 8) * (1.0f / 16777216.0f);
-}
-
-__device__ __forceinline__ float lin01(int i, int N) {               // torch.linspace(0,1,N)[i] in float32
-  const float step = 1.0f / (float)(N - 1);                          // upper half: one rounding (fused), as ATen computes it
-  return (i < N / 2) ? (float)i * step : __builtin_fmaf(-step, (float)(N - 1 - i), 1.0f);
-}
-
-// sample_rays_uniform (nerf_runner.py:67-87) for one sample index
-__device__ __forceinline__ float stratified(int i, int N, float near, float far, float u) {
-  const float t = lin01(i, N);
-  const float zi = near * (1.0f - t) + far * t;
-  float lower = zi, upper = zi;
-  if (i > 0) {
-    const float tp = lin01(i - 1, N);
-    const float zp = near * (1.0f - tp) + far * tp;
-    lower = 0.5f * (zi + zp);
-  }
-  if (i < N - 1) {
-    const float tn = lin01(i + 1, N);
-    const float zn = near * (1.0f - tn) + far * tn;
-    upper = 0.5f * (zn + zi);
-  }
-  float z = lower + (upper - lower) * u;
-  return fminf(fmaxf(z, near), far);
-}
-// the same with perturb=False (render_images, nerf_runner.py:597): the linspace itself, no jitter and no clip (:78-85 are skipped)
-__device__ __forceinline__ float unperturbed(int i, int N, float near, float far) {
-  const float t = lin01(i, N);
-  return near * (1.0f - t) + far * t;
-}
-
-// One workgroup per ray: lanes stage the (clipped) z intervals in LDS, lane 0 sums their lengths in
-// order, then every lane places its sample by the reference's sequential subtraction walk.
-__global__ void k_sample_points(NofSampleCfg cfg, const float* __restrict__ batch, const float* __restrict__ tf,
-                                const float* __restrict__ t_in_out, const int32_t* __restrict__ n_hits, int max_hits,
-                                const float* __restrict__ u_occ, const float* __restrict__ u_dep,
-                                float* __restrict__ z_vals, float* __restrict__ pts_w, uint8_t* __restrict__ valid,
-                                int32_t* __restrict__ flags) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* zin = smem;
-  float* zout = smem + max_hits;
-  __shared__ float s_total;
-  const int64_t r = blockIdx.x;
-  // a new batch starts here: a "this step's weight gradient is not finite" mark left by the PREVIOUS step (bit 2, raised by
-  // nof_reduce_partials / nof_grad_check and consumed by that step's Adam launches, which skipped) becomes the sticky bit 3 that
-  // the host polls to lower the loss scale (field.poll_flags) -- so that exactly the offending step is skipped, like GradScaler
-  if (blockIdx.x == 0 && threadIdx.x == 0 && flags != nullptr) {
-    if (atomicAnd(&flags[0], ~4) & 4) atomicOr(&flags[0], 8);
-  }
-  const int S = cfg.n_samples + cfg.n_around;
-  const float* row = batch + r * NOF_RAY_COLS;
-  const float dx = row[0], dy = row[1], dz = row[2];
-  const float depth = row[6];
-  const int f = (int)row[8];
-  const float nrm = sqrtf(dx * dx + dy * dy + dz * dz);
-  const float vz = fabsf(dz / nrm);                                   // |viewdirs_z| (nerf_runner.py:987-990)
-  const bool valid_depth = (depth >= cfg.near_sc) && (depth <= cfg.far_sc);
-  const int nh = n_hits[r];
-  for (int h = threadIdx.x; h < nh; h += blockDim.x) {
-    float zi = t_in_out[(r * max_hits + h) * 2] * vz;
-    float zo = t_in_out[(r * max_hits + h) * 2 + 1] * vz;
-    if (valid_depth && zi > 0.0f && zo > 0.0f) {                       // nerf_runner.py:995-999
-      const float cap = depth + cfg.trunc;
-      zi = fminf(fmaxf(zi, 0.0f), cap);
-      zo = fminf(fmaxf(zo, 0.0f), cap);
-    }
-    zin[h] = zi;
-    zout[h] = zo;
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    float tot = 0.0f;
-    for (int h = 0; h < nh; ++h) tot += zout[h] - zin[h];              // depths_lens.sum (:1002-1003), in order
-    s_total = tot;
-  }
-  __syncthreads();
-  const int s = threadIdx.x;
-  if (s >= S) return;
-  const float total = s_total;
-  float z;
-  bool occupied_mode;
-  int N, i;
-  float u;
-  if (s < cfg.n_samples) {
-    occupied_mode = true; N = cfg.n_samples; i = s;
-    u = u_occ ? u_occ[r * cfg.n_samples + i] : philox_uniform(cfg.seed, (uint32_t)r, (uint32_t)s, cfg.d_step ? *cfg.d_step : cfg.step, 0u);
-  } else {
-    N = cfg.n_around; i = s - cfg.n_samples;
-    occupied_mode = !valid_depth;                                       // nerf_runner.py:1072-1076
-    u = u_dep ? u_dep[r * cfg.n_around + i] : philox_uniform(cfg.seed, (uint32_t)r, (uint32_t)s, cfg.d_step ? *cfg.d_step : cfg.step, 0u);
-  }
-  if (!occupied_mode) {
-    const float nd = depth - cfg.trunc;                                  // nerf_runner.py:1067-1071
-    const float fd = depth + cfg.trunc * cfg.neg_trunc_ratio;
-    z = cfg.deterministic ? unperturbed(i, N, nd, fd) : stratified(i, N, nd, fd, u);
-  } else if (nh == 0) {
-    z = 0.0f;                                                            // common.cu:54 (no box -> z_vals stays 0)
-  } else {
-    float zr = cfg.deterministic ? unperturbed(i, N, 0.0f, total) : stratified(i, N, 0.0f, total, u);
-    int ib = 0;
-    for (;;) {                                                           // common.cu:56-104
-      if (ib >= nh) {
-        z = zout[nh - 1];
-        if (zr > 1e-4f && flags) atomicOr(&flags[0], 2);                // the reference would print + spin here
-        break;
+  if constexpr (SAMPLE) {
+    // k_sample_points for this ray, the wave instead of a workgroup: clip the intervals (nerf_runner.py:995-999), sum their lengths
+    // in order (:1002-1003), place the S samples
+    const int S = cfg.n_samples + cfg.n_around;
+    const float dx = row[0], dy = row[1], dz = row[2];
+    const float depth = row[6];
+    const float vz = fabsf(dz / nrm);                                   // |viewdirs_z| (nerf_runner.py:987-990)
+    const bool valid_depth = (depth >= cfg.near_sc) && (depth <= cfg.far_sc);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    for (int h = lane; h < nh; h += 64) {
+      float zi = wc->zin[h] * vz;
+      float zo = wc->zout[h] * vz;
+      if (valid_depth && zi > 0.0f && zo > 0.0f) {
+        const float cap = depth + cfg.trunc;
+        zi = fminf(fmaxf(zi, 0.0f), cap);
+        zo = fminf(fmaxf(zo, 0.0f), cap);
       }
-      const float bl = zout[ib] - zin[ib];
-      if (zr <= bl) { z = zin[ib] + zr; break; }
-      zr -= bl;
-      ++ib;
+      wc->zin[h] = zi;
+      wc->zout[h] = zo;
     }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    float tot = 0.0f;
+    for (int h = 0; h < nh; ++h) tot += wc->zout[h] - wc->zin[h];       // (every lane, the same order as the workgroup's thread 0)
+    for (int sidx = lane; sidx < S; sidx += 64)
+      sample_place(cfg, r, sidx, S, nh, tot, wc->zin, wc->zout, valid_depth, depth, dx, dy, dz, f, tf, u_occ, u_dep, z_vals, pts_w,
+                   valid, flags);
   }
-  const int64_t b = r * S + s;
-  z_vals[b] = z;
-  const float px = dx * z, py = dy * z, pz = dz * z;                     // pts = rays_d * z (nerf_runner.py:1083)
-  const float* T = tf + (int64_t)f * 12;
-  bool ok = true;
-#pragma unroll
-  for (int k = 0; k < 3; ++k) {                                           // transform_pts (Utils.py:253-257)
-    const float x = ((T[k * 4 + 0] * px + T[k * 4 + 1] * py) + T[k * 4 + 2] * pz) + T[k * 4 + 3];
-    pts_w[b * 3 + k] = x;
-    ok = ok && (fabsf(x) <= 1.0f);                                         // nerf_runner.py:1245
-  }
-  valid[b] = ok ? 1 : 0;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -699,9 +750,10 @@ extern "C" int nof_batch_trace(const float* pool, const int64_t* ids, const floa
   if (R == 0) return 0;
   if (g_trace_kernel == 1 && level <= 6) {                              // one wave per ray (k_batch_trace_wave)
     const size_t cells_off = (occ_lds_bytes(level) + 15) & ~(size_t)15;
-    hipLaunchKernelGGL(k_batch_trace_wave, dim3((unsigned)nof_div_up(R, 4)), dim3(256), cells_off + 4 * sizeof(WaveCells),
+    hipLaunchKernelGGL(k_raymarch_wave<false>, dim3((unsigned)nof_div_up(R, 4)), dim3(256), cells_off + 4 * sizeof(WaveCells),
                        (hipStream_t)stream, pool, ids, tf, frame_feat, ff, sh_degree, occ_bits, 1 << level, R, max_hits, batch,
-                       rays_o_w, viewdirs_w, view, t_in_out, cell_ids, n_hits, flags, (int)cells_off);
+                       rays_o_w, viewdirs_w, view, t_in_out, cell_ids, n_hits, flags, (int)cells_off, NofSampleCfg{}, nullptr, nullptr,
+                       nullptr, nullptr, nullptr);
     NOF_LAUNCH_OK();
     return 0;
   }
@@ -736,6 +788,21 @@ extern "C" int nof_raymarch_sample(const NofSampleCfg* cfg, const float* pool, c
                                     float* batch, float* rays_o_w, float* viewdirs_w, float* view, float* t_in_out,
                                     int32_t* cell_ids, int32_t* n_hits, float* z_vals, float* pts_w, uint8_t* valid,
                                     int32_t* flags, void* stream) {
+  if (g_trace_kernel == 1 && cfg && level >= 0 && level <= 6 && max_hits <= NOF_TW_SLOTS) {
+    // both halves in ONE launch: the wave that enumerated a ray's cells places its samples (k_raymarch_wave<true>)
+    NOF_ARG(pool && tf && occ_bits && batch && rays_o_w && viewdirs_w && view && t_in_out && n_hits && z_vals && pts_w && valid);
+    NOF_ARG(max_hits >= 1 && R >= 0 && sh_degree >= 1 && sh_degree <= 4);
+    NOF_ARG(ff >= 0 && ff + sh_degree * sh_degree <= NOF_VIEW_COLS && (ff == 0 || frame_feat));
+    NOF_ARG(cfg->n_samples >= 2 && cfg->n_around >= 0 && cfg->n_around != 1 && cfg->n_samples + cfg->n_around <= 1024);
+    if (R == 0) return 0;
+    const size_t cells_off = (occ_lds_bytes(level) + 15) & ~(size_t)15;
+    hipLaunchKernelGGL(k_raymarch_wave<true>, dim3((unsigned)nof_div_up(R, 4)), dim3(256), cells_off + 4 * sizeof(WaveCells),
+                       (hipStream_t)stream, pool, ids, tf, frame_feat, ff, sh_degree, occ_bits, 1 << level, R, max_hits, batch,
+                       rays_o_w, viewdirs_w, view, t_in_out, cell_ids, n_hits, flags, (int)cells_off, *cfg, u_occ, u_dep, z_vals,
+                       pts_w, valid);
+    NOF_LAUNCH_OK();
+    return 0;
+  }
   if (int e = nof_batch_trace(pool, ids, tf, frame_feat, ff, sh_degree, occ_bits, level, R, max_hits, batch, rays_o_w,
                               viewdirs_w, view, t_in_out, cell_ids, n_hits, flags, stream))
     return e;

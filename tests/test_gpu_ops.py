@@ -293,6 +293,53 @@ def test_wave_ray_marcher_equals_the_walk(nof, level, fill):
     assert int(full['nh'][tied].sum()) > 0
 
 
+@pytest.mark.parametrize("level", [4, 6])
+def test_fused_raymarch_sample_equals_the_two_launches(nof, level):
+    """nof_raymarch_sample with the wave-per-ray kernel is ONE launch (k_raymarch_wave<true>: the wave that enumerated a ray's cells
+    places its samples); with nof_set_trace_kernel(0) it is the walk kernel followed by k_sample_points.  Same bits in every output
+    -- intervals, hit counts, z, sample points, validity, flags (incl. the skipped-step mark 4 -> 8 the sampler half turns over) --
+    with injected uniforms, with Philox, and with perturb=False; rays with usable and unusable depth."""
+    cfg, occ, c2w, batch = _scene(nof, level=level, R=2000, seed=3)
+    R, F = batch.shape[0], c2w.shape[0]
+    bits = _build_occ(nof, occ, level)
+    rng = np.random.default_rng(2)
+    pose = (rng.normal(size=(F, 6)) * 0.3).astype(np.float32)
+    tf = torch.empty(F, 12, device='cuda')
+    nof.call('nof_pose_fwd', U.dev(pose), U.dev(c2w.reshape(F, 16)), C.c_float(cfg['max_trans'] * cfg['sc_factor']),
+             C.c_float(cfg['max_rot'] / 180 * np.pi), tf, F)
+    Ns, Na = cfg['N_samples'], cfg['N_samples_around_depth']
+    S, H = Ns + Na, 3 * (1 << level) + 2
+    u_occ, u_dep = U.dev(rng.random((R, Ns)).astype(np.float32)), U.dev(rng.random((R, Na)).astype(np.float32))
+    ids = torch.from_numpy(rng.permutation(R)).cuda()
+    trunc = O.get_truncation(cfg, 0)
+    default_kind = int(nof.load().nof_get_trace_kernel())
+    for uo, ud, det in ((u_occ, u_dep, 0), (None, None, 0), (None, None, 1)):
+        res = {}
+        for kind in (0, 1):
+            sc = nof.NofSampleCfg(Ns, Na, cfg['near'] * cfg['sc_factor'], cfg['far'] * cfg['sc_factor'], trunc, cfg['neg_trunc_ratio'], 77, 5,
+                                  None, det)
+            o = dict(batch=torch.empty(R, 12, device='cuda'), o_w=torch.empty(R, 3, device='cuda'), d_w=torch.empty(R, 3, device='cuda'),
+                     view=torch.empty(R, 16, device='cuda'), tio=torch.empty(R, H, 2, device='cuda'),
+                     cid=torch.empty(R, H, dtype=torch.int32, device='cuda'), nh=torch.empty(R, dtype=torch.int32, device='cuda'),
+                     z=torch.full((R, S), 7.0, device='cuda'), pts=torch.full((R * S, 3), 7.0, device='cuda'),
+                     valid=torch.full((R * S,), 7, dtype=torch.uint8, device='cuda'),
+                     flags=torch.tensor([4, 0, 0, 0], dtype=torch.int32, device='cuda'))
+            nof.load().nof_set_trace_kernel(kind)
+            try:
+                nof.call('nof_raymarch_sample', C.byref(sc), U.dev(batch), ids, tf, None, 0, 3, bits, level, R, H, uo, ud, o['batch'], o['o_w'],
+                         o['d_w'], o['view'], o['tio'], o['cid'], o['nh'], o['z'], o['pts'], o['valid'], o['flags'])
+                torch.cuda.synchronize()
+            finally:
+                nof.load().nof_set_trace_kernel(default_kind)
+            res[kind] = o
+        a, b = res[0], res[1]
+        for k in a:
+            x, y = (a[k].view(torch.int32), b[k].view(torch.int32)) if a[k].dtype == torch.float32 else (a[k], b[k])
+            assert torch.equal(x, y), (det, uo is None, k)
+        assert int(b['flags'][0]) == 8 and int(b['nh'].max()) > 0 and bool((b['valid'] <= 1).all())
+        assert float(b['z'].max()) > 0 and bool(torch.isfinite(b['pts']).all())
+
+
 def test_sample_points_bit_identical(nof):
     level = 4
     cfg, occ, c2w, batch = _scene(nof, level=level)
