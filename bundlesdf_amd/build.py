@@ -39,10 +39,36 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
 
 
+def _digest(paths, flags):
+    """sha256 over the CONTENT of the sources, the headers and the flags: what a library was built from.  Kept beside the library
+    as <lib>.stamp (git-ignored, travels with the gpurun snapshot): file times do not survive a snapshot, content does, so a
+    library that lags its sources is rebuilt wherever build() runs -- here and on the GPU box (round 4 shipped a stale test library
+    that way)."""
+    import hashlib
+    h = hashlib.sha256(' '.join(flags).encode())
+    for p in sorted(os.path.abspath(x) for x in paths):
+        h.update(os.path.basename(p).encode())
+        h.update(open(p, 'rb').read())
+    return h.hexdigest()
+
+
+def _fresh(lib, digest):
+    try:
+        return os.path.exists(lib) and open(lib + '.stamp').read().strip() == digest
+    except OSError:
+        return False
+
+
+def _stamp(lib, digest):
+    with open(lib + '.stamp', 'w') as f:
+        f.write(digest + '\n')
+
+
 def build(force=False, verbose=True):
     srcs = [os.path.join(CSRC, x) for x in SOURCES if os.path.exists(os.path.join(CSRC, x))]
-    if not force and not _stale(LIB, srcs + HEADERS):
-        return LIB                  # e.g. on the GPU box: the snapshot ships the .so but not the object cache
+    digest = _digest(srcs + HEADERS, FLAGS + [f'{k}:{v}' for k, v in sorted(EXTRA.items())])
+    if not force and _fresh(LIB, digest):
+        return LIB                  # e.g. on the GPU box: the snapshot ships the .so and its stamp but not the object cache
     os.makedirs(OBJ, exist_ok=True)
     cc = hipcc()
     objs, procs = [], []
@@ -65,6 +91,7 @@ def build(force=False, verbose=True):
         if verbose:
             print(' '.join(cmd), flush=True)
         subprocess.check_call(cmd)
+    _stamp(LIB, digest)
     return LIB
 
 
@@ -75,7 +102,8 @@ def build_perturb(force=False, verbose=True):
     """Test build of the hash kernels with -DNOF_AGG_PERTURB (extra live registers across the scatter's hand-written DPP block:
     a different register allocation around it).  tests/test_gpu_ops.py runs the table scatter through it."""
     srcs = [os.path.join(CSRC, x) for x in ('nof_hash.hip', 'nof_capi.hip')]
-    if not force and not _stale(PERTURB_LIB, srcs + HEADERS):
+    digest = _digest(srcs + HEADERS, FLAGS + ['perturb'])
+    if not force and _fresh(PERTURB_LIB, digest):
         return PERTURB_LIB
     # -Bsymbolic: this library's references bind to its OWN kernels and helpers even when libnof_hip.so (same symbol names) is
     # already loaded in the process -- without it the dynamic linker would hand it the first library's kernel stubs
@@ -83,6 +111,7 @@ def build_perturb(force=False, verbose=True):
     if verbose:
         print(' '.join(cmd), flush=True)
     subprocess.check_call(cmd)
+    _stamp(PERTURB_LIB, digest)
     return PERTURB_LIB
 
 

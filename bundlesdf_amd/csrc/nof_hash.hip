@@ -708,7 +708,7 @@ static int hash_bwd_parts(const NofHashGrid* g, const float* pts_w, const float*
     red.partials = nullptr;                                            // done
   }
   if (red.partials != nullptr)                                         // no LDS-level launch to ride in: on its own
-    return nof_reduce_partials(red.partials, red.n_rows, red.n_cols, red.out, red.flags, stream);
+    return reduce_partials_launch(red.partials, red.n_rows, red.n_cols, red.out, red.flags, stream);
   return 0;
 }
 
@@ -730,7 +730,7 @@ extern "C" int nof_hash_encode_bwd_parts_reduce(const NofHashGrid* g, const floa
   NOF_ARG(partials && grad_mlp && n_rows >= 0 && n_cols >= 0);
   RedArgs red{partials, grad_mlp, flags, n_rows, n_cols, (int)nof_div_up(n_cols, 32)};
   if (n_rows == 0 || n_cols == 0) red.partials = nullptr;
-  if (B == 0 && red.partials != nullptr) return nof_reduce_partials(partials, n_rows, n_cols, grad_mlp, flags, stream);
+  if (B == 0 && red.partials != nullptr) return reduce_partials_launch(partials, n_rows, n_cols, grad_mlp, flags, stream);
   return hash_bwd_parts(g, pts_w, table, dfeat, geik_, dedn, grad_table, dpts, level_lo, level_hi, tile_list, parts, wgs_per_cu, B, red,
                         stream);
 }

@@ -607,19 +607,9 @@ extern "C" int nof_adam_step(float* params, float* grads, float* exp_avg, float*
 }
 
 // ------------------------------------------------------------------------------------------------
-// (body: nof_reduce_dev.h)
-__global__ __launch_bounds__(1024) void k_reduce_partials(const float* __restrict__ partials, int n_rows, int n_cols,
-                                                           float* __restrict__ out, int32_t* __restrict__ flags) {
-  reduce_partials_block(partials, n_rows, n_cols, out, flags, (int)blockIdx.x, (int)blockIdx.y);
-}
-
+// (kernel and launch: nof_reduce_dev.h)
 extern "C" int nof_reduce_partials(const float* partials, int32_t n_rows, int32_t n_cols, float* out, int32_t* flags, void* stream) {
-  NOF_ARG(partials && out && n_rows >= 0 && n_cols >= 0);
-  if (n_cols == 0 || n_rows == 0) return 0;
-  hipLaunchKernelGGL(k_reduce_partials, dim3((unsigned)nof_div_up(n_cols, 32), RED_RSPLIT), dim3(1024), 0, (hipStream_t)stream,
-                     partials, n_rows, n_cols, out, flags);
-  NOF_LAUNCH_OK();
-  return 0;
+  return reduce_partials_launch(partials, n_rows, n_cols, out, flags, stream);
 }
 
 // flags[0] |= 4 when any of grad[0, n) is not finite: the check of nof_reduce_partials for a gradient that was summed over the

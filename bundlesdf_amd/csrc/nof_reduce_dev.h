@@ -36,3 +36,20 @@ __device__ __forceinline__ void reduce_partials_block(const float* __restrict__ 
     if (flags != nullptr && !(fabsf(s) <= 3.0e38f)) atomicOr(&flags[0], 4);
   }
 }
+
+// The stand-alone launch of the reduction.  `static` so that every translation unit that needs it (nof_loss.hip: the exported
+// nof_reduce_partials; nof_hash.hip: the fall-back of nof_hash_encode_bwd_parts_reduce when no LDS-level launch is there to ride in)
+// carries its own copy: no library of the build has an undefined reference to another's entry point.
+static __global__ __launch_bounds__(1024) void k_reduce_partials(const float* __restrict__ partials, int n_rows, int n_cols,
+                                                                  float* __restrict__ out, int32_t* __restrict__ flags) {
+  reduce_partials_block(partials, n_rows, n_cols, out, flags, (int)blockIdx.x, (int)blockIdx.y);
+}
+
+static inline int reduce_partials_launch(const float* partials, int32_t n_rows, int32_t n_cols, float* out, int32_t* flags, void* stream) {
+  NOF_ARG(partials && out && n_rows >= 0 && n_cols >= 0);
+  if (n_cols == 0 || n_rows == 0) return 0;
+  hipLaunchKernelGGL(k_reduce_partials, dim3((unsigned)nof_div_up(n_cols, 32), RED_RSPLIT), dim3(1024), 0, (hipStream_t)stream,
+                     partials, n_rows, n_cols, out, flags);
+  NOF_LAUNCH_OK();
+  return 0;
+}

@@ -147,6 +147,10 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    if not os.environ.get('NOF_LIB') and os.path.isdir(os.path.join(_HERE, 'csrc')):
+        # a library that lags its sources (content digest, build.py) is rebuilt before it is loaded: what runs is what is in the tree
+        from . import build as _build
+        _build.build(verbose=False)
     if not os.path.exists(LIB_PATH):
         raise NofError(f'{LIB_PATH} is missing: run `python -m bundlesdf_amd.build` (hipcc --offload-arch=gfx950). '
                        'There is no CPU fallback for the Neural Object Field hot path.')

@@ -27,6 +27,25 @@ def test_library_exports_every_header_symbol():
         assert hasattr(so, s), f'{s} declared in include/nof_hip.h but not exported'
 
 
+def test_every_built_library_is_self_contained_and_current():
+    """Round 4's driver run went red on `libnof_hash_perturb.so: undefined symbol: nof_reduce_partials`: the test library was linked
+    from nof_hash.hip alone while that file had started to call into nof_loss.hip, and a stale copy hid it.  Every library build()
+    produces (a) matches the content digest of its sources, (b) leaves no nof_* symbol undefined, (c) dlopens here, without a GPU."""
+    import subprocess
+    from bundlesdf_amd import build
+    libs = [build.build(verbose=False), build.build_perturb(verbose=False)]
+    for path in libs:
+        assert open(path + '.stamp').read().strip()
+        und = subprocess.run(['nm', '-D', '--undefined-only', path], capture_output=True, text=True, check=True).stdout
+        bad = [ln.split()[-1] for ln in und.splitlines() if re.search(r'\b(nof_|k_)', ln)]
+        assert not bad, (path, bad)
+        ctypes.CDLL(path)
+    # and the stamp is a function of content: a touched-but-unchanged source does not trigger a rebuild, an edited one does
+    srcs = [os.path.join(build.CSRC, x) for x in ('nof_hash.hip', 'nof_capi.hip')]
+    d0 = build._digest(srcs + build.HEADERS, build.FLAGS + ['perturb'])
+    assert build._fresh(build.PERTURB_LIB, d0) and not build._fresh(build.PERTURB_LIB, d0[::-1])
+
+
 def test_ctypes_table_matches_header():
     from bundlesdf_amd import lib
     declared = set(header_symbols())

@@ -12,6 +12,7 @@
 # PMC passes never share a rocprofv3 run with --stats / sys traces (gpurun refuses that); the databases are deleted once summarised (gpurun copies at most 64 MiB back).
 cd "$GRAFT_REPO_ROOT" || exit 1
 R=$GRAFT_REPO_ROOT; mkdir -p gpurun_out; export TMPDIR=/tmp
+python -c "import __graft_entry__ as g; g.build()" > gpurun_out/build.log 2>&1 || { tail -20 gpurun_out/build.log; exit 1; }   # never measure a stale library
 T=${1:-r04}; LEGS=${2:-"bench trace mfma traffic vmem calib cfg5"}
 SETTLED="--steps 60 --warmup 200 --settle 0 --round-steps 0 --preroll 0 --no-cpu-baseline --no-extra-configs --keyframes 16"
 CFG5="--mlp cfg5 --rays 16384 --log2_T 22 --finest 512 --width 1280 --height 720 --precision fp16 --no-cpu-baseline --no-extra-configs --settle 0 --round-steps 0"
