@@ -278,7 +278,7 @@ def main():
     ap.add_argument('--extract', type=int, default=0, help='after the timed steps: time the dense SDF query + marching cubes of an N^3 grid (BASELINE cfg4: 512)')
     ap.add_argument('--scatter-wgs', type=int, default=0, help='persistent workgroups per CU of the table scatter (0 = library default)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--trace-kernel', type=int, default=None, help='nof_set_trace_kernel: 0 = one lane per ray (walk), 1 = one wave per ray; default: the library\'s')
+    ap.add_argument('--trace-kernel', type=int, default=None, help='ray marcher of the step (NofSampleCfg.marcher): 0 = one lane per ray (walk), 1 = one wave per ray (the default)')
     ap.add_argument('--cpu-seconds', type=float, default=25.0)
     args = ap.parse_args()
 
@@ -293,9 +293,6 @@ def main():
     dev_index = local_rank % torch.cuda.device_count()      # (== local_rank on a real node; the 1-GPU gloo test wraps around)
     torch.cuda.set_device(dev_index)
     device = torch.device('cuda', dev_index)
-    if args.trace_kernel is not None:
-        from bundlesdf_amd import lib as _lib
-        _lib.load().nof_set_trace_kernel(int(args.trace_kernel))
     if world > 1 or ('RANK' in os.environ and 'MASTER_PORT' in os.environ):     # launched by torch.distributed.run
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         backend = os.environ.get('NOF_DIST_BACKEND', 'nccl')                    # 'nccl' is RCCL; 'gloo' only for the 1-GPU test
@@ -316,6 +313,8 @@ def main():
 
     if args.unfused:
         fld.fused_forward = False
+    if args.trace_kernel is not None:
+        fld.marcher = 1 - int(args.trace_kernel)             # (the option's 1 = wave per ray = lib.MARCHER_WAVE = 0)
     fwd_name = 'nof_encode_mlp_fwd' if fld.fused_forward else 'nof_hash_encode_fwd'     # the launch that holds the hash lookup
 
     def zero_fraction():

@@ -115,6 +115,35 @@ def build_perturb(force=False, verbose=True):
     return PERTURB_LIB
 
 
+PROBE_LIB = os.path.join(HERE, 'libnof_probe.so')
+
+
+def build_probe(force=False, verbose=True):
+    """TEST-ONLY library: the raw MFMA tile probe (tests/test_gpu_ops.py::test_mfma_operand_layout) and the atomic-rate probe
+    (tools/atomic_probe.py) -- csrc/test/nof_probe.hip.  Not part of libnof_hip.so, not declared in include/nof_hip.h."""
+    srcs = [os.path.join(CSRC, 'test', 'nof_probe.hip')]
+    digest = _digest(srcs + HEADERS, FLAGS + ['probe'])
+    if not force and _fresh(PROBE_LIB, digest):
+        return PROBE_LIB
+    cmd = [hipcc()] + FLAGS + ['-shared', '-Wl,-Bsymbolic', '-x', 'hip'] + srcs + ['-o', PROBE_LIB]
+    if verbose:
+        print(' '.join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    _stamp(PROBE_LIB, digest)
+    return PROBE_LIB
+
+
+def load_probe():
+    """ctypes handle of the probe library with its two signatures set (builds it when it lags its source)."""
+    import ctypes as C
+    so = C.CDLL(build_probe(verbose=False))
+    so.nof_mfma_probe.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
+    so.nof_atomic_probe.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
+    so.nof_mfma_probe.restype = so.nof_atomic_probe.restype = C.c_int
+    so.nof_probe_last_error.restype = C.c_char_p
+    return so
+
+
 def build_variant(name, defines, sources=('nof_mlp.hip',), verbose=True):
     """Development aid for A/B runs on the GPU box: the library with `sources` recompiled under extra -D flags, linked with the
     regular objects of everything else, as bundlesdf_amd/ab_<name>.so (git-ignored; travels with the gpurun snapshot).  Loaded

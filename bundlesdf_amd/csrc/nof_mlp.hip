@@ -20,49 +20,7 @@
 #include "nof_pose_dev.h"
 #include "nof_hash_dev.h"
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-
-struct PrecF32 {
-  static constexpr int KR = 1;
-  typedef float elem;
-  typedef float frag;
-  static __device__ __forceinline__ frag pack(const float* v) { return v[0]; }
-  static __device__ __forceinline__ f32x16 mma(frag a, frag b, f32x16 c) {
-    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
-  }
-};
-struct PrecBF16 {
-  static constexpr int KR = 8;
-  typedef __bf16 elem;
-  typedef bf16x8 frag;
-  static __device__ __forceinline__ frag pack(const float* v) {
-    frag f;
-#pragma unroll
-    for (int t = 0; t < 8; ++t) f[t] = (__bf16)v[t];
-    return f;
-  }
-  static __device__ __forceinline__ f32x16 mma(frag a, frag b, f32x16 c) {
-    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
-  }
-};
-struct PrecF16 {
-  static constexpr int KR = 8;
-  typedef _Float16 elem;
-  typedef f16x8 frag;
-  static __device__ __forceinline__ frag pack(const float* v) {
-    frag f;
-#pragma unroll
-    for (int t = 0; t < 8; ++t) f[t] = (_Float16)v[t];
-    return f;
-  }
-  static __device__ __forceinline__ f32x16 mma(frag a, frag b, f32x16 c) {
-    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
-  }
-};
-
-__host__ __device__ __forceinline__ constexpr int nloc(int hi, int r) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
+#include "nof_mfma_dev.h"
 
 // ---- layer bookkeeping (runtime, from the descriptor) -------------------------------------------
 // input blocks: hash features fit one block; colour layer 0 reads [sigma-out block | view block]; every other layer reads the
@@ -2240,37 +2198,6 @@ extern "C" int nof_sdf_grid_query(const NofHashGrid* g, const NofMlpDesc* d, con
 extern "C" int64_t nof_mlp_bwd_workspace_bytes(const NofMlpDesc* d) {
   if (check_desc(d)) return -1;
   return (int64_t)nof_mlp_bwd_blocks() * d->n_params * 4;
-}
-
-// ---- test hook: one 32x32 output tile with the operand layouts used above -----------------------------
-template <class P>
-__global__ void k_mfma_probe(const float* __restrict__ Am, const float* __restrict__ Bm, float* __restrict__ D, int K) {
-  constexpr int KR = P::KR;
-  const int lane = threadIdx.x, hi = lane >> 5, i = lane & 31;
-  f32x16 acc;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-  for (int k0 = 0; k0 < K; k0 += 2 * KR) {
-    float a[KR], b[KR];
-#pragma unroll
-    for (int t = 0; t < KR; ++t) {
-      const int k = k0 + KR * hi + t;                                  // A[i][k] (32xK row-major), B[k][j] (Kx32 row-major)
-      a[t] = Am[i * K + k];
-      b[t] = Bm[k * 32 + i];
-    }
-    acc = P::mma(P::pack(a), P::pack(b), acc);
-  }
-#pragma unroll
-  for (int r = 0; r < 16; ++r) D[nloc(hi, r) * 32 + i] = acc[r];
-}
-
-extern "C" int nof_mfma_probe(int32_t precision, const float* A, const float* Bm, float* D, int32_t K, void* stream) {
-  NOF_ARG(A && Bm && D && K > 0 && K % 16 == 0 && precision >= 0 && precision <= 2);
-  if (precision == 0) hipLaunchKernelGGL(k_mfma_probe<PrecF32>, dim3(1), dim3(64), 0, (hipStream_t)stream, A, Bm, D, K);
-  else if (precision == 1) hipLaunchKernelGGL(k_mfma_probe<PrecBF16>, dim3(1), dim3(64), 0, (hipStream_t)stream, A, Bm, D, K);
-  else hipLaunchKernelGGL(k_mfma_probe<PrecF16>, dim3(1), dim3(64), 0, (hipStream_t)stream, A, Bm, D, K);
-  NOF_LAUNCH_OK();
-  return 0;
 }
 
 /* Eikonal term (cfg eikonal_weight > 0; nerf_runner.py:734-738 with the normal of run_network_density, :1342-1345).

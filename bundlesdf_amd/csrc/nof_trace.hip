@@ -545,24 +545,30 @@ __device__ __forceinline__ int trace_wave(int n, const float o[3], const float d
     const bool leaves = q >= 1 && live && j == m_a - 1;
     k_end = min(k_end, wave_min_i(leaves ? rank : 0x7fffffff));
     if (live && !leaves) {
-      const int k = q >= 1 ? rank + 1 : 0;
       const int cc0 = c0[0] + (cnt[0] + (q >= 1 && a == 0 ? 1 : 0)) * ax[0].step;
       const int cc1 = c0[1] + (cnt[1] + (q >= 1 && a == 1 ? 1 : 0)) * ax[1].step;
       const int cc2 = c0[2] + (cnt[2] + (q >= 1 && a == 2 ? 1 : 0)) * ax[2].step;
-      float tmin[3], tmax[3];
-      cell_slab(ax[0], cc0, cs, tmin[0], tmax[0]);
-      cell_slab(ax[1], cc1, cs, tmin[1], tmax[1]);
-      cell_slab(ax[2], cc2, cs, tmin[2], tmax[2]);
-      const float tin = fmaxf(fmaxf(fmaxf(tmin[0], tmin[1]), tmin[2]), 0.0f);
-      const float tout = fminf(fminf(tmax[0], tmax[1]), tmax[2]);
-      int code = -2;
-      if (tin <= tout && occ_test_t<true>(nullptr, n, cc0, cc1, cc2)) {
-        if (tin == 0.0f || tout == 0.0f) code = -3;                    // common.cu:140 (terminator)
-        else if (!(fabsf(tout - tin) < MIN_LEN)) code = (int32_t)(((uint32_t)cc0 * n + cc1) * n + cc2);   // common.cu:142
+      // a crossing ranked behind the one that leaves the grid (rank > k_end: cnt[b] can reach m[b]) names a cell outside [0, n)^3.
+      // Its table entry is never read (the compaction below stops at k_end), so it is not computed either: no occupancy read
+      // outside the bitfield, no LDS write
+      const bool in_grid = (unsigned)cc0 < (unsigned)n && (unsigned)cc1 < (unsigned)n && (unsigned)cc2 < (unsigned)n;
+      const int k = q >= 1 ? rank + 1 : 0;
+      if (in_grid) {
+        float tmin[3], tmax[3];
+        cell_slab(ax[0], cc0, cs, tmin[0], tmax[0]);
+        cell_slab(ax[1], cc1, cs, tmin[1], tmax[1]);
+        cell_slab(ax[2], cc2, cs, tmin[2], tmax[2]);
+        const float tin = fmaxf(fmaxf(fmaxf(tmin[0], tmin[1]), tmin[2]), 0.0f);
+        const float tout = fminf(fminf(tmax[0], tmax[1]), tmax[2]);
+        int code = -2;
+        if (tin <= tout && occ_test_t<true>(nullptr, n, cc0, cc1, cc2)) {
+          if (tin == 0.0f || tout == 0.0f) code = -3;                    // common.cu:140 (terminator)
+          else if (!(fabsf(tout - tin) < MIN_LEN)) code = (int32_t)(((uint32_t)cc0 * n + cc1) * n + cc2);   // common.cu:142
+        }
+        wc->tin[k] = tin;
+        wc->tout[k] = tout;
+        wc->code[k] = code;
       }
-      wc->tin[k] = tin;
-      wc->tout[k] = tout;
-      wc->code[k] = code;
     }
   }
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");               // (one wave: LDS operations retire in order; nothing to wait for)
@@ -729,26 +735,16 @@ extern "C" int nof_trace_rays(const uint32_t* occ_bits, int32_t level, const flo
   return 0;
 }
 
-// which kernel nof_batch_trace (and through it nof_raymarch_sample) launches: 0 = one lane per ray walking its cells (k_batch_trace),
-// 1 (default) = one wave per ray, no walk (k_batch_trace_wave; levels <= 6, else 0 is used).  Process-wide; both give the same bits
-// (tests/test_gpu_ops.py::test_wave_ray_marcher_equals_the_walk); at cfg2 the launch takes 13 us instead of 25.
-static int g_trace_kernel = 1;
-extern "C" int nof_set_trace_kernel(int32_t kind) {
-  NOF_ARG(kind == 0 || kind == 1);
-  g_trace_kernel = kind;
-  return 0;
-}
-extern "C" int nof_get_trace_kernel(void) { return g_trace_kernel; }
-
 extern "C" int nof_batch_trace(const float* pool, const int64_t* ids, const float* tf, const float* frame_feat, int32_t ff,
                                 int32_t sh_degree, const uint32_t* occ_bits, int32_t level, int64_t R, int32_t max_hits,
-                                float* batch, float* rays_o_w, float* viewdirs_w, float* view, float* t_in_out,
+                                int32_t marcher, float* batch, float* rays_o_w, float* viewdirs_w, float* view, float* t_in_out,
                                 int32_t* cell_ids, int32_t* n_hits, int32_t* flags, void* stream) {
   NOF_ARG(pool && tf && occ_bits && batch && rays_o_w && viewdirs_w && view && t_in_out && n_hits);
+  NOF_ARG(marcher == NOF_MARCHER_WAVE || marcher == NOF_MARCHER_WALK);
   NOF_ARG(level >= 0 && level <= 8 && max_hits >= 1 && R >= 0 && sh_degree >= 1 && sh_degree <= 4);
   NOF_ARG(ff >= 0 && ff + sh_degree * sh_degree <= NOF_VIEW_COLS && (ff == 0 || frame_feat));
   if (R == 0) return 0;
-  if (g_trace_kernel == 1 && level <= 6) {                              // one wave per ray (k_batch_trace_wave)
+  if (marcher == NOF_MARCHER_WAVE && level <= 6) {                      // one wave per ray (k_raymarch_wave)
     const size_t cells_off = (occ_lds_bytes(level) + 15) & ~(size_t)15;
     hipLaunchKernelGGL(k_raymarch_wave<false>, dim3((unsigned)nof_div_up(R, 4)), dim3(256), cells_off + 4 * sizeof(WaveCells),
                        (hipStream_t)stream, pool, ids, tf, frame_feat, ff, sh_degree, occ_bits, 1 << level, R, max_hits, batch,
@@ -788,7 +784,7 @@ extern "C" int nof_raymarch_sample(const NofSampleCfg* cfg, const float* pool, c
                                     float* batch, float* rays_o_w, float* viewdirs_w, float* view, float* t_in_out,
                                     int32_t* cell_ids, int32_t* n_hits, float* z_vals, float* pts_w, uint8_t* valid,
                                     int32_t* flags, void* stream) {
-  if (g_trace_kernel == 1 && cfg && level >= 0 && level <= 6 && max_hits <= NOF_TW_SLOTS) {
+  if (cfg && cfg->marcher == NOF_MARCHER_WAVE && level >= 0 && level <= 6 && max_hits <= NOF_TW_SLOTS) {
     // both halves in ONE launch: the wave that enumerated a ray's cells places its samples (k_raymarch_wave<true>)
     NOF_ARG(pool && tf && occ_bits && batch && rays_o_w && viewdirs_w && view && t_in_out && n_hits && z_vals && pts_w && valid);
     NOF_ARG(max_hits >= 1 && R >= 0 && sh_degree >= 1 && sh_degree <= 4);
@@ -803,7 +799,8 @@ extern "C" int nof_raymarch_sample(const NofSampleCfg* cfg, const float* pool, c
     NOF_LAUNCH_OK();
     return 0;
   }
-  if (int e = nof_batch_trace(pool, ids, tf, frame_feat, ff, sh_degree, occ_bits, level, R, max_hits, batch, rays_o_w,
+  NOF_ARG(cfg);
+  if (int e = nof_batch_trace(pool, ids, tf, frame_feat, ff, sh_degree, occ_bits, level, R, max_hits, cfg->marcher, batch, rays_o_w,
                               viewdirs_w, view, t_in_out, cell_ids, n_hits, flags, stream))
     return e;
   return nof_sample_points(cfg, batch, tf, t_in_out, n_hits, R, max_hits, u_occ, u_dep, z_vals, pts_w, valid, flags, stream);

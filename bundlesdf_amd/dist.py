@@ -99,8 +99,12 @@ class GradSync:
         self._n += 1
 
     def max_flags_(self, flags):
-        """the ranks agree on the device flags (a skipped step must be skipped by everyone)"""
-        dist.all_reduce(flags, op=dist.ReduceOp.MAX)
+        """the ranks agree on the SKIP predicate of the device flag word (bit 2 of flags[0]: this step's gradient is not finite -- a
+        skipped step must be skipped by everyone).  Only that bit travels: MAX over a bit mask is not a bitwise OR (a rank holding
+        only bit 3 would beat a rank holding bit 2), and the other bits are per-rank diagnostics that stay what they were."""
+        skip = flags[0:1] & 4
+        dist.all_reduce(skip, op=dist.ReduceOp.MAX)
+        flags[0:1] |= skip
 
     def end_step(self):
         self.timed_steps += 1

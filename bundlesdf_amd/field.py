@@ -110,6 +110,7 @@ class NeuralObjectField:
         # the training forward as ONE launch with the embedding kept on chip (nof_encode_mlp_fwd; 64-wide networks, 16-bit operand
         # types); False: the two launches nof_hash_encode_fwd + nof_mlp_fwd with the fp32 [L,B,2] embedding in HBM between them
         self.fused_forward = not self.wide and self.desc.precision != 0
+        self.marcher = lib.MARCHER_WAVE   # NofSampleCfg.marcher: the ray marcher of nof_raymarch_sample (lib.MARCHER_WALK: the per-lane walk)
         self.scatter_wgs_per_cu = 0                  # persistent workgroups per CU of the table scatter (0 = the library's default)
         self._state = None           # NofStepState on the device (captured-step mode): see sync_step_state / GraphedStep
         if seed_init:
@@ -297,7 +298,7 @@ class NeuralObjectField:
         cfg = self.cfg
         return lib.NofSampleCfg(cfg['N_samples'], cfg['N_samples_around_depth'], cfg['near'] * cfg['sc_factor'],
                                 cfg['far'] * cfg['sc_factor'], self.truncation(), cfg['neg_trunc_ratio'], seed, step,
-                                self._state.data_ptr() if dyn else None, 1 if deterministic else 0)
+                                self._state.data_ptr() if dyn else None, 1 if deterministic else 0, self.marcher)
 
     # ---- device-resident step state (NofStepState): what makes a captured step replayable ----------------------
     def sync_step_state(self):
@@ -573,10 +574,10 @@ class NeuralObjectField:
             padded_g = self._grads_store[self._head:]
             n_pad, shard, lo, hi = GradSync.shard_range(self.n_total)
             assert padded_g.numel() == n_pad == self._params_store.numel(), 'field built for another world size'
-            if self.desc.precision in FP16_MODES:
-                # a non-finite partial sum on any rank: every rank skips (its own shard) -- the flag word is agreed on first
-                self._call('nof_grad_check', self._seg(self.grads, 'mlp'), self.n_mlp, self.flags)
-                grad_sync.max_flags_(self.flags)
+            # a non-finite partial sum on any rank: every rank skips (its own shard) -- the skip bit is agreed on first, in every
+            # precision (nof_reduce_partials raises it whatever the operand type)
+            self._call('nof_grad_check', self._seg(self.grads, 'mlp'), self.n_mlp, self.flags)
+            grad_sync.max_flags_(self.flags)
             grad_sync.reduce_scatter_(padded_g)
             if do_step:
                 if hi > lo:
@@ -599,9 +600,15 @@ class NeuralObjectField:
             if nr:
                 self._grads_store[h - nr:h].copy_(rest)
             grad_sync.start(self._grads_store[h - nr:h + a])
-            if do_step and not dyn and hasattr(grad_sync, 'finish_first'):
-                # Adam is element-wise: the first slice's share of it runs while the trailing collective is on the wire
+            if do_step and not dyn and hasattr(grad_sync, 'finish_first') and not compressed:
+                # Adam is element-wise: the first slice's share of it runs while the trailing collective is on the wire.  Adam
+                # skips on the step's flag (bit 2), and at this point a rank's flag only knows its OWN partial sums: a rank that
+                # overflowed alone would skip this slice while the others applied a summed gradient that holds its inf.  The
+                # first slice carries the MLP rows, SUMMED by now: the check on them raises the flag on every rank alike (a
+                # non-finite partial makes the sum non-finite everywhere) before the first Adam launch reads it.  With a bf16
+                # payload the MLP rows travel in the trailing call, so there is no early slice (Adam after the check below).
                 grad_sync.finish_first()
+                self._call('nof_grad_check', self._seg(self.grads, 'mlp'), self.n_mlp, self.flags)
                 self.adam_step(False, a, first_hi, advance=False)
                 adam_done = (a, first_hi)
             grad_sync.finish()
@@ -609,8 +616,9 @@ class NeuralObjectField:
                 rest.copy_(self._grads_store[h - nr:h])
         elif grad_sync is not None:
             grad_sync(self.grads)
-        if grad_sync is not None and self.desc.precision in FP16_MODES and self.world_size > 1:
-            # every rank must skip the same steps: the overflow check again, on the SUMMED weight gradient
+        if grad_sync is not None and self.world_size > 1:
+            # every rank must skip the same steps: the non-finite check again, on the SUMMED weight gradient -- in every precision
+            # (nof_reduce_partials raises the skip bit for a bf16 / fp32 backward too, and Adam honours it)
             self._call('nof_grad_check', self._seg(self.grads, 'mlp'), self.n_mlp, self.flags)
         if do_step:
             if adam_done is not None:                                  # (data parallel: everything on either side of the early slice)

@@ -19,6 +19,7 @@ NOF_MAX_LAYERS = 8
 RAY_COLS = 12
 VIEW_COLS = 16
 HASH_BWD_TABLE_BIG, HASH_BWD_TABLE_SMALL, HASH_BWD_INPUT, HASH_BWD_ALL = 1, 2, 4, 7
+MARCHER_WAVE, MARCHER_WALK = 0, 1
 
 
 class NofError(RuntimeError):
@@ -44,7 +45,8 @@ class NofFrameRaysCfg(C.Structure):
 class NofSampleCfg(C.Structure):
     _fields_ = [('n_samples', C.c_int32), ('n_around', C.c_int32),
                 ('near_sc', C.c_float), ('far_sc', C.c_float), ('trunc', C.c_float), ('neg_trunc_ratio', C.c_float),
-                ('seed', C.c_uint64), ('step', C.c_uint32), ('d_step', C.c_void_p), ('deterministic', C.c_int32)]
+                ('seed', C.c_uint64), ('step', C.c_uint32), ('d_step', C.c_void_p), ('deterministic', C.c_int32),
+                ('marcher', C.c_int32)]
 
 
 class NofMlpDesc(C.Structure):
@@ -74,9 +76,7 @@ _SIGNATURES = {
     'nof_occgrid_build': ([_P, _I64, _I32, _I32, _P, _P], C.c_int),
     'nof_occgrid_query': ([_P, _I32, _P, _P, _I64, _P], C.c_int),
     'nof_trace_rays': ([_P, _I32, _P, _P, _I64, _I32, _P, _P, _P, _P, _P], C.c_int),
-    'nof_batch_trace': ([_P, _P, _P, _P, _I32, _I32, _P, _I32, _I64, _I32, _P, _P, _P, _P, _P, _P, _P, _P, _P], C.c_int),
-    'nof_set_trace_kernel': ([_I32], C.c_int),
-    'nof_get_trace_kernel': ([], C.c_int),
+    'nof_batch_trace': ([_P, _P, _P, _P, _I32, _I32, _P, _I32, _I64, _I32, _I32, _P, _P, _P, _P, _P, _P, _P, _P, _P], C.c_int),
     'nof_sample_points': ([C.POINTER(NofSampleCfg), _P, _P, _P, _P, _I64, _I32, _P, _P, _P, _P, _P, _P, _P], C.c_int),
     'nof_mlp_packed_bytes': ([C.POINTER(NofMlpDesc)], C.c_int64),
     'nof_mlp_pack': ([C.POINTER(NofMlpDesc), _P, _P, _P], C.c_int),
@@ -130,8 +130,6 @@ _SIGNATURES = {
     'nof_mlp_wide_bwd_tiles': ([C.POINTER(NofMlpDesc), _P, _P, _I32, _P, _I32, _P, _P, _P, _P, _P, _P, _I64, _P], C.c_int),
     'nof_mlp_wide_bwd_parts': ([C.POINTER(NofMlpDesc), _P, _P, _I32, _P, _I32, _P, _P, _P, _P, _P, _P, _I32, _I64, _P], C.c_int),
     'nof_texture_bake_frame': ([_P, _P, _I32, _I32, _P, _P, _I64, _P, _P, _P, _F, _I32, _P, _P, _P, _P, _P], C.c_int),
-    'nof_mfma_probe': ([_I32, _P, _P, _P, _I32, _P], C.c_int),
-    'nof_atomic_probe': ([_I32, _P, _P, _I64, _P], C.c_int),
 }
 OPTIONAL = set()
 

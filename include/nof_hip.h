@@ -140,15 +140,15 @@ int nof_compact_rows(const float* rows, const uint8_t* keep, const int64_t* offs
 /* pool [N,12]; ids [R] int64 rows of the pool (NULL: rows 0..R-1); tf [F,12].
  * Outputs: batch [R,12] gathered rows; rays_o_w [R,3]; viewdirs_w [R,3]; view [R,16] = [ff|SH9|0];
  * frame_feat [F,ff] may be NULL when ff == 0. */
+/* `marcher` (an ARGUMENT, not library state: two callers in one process, or a captured graph's owner, each get what they asked for):
+ * NOF_MARCHER_WAVE = one wave per ray, the ray's cells enumerated from the ranks of its plane crossings (levels <= 6; above, the
+ * walk is used); NOF_MARCHER_WALK = one lane per ray walking its cells.  Same results, bit for bit. */
+#define NOF_MARCHER_WAVE 0
+#define NOF_MARCHER_WALK 1
 int nof_batch_trace(const float* pool, const int64_t* ids, const float* tf, const float* frame_feat, int32_t ff,
-                    int32_t sh_degree, const uint32_t* occ_bits, int32_t level, int64_t R, int32_t max_hits,
+                    int32_t sh_degree, const uint32_t* occ_bits, int32_t level, int64_t R, int32_t max_hits, int32_t marcher,
                     float* batch, float* rays_o_w, float* viewdirs_w, float* view,
                     float* t_in_out, int32_t* cell_ids, int32_t* n_hits, int32_t* flags, void* stream);
-/* Which kernel nof_batch_trace / nof_raymarch_sample launch (process-wide): 0 = one lane per ray walking its cells, 1 (default) = one
- * wave per ray with the cells enumerated from the ranks of the ray's plane crossings (levels <= 6; above, 0 is used).  Same results. */
-int nof_set_trace_kernel(int32_t kind);
-int nof_get_trace_kernel(void);
-
 typedef struct {
   int32_t  n_samples, n_around;           /* N_samples, N_samples_around_depth (config.yml:18-19) */
   float    near_sc, far_sc;               /* near*sc_factor, far*sc_factor */
@@ -160,6 +160,8 @@ typedef struct {
                                            * instead of `step` -- what lets a captured step be replayed (NofStepState.step) */
   int32_t  deterministic;                 /* != 0: perturb=False of sample_rays_uniform (nerf_runner.py:67-87) -- the linspace itself,
                                            * no jitter, no clip; u_occ / u_dep / seed are ignored (render_images, :597) */
+  int32_t  marcher;                       /* which ray marcher nof_raymarch_sample launches: NOF_MARCHER_WAVE (0, the default of a
+                                           * zero-initialised struct) or NOF_MARCHER_WALK; same bits either way (see nof_batch_trace) */
 } NofSampleCfg;
 /* z sampling + point generation (nerf_runner.py:979-1011,1063-1083,1242-1245; common.cu:41-105).
  * u_occ [R,n_samples], u_dep [R,n_around] injected uniforms or NULL (Philox4x32-10).
@@ -435,12 +437,6 @@ int nof_adam_step(float* params, float* grads, float* exp_avg, float* exp_avg_sq
 /* flags[0] |= 4 when any of grad[0, n) is not finite (the check of nof_reduce_partials, for a gradient that was summed over the
  * data-parallel ranks afterwards: every rank must skip the same step). */
 int nof_grad_check(const float* grad, int64_t n, int32_t* flags, void* stream);
-
-/* ---- test hook: raw MFMA tile  D[32,32] = A[32,K] * B[K,32] with the operand layouts nof_mlp uses ---- */
-int nof_mfma_probe(int32_t precision, const float* A, const float* Bm, float* D, int32_t K, void* stream);
-
-/* ---- test hook: fp32 atomic-add throughput for address patterns 0..9 (see nof_capi.hip); idx [n] uint32 < 2^19, table [2^19,2] */
-int nof_atomic_probe(int32_t variant, const uint32_t* idx, float* table, int64_t n, void* stream);
 
 #ifdef __cplusplus
 }

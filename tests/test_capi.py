@@ -33,17 +33,36 @@ def test_every_built_library_is_self_contained_and_current():
     produces (a) matches the content digest of its sources, (b) leaves no nof_* symbol undefined, (c) dlopens here, without a GPU."""
     import subprocess
     from bundlesdf_amd import build
-    libs = [build.build(verbose=False), build.build_perturb(verbose=False)]
+    libs = [build.build(verbose=False), build.build_perturb(verbose=False), build.build_probe(verbose=False)]
     for path in libs:
         assert open(path + '.stamp').read().strip()
         und = subprocess.run(['nm', '-D', '--undefined-only', path], capture_output=True, text=True, check=True).stdout
-        bad = [ln.split()[-1] for ln in und.splitlines() if re.search(r'\b(nof_|k_)', ln)]
+        bad = [ln.split()[-1] for ln in und.splitlines() if re.search(r'\b(nof_|k_)', ln) and '__hip' not in ln]
         assert not bad, (path, bad)
         ctypes.CDLL(path)
     # and the stamp is a function of content: a touched-but-unchanged source does not trigger a rebuild, an edited one does
     srcs = [os.path.join(build.CSRC, x) for x in ('nof_hash.hip', 'nof_capi.hip')]
     d0 = build._digest(srcs + build.HEADERS, build.FLAGS + ['perturb'])
     assert build._fresh(build.PERTURB_LIB, d0) and not build._fresh(build.PERTURB_LIB, d0[::-1])
+
+
+def test_product_library_keeps_no_mode_switch():
+    """include/nof_hip.h's contract is POD arguments in, status out.  Round 4 had a process-wide `nof_set_trace_kernel` (a static int
+    behind two entry points): invisible to a captured graph's owner, shared by every caller in the process.  It is an argument now
+    (NofSampleCfg.marcher, nof_batch_trace's `marcher`).  What the library may keep in writable data: the thread-local error text, the
+    write-once caches of a device property (CU count -> workgroup counts), the host shadows of __constant__ tables, toolchain
+    bookkeeping; kernels' handle objects.  And the hardware probes live in a test-only library."""
+    import subprocess
+    from bundlesdf_amd import build
+    out = subprocess.run(['nm', '-C', build.build(verbose=False)], capture_output=True, text=True, check=True).stdout
+    allowed = re.compile(r'^(g_nof_err|nof_cu_count\(\)::cus|g_bwd_blocks|kMcEdge|kTets|_DYNAMIC|_GLOBAL_OFFSET_TABLE_|__dso_handle|__init|__fini|'
+                         r'__do_init\..*|__do_fini\..*|__hip_\w+|completed\.\d+|__TMC_END__|.*k_\w+(<.*>)?(\(.*\))?)$')
+    for ln in out.splitlines():
+        m = re.match(r'^[0-9a-f]* ([bBdD]) (.*)$', ln)
+        if m:
+            assert allowed.match(m.group(2).replace('void ', '').strip()), ln
+    exported = subprocess.run(['nm', '-D', '--defined-only', build.LIB], capture_output=True, text=True, check=True).stdout
+    assert 'probe' not in exported and 'nof_set_trace_kernel' not in exported
 
 
 def test_ctypes_table_matches_header():

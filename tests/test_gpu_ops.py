@@ -24,7 +24,11 @@ def test_mfma_operand_layout(nof, precision, K, tol):
     A = rng.normal(size=(32, K)).astype(np.float32)
     Bm = rng.normal(size=(K, 32)).astype(np.float32)
     D = torch.zeros(32, 32, device='cuda')
-    nof.call('nof_mfma_probe', precision, U.dev(A), U.dev(Bm), D, K)
+    from bundlesdf_amd import build as Bld
+    probe = Bld.load_probe()                  # test-only library (csrc/test/nof_probe.hip over nof_mfma_dev.h): not in libnof_hip.so
+    dA, dB = U.dev(A), U.dev(Bm)
+    rc = probe.nof_mfma_probe(precision, dA.data_ptr(), dB.data_ptr(), D.data_ptr(), K, torch.cuda.current_stream().cuda_stream)
+    assert rc == 0, probe.nof_probe_last_error()
     torch.cuda.synchronize()
     ref = A.astype(np.float64) @ Bm.astype(np.float64)
     err = np.abs(cpu(D) - ref).max() / np.abs(ref).max()
@@ -227,7 +231,7 @@ def _scene(nof, R=300, level=4, seed=0, n_frames=5):
 
 @pytest.mark.parametrize("level,fill", [(2, 0.6), (4, 0.2), (5, 0.08), (6, 0.03)])
 def test_wave_ray_marcher_equals_the_walk(nof, level, fill):
-    """nof_set_trace_kernel(1): one wave per ray, the ray's cells from the ranks of its plane crossings instead of a walk
+    """marcher = NOF_MARCHER_WAVE: one wave per ray, the ray's cells from the ranks of its plane crossings instead of a walk
     (k_batch_trace_wave; NumPy statement of the algorithm: tools/dda_closed_form.py, checked against the walk on the CPU).  Every
     output of nof_batch_trace -- gathered rows, ray setup, view rows, intervals, cell ids, hit counts, the overflow flag -- must be
     the walk kernel's, bit for bit: random rays through random poses, rays built to tie (lattice origins, axis-parallel and diagonal
@@ -263,21 +267,16 @@ def test_wave_ray_marcher_equals_the_walk(nof, level, fill):
     feat = rng.normal(size=(F, ff)).astype(np.float32)
     ids = torch.from_numpy(rng.permutation(R)).cuda()
     outs = {}
-    default_kind = int(nof.load().nof_get_trace_kernel())
-    assert default_kind == 1
-    for kind in (0, 1):
+    for kind in (0, 1):                                            # (0 = the walk, 1 = the wave kernel: the keys below)
         for H, want_cells in ((3 * n + 2, True), (5, False)):
-            nof.load().nof_set_trace_kernel(kind)
-            try:
-                o = dict(batch=torch.full((R, 12), 7.0, device='cuda'), o_w=torch.empty(R, 3, device='cuda'), d_w=torch.empty(R, 3, device='cuda'),
-                         view=torch.empty(R, 16, device='cuda'), tio=torch.full((R, H, 2), 7.0, device='cuda'),
-                         cid=torch.full((R, H), 7, dtype=torch.int32, device='cuda') if want_cells else None,
-                         nh=torch.empty(R, dtype=torch.int32, device='cuda'), flags=torch.zeros(4, dtype=torch.int32, device='cuda'))
-                nof.call('nof_batch_trace', U.dev(batch), ids, U.dev(tf), U.dev(feat), ff, 3, bits, level, R, H, o['batch'], o['o_w'], o['d_w'],
-                         o['view'], o['tio'], o['cid'], o['nh'], o['flags'])
-                torch.cuda.synchronize()
-            finally:
-                nof.load().nof_set_trace_kernel(default_kind)
+            o = dict(batch=torch.full((R, 12), 7.0, device='cuda'), o_w=torch.empty(R, 3, device='cuda'), d_w=torch.empty(R, 3, device='cuda'),
+                     view=torch.empty(R, 16, device='cuda'), tio=torch.full((R, H, 2), 7.0, device='cuda'),
+                     cid=torch.full((R, H), 7, dtype=torch.int32, device='cuda') if want_cells else None,
+                     nh=torch.empty(R, dtype=torch.int32, device='cuda'), flags=torch.zeros(4, dtype=torch.int32, device='cuda'))
+            nof.call('nof_batch_trace', U.dev(batch), ids, U.dev(tf), U.dev(feat), ff, 3, bits, level, R, H,
+                     nof.MARCHER_WAVE if kind == 1 else nof.MARCHER_WALK, o['batch'], o['o_w'], o['d_w'],
+                     o['view'], o['tio'], o['cid'], o['nh'], o['flags'])
+            torch.cuda.synchronize()
             outs[(kind, H)] = o
     for H in (3 * n + 2, 5):
         a, b = outs[(0, H)], outs[(1, H)]
@@ -296,7 +295,7 @@ def test_wave_ray_marcher_equals_the_walk(nof, level, fill):
 @pytest.mark.parametrize("level", [4, 6])
 def test_fused_raymarch_sample_equals_the_two_launches(nof, level):
     """nof_raymarch_sample with the wave-per-ray kernel is ONE launch (k_raymarch_wave<true>: the wave that enumerated a ray's cells
-    places its samples); with nof_set_trace_kernel(0) it is the walk kernel followed by k_sample_points.  Same bits in every output
+    places its samples); with NofSampleCfg.marcher = NOF_MARCHER_WALK it is the walk kernel followed by k_sample_points.  Same bits in every output
     -- intervals, hit counts, z, sample points, validity, flags (incl. the skipped-step mark 4 -> 8 the sampler half turns over) --
     with injected uniforms, with Philox, and with perturb=False; rays with usable and unusable depth."""
     cfg, occ, c2w, batch = _scene(nof, level=level, R=2000, seed=3)
@@ -312,25 +311,20 @@ def test_fused_raymarch_sample_equals_the_two_launches(nof, level):
     u_occ, u_dep = U.dev(rng.random((R, Ns)).astype(np.float32)), U.dev(rng.random((R, Na)).astype(np.float32))
     ids = torch.from_numpy(rng.permutation(R)).cuda()
     trunc = O.get_truncation(cfg, 0)
-    default_kind = int(nof.load().nof_get_trace_kernel())
     for uo, ud, det in ((u_occ, u_dep, 0), (None, None, 0), (None, None, 1)):
         res = {}
         for kind in (0, 1):
             sc = nof.NofSampleCfg(Ns, Na, cfg['near'] * cfg['sc_factor'], cfg['far'] * cfg['sc_factor'], trunc, cfg['neg_trunc_ratio'], 77, 5,
-                                  None, det)
+                                  None, det, nof.MARCHER_WAVE if kind == 1 else nof.MARCHER_WALK)
             o = dict(batch=torch.empty(R, 12, device='cuda'), o_w=torch.empty(R, 3, device='cuda'), d_w=torch.empty(R, 3, device='cuda'),
                      view=torch.empty(R, 16, device='cuda'), tio=torch.empty(R, H, 2, device='cuda'),
                      cid=torch.empty(R, H, dtype=torch.int32, device='cuda'), nh=torch.empty(R, dtype=torch.int32, device='cuda'),
                      z=torch.full((R, S), 7.0, device='cuda'), pts=torch.full((R * S, 3), 7.0, device='cuda'),
                      valid=torch.full((R * S,), 7, dtype=torch.uint8, device='cuda'),
                      flags=torch.tensor([4, 0, 0, 0], dtype=torch.int32, device='cuda'))
-            nof.load().nof_set_trace_kernel(kind)
-            try:
-                nof.call('nof_raymarch_sample', C.byref(sc), U.dev(batch), ids, tf, None, 0, 3, bits, level, R, H, uo, ud, o['batch'], o['o_w'],
-                         o['d_w'], o['view'], o['tio'], o['cid'], o['nh'], o['z'], o['pts'], o['valid'], o['flags'])
-                torch.cuda.synchronize()
-            finally:
-                nof.load().nof_set_trace_kernel(default_kind)
+            nof.call('nof_raymarch_sample', C.byref(sc), U.dev(batch), ids, tf, None, 0, 3, bits, level, R, H, uo, ud, o['batch'], o['o_w'],
+                     o['d_w'], o['view'], o['tio'], o['cid'], o['nh'], o['z'], o['pts'], o['valid'], o['flags'])
+            torch.cuda.synchronize()
             res[kind] = o
         a, b = res[0], res[1]
         for k in a:
@@ -360,7 +354,7 @@ def test_sample_points_bit_identical(nof):
     nh = torch.empty(R, dtype=torch.int32, device='cuda')
     flags = torch.zeros(4, dtype=torch.int32, device='cuda')
     ids = torch.arange(R, device='cuda').flip(0).contiguous()
-    nof.call('nof_batch_trace', U.dev(batch), ids, tf, None, 0, 3, bits, level, R, H, d_batch, o_w, d_w, view, tio, cid,
+    nof.call('nof_batch_trace', U.dev(batch), ids, tf, None, 0, 3, bits, level, R, H, nof.MARCHER_WAVE, d_batch, o_w, d_w, view, tio, cid,
              nh, flags)
     torch.cuda.synchronize()
     bb = batch[::-1].copy()

@@ -2,8 +2,10 @@
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from bundlesdf_amd import lib
-lib.load()
+from bundlesdf_amd import build as _build
+_probe = _build.load_probe()          # the test-only probe library (csrc/test/nof_probe.hip), not libnof_hip.so
+def _atomic_probe(variant, idx, table, n):
+    assert _probe.nof_atomic_probe(variant, idx.data_ptr(), table.data_ptr(), n, torch.cuda.current_stream().cuda_stream) == 0, _probe.nof_probe_last_error()
 n = 1 << 24
 T = 1 << 19
 g = torch.Generator(device='cuda').manual_seed(0)
@@ -16,7 +18,7 @@ def run(name, variant, idx):
     for rep in range(3):
         table.zero_()
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        a.record(); lib.call('nof_atomic_probe', variant, idx, table, n); b.record(); torch.cuda.synchronize()
+        a.record(); _atomic_probe(variant, idx, table, n); b.record(); torch.cuda.synchronize()
     ms = a.elapsed_time(b)
     per = 1 if variant == 3 else 2
     print(f'{name:46s} {ms:8.3f} ms  {n * per / ms / 1e6:8.1f} G atomics/s  sum={table.sum().item():.0f}')
@@ -31,7 +33,7 @@ def run1(name, variant, idx):
     for rep in range(3):
         table.zero_()
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        a.record(); lib.call('nof_atomic_probe', variant, idx, table, n); b.record(); torch.cuda.synchronize()
+        a.record(); _atomic_probe(variant, idx, table, n); b.record(); torch.cuda.synchronize()
     ms = a.elapsed_time(b)
     print(f'{name:58s} {ms:8.3f} ms  {n / ms / 1e6:8.1f} G lane-ops/s  {n / 4 / ms / 1e6:8.1f} G lines/s  sum={table.sum().item():.0f}')
 run1('6 same ADDRESS, lanes 16 apart, 16 lines/instr', 6, idx_rand)
@@ -44,7 +46,7 @@ def run2(name, variant):
     for rep in range(3):
         table.zero_()
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        a.record(); lib.call('nof_atomic_probe', variant, idx_rand, table, n); b.record(); torch.cuda.synchronize()
+        a.record(); _atomic_probe(variant, idx_rand, table, n); b.record(); torch.cuda.synchronize()
     ms = a.elapsed_time(b)
     print(f'{name:62s} {ms:8.3f} ms  {n / ms / 1e6:8.1f} G line-requests/s  sum={table.sum().item():.0f}')
 for part, pn in enumerate(['random entries over the whole table', 'entries folded into the XCD-owned eighth (XCC_ID)', 'entries folded by blockIdx % 8']):
@@ -58,7 +60,7 @@ tg = torch.zeros((1 << 20) + n, device='cuda')          # 2^19 rows x 2 floats +
 def run3(name, variant):
     for rep in range(3):
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        a.record(); lib.call('nof_atomic_probe', variant, idx_rand, tg, n); b.record(); torch.cuda.synchronize()
+        a.record(); _atomic_probe(variant, idx_rand, tg, n); b.record(); torch.cuda.synchronize()
     ms = a.elapsed_time(b)
     print(f'{name:62s} {ms:8.3f} ms  {8 * n / ms / 1e6:8.1f} G lane-gathers/s')
 run3('30 8 gathers per lane, every lane its own random row', 30)
