@@ -176,19 +176,27 @@ def extra_configs():
     """Sub-records of the one line, so that the driver's run carries the other single-GPU BASELINE.json configurations: short runs
     of this same script in child processes (16 keyframes: a step does not depend on how many rows the ray table has).
       cfg4  configs[3]: 8192 rays per step, finest 512 + the 512^3 dense extraction (query + device marching cubes)
-      cfg5  configs[4]: 1280x720 frames, T = 2^22, MLP 4x128 + 4x128, fp16, 16 384 rays per step"""
+      cfg5  configs[4]: 1280x720 frames, T = 2^22, MLP 4x128 + 4x128, fp16, 16 384 rays per step
+      cfg1_shapes  configs[0]'s shapes (1024 rays, T = 2^14, the reference's 2+3-layer network, 4 keyframes) on the GPU
+      cfg2_bf16    the headline workload with bfloat16 operands (hi + lo split)"""
     import subprocess
     common = ['--keyframes', '16', '--steps', '20', '--warmup', '10', '--settle', '0', '--round-steps', '0', '--no-cpu-baseline',
               '--no-extra-configs']
     runs = [('cfg4', ['--rays', '8192', '--finest', '512', '--extract', '512']),
             ('cfg5', ['--mlp', 'cfg5', '--rays', '16384', '--log2_T', '22', '--finest', '512', '--width', '1280', '--height', '720',
-                      '--precision', 'fp16'])]
+                      '--precision', 'fp16']),
+            # configs[0]'s shapes on the GPU: the same workload the cpu_baseline leg of a `--rays 1024 --log2_T 14 --mlp reference`
+            # run times (SURVEY 8d: "also run the GPU path at cfg1 shapes for an apples-to-apples ratio"); 4 keyframes as BASELINE says
+            ('cfg1_shapes', ['--rays', '1024', '--log2_T', '14', '--mlp', 'reference', '--keyframes', '4']),
+            # configs[1] names bf16: the headline runs the reference's own autocast type (fp16, operands split hi + lo); the same
+            # workload with bfloat16 operands split the same way (parity-tested at full size like fp16x3)
+            ('cfg2_bf16', ['--precision', 'bf16x3'])]
     keep = ('value', 'unit', 'ms_per_step', 'steps', 'warmup', 'dtype', 'ms_per_step_dense_backward', 'zero_grad_sample_fraction',
             'train_iters_per_sec', 'loss', 'flags', 'step_ms_spread', 'extraction')
     out = []
     for name, extra in runs:
         try:
-            r = subprocess.run([sys.executable, os.path.abspath(__file__)] + extra + common, capture_output=True, text=True, timeout=600)
+            r = subprocess.run([sys.executable, os.path.abspath(__file__)] + common + extra, capture_output=True, text=True, timeout=600)
             d = json.loads(r.stdout.strip().splitlines()[-1])
             out.append({"name": name, **{k: d.get(k) for k in keep if k in d}, "workload": d['config']['workload'].split(';')[0],
                         "roofline": {k: d['roofline'].get(k) for k in ('kernel', 'bound', 'frac', 'avg_ms')} if d.get('roofline') else None})
@@ -323,9 +331,19 @@ def main():
 
     trace_steps = os.environ.get('NOF_BENCH_TRACE_STEPS') == '1'     # diagnosis: loss and parameter sums after every step (host syncs)
 
+    # test hook (tests/test_gpu_dp.py): NOF_DP_INJECT_OVERFLOW="rank:step" -- on that rank, in that step (0-based, warm-up included),
+    # the fp16 loss scale of the MLP backward is raised by 2^40, so its weight gradient overflows on THAT rank only
+    inject = os.environ.get('NOF_DP_INJECT_OVERFLOW')
+    inject = tuple(int(x) for x in inject.split(':')) if inject else None
+
     def step():
         """one iteration of NerfRunner.train()"""
-        runner.train_loop()
+        if inject is not None and inject == (rank, int(fld.global_step)):
+            keep, fld._scale_backoff = fld._scale_backoff, fld._scale_backoff - 40
+            runner.train_loop()
+            fld._scale_backoff = keep
+        else:
+            runner.train_loop()
         runner.global_step += 1
         if trace_steps:
             print(f"[step {fld.global_step}] loss {fld.losses()['loss']:.7f} table {float(fld.table.double().abs().sum().item()):.4f} "
@@ -564,7 +582,18 @@ def main():
                     # (tools/atomic_probe.py; same for every scope, cache flag and data type), and the launch needs one request per
                     # 64-byte line per atomic instruction.  The requests of THIS batch are counted from its own sample points.
                     try:
-                        roof["atomic"] = atomic_roofline(fld, runner, R, S, dom_ms)
+                        at = atomic_roofline(fld, runner, R, S, dom_ms)
+                        # the ceiling of this launch IS the atomic request rate (counter traffic is 0.14x the algorithmic bytes: the
+                        # read-modify-write happens memory-side): the line's primary figures are against it, the HBM pricing of
+                        # SURVEY 8d's algorithmic bytes is kept under "hbm"
+                        roof = {"kernel": dominant, "bound": "atomic", "achieved": at["achieved"], "peak": at["peak"], "unit": at["unit"],
+                                "frac": at["frac"], "traffic": traffic, "avg_ms": dom_ms, "line_requests": at["line_requests"],
+                                "floor_ms": at["floor_ms"], "sample": at["sample"], "traffic_source": src if traffic else None,
+                                "peak_source": "tools/atomic_probe.py on MI355X: 20.8 G fp32-atomic line requests/s, whatever the scope, "
+                                               "cache flags or data type (profiles/r02_d_atomic_probe.txt)",
+                                "hbm": {"achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                                        "algorithmic_bytes": amount,
+                                        "traffic_frac_of_peak": (traffic / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None}}
                     except Exception as ex:          # measurement aid only
                         roof["atomic"] = {"error": repr(ex)}
             else:

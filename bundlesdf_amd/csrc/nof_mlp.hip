@@ -498,23 +498,25 @@ NofMlpDesc d, const char* __restrict__ image,
 // Same values as k_hash_fwd + k_mlp_fwd, bit for bit (tests/test_gpu_ops.py): the encode is encode_level()'s arithmetic, the
 // chain is dense_o1().
 //
-// ONE level's gathers in flight per wave (NOF_ENC_GROUP = 1), although registers would allow four.  With two or more levels in
-// flight this kernel -- and only with the chain present and 8-12 waves per workgroup -- delivered, in a few 16-sample groups per
-// million samples and differently on every run, a wrong value for ONE of the eight corner loads of the LAST level of a group, always
-// in lanes 48-63 (the last quarter-wave a vector load returns): found because the kernel is compared bit for bit with the
-// two-launch path (tools/fused_debug.py, fused_debug2.py; profiles/r04_fused_forward_race.txt).  Ruled out by experiment: the
-// compiler's waits (an explicit s_waitcnt vmcnt(0) with the loaded registers tied to it, + 16 idle cycles), address registers being
-// reused as destinations or the saddr pair being overwritten after issue (kept live past the wait: enc_keep), the LDS stage (the
-// values are wrong before they reach it), the 16-byte pair loads, the points' load, SGPR spilling, per-lane branches around the
-// blend (selects now), XNACK replays (xnack-).  Not root-caused; with one level in flight: 0 differing samples in 180 runs x
-// 196 608 samples, and the same 115 us (the kernel is bound by gather issue + matrix pipe taking turns, not by gather latency).
-// tests/test_gpu_ops.py::test_fused_forward_is_repeatable guards it.
+// ONE level's gathers in flight per wave (NOF_ENC_GROUP = 1): the kernel is bound by gather issue and the matrix pipe taking turns,
+// not by gather latency, so more levels in flight buy nothing (measured: the same 105-115 us with 1, 2 and 4).
+// Round 4 met a fault here with two or more levels in flight -- wrong features of one level of a group in lanes 48-63, in a few
+// 16-sample groups per million samples, differently on every run (profiles/r04_fused_forward_race.txt) -- and shipped GROUP = 1 as a
+// workaround without knowing why.  Root cause (round 5; DESIGN 2.10, profiles/r05_*_fault_*.txt): with GROUP >= 2 clang's SLP
+// vectoriser blended that level with packed-fp32 instructions, among them `v_pk_mul_f32 vD, vA, vB op_sel:[0,1]`; on gfx950 a packed
+// fp32 instruction that reads SOURCE 1 through op_sel = 1 returns a wrong low result in its last quarter-wave whenever another wave
+// of the SIMD executes an MFMA at that moment (stand-alone: tools/repro/pk_swap_repro.hip, 1.6 % of the executions under MFMA load,
+// none without).  Bisected on this kernel's own assembly (tools/asm_variant.sh): rewriting that ONE instruction as two scalar
+// multiplies cures it, rewriting any other class of packed instruction does not.  The library is therefore built with
+// -fno-slp-vectorize (bundlesdf_amd/build.py; no measurable cost) and tests/test_capi.py disassembles every built library to
+// prove the form is absent; NOF_ENC_BLEND = 1 additionally keeps the two channels of enc_blend apart at the source level.
+// tests/test_gpu_ops.py::test_fused_forward_is_repeatable stays as the product-level guard.
 // =====================================================================================================
 #ifndef NOF_ENC_WAVES
 #define NOF_ENC_WAVES 12                                  // most waves per workgroup (one workgroup per CU, 3 waves per SIMD)
 #endif
 #ifndef NOF_ENC_GROUP
-#define NOF_ENC_GROUP 1                                   // levels whose gathers are in flight together (see above before raising it)
+#define NOF_ENC_GROUP 1                                   // levels whose gathers are in flight together (see above)
 #endif
 #ifndef NOF_ENC_ROLLED
 #define NOF_ENC_ROLLED 1
@@ -593,16 +595,42 @@ __device__ __forceinline__ void enc_keep(const EncCell& e) {
   asm volatile("" :: "v"(e.idx[0]), "v"(e.idx[1]), "v"(e.idx[2]), "v"(e.idx[3]), "v"(e.idx[4]), "v"(e.idx[5]), "v"(e.idx[6]), "v"(e.idx[7]),
                "s"(e.base));
 }
+#ifndef NOF_ENC_BLEND
+#define NOF_ENC_BLEND 0                                   // experiments (tools/fused_fault.sh): 1 = the two channels kept apart (no packed-fp32 pairing), 2 = forced packed
+#endif
 __device__ __forceinline__ float2 enc_blend(const EncCell& e, const float2 (&v)[8]) {   // encode_level's own weights and order
   float2 acc = make_float2(0.f, 0.f);
+#if NOF_ENC_BLEND == 2
+  typedef float v2f __attribute__((ext_vector_type(2)));
+  v2f a2 = {0.f, 0.f};
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
     float wk = 1.0f;
 #pragma unroll
     for (int d = 0; d < 3; ++d) wk *= (k & (1 << d)) ? e.f[d] : 1.0f - e.f[d];
+    const v2f vk = {v[k].x, v[k].y}, w2 = {wk, wk};
+    a2 = a2 + w2 * vk;
+  }
+  acc.x = a2.x;
+  acc.y = a2.y;
+#else
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    float wk = 1.0f;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) wk *= (k & (1 << d)) ? e.f[d] : 1.0f - e.f[d];
+#if NOF_ENC_BLEND == 1
+    float px = wk * v[k].x, py = wk * v[k].y;
+    asm volatile("" : "+v"(px));                       // an opaque value: the x and y products cannot be paired into one v_pk_mul_f32
+    acc.x += px;
+    asm volatile("" : "+v"(acc.x));
+    acc.y += py;
+#else
     acc.x += wk * v[k].x;
     acc.y += wk * v[k].y;
+#endif
   }
+#endif
   // an out-of-range point: zeros (gridencoder.cu:131-139), by a select -- no lane is switched off around the blend, so no
   // execution mask per level in flight has to be kept (they were being spilled to VGPR lanes)
   acc.x = e.oob ? 0.0f : acc.x;

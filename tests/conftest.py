@@ -25,7 +25,7 @@ def nof():
 # Collection order of the GPU suite: the driver runs `pytest -x`, so whatever is collected after the first failure is not evidence.
 # Cheap per-operation parity first (seconds each), whole-step / renderer / runner next, the multi-minute full-size and two-process
 # data-parallel tests last: a late failure then costs the fewest rows.  Files not listed keep their alphabetical place in the middle.
-_ORDER = ['test_gpu_ops', 'test_gpu_tiles', 'test_gpu_rays', 'test_gpu_reference_fixture', 'test_gpu_texture',
+_ORDER = ['test_gpu_erratum', 'test_gpu_ops', 'test_gpu_tiles', 'test_gpu_rays', 'test_gpu_reference_fixture', 'test_gpu_texture',
           'test_gpu_mesh', 'test_gpu_chain', 'test_gpu_step', 'test_gpu_render', 'test_gpu_runner']
 _LAST = ['test_gpu_fullsize', 'test_gpu_dp']
 

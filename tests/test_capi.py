@@ -46,6 +46,23 @@ def test_every_built_library_is_self_contained_and_current():
     assert build._fresh(build.PERTURB_LIB, d0) and not build._fresh(build.PERTURB_LIB, d0[::-1])
 
 
+def test_no_packed_fp32_instruction_reads_source_1_through_op_sel():
+    """gfx950: `v_pk_{mul,add,fma}_f32 ... op_sel:[_,1]` (source 1's high register feeds the low result) returns a wrong low result in
+    lanes 48-63 while another wave of the SIMD executes an MFMA (tools/repro/pk_swap_repro.hip, tests/test_gpu_erratum.py).
+    The compiler's SLP vectoriser is the only producer, and it is off (build.py FLAGS): the device code of every library build()
+    produces is disassembled here and must not contain the form."""
+    import sys
+    from bundlesdf_amd import build
+    sys.path.insert(0, os.path.join(ROOT, 'tools'))
+    import pk_opsel_scan
+    assert '-fno-slp-vectorize' in build.FLAGS
+    for path in (build.build(verbose=False), build.build_perturb(verbose=False), build.build_probe(verbose=False)):
+        hits = pk_opsel_scan.scan(path)
+        assert not hits, (path, len(hits), hits[:3])
+    assert pk_opsel_scan.hazardous('v[0:1], v[0:1], v[2:3] op_sel:[0,1]') and pk_opsel_scan.hazardous('v[0:1], v[0:1], v[2:3], v[4:5] op_sel:[0,0,1]')
+    assert not pk_opsel_scan.hazardous('v[0:1], v[0:1], v[2:3] op_sel:[1,0] op_sel_hi:[0,1]') and not pk_opsel_scan.hazardous('v[0:1], v[0:1], v[2:3]')
+
+
 def test_product_library_keeps_no_mode_switch():
     """include/nof_hip.h's contract is POD arguments in, status out.  Round 4 had a process-wide `nof_set_trace_kernel` (a static int
     behind two entry points): invisible to a captured graph's owner, shared by every caller in the process.  It is an argument now
@@ -213,15 +230,24 @@ def test_hot_kernels_have_no_scratch():
     backward at hidden 128 (2 registers = 12 bytes; the fp16 variant, cfg5's, is clean), and the mesh extractors' emit kernels
     (renderer side: the case table indexes the cell's corner values at run time).  The colour backward with THREE colour layers --
     the reference's own shape, nerf_runner.py:221 -- was an exception until round 4 (148 B): its first layer's weight gradient is
-    accumulated transposed (32 instead of 64 registers) and it is guarded here like every other shape."""
+    accumulated transposed (32 instead of 64 registers).  Round 5: the library is built without clang's SLP vectoriser (a
+    correctness matter on gfx950: test_no_packed_fp32_instruction_reads_source_1_through_op_sel), which had packed a few of that
+    kernel's values into register pairs: at its 256-register budget it now spills 2-4 registers (12-20 bytes) -- bounded here at 32
+    bytes, step time unchanged (profiles/r05_k_*); the eikonal kernel's two spills go to AGPRs (no private memory)."""
     import re
     allowed = (r'^k_mlp_bwd<', r'^k_wide_bwd_color<PrecBF16, 4>', r'^k_m[ct]_emit$')
+    small = {r'^k_mlp_bwd_color<Prec(BF|F)16, [23], 3>': 32}                # bytes of private memory tolerated
     bad = []
     seen = set()
     for name, md in _kernel_metadata():
         short = name.split('(')[0]
         seen.add(re.sub(r'<.*', '', short))
         if any(re.match(a, short) for a in allowed):
+            continue
+        cap = [v for k, v in small.items() if re.match(k, short)]
+        if cap and int(md['private_segment_fixed_size']) <= cap[0]:
+            continue
+        if short.startswith('k_eikonal<') and int(md['private_segment_fixed_size']) == 0:
             continue
         if int(md['private_segment_fixed_size']) or int(md['vgpr_spill_count']):
             bad.append((short, md['private_segment_fixed_size'], md['vgpr_spill_count']))
@@ -241,7 +267,10 @@ def test_reference_shape_backward_runs_two_waves_per_simd():
         if re.match(r'k_mlp_bwd_color<\w+, \d, 3>', name):
             assert int(md['max_flat_workgroup_size']) == 512, name
             assert int(md['vgpr_count']) + int(md['agpr_count']) <= 256, name
-            assert int(md['private_segment_fixed_size']) == 0 and int(md['vgpr_spill_count']) == 0, name
+            # (round 5: built without the SLP vectoriser -- see test_no_packed_fp32_instruction_reads_source_1_through_op_sel -- the
+            # kernel sits 2-4 registers over its 256: 12-20 bytes of private memory, no measurable time: profiles/r05_k_slp_ab_refshape.txt,
+            # nof_mlp_bwd_tiles 0.073 ms either way, the step 0.404 vs 0.410 ms with the vectoriser)
+            assert int(md['private_segment_fixed_size']) <= 32 and int(md['vgpr_spill_count']) <= 4, name
             n += 1
     assert n == 4
 

@@ -125,9 +125,11 @@ def _worker(rank, world, port, R, out):
     sz.end_step()
     assert torch.equal(pz[:n], torch.from_numpy(pa))
     assert sz.collectives_step == 2 and sz.bytes_step == 2 * 4 * n_pad and sz.timed_steps == 1
-    fl = torch.tensor([4 if rank == 1 else 0, 0, 0, 0], dtype=torch.int32)
+    # only the skip bit (4) travels; a rank's other bits -- 1: a ray exceeded max_hits, 8: the sticky mark of an EARLIER skipped step
+    # -- neither hide another rank's skip bit (MAX over the whole word would let 9 beat 4) nor spread
+    fl = torch.tensor([4 if rank == 1 else 9, 7, 0, 0], dtype=torch.int32)
     sz.max_flags_(fl)
-    assert int(fl[0]) == 4                                           # one rank's overflow is everybody's skipped step
+    assert int(fl[0]) == (4 if rank == 1 else 13) and int(fl[1]) == 7  # one rank's overflow is everybody's skipped step
     if rank == 0:
         out.put(flat.numpy())
     dist.barrier()

@@ -14,12 +14,16 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run(overlap, port, backend='gloo', ranks=2, force='0', steps=6, payload='fp32', mode='allreduce'):
+def _run(overlap, port, backend='gloo', ranks=2, force='0', steps=6, payload='fp32', mode='allreduce', inject=None, precision=None):
     env = dict(os.environ, NOF_DIST_BACKEND=backend, HSA_ENABLE_IPC_MODE_LEGACY='0', NOF_DP_OVERLAP=overlap, NOF_DP_FORCE=force,
                NOF_DP_PAYLOAD=payload, NOF_DP_MODE=mode)
+    if inject is not None:
+        env['NOF_DP_INJECT_OVERFLOW'] = inject
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(ranks), '--master-addr', '127.0.0.1',
            '--master-port', str(port), os.path.join(ROOT, 'bench.py'), '--gpus', str(ranks), '--steps', str(steps), '--warmup', '2',
            '--keyframes', '3', '--no-cpu-baseline', '--settle', '0', '--round-steps', '0']
+    if precision is not None:
+        cmd += ['--precision', precision]
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-3000:]
     line = [l for l in out.stdout.splitlines() if l.startswith('{"metric"')]
@@ -54,6 +58,28 @@ def test_bench_two_ranks_one_gpu_gloo(nof):
     # the trailing one carries a copy of the [features | poses] tail in the headroom in front of the gradient buffer
     assert d['collectives_per_step'] == 2 and d0['collectives_per_step'] == 1
     assert d['allreduce_bytes_per_step'] >= d0['allreduce_bytes_per_step'] > 4 * 9_000_000
+
+
+@pytest.mark.parametrize("overlap,payload,mode", [('1', 'fp32', 'allreduce'), ('1', 'bf16', 'allreduce'), ('0', 'fp32', 'allreduce'),
+                                                  ('1', 'fp32', 'zero1')])
+def test_overflow_on_one_rank_is_skipped_by_both(nof, overlap, payload, mode):
+    """the bucketed step ran the first slice's share of Adam before the ranks had agreed on the step's overflow flag -- a
+    rank that overflowed alone skipped the slice while the other applied a summed gradient that held its inf (NaN weights, replicas
+    apart).  Rank 1's fp16 loss scale is raised by 2^40 for step 3 (bench.py: NOF_DP_INJECT_OVERFLOW): its MLP weight gradient is not
+    finite in that step, rank 0's is.  Every form of the exchange must end with bit-identical, finite replicas that both skipped
+    that step (the skipped step's mark is the sticky bit the host polls: it must be up on rank 0, which did not overflow itself)."""
+    port = 29550 + 4 * ['allreduce', 'zero1'].index(mode) + 2 * int(overlap) + (payload == 'bf16')
+    d = _run(overlap, port, payload=payload, mode=mode, inject='1:3', precision='fp16x3')
+    assert d['dp_param_checksum_spread'] == 0.0, d['dp_param_checksum_spread']
+    assert d['param_checksum'] == d['param_checksum'] and d['param_checksum'] < 1e30 and d['loss'] == d['loss']
+    assert d['flags'] & 12, d['flags']                                  # the skipped step left its mark on rank 0 as well
+    clean = _run(overlap, port + 20, payload=payload, mode=mode, precision='fp16x3')
+    assert clean['flags'] == 0
+    # one step of eight was skipped: the parameters moved less far than in the clean run (Adam's first steps are +-lr each), and
+    # nothing blew up
+    assert 0.5 * clean['param_checksum'] < d['param_checksum'] < 1.5 * clean['param_checksum']
+    assert d['param_checksum'] != clean['param_checksum']
+    assert d['param_checksum_parts']['mlp'] == d['param_checksum_parts']['mlp'] and d['param_checksum_parts']['mlp'] < 1e9
 
 
 def test_bf16_payload_loss_drift_over_50_steps(nof):
