@@ -470,7 +470,7 @@ def main():
     log(f'dense backward (every tile listed): {dense_ms:.3f} ms/step')
     # cfg hip_graph = True replays the step as ONE captured HIP graph (NerfRunner.train_loop / GraphedStep): one chain instead of
     # the eager step's two streams, i.e. a free host for a few per cent of step time.  Same K steps, captured, for the record:
-    graph_ms = None
+    graph_ms, graph_alt_ms = None, None
     if not dist.is_initialized() or world == 1:
         runner.cfg['hip_graph'] = True              # opt-in (the product default is the eager two-stream step)
         for _ in range(4):
@@ -483,6 +483,20 @@ def main():
             torch.cuda.synchronize()
             graph_ms = (time.perf_counter() - t1) / args.steps * 1e3
             log(f'captured-step mode: {graph_ms:.3f} ms/step')
+        # the same with the captured step as ONE chain (what rounds 3-4 captured): the fork / join inside the graph against none
+        fld.graph_fork = not fld.graph_fork
+        runner._graph = None
+        for _ in range(4):
+            step()
+        if getattr(runner, '_graph', None) is not None:
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                step()
+            torch.cuda.synchronize()
+            graph_alt_ms = (time.perf_counter() - t1) / args.steps * 1e3
+            log(f'captured-step mode, graph_fork={fld.graph_fork}: {graph_alt_ms:.3f} ms/step')
+        fld.graph_fork = not fld.graph_fork
         runner.cfg['hip_graph'] = False
         runner._graph = None
     extraction = time_extraction(runner, args.extract) if args.extract > 0 and world == 1 else None
@@ -646,7 +660,7 @@ def main():
                        "rays_per_step": R, "samples_per_ray": S, "keyframes_per_gpu": args.keyframes,
                        "pool_rays": int(runner.rays.shape[0]), "parallelism": f"dp{world}",
                        "forward": "fused encode+MLP (nof_encode_mlp_fwd)" if fld.fused_forward else "nof_hash_encode_fwd + nof_mlp_fwd"},
-            "train_iters_per_sec": it_s * 1.0, "captured_step_ms_per_step": graph_ms,
+            "train_iters_per_sec": it_s * 1.0, "captured_step_ms_per_step": graph_ms, "captured_step_one_chain_ms_per_step": graph_alt_ms,
             # forward-only batches run before the warm-up steps (no parameter / optimiser / loader / RNG state touched)
             "preroll_forward_batches": args.preroll,
             # device-side duration of single steps (K more steps, one event after each): p10 / p50 / p90

@@ -110,6 +110,7 @@ class NeuralObjectField:
         # the training forward as ONE launch with the embedding kept on chip (nof_encode_mlp_fwd; 64-wide networks, 16-bit operand
         # types); False: the two launches nof_hash_encode_fwd + nof_mlp_fwd with the fp32 [L,B,2] embedding in HBM between them
         self.fused_forward = not self.wide and self.desc.precision != 0
+        self.graph_fork = True            # a captured step (GraphedStep) keeps the backward's two branches (False: one chain)
         self.marcher = lib.MARCHER_WAVE   # NofSampleCfg.marcher: the ray marcher of nof_raymarch_sample (lib.MARCHER_WALK: the per-lane walk)
         self.scatter_wgs_per_cu = 0                  # persistent workgroups per CU of the table scatter (0 = the library's default)
         self._state = None           # NofStepState on the device (captured-step mode): see sync_step_state / GraphedStep
@@ -511,12 +512,13 @@ class NeuralObjectField:
                 with torch.cuda.stream(self._st):
                     b['dview'].zero_()
 
-        if dyn:
-            # captured step: one chain (a second branch in the HIP graph costs more than the overlap returns)
+        if dyn and not self.graph_fork:
+            # captured step as ONE chain
             reduce_mlp()
             hash_bwd(ALL, 0, self.L)
             pose_kernels()
         else:
+            # (dyn and graph_fork: the capture follows the fork / join events below, so the captured step keeps the two branches)
             # The table scatter of the large levels (atomics that execute memory-side) is the longest launch of the backward; the
             # input gradient and the pose / frame-feature gradients that hang off it are independent of it and run beside it on a
             # second stream (fork / join by events); the LDS-accumulated small levels and the MLP row reduction follow it.

@@ -341,8 +341,10 @@ def test_eikonal_matches_oracle(nof, ns, nc):
     assert np.abs(cpu(segs['mlp'][0])[lo:hi] - cpu(segs['mlp'][1])[lo:hi]).max() < 1e-6 * np.abs(cpu(segs['mlp'][1])[lo:hi]).max() + 1e-9
 
 
-def test_graphed_step_equals_eager_steps(nof):
-    """The product's captured-step mode (GraphedStep: the step as one HIP graph, Philox step / Adam step sizes / learning-rate
+@pytest.mark.parametrize("fork", [True, False])
+def test_graphed_step_equals_eager_steps(nof, fork):
+    """(fork: the captured step keeps the backward's two branches -- the capture follows the fork / join events of the eager step --
+    or is ONE chain.)  The product's captured-step mode (GraphedStep: the step as one HIP graph, Philox step / Adam step sizes / learning-rate
     schedule in the device-resident NofStepState) against eager launches with the scalars passed by value, over 14 steps
     (the schedule changes the rate after step 10): same batches, same Philox streams -> same parameters up to the
     summation order of the atomics, and the device state counts the steps."""
@@ -353,6 +355,7 @@ def test_graphed_step_equals_eager_steps(nof):
     twin = NeuralObjectField(cfg, fld.F, c2w, precision='fp16x3')
     twin.params.copy_(fld.params)
     twin.occ_bits, twin.level, twin.max_level, twin.max_hits = fld.occ_bits, fld.level, fld.max_level, fld.max_hits
+    twin.graph_fork = fork
     pool = U.dev(batch)
     R = batch.shape[0]
     gen = torch.Generator(device='cuda').manual_seed(0)
