@@ -8,5 +8,6 @@ python -c "import __graft_entry__ as g; g.build()" > gpurun_out/${T}_build.log 2
 timeout 2400 python -m pytest tests -m gpu -x -q --durations=15 --timeout=600 -p no:cacheprovider "$@" 2>&1 | tail -70 > gpurun_out/${T}_gpu_tests.txt; tail -40 gpurun_out/${T}_gpu_tests.txt
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -3 | tee gpurun_out/${T}_smoke.txt
 if [ -z "$NO_BENCH" ]; then
-  timeout 900 python bench.py 2>gpurun_out/${T}_bench.log | tail -1 > gpurun_out/${T}_bench_driver_invocation.json; cut -c1-400 gpurun_out/${T}_bench_driver_invocation.json
+  # (the driver's own command line: BENCH_r0N.json records `python3 bench.py --gpus 1 --steps 20 --warmup 5`)
+  timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 2>gpurun_out/${T}_bench.log | tail -1 > gpurun_out/${T}_bench_driver_invocation.json; cut -c1-400 gpurun_out/${T}_bench_driver_invocation.json
 fi
