@@ -70,11 +70,33 @@ def _stamp(lib, digest):
         f.write(digest + '\n')
 
 
+class _Lock:
+    """one builder at a time (the ranks of a torchrun launch all call lib.load(), which builds a library that lags its sources)"""
+
+    def __enter__(self):
+        import fcntl
+        self.f = open(os.path.join(HERE, '.build.lock'), 'w')
+        fcntl.flock(self.f, fcntl.LOCK_EX)
+        return self
+
+    def __exit__(self, *a):
+        import fcntl
+        fcntl.flock(self.f, fcntl.LOCK_UN)
+        self.f.close()
+
+
 def build(force=False, verbose=True):
     srcs = [os.path.join(CSRC, x) for x in SOURCES if os.path.exists(os.path.join(CSRC, x))]
     digest = _digest(srcs + HEADERS, FLAGS + [f'{k}:{v}' for k, v in sorted(EXTRA.items())])
     if not force and _fresh(LIB, digest):
         return LIB                  # e.g. on the GPU box: the snapshot ships the .so and its stamp but not the object cache
+    with _Lock():
+        if not force and _fresh(LIB, digest):                         # (another process built it while this one waited)
+            return LIB
+        return _build_locked(force, verbose, digest)
+
+
+def _build_locked(force, verbose, digest):
     os.makedirs(OBJ, exist_ok=True)
     cc = hipcc()
     objs, procs = [], []
@@ -95,11 +117,11 @@ def build(force=False, verbose=True):
         raise RuntimeError(f'hipcc failed for {failed}')
     for _, _, o, od in procs:
         _stamp(o, od)
-    if force or procs or _stale(LIB, objs):
-        cmd = [cc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs
-        if verbose:
-            print(' '.join(cmd), flush=True)
-        subprocess.check_call(cmd)
+    # (always link here: the library's stamp did not match, whatever the objects' file times say -- one second)
+    cmd = [cc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs
+    if verbose:
+        print(' '.join(cmd), flush=True)
+    subprocess.check_call(cmd)
     _stamp(LIB, digest)
     return LIB
 
