@@ -302,12 +302,36 @@ __device__ __forceinline__ void store_dfeat_o1(float2* __restrict__ dfeat, int L
     if (level < L) *reinterpret_cast<float2*>(base + voff) = make_float2(df[2 * k] * scale, df[2 * k + 1] * scale);
   }
 }
+// the lane id recomputed on the spot (v_mbcnt on an opaque zero: three instructions).  Everything derived from threadIdx is
+// loop-invariant, and in a kernel that sits at its register cap the compiler hoists such values out of the persistent loop and
+// then SPILLS them instead of recomputing them; what hangs off this cannot be hoisted.
+__device__ __forceinline__ uint32_t lane_id_here() {
+  uint32_t zero = 0u;
+  asm volatile("" : "+v"(zero));
+  return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, zero));
+}
 __device__ __forceinline__ void load_view_o1(const float* __restrict__ view, int S, int64_t B, int64_t b, int hi,
                                              float (&x)[16]) {
 #pragma unroll
   for (int r = 0; r < 16; ++r) x[r] = 0.0f;
   if (b < B) {                                          // slot (hi, r < 8) = view column 8 hi + r (inmap)
     const float4* v = (const float4*)(view + (b / S) * NOF_VIEW_COLS + 8 * hi);
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+      const float4 t = v[g];
+      x[4 * g] = t.x; x[4 * g + 1] = t.y; x[4 * g + 2] = t.z; x[4 * g + 3] = t.w;
+    }
+  }
+}
+// the same with a uniform base + ONE 32-bit lane offset (see load_sig_tile_o1): the view rows of a batch are far below 4 GiB
+__device__ __forceinline__ void load_view_off_o1(const float* __restrict__ view, int S, int64_t B, int64_t b, int hi,
+                                                 float (&x)[16]) {
+#pragma unroll
+  for (int r = 0; r < 16; ++r) x[r] = 0.0f;
+  if (b < B) {
+    const uint32_t off = (uint32_t)(b / S) * (uint32_t)(NOF_VIEW_COLS * 4) + (lane_id_here() & 32u);      // (+ 32 hi bytes)
+    (void)hi;
+    const float4* v = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(view) + off);
 #pragma unroll
     for (int g = 0; g < 2; ++g) {
       const float4 t = v[g];
@@ -359,6 +383,24 @@ __device__ __forceinline__ void load_sig_o1(const typename P::elem* __restrict__
   for (int r = 0; r < 16; ++r) x[r] = 0.0f;
   if (b < B) {
     const typename P::frag f = *reinterpret_cast<const typename P::frag*>(sig + (b * 2 + hi) * 8);
+#pragma unroll
+    for (int t = 0; t < 8; ++t) x[t] = (float)f[t];
+  }
+}
+// the same for sample j of the (wave-uniform) tile: a uniform tile base + ONE 32-bit lane offset -- the form global_load takes
+// directly (saddr + voffset).  With `sig + (b * 2 + hi) * 8` the compiler keeps a 64-bit per-lane base (sig + 16 hi) alive across
+// the persistent loop: two registers the three-colour-layer backward, which sits at its 256, does not have (it spilled them).
+template <class P>
+__device__ __forceinline__ void load_sig_tile_o1(const typename P::elem* __restrict__ sig, int64_t B, int64_t tile, int j, int hi,
+                                                 float (&x)[16]) {
+#pragma unroll
+  for (int r = 0; r < 16; ++r) x[r] = 0.0f;
+  if (tile * 32 + j < B) {
+    const char* base = reinterpret_cast<const char*>(sig) + tile * (int64_t)(32 * 2 * 8 * sizeof(typename P::elem));
+    const uint32_t l = lane_id_here();                                 // (j = l & 31, hi = l >> 5: recomputed here, see lane_id_here)
+    const uint32_t off = (((l & 31u) << 1) | (l >> 5)) * (uint32_t)(8 * sizeof(typename P::elem));
+    (void)hi;
+    const typename P::frag f = *reinterpret_cast<const typename P::frag*>(base + off);
 #pragma unroll
     for (int t = 0; t < 8; ++t) x[t] = (float)f[t];
   }
@@ -1447,8 +1489,8 @@ __global__ __launch_bounds__(64 * ColorWaves<NC>::value, 2) void k_mlp_bwd_color
     if (!skip) {
     {
       if constexpr (!AHEAD) {
-        load_sig_o1<P>(sig, B, b, hi, cin[0]);
-        load_view_o1(view, S, B, b, hi, cin[1]);
+        load_sig_tile_o1<P>(sig, B, tile, j, hi, cin[0]);
+        load_view_off_o1(view, S, B, b, hi, cin[1]);
       }
       park_o2<P>(st, I, 0, cin[0]);
       park_o2<P>(st, I, 1, cin[1]);
