@@ -210,7 +210,7 @@ def time_extraction(runner, n):
     net) and the device iso-surface extraction (marching cubes), on the field as trained so far; a few hundred more steps first
     if no surface exists yet."""
     import time as _t
-    from bundlesdf_amd.mesh_gpu import marching_cubes_gpu
+    from bundlesdf_amd.mesh_gpu import marching_cubes_lewiner_gpu as marching_cubes_gpu     # (the runner's default extractor: skimage's method)
     fld = runner.field
     bounds = np.array(runner.cfg['bounding_box']).reshape(2, 3)
     axes = [np.linspace(bounds[0, d], bounds[1, d], n + 1)[:-1] + 0.5 * (bounds[1, d] - bounds[0, d]) / n for d in range(3)]

@@ -49,6 +49,13 @@ class NofSampleCfg(C.Structure):
                 ('marcher', C.c_int32)]
 
 
+NOF_MCL_TABLES = 47
+
+
+class NofMclLuts(C.Structure):
+    _fields_ = [('off', C.c_int32 * NOF_MCL_TABLES)]
+
+
 class NofMlpDesc(C.Structure):
     _fields_ = [('n_sigma', C.c_int32), ('n_color', C.c_int32), ('hidden', C.c_int32), ('in_feat', C.c_int32),
                 ('n_view', C.c_int32), ('geo', C.c_int32),
@@ -115,6 +122,9 @@ _SIGNATURES = {
     'nof_mc_count': ([_P, _I32, _I32, _I32, _F, _P, _P, _P], C.c_int),
     'nof_mc_emit': ([_P, _I32, _I32, _I32, _F, _P, _P, _P, _P], C.c_int),
     'nof_mt_vertices': ([_P, _I32, _I32, _I32, _F, _P, _I64, _P, _P], C.c_int),
+    'nof_mcl_count': ([_P, _I32, _I32, _I32, _F, _P, _P, _P, _P], C.c_int),
+    'nof_mcl_emit': ([_P, _I32, _I32, _I32, _F, _P, _P, _P, _P, _P], C.c_int),
+    'nof_mcl_vertices': ([_P, _I32, _I32, _I32, _F, _P, _I64, _P, _P], C.c_int),
     'nof_mask_dilate': ([_P, _I32, _I32, _I32, _P, _P, _P], C.c_int),
     'nof_frame_rays': ([C.POINTER(NofFrameRaysCfg), _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _P, _P, _P], C.c_int),
     'nof_cloud_filter': ([_P, _I64, _P, _P, _P, _I64, C.c_double, C.c_double, _P], C.c_int),

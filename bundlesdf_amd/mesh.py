@@ -71,6 +71,40 @@ _CORNERS = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0], [1, 1, 0], [0, 0, 1], [1, 
 _TETS = np.array([[0, 1, 3, 7], [0, 1, 5, 7], [0, 2, 3, 7], [0, 2, 6, 7], [0, 4, 5, 7], [0, 4, 6, 7]], dtype=np.int64)
 
 
+# Lewiner's lookup tables in the order include/nof_hip.h lists them (NofMclLuts.off[t] = byte offset of table t in the packed buffer)
+LEWINER_TABLE_ORDER = ('CASES', 'TILING1', 'TILING2', 'TILING3_1', 'TILING3_2', 'TILING4_1', 'TILING4_2', 'TILING5', 'TILING6_1_1',
+                       'TILING6_1_2', 'TILING6_2', 'TILING7_1', 'TILING7_2', 'TILING7_3', 'TILING7_4_1', 'TILING7_4_2', 'TILING8', 'TILING9',
+                       'TILING10_1_1', 'TILING10_1_1_', 'TILING10_1_2', 'TILING10_2', 'TILING10_2_', 'TILING11', 'TILING12_1_1',
+                       'TILING12_1_1_', 'TILING12_1_2', 'TILING12_2', 'TILING12_2_', 'TILING13_1', 'TILING13_1_', 'TILING13_2', 'TILING13_2_',
+                       'TILING13_3', 'TILING13_3_', 'TILING13_4', 'TILING13_5_1', 'TILING13_5_2', 'TILING14', 'TEST3', 'TEST4', 'TEST6',
+                       'TEST7', 'TEST10', 'TEST12', 'TEST13', 'SUBCONFIG13')
+
+
+def lewiner_lut_pack():
+    """(packed int8 [n] numpy, offsets int32 [47]) of the lookup tables of Lewiner et al. 2003 for nof_mcl_* -- the tables of the
+    paper's companion code (LookUpTable.h), stored as plain int8 arrays in bundlesdf_amd/lewiner_luts.npz (how they got there:
+    tools/make_lewiner_luts.py).  Shapes are checked against what the device code strides by."""
+    import os
+    L = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'lewiner_luts.npz'))
+    shapes = {'CASES': (256, 2), 'TILING1': (16, 3), 'TILING2': (24, 6), 'TILING3_1': (24, 6), 'TILING3_2': (24, 12), 'TILING4_1': (8, 6),
+              'TILING4_2': (8, 18), 'TILING5': (48, 9), 'TILING6_1_1': (48, 9), 'TILING6_1_2': (48, 27), 'TILING6_2': (48, 15),
+              'TILING7_1': (16, 9), 'TILING7_2': (16, 3, 15), 'TILING7_3': (16, 3, 27), 'TILING7_4_1': (16, 15), 'TILING7_4_2': (16, 27),
+              'TILING8': (6, 6), 'TILING9': (8, 12), 'TILING10_1_1': (6, 12), 'TILING10_1_1_': (6, 12), 'TILING10_1_2': (6, 24),
+              'TILING10_2': (6, 24), 'TILING10_2_': (6, 24), 'TILING11': (12, 12), 'TILING12_1_1': (24, 12), 'TILING12_1_1_': (24, 12),
+              'TILING12_1_2': (24, 24), 'TILING12_2': (24, 24), 'TILING12_2_': (24, 24), 'TILING13_1': (2, 12), 'TILING13_1_': (2, 12),
+              'TILING13_2': (2, 6, 18), 'TILING13_2_': (2, 6, 18), 'TILING13_3': (2, 12, 30), 'TILING13_3_': (2, 12, 30),
+              'TILING13_4': (2, 4, 36), 'TILING13_5_1': (2, 4, 18), 'TILING13_5_2': (2, 4, 30), 'TILING14': (12, 12), 'TEST3': (24,),
+              'TEST4': (8,), 'TEST6': (48, 3), 'TEST7': (16, 5), 'TEST10': (6, 3), 'TEST12': (24, 4), 'TEST13': (2, 7), 'SUBCONFIG13': (64,)}
+    parts, offs, pos = [], [], 0
+    for name in LEWINER_TABLE_ORDER:
+        t = np.ascontiguousarray(L[name]).astype(np.int8)
+        assert t.shape == shapes[name], (name, t.shape)
+        offs.append(pos)
+        parts.append(t.reshape(-1))
+        pos += t.size
+    return np.concatenate(parts), np.array(offs, dtype=np.int32)
+
+
 def marching_tetrahedra(vol, iso=0.0):
     """vol [nx,ny,nz] float -> (vertices [V,3] in index coordinates, faces [T,3] int64).  Raises ValueError when
     the level set is empty (skimage raises too: the caller maps that to `None`, nerf_runner.py:1390-1394)."""

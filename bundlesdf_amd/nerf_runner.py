@@ -25,7 +25,7 @@ import torch
 from . import lib
 from .checkpoint import load_reference_checkpoint, to_reference_checkpoint
 from .field import GraphedStep, NeuralObjectField
-from .mesh_gpu import marching_cubes_gpu, marching_tetrahedra_gpu
+from .mesh_gpu import marching_cubes_gpu, marching_cubes_lewiner_gpu, marching_tetrahedra_gpu
 from .mesh import make_mesh, marching_tetrahedra
 from .nerf_helpers import *          # noqa: F401,F403  (re-exported on purpose, like the reference module does)
 from .nerf_helpers import set_seed, get_optimized_poses_in_real_world, mesh_to_real_world, glcam_in_cvcam
@@ -368,9 +368,14 @@ class NerfRunner:
         logging.info(f'query grid:{tuple(sigma_dev.shape)}, valid:{int((sigma_dev != 1.0).sum().item())}')
         logging.info('Running iso-surface extraction')
         try:
-            # marching cubes like the reference's skimage call (:1388-1394); cfg mesh_extractor: 'tetrahedra' selects the
-            # marching-tetrahedra kernels instead (no ambiguous cases, ~4x the triangles)
-            extract = marching_tetrahedra_gpu if self.cfg.get('mesh_extractor', 'cubes') == 'tetrahedra' else marching_cubes_gpu
+            # the reference's skimage call (:1388-1394) with skimage's default method: marching cubes with Lewiner's topological
+            # disambiguation -- skimage's triangles, one for one.  cfg mesh_extractor: 'cubes' = classic marching cubes (same
+            # vertices on the grid edges, one fixed tiling per sign configuration), 'tetrahedra' = marching tetrahedra (~4x the
+            # triangles)
+            kind = self.cfg.get('mesh_extractor', 'lewiner')
+            if kind not in ('lewiner', 'cubes', 'tetrahedra'):
+                raise ValueError(f"mesh_extractor must be 'lewiner', 'cubes' or 'tetrahedra', not {kind!r}")
+            extract = {'lewiner': marching_cubes_lewiner_gpu, 'cubes': marching_cubes_gpu, 'tetrahedra': marching_tetrahedra_gpu}[kind]
             vertices, triangles = extract(sigma_dev, isolevel)
         except Exception as e:
             logging.info(f"ERROR Marching Cubes {e}")

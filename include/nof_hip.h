@@ -338,6 +338,26 @@ int nof_mc_count(const float* vol, int32_t nx, int32_t ny, int32_t nz, float iso
 int nof_mc_emit(const float* vol, int32_t nx, int32_t ny, int32_t nz, float iso, const int8_t* case_table,
                 const int64_t* offsets, int64_t* keys, void* stream);
 
+/* Marching cubes with Lewiner's topological disambiguation = skimage.measure.marching_cubes(volume, level) with its default
+ * method='lewiner', the call the reference makes (nerf_runner.py:1388-1394): per cell the tiling of one of the 33 topological cases,
+ * chosen by the paper's face tests and interior test (Lewiner, Lopes, Vieira, Tavares, JGT 8(2) 2003).  Same scheme as nof_mc_*:
+ * counts -> (host: exclusive scan) -> keys -> (host: sort / unique) -> vertices.  `luts` = the paper's lookup tables as ONE packed int8
+ * buffer on the device, `offs->off[t]` = byte offset of table t in it, tables in the order
+ *   CASES, TILING1, 2, 3_1, 3_2, 4_1, 4_2, 5, 6_1_1, 6_1_2, 6_2, 7_1, 7_2, 7_3, 7_4_1, 7_4_2, 8, 9, 10_1_1, 10_1_1_, 10_1_2, 10_2, 10_2_,
+ *   11, 12_1_1, 12_1_1_, 12_1_2, 12_2, 12_2_, 13_1, 13_1_, 13_2, 13_2_, 13_3, 13_3_, 13_4, 13_5_1, 13_5_2, 14, TEST3, 4, 6, 7, 10, 12,
+ *   13, SUBCONFIG13                                                       (bundlesdf_amd/mesh.py:lewiner_lut_pack builds both).
+ * A key >= 0 is an edge key as above; a key < 0 is the CENTRE vertex of cell -(key + 1) (tilings 6.1.2, 7.3, 10.2, 12.2, 13.3,
+ * 13.4), which nof_mcl_vertices places like scikit-image does (the cell's corners weighted by 1 / (eps + |value - iso|)).  Triangles
+ * are wound like scikit-image's default (gradient_direction='descent').  Vertices on grid edges: float64 linear interpolation. */
+#define NOF_MCL_TABLES 47
+typedef struct { int32_t off[NOF_MCL_TABLES]; } NofMclLuts;
+int nof_mcl_count(const float* vol, int32_t nx, int32_t ny, int32_t nz, float iso, const int8_t* luts, const NofMclLuts* offs,
+                  int32_t* counts, void* stream);
+int nof_mcl_emit(const float* vol, int32_t nx, int32_t ny, int32_t nz, float iso, const int8_t* luts, const NofMclLuts* offs,
+                 const int64_t* offsets, int64_t* keys, void* stream);
+int nof_mcl_vertices(const float* vol, int32_t nx, int32_t ny, int32_t nz, float iso, const int64_t* keys, int64_t V,
+                     double* verts, void* stream);
+
 /* ---- texture bake helper (replaces common.rayColorToTextureImageCUDA, mycuda/common.h:30, common.cu:171-238) ----------
  * faces [nf,3] int64, verts [nv,3] f32, hit_locations [n,3] f32 (points on the mesh), hit_face_ids [n] int64,
  * uvs_tex [nv,2] f32 per-vertex texture coordinates -> uvs [n,2]: barycentric blend of the hit triangle's uvs. */

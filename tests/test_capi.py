@@ -72,7 +72,7 @@ def test_product_library_keeps_no_mode_switch():
     import subprocess
     from bundlesdf_amd import build
     out = subprocess.run(['nm', '-C', build.build(verbose=False)], capture_output=True, text=True, check=True).stdout
-    allowed = re.compile(r'^(g_nof_err|nof_cu_count\(\)::cus|g_bwd_blocks|kMcEdge|kTets|_DYNAMIC|_GLOBAL_OFFSET_TABLE_|__dso_handle|__init|__fini|'
+    allowed = re.compile(r'^(g_nof_err|nof_cu_count\(\)::cus|g_bwd_blocks|kMcEdge|kTets|kMcl\w+|_DYNAMIC|_GLOBAL_OFFSET_TABLE_|__dso_handle|__init|__fini|'
                          r'__do_init\..*|__do_fini\..*|__hip_\w+|completed\.\d+|__TMC_END__|.*k_\w+(<.*>)?(\(.*\))?)$')
     for ln in out.splitlines():
         m = re.match(r'^[0-9a-f]* ([bBdD]) (.*)$', ln)
@@ -228,7 +228,8 @@ def test_hot_kernels_have_no_scratch():
     wide-network step launches may.  Known exceptions, listed so that a new one is noticed: the one-kernel MLP backward
     (`k_mlp_bwd`: fp32 mode and the entry point without a split workspace; 512 registers + AGPRs by design), the bf16 colour
     backward at hidden 128 (2 registers = 12 bytes; the fp16 variant, cfg5's, is clean), and the mesh extractors' emit kernels
-    (renderer side: the case table indexes the cell's corner values at run time).  The colour backward with THREE colour layers --
+    (renderer side: the case table indexes the cell's corner values at run time; likewise the Lewiner extractor's count / emit
+    kernels, whose face and interior tests pick corners by table entries).  The colour backward with THREE colour layers --
     the reference's own shape, nerf_runner.py:221 -- was an exception until round 4 (148 B): its first layer's weight gradient is
     accumulated transposed (32 instead of 64 registers).  Round 5: the library is built without clang's SLP vectoriser (a
     correctness matter on gfx950: test_no_packed_fp32_instruction_reads_source_1_through_op_sel), which had packed a few of that
@@ -237,7 +238,7 @@ def test_hot_kernels_have_no_scratch():
     from a lane id that is re-derived on the spot (lane_id_here): nothing to hoist, nothing spilled -- guarded like every other
     shape again.  The eikonal kernel's two spilled registers (three sigma layers) go to AGPRs: no private memory."""
     import re
-    allowed = (r'^k_mlp_bwd<', r'^k_wide_bwd_color<PrecBF16, 4>', r'^k_m[ct]_emit$')
+    allowed = (r'^k_mlp_bwd<', r'^k_wide_bwd_color<PrecBF16, 4>', r'^k_m[ct]_emit$', r'^k_mcl_(count|emit)$')
     bad = []
     seen = set()
     for name, md in _kernel_metadata():

@@ -221,3 +221,73 @@ def test_wide_network_grid_query_matches_oracle(nof):
         assert (got[~m] == 1.0).all()
         err = np.abs(got[m] - ref_all[m]).max() / np.abs(ref_all[m]).max()
         assert err < 2e-3, err                                         # plain fp16 wide forward vs the oracle with fp16 operand rounding
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# The runner's default extractor: marching cubes with Lewiner's disambiguation on the device (nof_mcl_*) = the reference's
+# skimage.measure.marching_cubes call.  Against scikit-image 0.18.3's own outputs (tests/golden/mc_skimage_vectors.npz) and against
+# the oracle's restatement on volumes the fixture does not hold.
+# ----------------------------------------------------------------------------------------------------------------------
+def test_lewiner_gpu_equals_skimage_on_volumes(nof):
+    from bundlesdf_amd.mesh_gpu import marching_cubes_lewiner_gpu
+    from tests.test_mesh import _mc_golden, same_mesh
+    G = _mc_golden()
+    for name in ('sphere', 'blobs', 'smooth_noise', 'rough_noise', 'sdf_noisy', 'slab'):
+        v, f = marching_cubes_lewiner_gpu(torch.from_numpy(G['vol_' + name]).cuda(), 0.0)
+        ok, why = same_mesh(v, f, G[f'lewiner_{name}_v'], G[f'lewiner_{name}_f'])
+        assert ok, (name, why)
+
+
+def test_lewiner_gpu_equals_skimage_on_single_cells(nof):
+    """every corner-sign configuration x 24 magnitude sets, and 4000 cells of the ambiguous configurations incl. every rare tiling the
+    fixture holds, each as its own 2x2x2 volume"""
+    from bundlesdf_amd.mesh_gpu import marching_cubes_lewiner_gpu
+    from oracle import marching_cubes_lewiner as ML
+    from tests.test_mesh import _mc_golden, same_mesh, _canon_tris
+    G = _mc_golden()
+    vals, gv, gnv, gf, gnf = G['cell_values'], G['cell_verts'], G['cell_nverts'], G['cell_faces'], G['cell_nfaces']
+    for i in range(len(vals)):
+        v, f = marching_cubes_lewiner_gpu(torch.from_numpy(vals[i].reshape(2, 2, 2).copy()).cuda(), 0.0)
+        ok, why = same_mesh(v, f, gv[i][:gnv[i]], gf[i][:gnf[i]], tol=2e-5)
+        assert ok, (i, why)
+    V, T, N = G['amb_values'], G['amb_tris'], G['amb_ntris']
+    pick = np.unique(np.concatenate([np.arange(0, len(V), 11), np.arange(len(V) - 64, len(V))]))       # (the rare tilings are at the end)
+    EDGE_MID = np.array([(ML.CORNER[a] + ML.CORNER[b]) / 2.0 for a, b in ML.EDGE])
+    for i in pick:
+        vol = V[i].reshape(2, 2, 2).copy()
+        v, f = marching_cubes_lewiner_gpu(torch.from_numpy(vol).cuda(), 0.0)
+        # a vertex -> the cube edge it lies on (two integral coordinates), 12 = the centre vertex
+        eid = []
+        for p in v:
+            integral = np.abs(p - np.round(p)) < 1e-9
+            if integral.sum() < 2:
+                eid.append(12)
+            else:
+                d = np.abs(EDGE_MID - np.where(integral, np.round(p), 0.5)).sum(1)
+                eid.append(int(np.argmin(d)))
+        assert _canon_tris(np.array(eid)[f]) == _canon_tris(T[i][:N[i]]), i
+
+
+@pytest.mark.parametrize("shape_", [(33, 29, 31), (64, 64, 64)])
+def test_lewiner_gpu_equals_the_oracle_on_rough_volumes(nof, shape_):
+    """random fields with many ambiguous cells (volumes the fixture does not hold): device == oracle, vertex for vertex and triangle
+    for triangle, incl. the centre vertices; iso value 0 and a non-zero iso value"""
+    from scipy.ndimage import gaussian_filter
+    from bundlesdf_amd.mesh_gpu import marching_cubes_lewiner_gpu
+    from oracle import marching_cubes_lewiner as ML
+    from tests.test_mesh import same_mesh
+    rng = np.random.default_rng(shape_[0])
+    vol = gaussian_filter(rng.normal(size=shape_), 0.7).astype(np.float32)
+    for iso in (0.0, 0.05):
+        v, f = marching_cubes_lewiner_gpu(torch.from_numpy(vol).cuda(), iso)
+        vr, fr = ML.marching_cubes(vol, iso)
+        ok, why = same_mesh(v, f, vr, fr, tol=1e-9 if iso == 0.0 else 1e-6)
+        assert ok, (shape_, iso, why)
+        assert (np.abs(v - np.round(v)) > 1e-9).all(1).sum() > 10                                   # centre vertices are present
+
+
+def test_extract_mesh_uses_the_lewiner_extractor_by_default(nof):
+    from bundlesdf_amd import nerf_runner
+    import inspect
+    src = inspect.getsource(nerf_runner.NerfRunner.extract_mesh)
+    assert "self.cfg.get('mesh_extractor', 'lewiner')" in src

@@ -297,3 +297,94 @@ def test_vertex_set_is_the_set_of_sign_changing_grid_edges(seed, noise):
     edges = _crossed_edges(vol)
     assert len(v) == len(edges) and _vertex_edges(v, vol.shape) == edges
     assert set(np.unique(f).tolist()) == set(range(len(v)))                          # every vertex is used by a triangle
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# Marching cubes as the reference calls it: skimage.measure.marching_cubes(volume, level), default method 'lewiner'
+# (nerf_runner.py:1388-1394).  The oracle's restatement (oracle/marching_cubes_lewiner.py) against scikit-image 0.18.3's OWN outputs
+# (tests/golden/mc_skimage_vectors.npz, generated by tests/golden/make_mc_golden.py with the build container's Anaconda interpreter).
+# ----------------------------------------------------------------------------------------------------------------------
+def _mc_golden():
+    import os
+    return np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'mc_skimage_vectors.npz'))
+
+
+def _canon_tris(tris):
+    """triangles as sorted tuples, each rotated to start at its smallest vertex (orientation kept)"""
+    out = []
+    for t in tris:
+        a = [int(x) for x in t]
+        i = a.index(min(a))
+        out.append((a[i], a[(i + 1) % 3], a[(i + 2) % 3]))
+    return sorted(out)
+
+
+def same_mesh(v1, f1, v2, f2, tol=1e-4):
+    """the same vertices (matched by position within tol voxel) and the same oriented triangles, one for one"""
+    from scipy.spatial import cKDTree
+    if len(v1) != len(v2) or len(f1) != len(f2):
+        return False, ('counts', len(v1), len(v2), len(f1), len(f2))
+    d, m = cKDTree(np.asarray(v2, np.float64)).query(np.asarray(v1, np.float64))
+    if d.max() > tol or len(set(m.tolist())) != len(m):
+        return False, ('positions', float(d.max()))
+    a, b = _canon_tris(m[np.asarray(f1)]), _canon_tris(f2)
+    return a == b, ('triangles', len(set(a) ^ set(b)))
+
+
+def test_lewiner_oracle_equals_skimage_on_every_sign_configuration():
+    """254 corner-sign configurations x 24 magnitude sets as single cells: the same vertices (incl. the centre vertex of the 'c'
+    tilings) and the same oriented triangles as scikit-image returned."""
+    from oracle import marching_cubes_lewiner as ML
+    G = _mc_golden()
+    vals, gv, gnv, gf, gnf = G['cell_values'], G['cell_verts'], G['cell_nverts'], G['cell_faces'], G['cell_nfaces']
+    assert len(vals) == 254 * 24 and str(G['skimage_version']).startswith('0.')
+    for i in range(len(vals)):
+        v, f = ML.marching_cubes(vals[i].reshape(2, 2, 2), 0.0)
+        ok, why = same_mesh(v, f, gv[i][:gnv[i]], gf[i][:gnf[i]], tol=2e-5)
+        assert ok, (i, why)
+
+
+def test_lewiner_oracle_equals_skimage_on_the_ambiguous_configurations():
+    """43 000 cells of the configurations whose tiling depends on the magnitudes (Lewiner's cases 3, 4, 6, 7, 10, 12, 13; 4000 each
+    for the two 'case 13' configurations) + cells found by rejection sampling for the tilings random magnitudes do not reach (6.1.2,
+    7.4.2): the triangles, as cube-edge ids, equal scikit-image's.  Every tiling family the fixture reaches is listed."""
+    from oracle import marching_cubes_lewiner as ML
+    G = _mc_golden()
+    V, T, N = G['amb_values'], G['amb_tris'], G['amb_ntris']
+    seen = set()
+    for i in range(len(V)):
+        vol = V[i].reshape(2, 2, 2)
+        c = np.array([float(vol[tuple(ML.CORNER[p])]) for p in range(8)])
+        row, nt = ML.cell_tiling(c)
+        ours = _canon_tris([row[3 * t:3 * t + 3][::-1] for t in range(nt)])              # ('descent': flipped winding)
+        assert ours == _canon_tris(T[i][:N[i]]), i
+        idx = sum((1 << p) for p in range(8) if c[p] > 0)
+        seen.add((int(ML._L['CASES'][idx][0]), nt, bool(12 in row[:3 * nt])))
+    assert len(V) > 43000
+    assert {(3, 2, False), (3, 4, False), (6, 3, False), (6, 5, False), (7, 3, False), (7, 5, False), (7, 9, True),
+            (10, 4, False), (10, 8, False), (10, 8, True), (12, 4, False), (12, 8, True), (13, 4, False), (13, 6, False),
+            (13, 10, True), (13, 12, True)} <= seen, seen
+
+
+@pytest.mark.parametrize("name", ['sphere', 'blobs', 'smooth_noise', 'rough_noise', 'sdf_noisy', 'slab'])
+def test_lewiner_oracle_equals_skimage_on_volumes(name):
+    """whole volumes (vertices welded per grid edge): vertex for vertex, triangle for triangle scikit-image's mesh"""
+    from oracle import marching_cubes_lewiner as ML
+    G = _mc_golden()
+    v, f = ML.marching_cubes(G['vol_' + name], 0.0)
+    ok, why = same_mesh(v, f, G[f'lewiner_{name}_v'], G[f'lewiner_{name}_f'])
+    assert ok, why
+
+
+def test_lewiner_tables_of_product_and_oracle_are_the_same_bytes():
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    a, b = np.load(os.path.join(root, 'oracle', 'lewiner_luts.npz')), np.load(os.path.join(root, 'bundlesdf_amd', 'lewiner_luts.npz'))
+    assert sorted(a.files) == sorted(b.files) and len(a.files) == 47
+    for k in a.files:
+        assert a[k].dtype == np.int8 and np.array_equal(a[k], b[k]), k
+    from bundlesdf_amd.mesh import lewiner_lut_pack, LEWINER_TABLE_ORDER
+    packed, offs = lewiner_lut_pack()
+    assert len(offs) == 47 == len(LEWINER_TABLE_ORDER) and packed.dtype == np.int8 and offs[0] == 0
+    for t, name in enumerate(LEWINER_TABLE_ORDER):
+        assert np.array_equal(packed[offs[t]:offs[t] + a[name].size], a[name].reshape(-1)), name
