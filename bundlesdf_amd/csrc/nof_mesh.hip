@@ -332,8 +332,8 @@ __device__ __forceinline__ bool mcl_test_interior(const MclCell& m, int s, int c
   const int test = (At >= 0.0 ? 1 : 0) + (Bt >= 0.0 ? 2 : 0) + (Ct >= 0.0 ? 4 : 0) + (Dt >= 0.0 ? 8 : 0);
   switch (test) {
     case 7: case 11: case 13: case 14: case 15: return s < 0;
-    case 5: return At * Ct - Bt * Dt < MCL_EPS && s > 0;               // (scikit-image's answer where the determinant test fails:
-    case 10: return At * Ct - Bt * Dt >= MCL_EPS && s > 0;             //  false whatever the sign of s -- see the oracle)
+    case 5: return At * Ct - Bt * Dt < 0.0 && s > 0;                   // (scikit-image's form of the paper's determinant test: against
+    case 10: return At * Ct - Bt * Dt >= 0.0 && s > 0;                 //  zero, and false whatever the sign of s -- see the oracle)
     default: return s > 0;
   }
 }

@@ -22,7 +22,11 @@ Pinning status (see DESIGN.md "Oracle"):
     (oracle/ref_build.py -> oracle/_ref/libnof_ref.so, tests/test_ref_native.py), and the
     committed train_loop fixture was generated with those compiled kernels under the
     reference's own grid.py / OctreeManager.ray_trace.
+  * skimage.measure.marching_cubes (default method 'lewiner'; nerf_runner.py:1388-1394) is third-party code absent
+    from the reference tree but importable by the build container's Anaconda interpreter (scikit-image 0.18.3):
+    oracle/marching_cubes_lewiner.py restates Lewiner et al. 2003 and is PINNED on scikit-image's own outputs
+    (tests/golden/make_mc_golden.py -> tests/golden/mc_skimage_vectors.npz, tests/test_mesh.py).
   * kaolin's octree ray tracer (unbatched_raytrace) and pytorch3d's se3_exp_map are
-    third-party code absent from the reference tree: for those two the oracle is a
+    third-party code absent from the reference tree AND from this container: for those two the oracle is a
     restatement of the published algorithm and parity is UNPINNED.
 """

@@ -1,15 +1,17 @@
 """Classic marching cubes (vertices on grid edges by linear interpolation, one or more polygons per sign configuration) as a
 NumPy restatement -- TEST INFRASTRUCTURE (see oracle/__init__.py).
 
-The reference extracts its mesh with skimage.measure.marching_cubes(sigma, isolevel) on the host (nerf_runner.py:1388-1394);
-scikit-image is a third-party dependency absent from this image and from /root/reference (docker/dockerfile:99, unpinned), so its
-result cannot be reproduced here.  What marching cubes IS, though, is fully defined by its construction, which this file
-restates without a hand-typed case table: for every one of the 256 corner-sign configurations the iso-polygons are DERIVED --
+The reference extracts its mesh with skimage.measure.marching_cubes(sigma, isolevel) on the host (nerf_runner.py:1388-1394), whose
+default method is Lewiner's variant: THAT is restated in oracle/marching_cubes_lewiner.py and pinned on scikit-image's own outputs.
+This file is the CLASSIC algorithm (one fixed tiling per corner-sign configuration; scikit-image's method='lorensen' family), kept as
+the yardstick of the product's classic extractor (cfg mesh_extractor: 'cubes').  It is fully defined by its construction, which this
+file restates without a hand-typed case table: for every one of the 256 corner-sign configurations the iso-polygons are DERIVED --
 on each cube face the crossed edges are joined by segments (two crossed edges: one segment; four, the ambiguous face: two
 segments that cut off the inside corners, a rule that depends on that face's corner signs only and is therefore applied
 identically by the two cubes sharing the face, which is what makes the surface watertight), the segments are chained into
-closed loops, every loop is fan-triangulated.  skimage's 'lewiner' variant resolves ambiguous configurations with extra
-interior tests; like every marching-cubes variant it puts its vertices on the same grid-edge crossings.
+closed loops, every loop is fan-triangulated.  Against scikit-image 0.18.3 (tests/golden/mc_skimage_vectors.npz): the same
+vertices as its classic method on every volume of the fixture, the same polygons with other diagonals (54 % of the triangles
+identical); Lewiner's variant differs from both in the ambiguous cells (other tilings, extra centre vertices).
 
 It is the yardstick of the product's marching-cubes extractor (nof_mc_*, bundlesdf_amd/mesh_gpu.py: the same vertices and the
 same triangles, tests/test_gpu_mesh.py; the product derives its own case table by a different construction -- directed face

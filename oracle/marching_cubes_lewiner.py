@@ -68,12 +68,12 @@ def _test_interior(c, s, case, config, subconfig):
         return s > 0
     if test in (7, 11, 13, 14, 15):
         return s < 0
-    # (the companion code falls through to `return s < 0` when the determinant test of 5 / 10 fails; scikit-image 0.18.3 answers
-    # False there whatever the sign of s -- established on its outputs, tests/golden/mc_skimage_vectors.npz -- and scikit-image is
-    # what the reference calls)
+    # (the companion code compares the determinant with FLT_EPSILON and falls through to `return s < 0` when that test fails;
+    # scikit-image 0.18.3 compares with ZERO and answers False there whatever the sign of s -- both established on its outputs for
+    # cells of ordinary and of tiny magnitudes, tests/golden/mc_skimage_vectors.npz -- and scikit-image is what the reference calls)
     if test == 5:
-        return At * Ct - Bt * Dt < FLT_EPSILON and s > 0
-    return At * Ct - Bt * Dt >= FLT_EPSILON and s > 0                   # test == 10
+        return At * Ct - Bt * Dt < 0 and s > 0
+    return At * Ct - Bt * Dt >= 0 and s > 0                             # test == 10
 
 
 def cell_tiling(c):

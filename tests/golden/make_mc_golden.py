@@ -39,7 +39,7 @@ for case in range(1, 255):
 out = dict(cell_values=np.array(cells), cell_verts=np.array(cverts), cell_nverts=np.array(cnv, np.int32), cell_faces=np.array(cfaces),
            cell_nfaces=np.array(cnf, np.int32), skimage_version=np.array(skimage.__version__))
 
-# (1b) many more magnitude sets for the AMBIGUOUS configurations (Lewiner's cases 3, 4, 6, 7, 10, 12, 13: which tiling a cell gets
+# (1b) many more magnitude sets for the configurations whose tiling depends on the magnitudes (Lewiner's cases 3, 4, 6, 7, 10, 12, 13: which tiling a cell gets
 # depends on its face tests and interior test), stored compactly: a triangle = three cube-edge ids (0..11; 12 = the centre vertex of
 # the 'c' tilings), read off the returned vertex positions -- a vertex on a cube edge has two integral coordinates.
 CORNER = np.array([(0, 0, 0), (0, 0, 1), (0, 1, 1), (0, 1, 0), (1, 0, 0), (1, 0, 1), (1, 1, 1), (1, 1, 0)])
@@ -58,10 +58,14 @@ def edge_of(p):
 
 
 def n_components(case):
-    """ambiguous <=> some face of the cube has its two positive corners on a diagonal"""
+    """the tiling depends on the magnitudes <=> some face of the cube has its two positive corners on a diagonal (Lewiner's cases
+    3, 6, 7, 10, 12, 13), or the two minority corners are opposite ends of a body diagonal (case 4: interior test only)"""
     pos = [(case >> q) & 1 for q in range(8)]
     faces = [(0, 1, 2, 3), (4, 5, 6, 7), (0, 1, 5, 4), (1, 2, 6, 5), (2, 3, 7, 6), (3, 0, 4, 7)]
-    return any(pos[f[0]] == pos[f[2]] and pos[f[1]] == pos[f[3]] and pos[f[0]] != pos[f[1]] for f in faces)
+    if any(pos[f[0]] == pos[f[2]] and pos[f[1]] == pos[f[3]] and pos[f[0]] != pos[f[1]] for f in faces):
+        return True
+    minority = [q for q in range(8) if pos[q] == (1 if sum(pos) <= 4 else 0)]
+    return len(minority) == 2 and int(np.abs(CORNER[minority[0]] - CORNER[minority[1]]).sum()) == 3
 
 
 xv, xt, xn = [], [], []
@@ -81,46 +85,26 @@ for case in range(1, 255):
         tri = np.full((12, 3), -1, np.int8)
         tri[:len(f)] = eid[f]
         xv.append(vol.reshape(8)); xt.append(tri); xn.append(len(f))
-# (1c) tilings random magnitudes (almost) never reach -- 6.1.2 and 7.4.2, whose interior test must FAIL -- found by rejection sampling
-# with this repository's restatement as the classifier (it only SELECTS inputs; what is stored is scikit-image's output for them).
-# 12.1.2 and 13.5.2 were not reached by 700 000 such cells each and are not in the fixture.
-import importlib.util                                                # noqa: E402
-spec = importlib.util.spec_from_file_location('mcl', os.path.join(HERE, '..', '..', 'oracle', 'marching_cubes_lewiner.py'))
-mcl = importlib.util.module_from_spec(spec)
-spec.loader.exec_module(mcl)
-cases_of = {}
-for idx in range(1, 255):
-    cases_of.setdefault(int(mcl._L['CASES'][idx][0]), []).append(idx)
-n_rare = 0
-for cs, want in ((6, (9, True)), (7, (9, False))):
-    found, it = 0, 0
-    while found < 16 and it < 400000:
-        idx = cases_of[cs][it % len(cases_of[cs])]
-        it += 1
-        mode = it % 3
-        if mode == 0:
-            mag = np.exp(rng.uniform(np.log(1e-3), 0, size=8))
-        elif mode == 1:
-            mag = rng.choice([1e-3, 1e-2, 0.1, 1.0], size=8) * np.exp(rng.normal(0, 0.3, size=8))
-        else:
-            mag = np.abs(rng.standard_cauchy(size=8)) * 0.05 + 1e-4
-        c = np.clip(np.array([(1.0 if (idx >> q) & 1 else -1.0) * mag[q] for q in range(8)]), -1, 1).astype(np.float32)
-        row, nt = mcl.cell_tiling(c.astype(np.float64))
-        if (nt, bool(12 in row[:3 * nt])) != want:
-            continue
+# (1c) the same configurations with TINY magnitudes (3e-4 ... 3e-3): the face tests' determinants A C - B D are then 1e-8 ... 1e-5,
+# on both sides of FLT_EPSILON -- where the paper's companion code has a special branch (`return face >= 0`) and scikit-image has none.
+n_tiny = 0
+for case in range(1, 255):
+    if not n_components(case):
+        continue
+    pos = [(case >> q) & 1 for q in range(8)]
+    for k in range(40):
+        mag = np.exp(rng.uniform(np.log(3e-4), np.log(3e-3), size=8))
         vol = np.zeros((2, 2, 2), np.float32)
         for q in range(8):
-            vol[tuple(CORNER[q])] = c[q]
+            vol[tuple(CORNER[q])] = (1.0 if pos[q] else -1.0) * mag[q]
         v, f, _, _ = measure.marching_cubes(vol, 0.0)
         eid = np.array([edge_of(p) for p in v.astype(np.float64)], np.int8)
         tri = np.full((12, 3), -1, np.int8)
         tri[:len(f)] = eid[f]
         xv.append(vol.reshape(8)); xt.append(tri); xn.append(len(f))
-        found += 1
-    n_rare += found
-    print('case', cs, want, ':', found, 'cells after', it, 'tries')
+        n_tiny += 1
 out.update(amb_values=np.array(xv), amb_tris=np.array(xt), amb_ntris=np.array(xn, np.int8))
-print('ambiguous-configuration cells', len(xv), 'of which rare tilings', n_rare)
+print('ambiguous-configuration cells', len(xv), 'of which with tiny magnitudes', n_tiny)
 n = 20
 x, y, z = np.mgrid[-1:1:n * 1j, -1:1:n * 1j, -1:1:n * 1j]
 vols = {

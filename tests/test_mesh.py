@@ -345,9 +345,11 @@ def test_lewiner_oracle_equals_skimage_on_every_sign_configuration():
 
 
 def test_lewiner_oracle_equals_skimage_on_the_ambiguous_configurations():
-    """43 000 cells of the configurations whose tiling depends on the magnitudes (Lewiner's cases 3, 4, 6, 7, 10, 12, 13; 4000 each
-    for the two 'case 13' configurations) + cells found by rejection sampling for the tilings random magnitudes do not reach (6.1.2,
-    7.4.2): the triangles, as cube-edge ids, equal scikit-image's.  Every tiling family the fixture reaches is listed."""
+    """50 000 cells of the configurations whose tiling depends on the magnitudes (Lewiner's cases 3, 4, 6, 7, 10, 12, 13; 4000 each
+    for the two 'case 13' configurations), 5000 of them with TINY magnitudes (determinants of the face and interior tests on both sides
+    of FLT_EPSILON: where scikit-image departs from the paper's companion code): the triangles, as cube-edge ids, equal scikit-image's.
+    Every tiling family the fixture reaches is listed; 6.1.2, 7.4.2, 12.1.2 and 13.5.2 are not among them -- with a reference edge the
+    interior test has At = 0 and cannot fail for these cases (2.3 million random cells: none)."""
     from oracle import marching_cubes_lewiner as ML
     G = _mc_golden()
     V, T, N = G['amb_values'], G['amb_tris'], G['amb_ntris']
@@ -360,8 +362,8 @@ def test_lewiner_oracle_equals_skimage_on_the_ambiguous_configurations():
         assert ours == _canon_tris(T[i][:N[i]]), i
         idx = sum((1 << p) for p in range(8) if c[p] > 0)
         seen.add((int(ML._L['CASES'][idx][0]), nt, bool(12 in row[:3 * nt])))
-    assert len(V) > 43000
-    assert {(3, 2, False), (3, 4, False), (6, 3, False), (6, 5, False), (7, 3, False), (7, 5, False), (7, 9, True),
+    assert len(V) > 50000
+    assert {(4, 2, False), (4, 6, False), (3, 2, False), (3, 4, False), (6, 3, False), (6, 5, False), (7, 3, False), (7, 5, False), (7, 9, True),
             (10, 4, False), (10, 8, False), (10, 8, True), (12, 4, False), (12, 8, True), (13, 4, False), (13, 6, False),
             (13, 10, True), (13, 12, True)} <= seen, seen
 
