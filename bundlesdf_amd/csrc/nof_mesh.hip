@@ -467,8 +467,15 @@ __global__ __launch_bounds__(256) void k_mcl_vertices(const float* __restrict__ 
   const int64_t npts = (int64_t)nx * ny * nz;
   double v[3];
   if (keys[i] >= 0) {
+    // scikit-image's edge vertex: the two grid points weighted by 1 / (eps + |value - iso|) -- linear interpolation up to eps
+    // (the two part by 1e-5 ... 1e-4 voxel where a corner value is within 1e-3 of the iso value; this extractor IS skimage's)
     const int64_t a = keys[i] / npts, b = keys[i] % npts;
-    mt_edge_vertex(a, b, vol[a], vol[b], (double)iso, ny, nz, v);
+    const double wa = 1.0 / (MCL_EPS + fabs((double)vol[a] - (double)iso)), wb = 1.0 / (MCL_EPS + fabs((double)vol[b] - (double)iso));
+    double pa[3], pb[3];
+    mt_point(a, ny, nz, pa);
+    mt_point(b, ny, nz, pb);
+#pragma unroll
+    for (int d = 0; d < 3; ++d) v[d] = pa[d] + (pb[d] - pa[d]) * (wb / (wa + wb));
   } else {
     // scikit-image's centre vertex: the cell's corners weighted by 1 / (eps + |value - iso|)
     const int64_t cell = -(keys[i] + 1);

@@ -347,8 +347,9 @@ int nof_mc_emit(const float* vol, int32_t nx, int32_t ny, int32_t nz, float iso,
  *   11, 12_1_1, 12_1_1_, 12_1_2, 12_2, 12_2_, 13_1, 13_1_, 13_2, 13_2_, 13_3, 13_3_, 13_4, 13_5_1, 13_5_2, 14, TEST3, 4, 6, 7, 10, 12,
  *   13, SUBCONFIG13                                                       (bundlesdf_amd/mesh.py:lewiner_lut_pack builds both).
  * A key >= 0 is an edge key as above; a key < 0 is the CENTRE vertex of cell -(key + 1) (tilings 6.1.2, 7.3, 10.2, 12.2, 13.3,
- * 13.4), which nof_mcl_vertices places like scikit-image does (the cell's corners weighted by 1 / (eps + |value - iso|)).  Triangles
- * are wound like scikit-image's default (gradient_direction='descent').  Vertices on grid edges: float64 linear interpolation. */
+ * 13.4), which nof_mcl_vertices places like scikit-image does (the cell's corners weighted by 1 / (eps + |value - iso|)); the vertices on
+ * grid edges likewise (the edge's two points with those weights: linear interpolation up to eps), in float64.  Triangles are wound like
+ * scikit-image's default (gradient_direction='descent'). */
 #define NOF_MCL_TABLES 47
 typedef struct { int32_t off[NOF_MCL_TABLES]; } NofMclLuts;
 int nof_mcl_count(const float* vol, int32_t nx, int32_t ny, int32_t nz, float iso, const int8_t* luts, const NofMclLuts* offs,

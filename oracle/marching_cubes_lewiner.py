@@ -160,7 +160,9 @@ def _edge_point(c, e):
     """scikit-image's vertex on cube edge e: the two end points weighted by 1 / (eps + |value|) (= linear interpolation up to eps)"""
     p, q = EDGE[e]
     w1, w2 = 1.0 / (FLT_EPSILON + abs(c[p])), 1.0 / (FLT_EPSILON + abs(c[q]))
-    return (CORNER[p] * w1 + CORNER[q] * w2) / (w1 + w2)
+    if tuple(CORNER[p]) > tuple(CORNER[q]):                            # (from the end point with the smaller grid index: an edge shared by
+        p, q, w1, w2 = q, p, w2, w1                                    #  four cells gets the same float64 position from each of them)
+    return CORNER[p] + (CORNER[q] - CORNER[p]) * (w2 / (w1 + w2))
 
 
 def _centre_point(c):

@@ -280,10 +280,8 @@ def test_lewiner_gpu_equals_the_oracle_on_rough_volumes(nof, shape_):
     vol = gaussian_filter(rng.normal(size=shape_), 0.7).astype(np.float32)
     for iso in (0.0, 0.05):
         v, f = marching_cubes_lewiner_gpu(torch.from_numpy(vol).cuda(), iso)
-        vr, fr = ML.marching_cubes(vol, iso)
-        # (positions: the device interpolates edge vertices linearly in float64, the oracle with scikit-image's 1 / (eps + |value|)
-        # weights: the two part by up to a few 1e-5 voxel where a corner value is tiny; the centre vertices use the same formula)
-        ok, why = same_mesh(v, f, vr, fr, tol=1e-4)
+        vr, fr = ML.marching_cubes(vol, float(np.float32(iso)))     # (the C ABI takes the iso value as a float32)
+        ok, why = same_mesh(v, f, vr, fr, tol=1e-9)
         assert ok, (shape_, iso, why)
         assert (np.abs(v - np.round(v)) > 1e-9).all(1).sum() > 10                                   # centre vertices are present
 
