@@ -282,15 +282,23 @@ __device__ __forceinline__ bool mcl_load(const float* __restrict__ vol, int nx, 
   const int k = (int)(cell % cz);
   const int64_t t = cell / cz;
   const int j = (int)(t % cy), i = (int)(t / cy);
-  m.idx = 0;
+  // first the signs alone ((double)v - (double)iso > 0 <=> v > iso): 99 % of the cells of a dense grid end here, before anything of
+  // the cell record is written (the record lives in private memory: the tests pick corners by table entries)
+  const int64_t base = ((int64_t)i * ny + j) * nz + k;
+  const int64_t sj = nz, si = (int64_t)ny * nz;
+  const float v0 = vol[base], v1 = vol[base + 1], v2 = vol[base + sj + 1], v3 = vol[base + sj];
+  const float v4 = vol[base + si], v5 = vol[base + si + 1], v6 = vol[base + si + sj + 1], v7 = vol[base + si + sj];
+  const int idx = (v0 > iso ? 1 : 0) | (v1 > iso ? 2 : 0) | (v2 > iso ? 4 : 0) | (v3 > iso ? 8 : 0) | (v4 > iso ? 16 : 0) |
+                  (v5 > iso ? 32 : 0) | (v6 > iso ? 64 : 0) | (v7 > iso ? 128 : 0);
+  m.idx = idx;
+  if (idx == 0 || idx == 0xFF) return false;
+  const float v[8] = {v0, v1, v2, v3, v4, v5, v6, v7};
 #pragma unroll
   for (int p = 0; p < 8; ++p) {
-    const int64_t id = ((int64_t)(i + kMclCorner[p][0]) * ny + (j + kMclCorner[p][1])) * nz + (k + kMclCorner[p][2]);
-    m.id[p] = id;
-    m.c[p] = (double)vol[id] - (double)iso;
-    if (m.c[p] > 0.0) m.idx |= 1 << p;
+    m.id[p] = base + kMclCorner[p][0] * si + kMclCorner[p][1] * sj + kMclCorner[p][2];
+    m.c[p] = (double)v[p] - (double)iso;
   }
-  return m.idx != 0 && m.idx != 0xFF;
+  return true;
 }
 __device__ __forceinline__ double mcl_pick(const MclCell& m, int p) {   // (a select chain: no run-time index into registers)
   double v = m.c[0];
