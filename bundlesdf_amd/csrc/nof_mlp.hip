@@ -563,6 +563,15 @@ NofMlpDesc d, const char* __restrict__ image,
 #ifndef NOF_ENC_ROLLED
 #define NOF_ENC_ROLLED 1
 #endif
+#ifndef NOF_ENC_PRIO
+#define NOF_ENC_PRIO 1                                    // s_setprio by phase (below); 0: none
+#endif
+#ifndef NOF_ENC_PRIO_ENC
+#define NOF_ENC_PRIO_ENC 3
+#endif
+#ifndef NOF_ENC_PRIO_CHAIN
+#define NOF_ENC_PRIO_CHAIN 0
+#endif
 #ifndef NOF_ENC_DEBUG_FEAT
 #define NOF_ENC_DEBUG_FEAT 0                              // tools/fused_debug*.py: the features as computed, before the LDS stage
 #endif
@@ -777,6 +786,9 @@ __global__ __launch_bounds__(64 * NOF_ENC_WAVES, (NOF_ENC_WAVES + 3) / 4) void k
   const int64_t npairs = (B + 63) / 64;
   for (int64_t tp = (int64_t)blockIdx.x * NW + wave; tp < npairs; tp += (int64_t)gridDim.x * NW) {
     asm volatile("" ::: "memory");                    // keep the weight fragments in LDS (no hoisting into VGPRs)
+#if NOF_ENC_PRIO
+    __builtin_amdgcn_s_setprio(NOF_ENC_PRIO_ENC);      // (see NOF_ENC_PRIO)
+#endif
     // ---------------- encode: lane = sample tp*64 + lane, all levels, GR levels' gathers in flight together ----------------
     // The features go to a wave-private LDS stage as they are produced, feature-major: stage[feature][sample] -- one conflict-free
     // ds_write_b32 per feature -- so that no register holds them while the next group's gathers are in flight (32 accumulated
@@ -829,6 +841,9 @@ __global__ __launch_bounds__(64 * NOF_ENC_WAVES, (NOF_ENC_WAVES + 3) / 4) void k
           if (2 * l0 + u < 32) stage[(2 * l0 + u) * 64 + lane] = 0.0f;                     // levels the grid does not have
       }
     }
+#if NOF_ENC_PRIO
+    __builtin_amdgcn_s_setprio(NOF_ENC_PRIO_CHAIN);
+#endif
     // ---------------- the two tiles through the chain: lane (j, hi) of tile t reads features 16 hi .. 16 hi + 15 of sample
     //                  32 t + j = stage[16 hi + r][32 t + j] (conflict-free: a half-wave reads 32 consecutive words) ----------------
 #pragma unroll
@@ -1368,6 +1383,9 @@ __global__ __launch_bounds__(256) void k_mlp_bwd(NofMlpDesc d, const char* __res
 // Waves per workgroup of the two split-backward kernels.  Three colour layers (the reference's own shape, nerf_runner.py:221): the
 // fragments (40 KB) + four waves' parked operands (48 KB) + bias sums are 95 KB, i.e. ONE 4-wave workgroup per CU = one wave per
 // SIMD; eight waves around ONE copy of the fragments are 148 KB: one workgroup per CU, two waves per SIMD.
+#ifndef NOF_BWD_PRIO
+#define NOF_BWD_PRIO 0                                    // s_setprio around the loads of a tile in the split backward kernels (A/B: profiles/r05_t_*)
+#endif
 #ifndef NOF_BWD_WAVES_C2
 #define NOF_BWD_WAVES_C2 4
 #endif
@@ -1451,6 +1469,9 @@ __global__ __launch_bounds__(64 * ColorWaves<NC>::value, 2) void k_mlp_bwd_color
   if (hi == 0 && tile_n * 32 + j < B) drn = draw[tile_n * 32 + j];
   for (int64_t wi = w0; wi < work.n; wi += tstride) {
     asm volatile("" ::: "memory");
+#if NOF_BWD_PRIO
+    __builtin_amdgcn_s_setprio(3);                     // the tile's loads (and the next tile's prefetch) issue ahead of the other wave's chain
+#endif
     const int64_t tile = tile_n;
     tile_n = work.at(wi + tstride);
     const int64_t t0 = tile * 32;
@@ -1486,6 +1507,9 @@ __global__ __launch_bounds__(64 * ColorWaves<NC>::value, 2) void k_mlp_bwd_color
     float ds1[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) ds1[r] = 0.0f;
+#if NOF_BWD_PRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
     if (!skip) {
     {
       if constexpr (!AHEAD) {
@@ -1648,6 +1672,9 @@ __global__ __launch_bounds__(64 * SigmaWaves<NS>::value, 2) void k_mlp_bwd_sigma
   typename P::frag dsn = load_sig_raw<P>(dsig, B, tile_n * 32 + j, hi);
   for (int64_t wi = w0; wi < work.n; wi += tstride) {
     asm volatile("" ::: "memory");
+#if NOF_BWD_PRIO
+    __builtin_amdgcn_s_setprio(3);                     // the tile's loads (and the next tile's prefetch) issue ahead of the other wave's chain
+#endif
     const int64_t tile = tile_n;
     tile_n = work.at(wi + tstride);
     const int64_t b = tile * 32 + j;
@@ -1671,6 +1698,9 @@ __global__ __launch_bounds__(64 * SigmaWaves<NS>::value, 2) void k_mlp_bwd_sigma
     float df1[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) df1[r] = 0.0f;
+#if NOF_BWD_PRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
     if (!skip) {
     {
       park_o2<P>(st, I, 0, x[0]);
