@@ -566,6 +566,9 @@ NofMlpDesc d, const char* __restrict__ image,
 #ifndef NOF_ENC_PRIO
 #define NOF_ENC_PRIO 1                                    // s_setprio by phase (below); 0: none
 #endif
+#ifndef NOF_GRID_PRIO
+#define NOF_GRID_PRIO 0                                   // the same in k_sdf_grid (A/B: profiles/r05_u_*)
+#endif
 #ifndef NOF_ENC_PRIO_ENC
 #define NOF_ENC_PRIO_ENC 3
 #endif
@@ -901,6 +904,9 @@ __global__ __launch_bounds__(256, 2) void k_sdf_grid(NofMlpDesc d, const char* _
 #pragma unroll
     for (int dd = 0; dd < 3; ++dd) p[dd] = fminf(fmaxf(p[dd], -1.0f), 1.0f);      // run_network_density clips (nerf_runner.py:1313)
     float x[1][16];
+#if NOF_GRID_PRIO
+    __builtin_amdgcn_s_setprio(3);                     // (as in k_enc_mlp_fwd: the gather phase issues first)
+#endif
 #pragma unroll
     for (int kk = 0; kk < 8; ++kk) {
       const int level = 8 * hi + kk;
@@ -912,6 +918,9 @@ __global__ __launch_bounds__(256, 2) void k_sdf_grid(NofMlpDesc d, const char* _
       x[0][2 * kk] = v.x;
       x[0][2 * kk + 1] = v.y;
     }
+#if NOF_GRID_PRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
     float h[2][16], so[1][16];
     dense_o1<P, 1, 2, SPLIT>(smem, FW_OFF(0), BIAS_OFF(0), x, h, lane, LO_OFF(0));
     relu_mask<2>(h);
