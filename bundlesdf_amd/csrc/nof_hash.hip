@@ -19,6 +19,9 @@
 #include <type_traits>
 #include "nof_hash_dev.h"
 #include "nof_reduce_dev.h"
+#ifndef NOF_AGG_PRIO
+#define NOF_AGG_PRIO 1                                    // s_setprio by phase in the table scatter (A/B: profiles/r05_v_*): 1 = emission high, 2 = loads high
+#endif
 #pragma clang fp contract(off)
 
 struct LevelList {
@@ -269,6 +272,11 @@ __global__ __launch_bounds__(256) void k_hash_bwd_agg(NofHashGrid g, LevelList l
         if (__ballot(b < B && (g0.x != 0.0f || g0.y != 0.0f)) == 0ull) continue;
       }
     }
+#if NOF_AGG_PRIO == 2
+    __builtin_amdgcn_s_setprio(3);                                    // (A/B: the loads of the next item first)
+#elif NOF_AGG_PRIO == 1
+    __builtin_amdgcn_s_setprio(0);
+#endif
     Scatter sc = make_scatter(lv, pts_w, dfeat, level, b, B, EIK ? geik : nullptr, EIK ? dedn : nullptr);
     const bool valid = sc.key != AGG_NONE;
     // neighbours' cells through ds_bpermute (the DPP wavefront shifts do not cross the 16-lane rows on gfx950)
@@ -331,6 +339,11 @@ __global__ __launch_bounds__(256) void k_hash_bwd_agg(NofHashGrid g, LevelList l
     uint32_t take2 = take1 & shared_corners(sc.key, kp2, sh2);        // ... and the one before it
     const int slot = __popcll(heads & le) - 1;
     float* __restrict__ gt = grad_table + 2 * (size_t)lv.offset;
+#if NOF_AGG_PRIO == 1
+    __builtin_amdgcn_s_setprio(3);                                    // (A/B: the emission -- LDS stage, atomics -- first)
+#elif NOF_AGG_PRIO == 2
+    __builtin_amdgcn_s_setprio(0);
+#endif
     for (int base = 0; base < nl; base += AGG_RUNS) {
       const int cnt = nl - base < AGG_RUNS ? nl - base : AGG_RUNS;
       // 3. the runs of this window (a window edge breaks the chains, too)
