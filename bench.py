@@ -398,12 +398,19 @@ def main():
         torch.cuda.synchronize()
 
     def timed(n):
+        # (no cyclic garbage collection inside the timed region: a generation-2 pass of the interpreter is milliseconds of host
+        # time, i.e. ten steps' worth -- one driver-style run in eleven read 0.73 instead of 0.47-0.48 ms/step, profiles/r05_final4_*,
+        # r05_x_headline_repeat.txt; collected right before instead)
+        import gc
+        gc.collect()
+        gc.disable()
         barrier()
         t0 = time.perf_counter()
         for _ in range(n):
             step()
         barrier()
         dt = time.perf_counter() - t0
+        gc.enable()
         if world > 1:
             t = torch.tensor([dt], device=device, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
