@@ -399,8 +399,9 @@ def main():
 
     def timed(n):
         # (no cyclic garbage collection inside the timed region: a generation-2 pass of the interpreter is milliseconds of host
-        # time, i.e. ten steps' worth -- one driver-style run in eleven read 0.73 instead of 0.47-0.48 ms/step, profiles/r05_final4_*,
-        # r05_x_headline_repeat.txt; collected right before instead)
+        # time, i.e. ten steps' worth.  One driver-style run in eleven read 0.73 instead of 0.47-0.48 ms/step -- a one-off host stall
+        # of unknown origin, profiles/r05_final4_*, r05_x_headline_repeat.txt -- and this is the one such pause the script can rule
+        # out; collected right before instead)
         import gc
         gc.collect()
         gc.disable()
