@@ -1479,7 +1479,7 @@ __global__ __launch_bounds__(64 * ColorWaves<NC>::value, 2) void k_mlp_bwd_color
   for (int64_t wi = w0; wi < work.n; wi += tstride) {
     asm volatile("" ::: "memory");
 #if NOF_BWD_PRIO
-    __builtin_amdgcn_s_setprio(3);                     // the tile's loads (and the next tile's prefetch) issue ahead of the other wave's chain
+    __builtin_amdgcn_s_setprio(NOF_BWD_PRIO == 1 ? 3 : 0);   // 1: the tile's loads (and the next tile's prefetch) ahead of the other wave's chain; 2: the chain ahead
 #endif
     const int64_t tile = tile_n;
     tile_n = work.at(wi + tstride);
@@ -1517,7 +1517,7 @@ __global__ __launch_bounds__(64 * ColorWaves<NC>::value, 2) void k_mlp_bwd_color
 #pragma unroll
     for (int r = 0; r < 16; ++r) ds1[r] = 0.0f;
 #if NOF_BWD_PRIO
-    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_s_setprio(NOF_BWD_PRIO == 1 ? 0 : 3);
 #endif
     if (!skip) {
     {
@@ -1682,7 +1682,7 @@ __global__ __launch_bounds__(64 * SigmaWaves<NS>::value, 2) void k_mlp_bwd_sigma
   for (int64_t wi = w0; wi < work.n; wi += tstride) {
     asm volatile("" ::: "memory");
 #if NOF_BWD_PRIO
-    __builtin_amdgcn_s_setprio(3);                     // the tile's loads (and the next tile's prefetch) issue ahead of the other wave's chain
+    __builtin_amdgcn_s_setprio(NOF_BWD_PRIO == 1 ? 3 : 0);   // 1: the tile's loads (and the next tile's prefetch) ahead of the other wave's chain; 2: the chain ahead
 #endif
     const int64_t tile = tile_n;
     tile_n = work.at(wi + tstride);
@@ -1708,7 +1708,7 @@ __global__ __launch_bounds__(64 * SigmaWaves<NS>::value, 2) void k_mlp_bwd_sigma
 #pragma unroll
     for (int r = 0; r < 16; ++r) df1[r] = 0.0f;
 #if NOF_BWD_PRIO
-    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_s_setprio(NOF_BWD_PRIO == 1 ? 0 : 3);
 #endif
     if (!skip) {
     {
