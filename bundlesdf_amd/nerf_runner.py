@@ -367,15 +367,14 @@ class NerfRunner:
         sigma_dev = f.query_sdf_grid(tx, ty, tz, outside_value=1.0, use_octree=f.occ_bits is not None)
         logging.info(f'query grid:{tuple(sigma_dev.shape)}, valid:{int((sigma_dev != 1.0).sum().item())}')
         logging.info('Running iso-surface extraction')
+        # the reference's skimage call (:1388-1394) with skimage's default method: marching cubes with Lewiner's topological
+        # disambiguation -- skimage's triangles, one for one.  cfg mesh_extractor: 'cubes' = classic marching cubes (same vertices on
+        # the grid edges, one fixed tiling per sign configuration), 'tetrahedra' = marching tetrahedra (~4x the triangles)
+        kind = self.cfg.get('mesh_extractor', 'lewiner')
+        if kind not in ('lewiner', 'cubes', 'tetrahedra'):             # (a configuration error is not an empty level set: raised, not logged)
+            raise ValueError(f"mesh_extractor must be 'lewiner', 'cubes' or 'tetrahedra', not {kind!r}")
+        extract = {'lewiner': marching_cubes_lewiner_gpu, 'cubes': marching_cubes_gpu, 'tetrahedra': marching_tetrahedra_gpu}[kind]
         try:
-            # the reference's skimage call (:1388-1394) with skimage's default method: marching cubes with Lewiner's topological
-            # disambiguation -- skimage's triangles, one for one.  cfg mesh_extractor: 'cubes' = classic marching cubes (same
-            # vertices on the grid edges, one fixed tiling per sign configuration), 'tetrahedra' = marching tetrahedra (~4x the
-            # triangles)
-            kind = self.cfg.get('mesh_extractor', 'lewiner')
-            if kind not in ('lewiner', 'cubes', 'tetrahedra'):
-                raise ValueError(f"mesh_extractor must be 'lewiner', 'cubes' or 'tetrahedra', not {kind!r}")
-            extract = {'lewiner': marching_cubes_lewiner_gpu, 'cubes': marching_cubes_gpu, 'tetrahedra': marching_tetrahedra_gpu}[kind]
             vertices, triangles = extract(sigma_dev, isolevel)
         except Exception as e:
             logging.info(f"ERROR Marching Cubes {e}")
