@@ -10,8 +10,9 @@ a steady MFMA load, none when no MFMA is issued; op_sel on source 0 and plain pa
 -fno-slp-vectorize and tests/test_capi.py scans the built code for it.
 
 Collected FIRST (tests/conftest.py).  What is asserted is what the product relies on: without MFMAs every form is exact; under MFMA
-load the forms the library may contain (plain, op_sel on source 0) are exact; and IF the source-1 forms misbehave on this box, then
-only in the last quarter-wave and only in the low result -- the signature the round-4 bisect found.  Their counts are printed."""
+load the forms the library may contain (plain, op_sel on source 0) are exact.  What the source-1 forms do on this box is printed
+(every box of round 5: wrong only in the last quarter-wave, only in the low result -- the signature the round-4 bisect found); a
+different signature is reported as a warning, not as a failure: the product contains none of these forms."""
 import ctypes as C
 import os
 import subprocess
@@ -55,5 +56,8 @@ def test_packed_fp32_source1_op_sel_under_mfma_load(nof, tmp_path):
               f'low {int(loaded[..., 1].sum())}, high {int(loaded[..., 2].sum())}')
         if form in SAFE:
             assert wrong == 0, f'{text}: a form the library may contain is wrong under MFMA load'
-        else:
-            assert by_quarter[0] == by_quarter[1] == by_quarter[2] == 0 and int(loaded[..., 2].sum()) == 0, (text, by_quarter)
+        elif not (by_quarter[0] == by_quarter[1] == by_quarter[2] == 0 and int(loaded[..., 2].sum()) == 0):
+            # (observed on every box of this round: only lanes 48-63, only the low result.  Another signature is news about the
+            # hardware, not a defect of the product -- which contains none of these forms --: reported, the suite goes on)
+            import warnings
+            warnings.warn(f'{text}: wrong results outside the last quarter-wave / in the high result: {by_quarter}')
