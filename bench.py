@@ -574,11 +574,9 @@ def main():
             'nof_mlp_fwd': ('mfma', B * fl_fwd),
             'nof_mlp_bwd_tiles': ('mfma', B * (1.0 - zero_frac) * 3.0 * fl_fwd),
             'nof_mlp_wide_fwd': ('mfma', B * fl_fwd),
-            'nof_mlp_wide_bwd': ('mfma', B * (1.0 - zero_frac) * 2.0 * fl_fwd),   # no recompute on the wide path: data + weight gradients
-            # the wide backward as the step launches it (nof_mlp_wide_bwd_parts): data path / weight-gradient passes per network,
-            # over the listed tiles only; one pass of a network = its 2 * MAC
-            'wide_bwd[data colour]': ('mfma', B * (1.0 - zero_frac) * fl_net[1]), 'wide_bwd[data sigma]': ('mfma', B * (1.0 - zero_frac) * fl_net[0]),
-            'wide_bwd[dW colour]': ('mfma', B * (1.0 - zero_frac) * fl_net[1]), 'wide_bwd[dW sigma]': ('mfma', B * (1.0 - zero_frac) * fl_net[0]),
+            # the wide backward (one kernel per network, round 6): forward recompute + data gradients + weight gradients of the listed
+            # tiles = 3 x the forward's MACs (the transposing MFMAs that feed the weight gradient are not counted as useful work)
+            'nof_mlp_wide_bwd': ('mfma', B * (1.0 - zero_frac) * 3.0 * fl_fwd),
             'nof_adam_step': ('hbm', fld.n_total * 32.0),
         }
         traffic = None          # HBM bytes per launch from the committed PMC passes (profiles/pmc_traffic.json), same workload only

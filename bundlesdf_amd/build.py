@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 OBJ = os.path.join(CSRC, 'build')
 LIB = os.path.join(HERE, 'libnof_hip.so')
-SOURCES = ['nof_capi.hip', 'nof_hash.hip', 'nof_trace.hip', 'nof_loss.hip', 'nof_pose.hip', 'nof_mlp.hip', 'nof_mesh.hip', 'nof_texture.hip']
+SOURCES = ['nof_capi.hip', 'nof_hash.hip', 'nof_trace.hip', 'nof_loss.hip', 'nof_pose.hip', 'nof_mlp.hip', 'nof_mlp_wide.hip', 'nof_mesh.hip', 'nof_texture.hip']
 HEADERS = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith('.h')) + [os.path.join(HERE, '..', 'include', 'nof_hip.h')]
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=off', '-munsafe-fp-atomics',
          '-Wno-unused-result', '-Wno-pass-failed', '-fno-slp-vectorize']
@@ -28,7 +28,7 @@ FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=o
 # caught it) -- do not enable it.
 # nof_mlp.hip: without -fno-honor-nans every fmaxf(h, 0) of the ReLUs is TWO v_max_f32 (IEEE maxnum quiets signalling NaNs
 # first); the file has no NaN-dependent logic.
-EXTRA = {'nof_mlp.hip': ['-fno-honor-nans']}
+EXTRA = {'nof_mlp.hip': ['-fno-honor-nans'], 'nof_mlp_wide.hip': ['-fno-honor-nans']}
 
 
 def hipcc():

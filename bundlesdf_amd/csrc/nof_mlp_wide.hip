@@ -1,0 +1,761 @@
+// Wide / deep NeRFSmall shapes (hidden 128 and/or 4 layers per network: BASELINE.json cfg5's "MLP 4x128", nerf_helpers.py:243-321
+// is parameterised in hidden_dim / num_layers) on the gfx950 matrix cores -- ON CHIP since round 6.  Its own translation unit on
+// top of nof_mlp_dev.h (operand layouts, the fragment image of k_mlp_pack, the hash-encode pieces).
+//
+// Why a second set of kernels: the register-resident design of nof_mlp.hip keeps every weight fragment of both orientations in LDS
+// and every dW accumulator in one wave's registers.  A 128x128 layer is 32 KB of fragments per orientation and 256 accumulator
+// registers per wave; one 4x128 network is 78 KB per orientation and 608 accumulator registers.
+//
+// Rounds 2-5 staged everything through HBM (the forward stored six hidden activation rows per sample, the backward eight gradient
+// rows, eight split-K weight-gradient launches read fourteen: 12.6 GB per cfg5 step, HBM-bound by construction).  Round 6:
+//   * the forward stores NOTHING but raw, the sigma head's 16 outputs and (fused-encode entry point) the operand-precision
+//     embedding -- 112 B per sample;
+//   * the backward of one network is ONE kernel, k_wide_bwd_net: per 32-sample tile the forward is recomputed in registers, the
+//     data gradients walk back through the layers, and the weight gradient is accumulated COOPERATIVELY by the four waves of a
+//     workgroup: every wave transposes its tile's (delta_l, a_{l-1}) blocks on the matrix core (identity multiply, exact) and
+//     parks the operand fragments in an LDS exchange buffer; behind a workgroup barrier every wave adds the four tiles' products
+//     to the dW blocks it OWNS (block idx = wave + 4 i of the layer's PN x QN blocks: 38.9 k fp32 accumulators of a 4x128 network =
+//     152 registers per lane spread over the workgroup's four waves; one wave per SIMD, 512-register budget);
+//   * neither orientation of the weights is resident: the layer the workgroup is at streams through a two-slot LDS ring (one
+//     chunk = one layer's fragments of one orientation, <= 32 KB, requested one phase ahead with global_load ... lds, shared by the
+//     four waves), so LDS holds ring 64 KB + exchange 64 KB + biases;
+//   * per workgroup ONE partial row of dW / db -> nof_reduce_partials, like the narrow path.
+// Per tile and 128x128 layer: 32 (forward) + 32 (data gradient) + 16 (transposes) + 32 (dW) MFMAs against 64 KB of weight reads,
+// 16 KB of exchange writes and 40 KB of exchange reads from LDS: matrix-pipe-bound on paper.
+// 16-bit operand types only; precisions 3 / 4 run as 2 / 1 here (no operand split).
+#include "nof_mlp_dev.h"
+#include <utility>
+
+// ReLU in place + the 16 PN derivative bits of the lane (relu_mask of nof_mlp_dev.h, two blocks per 32-bit word)
+template <int HB>
+__device__ __forceinline__ uint2 relu_bits(float (&h)[HB][16]) {
+  static_assert(HB == 2 || HB == 4, "hidden width 64 or 128");
+  uint32_t off[2] = {0u, 0u};
+#pragma unroll
+  for (int p = 0; p < HB; ++p)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {                                     // (plain indexing: a reinterpret_cast of the array sent it to scratch)
+      const int bits = __float_as_int(h[p][r]);
+      off[p >> 1] = __builtin_amdgcn_alignbit(off[p >> 1], (uint32_t)bits, 31);
+      h[p][r] = __int_as_float(bits > 0 ? bits : 0);
+    }
+  return make_uint2(~off[0], HB == 4 ? ~off[1] : 0u);
+}
+// element r of block p sits in word p >> 1 at bit 31 - (16 (p & 1) + r), 1 = the unit was on
+__device__ __forceinline__ void apply_bits_blk(float (&g)[16], uint2 m, int p) {
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const uint32_t keep = (uint32_t)__builtin_amdgcn_sbfe((int)(p < 2 ? m.x : m.y), 31 - (16 * (p & 1) + r), 1);
+    g[r] = __uint_as_float(__float_as_uint(g[r]) & keep);
+  }
+}
+
+template <int PN>
+__device__ __forceinline__ void relu_inplace(float (&h)[PN][16]) {
+#pragma unroll
+  for (int p = 0; p < PN; ++p)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {                                     // signed-integer max on the bits: one instruction (see relu_mask)
+      const int bits = __float_as_int(h[p][r]);
+      h[p][r] = __int_as_float(bits > 0 ? bits : 0);
+    }
+}
+
+#define WPAIR ((int)(16 * 64 * sizeof(typename P::elem)))
+
+// =====================================================================================================
+// forward, sigma net: features -> hidden layers -> head: sdf -> raw[b].w (or sdf[b]), sig[b] = 16 head outputs
+// =====================================================================================================
+// threads per workgroup of the forward kernels: 768 (3 waves per SIMD, 168 registers) where that fits without scratch (hidden 64);
+// hidden 128 needs ~190 (two 64-register activation sets + the operand and weight fragments of a chain): 512 threads
+template <int HB> struct WideFwdThreads { static constexpr int value = HB >= 4 ? 512 : 768; };
+
+template <class P, int HB>
+__global__ __launch_bounds__(WideFwdThreads<HB>::value) void k_wide_fwd_sigma(NofMlpDesc d, const char* __restrict__ image,
+                                                         const float2* __restrict__ feat, int L,
+                                                         float* __restrict__ out, int out_stride, int out_off,
+                                                         typename P::elem* __restrict__ sig, int64_t B) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int NS = d.n_sigma, NL = d.n_sigma + d.n_color;
+  const int bias_base = pair_base(d, NS) * WPAIR;
+  copy16(smem, image, (size_t)bias_base);
+  copy16(smem + bias_base, image + 2 * (size_t)pair_base(d, NL) * WPAIR, (size_t)oblk_base(d, NS) * 128);
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  const int hi = lane >> 5, j = lane & 31;
+  const int64_t ntiles = (B + 31) / 32, tstride = (int64_t)gridDim.x * nw;
+  float xn[1][16];                                                      // the NEXT tile's features, a whole tile ahead
+  load_feat_o1(feat, L, B, ((int64_t)blockIdx.x * nw + wave) * 32 + j, hi, xn);
+  for (int64_t tile = (int64_t)blockIdx.x * nw + wave; tile < ntiles; tile += tstride) {
+    asm volatile("" ::: "memory");
+    const int64_t b = tile * 32 + j;
+    const bool ok = b < B;
+    float x[1][16], h[HB][16], so[1][16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) x[0][r] = xn[0][r];
+    pin16(x[0]);
+    load_feat_o1(feat, L, B, (tile + tstride) * 32 + j, hi, xn);
+    dense_o1<P, 1, HB>(smem, 0, bias_base, x, h, lane);
+    relu_inplace<HB>(h);
+    int foff = HB * WPAIR, boff = bias_base + HB * 128;
+    for (int l = 1; l < NS - 1; ++l) {
+      float h2[HB][16];
+      dense_o1<P, HB, HB>(smem, foff, boff, h, h2, lane);
+      relu_inplace<HB>(h2);
+#pragma unroll
+      for (int p = 0; p < HB; ++p)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) h[p][r] = h2[p][r];
+      foff += HB * HB * WPAIR;
+      boff += HB * 128;
+    }
+    dense_o1<P, HB, 1>(smem, foff, boff, h, so, lane);
+    if (sig != nullptr) store_sig_o1<P>(sig, B, b, hi, so[0]);
+    if (hi == 0 && ok) out[b * out_stride + out_off] = so[0][0];
+  }
+}
+
+// =====================================================================================================
+// forward, colour net: [sig | view] -> hidden layers -> rgb_raw -> raw[b].xyz
+// =====================================================================================================
+template <class P, int HB>
+__global__ __launch_bounds__(WideFwdThreads<HB>::value) void k_wide_fwd_color(NofMlpDesc d, const char* __restrict__ image,
+                                                         const typename P::elem* __restrict__ sig,
+                                                         const float* __restrict__ view, int S,
+                                                         float* __restrict__ raw, int64_t B) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int NS = d.n_sigma, NC = d.n_color, NL = NS + NC;
+  const int PA = pair_base(d, NS), PB = pair_base(d, NL), OA = oblk_base(d, NS), OB = oblk_base(d, NL);
+  const int bias_base = (PB - PA) * WPAIR;
+  copy16(smem, image + (size_t)PA * WPAIR, (size_t)bias_base);
+  copy16(smem + bias_base, image + 2 * (size_t)PB * WPAIR + OA * 128, (size_t)(OB - OA) * 128);
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  const int hi = lane >> 5, j = lane & 31;
+  const int64_t ntiles = (B + 31) / 32;
+  for (int64_t tile = (int64_t)blockIdx.x * nw + wave; tile < ntiles; tile += (int64_t)gridDim.x * nw) {
+    asm volatile("" ::: "memory");
+    const int64_t b = tile * 32 + j;
+    const bool ok = b < B;
+    float cin[2][16], h[HB][16], co[1][16];
+    load_sig_o1<P>(sig, B, b, hi, cin[0]);            // (requested a tile ahead: 4-10 % slower at cfg5, measured twice)
+    load_view_o1(view, S, B, b, hi, cin[1]);
+    dense_o1<P, 2, HB>(smem, 0, bias_base, cin, h, lane);
+    relu_inplace<HB>(h);
+    int foff = 2 * HB * WPAIR, boff = bias_base + HB * 128;
+    for (int l = 1; l < NC - 1; ++l) {
+      float h2[HB][16];
+      dense_o1<P, HB, HB>(smem, foff, boff, h, h2, lane);
+      relu_inplace<HB>(h2);
+#pragma unroll
+      for (int p = 0; p < HB; ++p)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) h[p][r] = h2[p][r];
+      foff += HB * HB * WPAIR;
+      boff += HB * 128;
+    }
+    dense_o1<P, HB, 1>(smem, foff, boff, h, co, lane);
+    if (hi == 0 && ok) { raw[b * 4] = co[0][0]; raw[b * 4 + 1] = co[0][1]; raw[b * 4 + 2] = co[0][2]; }
+  }
+}
+
+// =====================================================================================================
+// backward of ONE network, everything on chip (header).  NET: 0 = sigma net (x0 = hash features, head gradient = dsig, input
+// gradient = dfeat), 1 = colour net (x0 = [sigma head | view], head gradient = draw.xyz, input gradient = dsig (+ draw.w) and
+// dview).  N = the network's layers (2..4), local layer k = 0..N-1 = global layer lbase + k.
+// =====================================================================================================
+template <int HB, int NET, int N>
+struct WNet {
+  static constexpr int QN0 = NET ? 2 : 1;
+  static constexpr __host__ __device__ int qn(int k) { return k == 0 ? QN0 : HB; }
+  static constexpr __host__ __device__ int pn(int k) { return k == N - 1 ? 1 : HB; }
+  static constexpr __host__ __device__ int rel_pair(int k) { int s = 0; for (int i = 0; i < k; ++i) s += pn(i) * qn(i); return s; }
+  static constexpr __host__ __device__ int rel_oblk(int k) { int s = 0; for (int i = 0; i < k; ++i) s += pn(i); return s; }
+  static constexpr __host__ __device__ int nb(int k) { return (pn(k) * qn(k) + 3) / 4; }            // dW blocks a wave owns of layer k
+  static constexpr __host__ __device__ int aoff(int k) { int s = 0; for (int i = 0; i < k; ++i) s += nb(i); return s; }
+  static constexpr __host__ __device__ int slot_pairs() { int m = 0; for (int k = 0; k < N; ++k) m = pn(k) * qn(k) > m ? pn(k) * qn(k) : m; return m; }
+  static constexpr int NACC = aoff(N);                                  // accumulator blocks per wave (x 16 registers)
+  static constexpr int NDB = rel_oblk(N);                               // bias-gradient sums per wave (one register each)
+  static constexpr int SLOTB = slot_pairs() * 2048;                     // bytes of one ring slot
+  static constexpr int XWAVE = 2 * HB * 2048;                           // exchange bytes per wave: HB delta blocks + HB input blocks
+  static constexpr int XB = 2 * SLOTB, BIASB = XB + 4 * XWAVE, DBB = BIASB + (N - 1) * HB * 128;   // DBB: [wave][NDB][64] floats
+  static constexpr int LDS_BYTES = DBB + 4 * NDB * 256;
+};
+
+// the scheduler of a 512-register kernel hoists every LDS read it can see (all blocks' weight fragments, all tiles' operands) in
+// front of the first MFMA and then spills what it hoisted: a scheduling fence per block keeps a block's reads beside its MFMAs
+#ifndef NOF_WIDE_FENCE
+#define NOF_WIDE_FENCE 1
+#endif
+#if NOF_WIDE_FENCE
+#define WIDE_FENCE() __builtin_amdgcn_sched_barrier(0)
+#else
+#define WIDE_FENCE() ((void)0)
+#endif
+#ifndef NOF_WIDE_DMA
+#define NOF_WIDE_DMA 1                                    // weight chunks global -> LDS with global_load ... lds (0: through registers)
+#endif
+
+// one weight chunk (BYTES of the fragment image, contiguous) -> an LDS ring slot, by the workgroup's 256 threads.
+// issue(): requests it; commit(): the requesting thread's part has landed (a workgroup barrier then publishes the slot).
+template <int BYTES>
+struct ChunkLoad {
+#if NOF_WIDE_DMA
+  __device__ __forceinline__ void issue(const char* __restrict__ src, char* slot, int wave_s, int lane) {
+    // a wave instruction moves one contiguous kilobyte: LDS address = M0 (wave-uniform) + 16 * lane
+#pragma unroll
+    for (int t = 0; t < BYTES / 4096; ++t) {
+      const int piece = wave_s + 4 * t;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + piece * 1024 + lane * 16),
+                                       (__attribute__((address_space(3))) void*)(slot + piece * 1024), 16, 0, 0);
+    }
+  }
+  __device__ __forceinline__ void commit(char*, int, int) { __builtin_amdgcn_s_waitcnt(0x0f70); /* vmcnt(0) */ }
+#else
+  uint4 v[BYTES / 4096];
+  __device__ __forceinline__ void issue(const char* __restrict__ src, char*, int wave_s, int lane) {
+#pragma unroll
+    for (int t = 0; t < BYTES / 4096; ++t) v[t] = *reinterpret_cast<const uint4*>(src + (wave_s + 4 * t) * 1024 + lane * 16);
+  }
+  __device__ __forceinline__ void commit(char* slot, int wave_s, int lane) {
+#pragma unroll
+    for (int t = 0; t < BYTES / 4096; ++t) *reinterpret_cast<uint4*>(slot + (wave_s + 4 * t) * 1024 + lane * 16) = v[t];
+  }
+#endif
+};
+
+template <class F, int... Is>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, Is...>) {
+  (f(std::integral_constant<int, Is>()), ...);
+}
+template <int NN, class F>
+__device__ __forceinline__ void static_for(F&& f) { static_for_impl(f, std::make_integer_sequence<int, NN>()); }
+
+// one dense layer on packed operands: out[p] = bias + W[p][:] in   (fragments of the layer at `wl` = slot + 16 * lane)
+template <class P, int QN, int PN>
+__device__ __forceinline__ void dense_pk(const char* wl, const char* bias_hi, const typename P::frag (&in)[QN][2], float (&out)[PN][16]) {
+#pragma unroll
+  for (int p = 0; p < PN; ++p) {
+    f32x16 acc;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const float4 bv = *(const float4*)(bias_hi + (32 * p + 8 * g) * 4);
+      acc[4 * g] = bv.x; acc[4 * g + 1] = bv.y; acc[4 * g + 2] = bv.z; acc[4 * g + 3] = bv.w;
+    }
+    typename P::frag a[QN * 2];
+#pragma unroll
+    for (int t = 0; t < QN * 2; ++t) a[t] = *(const typename P::frag*)(wl + (p * QN * 2 + t) * 1024);
+#pragma unroll
+    for (int q = 0; q < QN; ++q)
+#pragma unroll
+      for (int s = 0; s < 2; ++s) acc = P::mma(a[q * 2 + s], in[q][s], acc);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) out[p][r] = acc[r];
+    WIDE_FENCE();
+  }
+}
+// gradient of input block q: din = W^T[q][:] dout   (bw fragments of the layer at `wl`)
+template <class P, int PN, int GB>
+__device__ __forceinline__ void bwd_pk(const char* wl, int q, const typename P::frag (&dout)[GB][2], float (&din)[16]) {
+  static_assert(PN <= GB, "the layer's output blocks are the first PN of the array");
+  f32x16 a1;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) a1[r] = 0.0f;
+  typename P::frag w[PN * 2];
+#pragma unroll
+  for (int t = 0; t < PN * 2; ++t) w[t] = *(const typename P::frag*)(wl + (q * PN * 2 + t) * 1024);
+#pragma unroll
+  for (int p = 0; p < PN; ++p)
+#pragma unroll
+    for (int s = 0; s < 2; ++s) a1 = P::mma(w[p * 2 + s], dout[p][s], a1);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) din[r] = a1[r];
+}
+template <class P>
+__device__ __forceinline__ void pack_blk(const float (&x)[16], typename P::frag (&f)[2]) {
+  f[0] = P::pack(&x[0]);
+  f[1] = P::pack(&x[8]);
+}
+// a sample-per-lane block (two operand fragments) -> slot-per-lane on the matrix core (transpose32 of nof_mlp_dev.h on packed
+// operands: x 1 + 0 is exact), as two operand fragments of the sample-contracted MFMA; returns the sum of the lane's 16 values
+// (lane = neuron: its bias gradient over the tile's samples)
+template <class P>
+__device__ __forceinline__ float transpose_pk(const Ident<P>& I, const typename P::frag (&x)[2], typename P::frag (&y)[2]) {
+  f32x16 t;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) t[r] = 0.0f;
+  t = P::mma(x[0], I.f[0], t);
+  t = P::mma(x[1], I.f[1], t);
+  float v[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) v[r] = t[r];
+  float s = 0.0f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) s += v[r];
+  y[0] = P::pack(&v[0]);
+  y[1] = P::pack(&v[8]);
+  return s;
+}
+
+// ---- the DATA role (waves 0-3 of the workgroup): one 32-sample tile per wave and pass -- forward recompute, data gradients,
+//      the exchange operands.  Barriers: one per recomputed layer, two per layer of the walk -- the OWNER role runs the same sequence.
+template <class P, int HB, int NET, int N>
+__device__ __forceinline__ void wide_data_role(const NofMlpDesc& d, char* smem, int wave_s, int lane,
+                                               const float2* __restrict__ feat, const typename P::elem* __restrict__ featq, int L,
+                                               const typename P::elem* __restrict__ sig, const float* __restrict__ view, int S,
+                                               const float4* __restrict__ draw, typename P::elem* __restrict__ dsig,
+                                               float2* __restrict__ dfeat, float* __restrict__ dview, int64_t B,
+                                               const TileWork& work, int64_t nbatch) {
+  typedef WNet<HB, NET, N> W;
+  typedef typename P::frag frag;
+  const int hi = lane >> 5, j = lane & 31;
+  Ident<P> I;
+  I.init(lane);
+  const float gscale = d.grad_scale > 0.0f ? d.grad_scale : 1.0f, gunscale = 1.0f / gscale;
+  // this wave's bias-gradient sums (its own tiles; lane = neuron): lane-private LDS words, no register across the passes
+  float* const db = reinterpret_cast<float*>(smem + W::DBB) + wave_s * W::NDB * 64 + lane;
+#pragma unroll
+  for (int a = 0; a < W::NDB; ++a) db[a * 64] = 0.0f;
+  char* const xw = smem + W::XB + wave_s * W::XWAVE + lane * 16;        // this wave's exchange region (+ its lane)
+  const char* const bias_hi = smem + W::BIASB + hi * 16;
+  int par = 0;                                                          // ring slot of the pass's first chunk (see the kernel)
+  auto slot_of = [&](int c) { return smem + ((par + c) & 1) * W::SLOTB; };
+  for (int64_t bi = blockIdx.x; bi < nbatch; bi += gridDim.x) {
+    asm volatile("" ::: "memory");
+    const int64_t tile = work.at(bi * 4 + wave_s);                       // (past the end: a tile that does not exist -> zeros everywhere)
+    const int64_t t0 = tile * 32, b = t0 + j;
+    const bool ok = b < B;
+    // ---------------- inputs (read again for layer 0's exchange at the end of the walk: nothing of them lives through the pass) ----
+    auto load_x0 = [&](frag (&x0)[W::QN0][2]) __attribute__((always_inline)) {
+      if constexpr (NET == 0) {
+        float x[1][16];
+        if (featq != nullptr) load_featq_o1<P>(featq, B, b, hi, x);
+        else load_feat_o1(feat, L, B, b, hi, x);
+        pack_blk<P>(x[0], x0[0]);
+      } else {
+        float x[16];
+        load_sig_o1<P>(sig, B, b, hi, x);
+        pack_blk<P>(x, x0[0]);
+        load_view_o1(view, S, B, b, hi, x);
+        pack_blk<P>(x, x0[1]);
+      }
+    };
+    // ---------------- forward recompute: a[k] = relu(W_k a[k-1] + b_k), k < N - 1 ----------------
+    frag a[N - 1][HB][2];
+    uint2 bits[N - 1];
+    static_for<N - 1>([&](auto K) __attribute__((always_inline)) {
+      constexpr int k = decltype(K)::value;
+      frag x0[W::QN0][2];
+      if constexpr (k == 0) load_x0(x0);
+      __syncthreads();                                                  // chunk k is in its slot
+      const char* wl = slot_of(k) + lane * 16;
+      uint32_t off[2] = {0u, 0u};
+#pragma unroll
+      for (int p = 0; p < HB; ++p) {                                    // block by block: 16 fp32 values live, not 64
+        float h[1][16];
+        if constexpr (k == 0) dense_pk<P, W::QN0, 1>(wl + p * W::QN0 * 2048, bias_hi + (W::rel_oblk(k) + p) * 128, x0, h);
+        else dense_pk<P, HB, 1>(wl + p * HB * 2048, bias_hi + (W::rel_oblk(k) + p) * 128, a[k - 1], h);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {                                  // relu_bits, one block
+          const int hb = __float_as_int(h[0][r]);
+          off[p >> 1] = __builtin_amdgcn_alignbit(off[p >> 1], (uint32_t)hb, 31);
+          h[0][r] = __int_as_float(hb > 0 ? hb : 0);
+        }
+        pack_blk<P>(h[0], a[k][p]);
+        WIDE_FENCE();
+      }
+      bits[k] = make_uint2(~off[0], HB == 4 ? ~off[1] : 0u);
+    });
+    // ---------------- the head's gradient ----------------
+    frag g[HB][2];                                                      // delta of the layer the walk is at (block 0 only for the head)
+    float dsdf1 = 0.0f;
+    {
+      float gh[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) gh[r] = 0.0f;
+      if constexpr (NET == 1) {
+        float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (hi == 0 && ok) t = draw[b];
+        gh[0] = t.x * gscale; gh[1] = t.y * gscale; gh[2] = t.z * gscale;
+        dsdf1 = t.w * gscale;
+        pack_blk<P>(gh, g[0]);
+      } else {
+        const frag f = load_sig_raw<P>(dsig, B, b, hi);
+        sig_to_o1<P>(f, gh);
+        pack_blk<P>(gh, g[0]);
+      }
+    }
+    // ---------------- backward walk: layer k = N - 1 .. 0 ----------------
+    static_for<N>([&](auto KK) __attribute__((always_inline)) {
+      constexpr int k = N - 1 - decltype(KK)::value;
+      constexpr int PN = W::pn(k), QN = W::qn(k), c = 2 * N - 2 - k;
+      // exchange: delta_k (PN blocks) and the layer's input (QN blocks), transposed on the matrix core
+#pragma unroll
+      for (int p = 0; p < PN; ++p) {
+        frag y[2];
+        db[(W::rel_oblk(k) + p) * 64] += transpose_pk<P>(I, g[p], y);
+        *reinterpret_cast<frag*>(xw + (p * 2) * 1024) = y[0];
+        *reinterpret_cast<frag*>(xw + (p * 2 + 1) * 1024) = y[1];
+        WIDE_FENCE();
+      }
+      frag x0[W::QN0][2];
+      if constexpr (k == 0) load_x0(x0);
+#pragma unroll
+      for (int q = 0; q < QN; ++q) {
+        frag y[2];
+        if constexpr (k == 0) (void)transpose_pk<P>(I, x0[q], y);
+        else (void)transpose_pk<P>(I, a[k - 1][q], y);
+        *reinterpret_cast<frag*>(xw + ((HB + q) * 2) * 1024) = y[0];
+        *reinterpret_cast<frag*>(xw + ((HB + q) * 2 + 1) * 1024) = y[1];
+        WIDE_FENCE();
+      }
+      __syncthreads();                                                  // (A) the four tiles' operands are in place; chunk c too
+      // the data gradient of the layer's input
+      const char* wl = slot_of(c) + lane * 16;
+      if constexpr (k > 0) {
+        frag gn[HB][2];
+#pragma unroll
+        for (int q = 0; q < HB; ++q) {
+          float gq[16];
+          bwd_pk<P, PN>(wl, q, g, gq);
+          apply_bits_blk(gq, bits[k - 1], q);
+          pack_blk<P>(gq, gn[q]);
+          WIDE_FENCE();
+        }
+#pragma unroll
+        for (int q = 0; q < HB; ++q) { g[q][0] = gn[q][0]; g[q][1] = gn[q][1]; }
+      } else if constexpr (NET == 0) {
+        float df1[16];
+        bwd_pk<P, PN>(wl, 0, g, df1);
+        store_dfeat_o1(dfeat, L, B, b, hi, df1, gunscale);
+      } else {
+        float ds1[16], dv1[16], dv2[16];
+        bwd_pk<P, PN>(wl, 0, g, ds1);
+        bwd_pk<P, PN>(wl, 1, g, dv1);
+        transpose32<P>(I, dv1, dv2);
+        // dview[ray][u] += sum over the tile's samples (lane = view slot, regs <-> samples; a tile may straddle two rays)
+        const int64_t ray0 = t0 / S;
+        const int64_t end0 = (ray0 + 1) * S, endB = end0 < B ? end0 : B;
+        float sa = 0.0f, sb = 0.0f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int64_t bs = t0 + nloc(hi, r);
+          if (bs < endB) sa += dv2[r];
+          else if (bs < B) sb += dv2[r];
+        }
+        sa += __shfl_xor(sa, 32, 64);
+        sb += __shfl_xor(sb, 32, 64);
+        const int u = view_col_of_lane(j);
+        if (hi == 0 && u >= 0 && u < d.n_view) {
+          if (sa != 0.0f) atomicAdd(&dview[ray0 * NOF_VIEW_COLS + u], sa * gunscale);
+          if (sb != 0.0f) atomicAdd(&dview[(ray0 + 1) * NOF_VIEW_COLS + u], sb * gunscale);
+        }
+        if (hi == 0) ds1[0] += dsdf1;                                   // the loss' own d sdf rides with the sigma head's gradient
+        store_sig_o1<P>(dsig, B, b, hi, ds1);
+      }
+      __syncthreads();                                                  // (B) the exchange buffer is free again
+    });
+    par ^= 1;
+  }
+}
+
+// ---- the OWNER role (waves 4-7): owner o = wave - 4 holds the dW blocks idx = o + 4 i of every layer, adds the four tiles' products
+//      between the barriers (A) and (B) of a layer's step, and streams the weight chunks into the ring for everybody.
+template <class P, int HB, int NET, int N>
+__device__ __forceinline__ void wide_owner_role(const NofMlpDesc& d, char* smem, int ow, int lane, const char* __restrict__ fw_img,
+                                                const char* __restrict__ bw_img, float* __restrict__ dst, int lbase, int64_t nbatch) {
+  typedef WNet<HB, NET, N> W;
+  typedef typename P::frag frag;
+  const int hi = lane >> 5, j = lane & 31;
+  const float gunscale = d.grad_scale > 0.0f ? 1.0f / d.grad_scale : 1.0f;
+  f32x16 acc[W::NACC];                                                  // the dW blocks this wave owns, all layers
+#pragma unroll
+  for (int a = 0; a < W::NACC; ++a)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[a][r] = 0.0f;
+  const char* const xr = smem + W::XB + lane * 16;                      // the exchange buffer as the owners read it
+  int par = 0;
+  auto slot_of = [&](int c) { return smem + ((par + c) & 1) * W::SLOTB; };
+  for (int64_t bi = blockIdx.x; bi < nbatch; bi += gridDim.x) {
+    asm volatile("" ::: "memory");
+    static_for<N - 1>([&](auto K) __attribute__((always_inline)) {
+      constexpr int k = decltype(K)::value;
+      __syncthreads();                                                  // chunk k is published; the other slot's readers are done
+      constexpr int kn = k + 1 < N - 1 ? k + 1 : N - 1;                 // next chunk: fw of layer k + 1, or bw of the head
+      ChunkLoad<W::pn(kn) * W::qn(kn) * 2048> cl;
+      cl.issue((k + 1 < N - 1 ? fw_img : bw_img) + W::rel_pair(kn) * 2048, slot_of(k + 1), ow, lane);
+      cl.commit(slot_of(k + 1), ow, lane);
+    });
+    static_for<N>([&](auto KK) __attribute__((always_inline)) {
+      constexpr int k = N - 1 - decltype(KK)::value;
+      constexpr int PN = W::pn(k), QN = W::qn(k), c = 2 * N - 2 - k;
+      __syncthreads();                                                  // (A)
+      // next chunk: bw of layer k - 1, or -- the last step -- fw of layer 0 for the workgroup's next pass
+      constexpr int kn = k > 0 ? k - 1 : 0;
+      ChunkLoad<W::pn(kn) * W::qn(kn) * 2048> cl;
+      const bool more = k > 0 || bi + gridDim.x < nbatch;
+      if (more) cl.issue((k > 0 ? bw_img : fw_img) + W::rel_pair(kn) * 2048, slot_of(c + 1), ow, lane);
+      // idx = o + 4 i -> (p, q) = (idx / QN, idx % QN); the four tiles one after the other, the wave's blocks interleaved so that
+      // consecutive MFMAs go to different accumulators
+      {
+        const char* xd[W::nb(k)];
+        const char* xa[W::nb(k)];
+#pragma unroll
+        for (int i = 0; i < W::nb(k); ++i) {
+          const int idx = ow + 4 * i;
+          const int p = idx / QN, q = idx % QN;
+          xd[i] = xr + (p * 2) * 1024;
+          xa[i] = xr + ((HB + q) * 2) * 1024;
+        }
+#pragma unroll
+        for (int w4 = 0; w4 < 4; ++w4) {
+#pragma unroll
+          for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int i = 0; i < W::nb(k); ++i)
+              if (ow + 4 * i < PN * QN)                                 // (wave-uniform)
+                acc[W::aoff(k) + i] = P::mma(*reinterpret_cast<const frag*>(xd[i] + w4 * W::XWAVE + s * 1024),
+                                             *reinterpret_cast<const frag*>(xa[i] + w4 * W::XWAVE + s * 1024), acc[W::aoff(k) + i]);
+          WIDE_FENCE();
+        }
+      }
+      if (more) cl.commit(slot_of(c + 1), ow, lane);
+      __syncthreads();                                                  // (B)
+    });
+    par ^= 1;
+  }
+  // ---------------- the workgroup's row of `partials`: every (layer, block) has exactly one owner ----------------
+  const int hi_j = (j >> 2) & 1, r_j = (j & 3) + 4 * (j >> 3);          // lane j = input slot (hi_j, r_j) of block q
+  static_for<N>([&](auto K) __attribute__((always_inline)) {
+    constexpr int k = decltype(K)::value;
+    constexpr int PN = W::pn(k), QN = W::qn(k);
+    const int l = lbase + k;
+    const int in_dim = d.in_dim[l], out_dim = d.out_dim[l];
+#pragma unroll
+    for (int i = 0; i < W::nb(k); ++i) {
+      const int idx = ow + 4 * i;
+      if (idx < PN * QN) {
+        const int p = idx / QN, q = idx % QN;
+        const int col = inmap(d, l, q, hi_j, r_j);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int orow = 32 * p + nloc(hi, r);
+          if (col >= 0 && orow < out_dim) dst[d.w_off[l] + orow * in_dim + col] = acc[W::aoff(k) + i][r] * gunscale;
+        }
+      }
+    }
+  });
+}
+
+template <class P, int HB, int NET, int N>
+__global__ __launch_bounds__(512, 2) void k_wide_bwd_net(NofMlpDesc d, const char* __restrict__ image,
+                                                          const float2* __restrict__ feat, const typename P::elem* __restrict__ featq,
+                                                          int L, const typename P::elem* __restrict__ sig,
+                                                          const float* __restrict__ view, int S, const float4* __restrict__ draw,
+                                                          typename P::elem* __restrict__ dsig, float2* __restrict__ dfeat,
+                                                          float* __restrict__ dview, float* __restrict__ partials, int64_t B,
+                                                          const void* __restrict__ tile_list) {
+  typedef WNet<HB, NET, N> W;
+  static_assert(P::KR == 8, "16-bit operand types");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave_s = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int lbase = NET ? d.n_sigma : 0, NL = d.n_sigma + d.n_color;
+  const int PA = pair_base(d, lbase), NPALL = pair_base(d, NL), OA = oblk_base(d, lbase);
+  const char* __restrict__ fw_img = image + (size_t)PA * 2048;
+  const char* __restrict__ bw_img = image + (size_t)(NPALL + PA) * 2048;
+  // biases of the layers the recompute runs (k < N - 1)
+  copy16(smem + W::BIASB, image + 2 * (size_t)NPALL * 2048 + (size_t)OA * 128, (size_t)(N - 1) * HB * 128);
+  const int64_t ntiles = (B + 31) / 32;
+  const TileWork work(tile_list, ntiles);
+  const int64_t nbatch = (work.n + 3) / 4;                              // four tiles per workgroup pass: one per data wave
+  // Weight chunks: chunk c of a pass = the fw fragments of layer c (c < N - 1), else the bw fragments of layer 2 N - 2 - c; global
+  // chunk g = pass * (2 N - 1) + c sits in ring slot g & 1 = (par + c) & 1 (2 N - 1 is odd: par flips every pass).  Chunk g + 1 is
+  // requested while chunk g is in use, into the slot chunk g - 1 was read from one barrier ago.
+  float* __restrict__ dst = partials + (size_t)blockIdx.x * d.n_params;
+#ifndef NOF_WIDE_ROLES
+#define NOF_WIDE_ROLES 3                                  // (register-budget experiments: 1 = data role only, 2 = owner role only)
+#endif
+  if (wave_s < 4) {
+    if (NOF_WIDE_ROLES & 1) wide_data_role<P, HB, NET, N>(d, smem, wave_s, lane, feat, featq, L, sig, view, S, draw, dsig, dfeat, dview, B, work, nbatch);
+  } else {
+    if ((int64_t)blockIdx.x < nbatch) {
+      ChunkLoad<W::pn(0) * W::qn(0) * 2048> c0;
+      c0.issue(fw_img, smem, wave_s - 4, lane);
+      c0.commit(smem, wave_s - 4, lane);
+    }
+    if (NOF_WIDE_ROLES & 2) wide_owner_role<P, HB, NET, N>(d, smem, wave_s - 4, lane, fw_img, bw_img, dst, lbase, nbatch);
+  }
+  // bias gradients: the four data waves' lane-private sums, wave 0 writes
+  __syncthreads();
+  if (wave_s == 0) {
+    const int hi = lane >> 5, j = lane & 31;
+    const float gunscale = d.grad_scale > 0.0f ? 1.0f / d.grad_scale : 1.0f;
+    const float* red = reinterpret_cast<const float*>(smem + W::DBB) + lane;
+    static_for<N>([&](auto K) __attribute__((always_inline)) {
+      constexpr int k = decltype(K)::value;
+      const int l = lbase + k, out_dim = d.out_dim[l];
+#pragma unroll
+      for (int p = 0; p < W::pn(k); ++p) {
+        const int a = W::rel_oblk(k) + p;
+        float v = ((red[a * 64] + red[(W::NDB + a) * 64]) + red[(2 * W::NDB + a) * 64]) + red[(3 * W::NDB + a) * 64];
+        v += __shfl_xor(v, 32, 64);
+        if (hi == 0 && 32 * p + j < out_dim) dst[d.b_off[l] + 32 * p + j] = v * gunscale;
+      }
+    });
+  }
+}
+
+// =====================================================================================================
+// host side
+// =====================================================================================================
+static int check_wide(const NofMlpDesc* d) {
+  if (int e = check_desc(d)) return e;
+  if (d->precision == 0)
+    return nof_set_error(-1, "mlp (wide path, hidden %d depths %d,%d): 16-bit operand types only (fp32 fragments do not fit LDS)",
+                         d->hidden, d->n_sigma, d->n_color);
+  return 0;
+}
+
+// workspace layout (bytes, 256-aligned): [sig : B * 16 elems][dsig : B * 16 elems] -- the sigma head's output (forward -> colour
+// forward, colour backward) and its gradient (colour backward -> sigma backward), operand precision
+struct WideWs { char *sig, *dsig; int64_t total; };
+static WideWs wide_ws(const NofMlpDesc*, void* base, int64_t B) {
+  auto up = [](int64_t x) { return (x + 255) / 256 * 256; };
+  WideWs w;
+  int64_t off = 0;
+  w.sig = (char*)base + off; off += up(B * 32);
+  w.dsig = (char*)base + off; off += up(B * 32);
+  w.total = off;
+  return w;
+}
+extern "C" int64_t nof_mlp_wide_workspace_bytes(const NofMlpDesc* d, int64_t B) {
+  if (check_wide(d) || B < 0) return -1;
+  return wide_ws(d, nullptr, B).total;
+}
+// rows of `partials`: one per workgroup of the backward kernels = one per compute unit
+extern "C" int nof_mlp_wide_partial_rows(void) { return nof_cu_count(); }
+
+template <class P, int HB>
+static int wide_fwd_launch(const NofMlpDesc* d, const void* packed, const float* feat, int32_t L, const float* view, int32_t S,
+                           float* out, int out_stride, int out_off, const WideWs* ws, bool sdf_only, int64_t B, hipStream_t st) {
+  const int ns = d->n_sigma, nl = d->n_sigma + d->n_color;
+  const size_t pair_bytes = 16 * 64 * 2;
+  const size_t shm_s = (size_t)pair_base(*d, ns) * pair_bytes + (size_t)oblk_base(*d, ns) * 128;
+  const size_t shm_c = (size_t)(pair_base(*d, nl) - pair_base(*d, ns)) * pair_bytes + (size_t)(oblk_base(*d, nl) - oblk_base(*d, ns)) * 128;
+  const int64_t ntiles = (B + 31) / 32;
+  constexpr int NT = WideFwdThreads<HB>::value;
+  const unsigned blocks = (unsigned)(nof_div_up(ntiles, NT / 64) < (int64_t)nof_cu_count() ? nof_div_up(ntiles, NT / 64) : nof_cu_count());
+  typedef typename P::elem elem;
+  auto ks = k_wide_fwd_sigma<P, HB>;
+  if (int e = set_smem(ks, shm_s)) return e;
+  hipLaunchKernelGGL(ks, dim3(blocks), dim3(NT), shm_s, st, *d, (const char*)packed, (const float2*)feat, (int)L, out, out_stride,
+                     out_off, sdf_only ? (elem*)nullptr : (elem*)ws->sig, B);
+  if (!sdf_only) {
+    auto kc = k_wide_fwd_color<P, HB>;
+    if (int e = set_smem(kc, shm_c)) return e;
+    hipLaunchKernelGGL(kc, dim3(blocks), dim3(NT), shm_c, st, *d, (const char*)packed, (const elem*)ws->sig, view, (int)S, out, B);
+  }
+  return 0;
+}
+
+#define WIDE_DISPATCH(FN, ...)                                                                            \
+  if (is_bf16(d->precision)) {                                                                            \
+    if (d->hidden == 128) { if (int e = FN<PrecBF16, 4>(__VA_ARGS__)) return e; }                         \
+    else { if (int e = FN<PrecBF16, 2>(__VA_ARGS__)) return e; }                                          \
+  } else {                                                                                                \
+    if (d->hidden == 128) { if (int e = FN<PrecF16, 4>(__VA_ARGS__)) return e; }                          \
+    else { if (int e = FN<PrecF16, 2>(__VA_ARGS__)) return e; }                                           \
+  }
+
+/* feat [L,B,2], view [R,16] -> raw [B,4]; the sigma head's output stays in `workspace` for nof_mlp_wide_bwd
+ * (workspace: nof_mlp_wide_workspace_bytes(desc, B) bytes, caller-allocated). */
+extern "C" int nof_mlp_wide_fwd(const NofMlpDesc* d, const void* packed, const float* feat, int32_t L, const float* view,
+                                 int32_t S, float* raw, void* workspace, int64_t B, void* stream) {
+  if (int e = check_wide(d)) return e;
+  NOF_ARG(packed && feat && view && raw && workspace && B >= 0 && S >= 1 && L >= 1 && L * 2 == d->in_feat);
+  NOF_ARG((int64_t)L * B * 8 < (1ll << 32));                   // level-major arrays are addressed with 32-bit lane offsets
+  if (B == 0) return 0;
+  const WideWs ws = wide_ws(d, workspace, B);
+  WIDE_DISPATCH(wide_fwd_launch, d, packed, feat, L, view, S, raw, 4, 3, &ws, false, B, (hipStream_t)stream)
+  NOF_LAUNCH_OK();
+  return 0;
+}
+
+/* sigma net only: feat [L,B,2] -> sdf [B] (NeRFSmall.forward_sdf); needs no workspace */
+extern "C" int nof_mlp_wide_sdf(const NofMlpDesc* d, const void* packed, const float* feat, int32_t L, float* sdf, int64_t B,
+                                 void* stream) {
+  if (int e = check_wide(d)) return e;
+  NOF_ARG(packed && feat && sdf && B >= 0 && L >= 1 && L * 2 == d->in_feat);
+  NOF_ARG((int64_t)L * B * 8 < (1ll << 32));                   // level-major arrays are addressed with 32-bit lane offsets
+  if (B == 0) return 0;
+  WIDE_DISPATCH(wide_fwd_launch, d, packed, feat, L, (const float*)nullptr, 1, sdf, 1, 0, (const WideWs*)nullptr, true, B,
+                (hipStream_t)stream)
+  NOF_LAUNCH_OK();
+  return 0;
+}
+
+template <class P, int HB, int NET, int N>
+static int wide_bwd_net_launch(const NofMlpDesc* d, const void* packed, const float* feat, const void* featq, int32_t L,
+                               const float* view, int32_t S, const float* draw, const WideWs* ws, float* dfeat, float* dview,
+                               float* partials, int64_t B, hipStream_t st, const void* tile_list) {
+  typedef typename P::elem elem;
+  typedef WNet<HB, NET, N> W;
+  auto k = k_wide_bwd_net<P, HB, NET, N>;
+  if (int e = set_smem(k, (size_t)W::LDS_BYTES)) return e;
+  hipLaunchKernelGGL(k, dim3((unsigned)nof_cu_count()), dim3(512), (size_t)W::LDS_BYTES, st, *d, (const char*)packed,
+                     (const float2*)feat, (const elem*)featq, (int)L, (const elem*)ws->sig, view, (int)S, (const float4*)draw,
+                     (elem*)ws->dsig, (float2*)dfeat, dview, partials, B, tile_list);
+  return 0;
+}
+template <class P, int HB>
+static int wide_bwd_launch(const NofMlpDesc* d, const void* packed, const float* feat, const void* featq, int32_t L, const float* view,
+                           int32_t S, const float* draw, const WideWs* ws, float* dfeat, float* dview, float* partials, int64_t B,
+                           hipStream_t st, const void* tile_list, int parts) {
+#define WIDE_NET(NET_, n_)                                                                                               \
+  switch (n_) {                                                                                                          \
+    case 2: if (int e = wide_bwd_net_launch<P, HB, NET_, 2>(d, packed, feat, featq, L, view, S, draw, ws, dfeat, dview, partials, B, st, tile_list)) return e; break; \
+    case 3: if (int e = wide_bwd_net_launch<P, HB, NET_, 3>(d, packed, feat, featq, L, view, S, draw, ws, dfeat, dview, partials, B, st, tile_list)) return e; break; \
+    default: if (int e = wide_bwd_net_launch<P, HB, NET_, 4>(d, packed, feat, featq, L, view, S, draw, ws, dfeat, dview, partials, B, st, tile_list)) return e; break; \
+  }
+  if (parts & NOF_WIDE_BWD_COLOR) { WIDE_NET(1, d->n_color) }
+  if (parts & NOF_WIDE_BWD_SIGMA) { WIDE_NET(0, d->n_sigma) }
+#undef WIDE_NET
+  return 0;
+}
+
+/* draw [B,4] -> dfeat [L,B,2] (overwritten), dview [R,16] ACCUMULATED, partials [nof_mlp_wide_partial_rows(), n_params]
+ * overwritten (sum the rows with nof_reduce_partials).  `workspace` as left by nof_mlp_wide_fwd of the same batch. */
+extern "C" int nof_mlp_wide_bwd(const NofMlpDesc* d, const void* packed, const float* feat, int32_t L, const float* view,
+                                 int32_t S, const float* draw, void* workspace, float* dfeat, float* dview, float* partials,
+                                 int64_t B, void* stream) {
+  return nof_mlp_wide_bwd_tiles(d, packed, feat, L, view, S, draw, workspace, dfeat, dview, partials, nullptr, B, stream);
+}
+
+/* the same over a work list (NofTileList): only the listed tiles are computed, four at a time per workgroup; dfeat of unlisted
+ * tiles is not written */
+extern "C" int nof_mlp_wide_bwd_tiles(const NofMlpDesc* d, const void* packed, const float* feat, int32_t L, const float* view,
+                                       int32_t S, const float* draw, void* workspace, float* dfeat, float* dview, float* partials,
+                                       const void* tile_list, int64_t B, void* stream) {
+  return nof_mlp_wide_bwd_parts(d, packed, feat, nullptr, L, view, S, draw, workspace, dfeat, dview, partials, tile_list,
+                                NOF_WIDE_BWD_ALL, B, stream);
+}
+
+/* The same, restricted to `parts` (all on `stream`): the colour net's kernel (needs draw; writes the sigma head's gradient into the
+ * workspace, dview and the colour layers' entries of every partial row) and the sigma net's (needs the colour part; writes dfeat
+ * and the sigma layers' entries).  `featq` (may be NULL): the embedding in operand precision as nof_encode_mlp_wide_fwd leaves it,
+ * [B][2][16] elements, read instead of `feat` (which may then be NULL). */
+extern "C" int nof_mlp_wide_bwd_parts(const NofMlpDesc* d, const void* packed, const float* feat, const void* featq, int32_t L,
+                                       const float* view, int32_t S, const float* draw, void* workspace, float* dfeat, float* dview,
+                                       float* partials, const void* tile_list, int32_t parts, int64_t B, void* stream) {
+  if (int e = check_wide(d)) return e;
+  NOF_ARG(parts >= 0 && parts <= NOF_WIDE_BWD_ALL);
+  NOF_ARG(packed && (feat || featq) && view && draw && workspace && dfeat && dview && partials && B >= 0 && S >= 32 && L * 2 == d->in_feat);
+  NOF_ARG((int64_t)L * B * 8 < (1ll << 32));                   // level-major arrays are addressed with 32-bit lane offsets
+  if (B == 0) return 0;
+  const WideWs ws = wide_ws(d, workspace, B);
+  WIDE_DISPATCH(wide_bwd_launch, d, packed, feat, featq, L, view, S, draw, &ws, dfeat, dview, partials, B, (hipStream_t)stream, tile_list, (int)parts)
+  NOF_LAUNCH_OK();
+  return 0;
+}
+#undef WPAIR

@@ -424,28 +424,11 @@ class NeuralObjectField:
         if tiles is not None and self.backward_tiles == 'all':
             self._call('nof_tile_list_build', None, B, 1, tiles)
         self._set_grad_scale(B)                    # (dview is zero: allocated so, and re-zeroed after its last use in every step)
-        # wide networks: the weight-gradient passes (8 launches that re-read the staged gradients / activations: the longest part
-        # of that backward) only need their own net's data path, and the hash backward only needs dfeat: on a third stream the
-        # colour net's passes run beside the sigma net's data path and both beside the table scatter (captured step: one chain)
-        wide_aux = None
+        # wide networks (hidden 128 / 4 layers): one kernel per network, colour then sigma, forward recomputed and the weight
+        # gradient accumulated on chip (round 6; rounds 3-5: two data kernels + eight weight-gradient passes on a third stream)
         if self.wide:
-            def wide_bwd(parts, tag):
-                self._call('nof_mlp_wide_bwd_parts', C.byref(self.desc), self.packed, b['feat'], self.L, b['view'], S, b['draw'],
-                           b['wide_ws'], b['dfeat'], b['dview'], b['partials'], tiles, parts, B, tag=tag)
-            if dyn:
-                wide_bwd(15, 'nof_mlp_wide_bwd')
-            else:
-                main = self._st
-                wide_aux = self._aux_stream()
-                wide_bwd(1, 'wide_bwd[data colour]')
-                self._after(wide_aux, main, 'aux0')
-                with self._on(wide_aux):
-                    wide_bwd(4, 'wide_bwd[dW colour]')
-                wide_bwd(2, 'wide_bwd[data sigma]')
-                self._after(wide_aux, main, 'aux1')
-                with self._on(wide_aux):
-                    wide_bwd(8, 'wide_bwd[dW sigma]')
-                    self._call('nof_reduce_partials', b['partials'], self.nblk, self.n_mlp, self._seg(self.grads, 'mlp'), self.flags)
+            self._call('nof_mlp_wide_bwd_parts', C.byref(self.desc), self.packed, b['feat'], b['featq'], self.L, b['view'], S, b['draw'],
+                       b['wide_ws'], b['dfeat'], b['dview'], b['partials'], tiles, 3, B, tag='nof_mlp_wide_bwd')
         elif self.fused_forward:
             self._call('nof_mlp_bwd_featq', C.byref(self.desc), self.packed, b['featq'], self.L, b['view'], S, b['draw'], b['sig'],
                        b['dsig'], b['dfeat'], b['dview'], b['partials'], tiles, B, tag='nof_mlp_bwd_tiles')
@@ -471,8 +454,7 @@ class NeuralObjectField:
         adam_done = None                               # flat entries [adam_done) that have had their Adam update already
 
         def reduce_mlp():
-            if wide_aux is None:                                     # (the wide path reduced its rows on its third stream)
-                self._call('nof_reduce_partials', b['partials'], self.nblk, self.n_mlp, self._seg(self.grads, 'mlp'), self.flags)
+            self._call('nof_reduce_partials', b['partials'], self.nblk, self.n_mlp, self._seg(self.grads, 'mlp'), self.flags)
             if self.eikonal:
                 self._call('nof_reduce_partials', b['partials_e'], self.nblk, self.n_mlp, self._seg(self.grads, 'mlp'), self.flags)
 
@@ -535,8 +517,6 @@ class NeuralObjectField:
                 first_hi = self.n_table if compressed else self.n_table + self.n_mlp
                 reduce_mlp()
                 hash_bwd(BIG | SMALL, split, self.L)
-                if wide_aux is not None:                             # the MLP gradient is part of what goes out
-                    self._after(main, wide_aux, 'aux_dp')
                 grad_sync.start(self.grads[a:first_hi], compressed=compressed)
                 with self._on(side):
                     hash_bwd(INPUT, 0, self.L)
@@ -550,7 +530,7 @@ class NeuralObjectField:
                     pose_kernels()
                 # (the LDS levels on a third stream beside both: no gain; the two chains swapped between the streams: 2 % slower; the
                 # MLP row reduction at the HEAD of the second chain: settled 0.417-0.422 vs 0.411)
-                if wide_aux is None and not self.eikonal:
+                if not self.eikonal:
                     hash_bwd(BIG | SMALL, 0, self.L, with_reduce=True)
                 else:
                     hash_bwd(BIG | SMALL, 0, self.L)
@@ -559,8 +539,6 @@ class NeuralObjectField:
                 # here, the rest at the end of the side stream.  Measured: 0.518 vs 0.521 ms at cfg2 (noise), 4.9-5.0 vs 4.7-4.8 ms
                 # at cfg5, where it takes HBM bandwidth from the weight-gradient passes that are the critical path: not done)
             self._after(main, side, 'join')
-            if wide_aux is not None:
-                self._after(main, wide_aux, 'join_aux')
         if self.optimize_poses and float(cfg.get('pose_reg_weight', 0)) > 0:
             self._call('nof_pose_reg', self.pose, self._seg(self.grads, 'pose'), self.F, C.c_float(cfg['pose_reg_weight']),
                        C.c_float(1.0 / self.world_size), self.loss_out)

@@ -281,17 +281,17 @@ int nof_mlp_wide_bwd(const NofMlpDesc* h_desc, const void* packed, const float* 
 int nof_mlp_wide_bwd_tiles(const NofMlpDesc* h_desc, const void* packed, const float* feat, int32_t L, const float* view, int32_t S,
                            const float* draw, void* workspace, float* dfeat, float* dview, float* partials, const void* tile_list,
                            int64_t B, void* stream);
-/* restricted to `parts` (all on `stream`): the data path of the colour net (needs draw; writes dview and the sigma head's gradient),
- * of the sigma net (needs the colour part; writes dfeat), and the two nets' weight-gradient passes, each of which needs only its
- * own net's data part -- so a caller with several streams can run the weight gradients beside the hash backward */
-#define NOF_WIDE_BWD_DATA_COLOR 1
-#define NOF_WIDE_BWD_DATA_SIGMA 2
-#define NOF_WIDE_BWD_DW_COLOR 4
-#define NOF_WIDE_BWD_DW_SIGMA 8
-#define NOF_WIDE_BWD_ALL 15
-int nof_mlp_wide_bwd_parts(const NofMlpDesc* h_desc, const void* packed, const float* feat, int32_t L, const float* view, int32_t S,
-                           const float* draw, void* workspace, float* dfeat, float* dview, float* partials, const void* tile_list,
-                           int32_t parts, int64_t B, void* stream);
+/* restricted to `parts` (all on `stream`): the colour net's kernel (needs draw; writes dview, the sigma head's gradient and the
+ * colour layers' entries of every partial row) and / or the sigma net's (needs the colour part; writes dfeat and the sigma layers'
+ * entries).  `featq` (may be NULL): the embedding in MFMA operand precision and order as nof_encode_mlp_wide_fwd leaves it
+ * ([B][2][16] elements), read instead of the fp32 `feat` [L,B,2] (which may then be NULL).  Round 6: the four-way split of round 3
+ * (data path / weight-gradient passes per network) is gone -- a network's backward is one kernel. */
+#define NOF_WIDE_BWD_COLOR 1
+#define NOF_WIDE_BWD_SIGMA 2
+#define NOF_WIDE_BWD_ALL 3
+int nof_mlp_wide_bwd_parts(const NofMlpDesc* h_desc, const void* packed, const float* feat, const void* featq, int32_t L,
+                           const float* view, int32_t S, const float* draw, void* workspace, float* dfeat, float* dview,
+                           float* partials, const void* tile_list, int32_t parts, int64_t B, void* stream);
 
 /* ---- eikonal option (cfg eikonal_weight > 0; nerf_runner.py:734-738 with the normal of run_network_density, :1342-1345):
  * E = w * mean over {sdf < 1} of (|d sdf / d x| - 1)^2, evaluated with the exact-fp32 MFMA.  h_desc32 / packed32: the network

@@ -117,7 +117,7 @@ def test_mlp_kernels_have_no_inline_assembly_instructions():
     (scheduling / liveness pins)."""
     import re
     src = os.path.join(ROOT, 'bundlesdf_amd', 'csrc')
-    for name in ('nof_mlp.hip', 'nof_mlp_wide.h'):
+    for name in ('nof_mlp.hip', 'nof_mlp_dev.h', 'nof_mlp_wide.hip'):
         text = open(os.path.join(src, name)).read()
         for m in re.finditer(r'asm\s*(?:volatile)?\s*\(\s*"([^"]*)"', text):
             assert m.group(1).strip() == '', (name, m.group(1))
@@ -252,7 +252,7 @@ def test_hot_kernels_have_no_scratch():
             bad.append((short, md['private_segment_fixed_size'], md['vgpr_spill_count']))
     assert not bad, bad
     for k in ('k_hash_fwd', 'k_hash_bwd_agg', 'k_hash_bwd_lds', 'k_hash_dx', 'k_batch_trace', 'k_sample_points', 'k_mlp_fwd',
-              'k_mlp_bwd_sigma', 'k_mlp_bwd_color', 'k_composite_loss', 'k_loss_reduce', 'k_adam', 'k_wide_dw', 'k_wide_fwd_sigma',
+              'k_mlp_bwd_sigma', 'k_mlp_bwd_color', 'k_composite_loss', 'k_loss_reduce', 'k_adam', 'k_wide_bwd_net', 'k_wide_fwd_sigma',
               'k_pose_grad_accum', 'k_pose_reduce_bwd', 'k_reduce_partials', 'k_sdf_grid', 'k_mc_emit'):
         assert k in seen, k                                            # (the metadata reader really saw the library's kernels)
 
