@@ -405,13 +405,15 @@ def main():
         import gc
         gc.collect()
         gc.disable()
-        barrier()
-        t0 = time.perf_counter()
-        for _ in range(n):
-            step()
-        barrier()
-        dt = time.perf_counter() - t0
-        gc.enable()
+        try:                                                           # (an exception in step() must not leave the collector off)
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(n):
+                step()
+            barrier()
+            dt = time.perf_counter() - t0
+        finally:
+            gc.enable()
         if world > 1:
             t = torch.tensor([dt], device=device, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)

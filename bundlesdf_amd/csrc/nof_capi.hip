@@ -25,4 +25,4 @@ int nof_cu_count(void) {
 }
 
 extern "C" const char* nof_last_error(void) { return g_nof_err; }
-extern "C" int nof_version(void) { return 100; }
+extern "C" int nof_version(void) { return NOF_ABI_VERSION; }

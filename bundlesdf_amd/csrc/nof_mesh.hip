@@ -270,7 +270,7 @@ __device__ __constant__ int kMclEdge[12][2] = {{0, 1}, {1, 2}, {2, 3}, {3, 0}, {
 __device__ __constant__ int kMclPar[12][8] = {{0, 1, 3, 2, 7, 6, 4, 5}, {1, 2, 0, 3, 4, 7, 5, 6}, {2, 3, 1, 0, 5, 4, 6, 7}, {3, 0, 2, 1, 6, 5, 7, 4},
                                              {4, 5, 0, 1, 3, 2, 7, 6}, {5, 6, 1, 2, 0, 3, 4, 7}, {6, 7, 2, 3, 1, 0, 5, 4}, {7, 4, 3, 0, 2, 1, 6, 5},
                                              {0, 4, 3, 7, 2, 6, 1, 5}, {1, 5, 0, 4, 3, 7, 2, 6}, {2, 6, 1, 5, 0, 4, 3, 7}, {3, 7, 2, 6, 1, 5, 0, 4}};
-#define MCL_EPS 1.1920928955078125e-07                                  /* FLT_EPSILON, as a double */
+#define MCL_EPS 2.220446049250313e-16   /* scikit-image's 'FLT_EPSILON' = np.spacing(1.0): the weights 1 / (eps + |value|) are an exact linear interpolation */
 
 struct MclCell {
   double c[8];                                                         // corner values minus the iso value, Lewiner's corner order

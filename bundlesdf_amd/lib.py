@@ -142,6 +142,7 @@ _SIGNATURES = {
     'nof_texture_bake_frame': ([_P, _P, _I32, _I32, _P, _P, _I64, _P, _P, _P, _F, _I32, _P, _P, _P, _P, _P], C.c_int),
 }
 OPTIONAL = set()
+ABI_VERSION = 120           # include/nof_hip.h: NOF_ABI_VERSION
 
 _lib = None
 
@@ -155,10 +156,19 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.environ.get('NOF_LIB') and os.path.isdir(os.path.join(_HERE, 'csrc')):
-        # a library that lags its sources (content digest, build.py) is rebuilt before it is loaded: what runs is what is in the tree
+    if not os.environ.get('NOF_LIB') and not os.environ.get('NOF_NO_REBUILD') and os.path.isdir(os.path.join(_HERE, 'csrc')):
+        # a library that lags its sources (content digest, build.py) is rebuilt before it is loaded: what runs is what is in the tree.
+        # Where that is not possible (no hipcc on the box, a read-only package directory, a compile error in a tree someone is
+        # editing) an EXISTING library is still loaded -- with a warning that names it stale; only a missing library raises.
         from . import build as _build
-        _build.build(verbose=False)
+        try:
+            _build.build(verbose=False)
+        except Exception as e:                                         # noqa: BLE001 (hipcc missing, lock file not writable, compile error)
+            if not os.path.exists(LIB_PATH):
+                raise
+            import warnings
+            warnings.warn(f'{LIB_PATH} could not be checked against / rebuilt from its sources ({type(e).__name__}: {e}); '
+                          'loading the existing library, which may be STALE', RuntimeWarning)
     if not os.path.exists(LIB_PATH):
         raise NofError(f'{LIB_PATH} is missing: run `python -m bundlesdf_amd.build` (hipcc --offload-arch=gfx950). '
                        'There is no CPU fallback for the Neural Object Field hot path.')
@@ -174,6 +184,10 @@ def load():
             raise NofError(f'{LIB_PATH} does not export {name}; rebuild it')
         fn.argtypes = args
         fn.restype = res
+    # the header this table was written against (include/nof_hip.h: NOF_ABI_VERSION): a library of another ABI would take these
+    # argument lists apart differently
+    if lib.nof_version() != ABI_VERSION:
+        raise NofError(f'{LIB_PATH} has ABI version {lib.nof_version()}, this binding was written for {ABI_VERSION}; rebuild it')
     _lib = lib
     return lib
 

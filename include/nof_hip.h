@@ -33,6 +33,12 @@ extern "C" {
 #define NOF_VIEW_COLS 16         /* per-ray view vector: [frame_features(ff) | SH(9) | 0 pad] */
 
 const char* nof_last_error(void);
+/* ABI version of THIS header (nof_version() returns the library's): bumped whenever a signature or a struct layout changes, so that
+ * an out-of-tree caller built against another header can refuse to run instead of passing misaligned arguments.
+ *   100  rounds 1-4
+ *   110  round 5: nof_batch_trace gained `marcher` (in the middle of its argument list); NofSampleCfg gained `marcher` (trailing)
+ *   120  round 6: nof_mlp_wide_bwd_parts gained `featq`; the wide networks' workspace holds the sigma head's hand-off only */
+#define NOF_ABI_VERSION 120
 int nof_version(void);
 
 /* ---- multires hash grid (replaces gridencoder.*) --------------------------------------------- */

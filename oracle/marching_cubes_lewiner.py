@@ -22,7 +22,10 @@ import os
 import numpy as np
 
 _L = {k: v.astype(np.int64) for k, v in np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'lewiner_luts.npz')).items()}
-FLT_EPSILON = float(np.finfo(np.float32).eps)
+# scikit-image 0.18.3's Cython source names this FLT_EPSILON but defines it as np.spacing(1.0) = 2.2e-16 (double precision): its
+# edge vertices are exact linear interpolations down to |value| ~ 1e-15 (pinned by the near-iso cells of the fixture, whose
+# POSITIONS are compared at 2e-7 voxel; with binary32's 1.19e-7 here a vertex between -1e-4 and 3e-4 sat at 0.25015 instead of 0.25)
+FLT_EPSILON = float(np.spacing(1.0))
 # corner p -> (di, dj, dk)
 CORNER = np.array([(0, 0, 0), (0, 0, 1), (0, 1, 1), (0, 1, 0), (1, 0, 0), (1, 0, 1), (1, 1, 1), (1, 1, 0)], dtype=np.int64)
 EDGE = np.array([(0, 1), (1, 2), (2, 3), (3, 0), (4, 5), (5, 6), (6, 7), (7, 4), (0, 4), (1, 5), (2, 6), (3, 7)], dtype=np.int64)

@@ -105,6 +105,26 @@ for case in range(1, 255):
         n_tiny += 1
 out.update(amb_values=np.array(xv), amb_tris=np.array(xt), amb_ntris=np.array(xn, np.int8))
 print('ambiguous-configuration cells', len(xv), 'of which with tiny magnitudes', n_tiny)
+# (1d) every configuration with magnitudes CLOSE TO THE ISO VALUE (1e-6 ... 1e-3), vertex POSITIONS kept: scikit-image places an edge
+# vertex with weights 1 / (eps + |value|) where its eps is np.spacing(1.0) = 2.2e-16 (its Cython source calls it FLT_EPSILON), i.e. an
+# exact linear interpolation; with binary32's 1.19e-7 in its place the vertex moves by 1e-4 ... 1e-2 of a voxel at these magnitudes
+# (ADVICE r5).  Its own generator: the arrays above keep their bytes.
+rng_d = np.random.default_rng(20260930)
+nv_, nvv, nnv, nf_, nnf = [], [], [], [], []
+for case in range(1, 255):
+    sign = np.array([1.0 if (case >> p) & 1 else -1.0 for p in range(8)])
+    for k in range(6):
+        mag = np.exp(rng_d.uniform(np.log(1e-6), np.log(1e-3), size=8))
+        vol = (sign * mag).astype(np.float32).reshape(2, 2, 2)
+        v, f, _, _ = measure.marching_cubes(vol, 0.0)
+        pv = np.full((16, 3), np.nan, np.float32)
+        pf = np.full((16, 3), -1, np.int32)
+        pv[:len(v)] = v
+        pf[:len(f)] = f
+        nv_.append(vol.reshape(8)); nvv.append(pv); nnv.append(len(v)); nf_.append(pf); nnf.append(len(f))
+out.update(near_values=np.array(nv_), near_verts=np.array(nvv), near_nverts=np.array(nnv, np.int32), near_faces=np.array(nf_),
+           near_nfaces=np.array(nnf, np.int32))
+print('near-iso cells', len(nv_))
 n = 20
 x, y, z = np.mgrid[-1:1:n * 1j, -1:1:n * 1j, -1:1:n * 1j]
 vols = {

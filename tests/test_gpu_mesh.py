@@ -268,6 +268,19 @@ def test_lewiner_gpu_equals_skimage_on_single_cells(nof):
         assert _canon_tris(np.array(eid)[f]) == _canon_tris(T[i][:N[i]]), i
 
 
+def test_lewiner_gpu_vertex_positions_close_to_the_iso_value(nof):
+    """corner values of 1e-6 ... 1e-3 (every configuration x 6): scikit-image's vertex positions to 2e-7 voxel (its interpolation
+    epsilon is np.spacing(1.0), not binary32's)"""
+    from bundlesdf_amd.mesh_gpu import marching_cubes_lewiner_gpu
+    from tests.test_mesh import _mc_golden, same_mesh
+    G = _mc_golden()
+    vals, gv, gnv, gf, gnf = G['near_values'], G['near_verts'], G['near_nverts'], G['near_faces'], G['near_nfaces']
+    for i in range(0, len(vals), 2):
+        v, f = marching_cubes_lewiner_gpu(torch.from_numpy(vals[i].reshape(2, 2, 2).copy()).cuda(), 0.0)
+        ok, why = same_mesh(v, f, gv[i][:gnv[i]], gf[i][:gnf[i]], tol=2e-7)
+        assert ok, (i, why)
+
+
 @pytest.mark.parametrize("shape_", [(33, 29, 31), (64, 64, 64)])
 def test_lewiner_gpu_equals_the_oracle_on_rough_volumes(nof, shape_):
     """random fields with many ambiguous cells (volumes the fixture does not hold): device == oracle, vertex for vertex and triangle

@@ -344,6 +344,20 @@ def test_lewiner_oracle_equals_skimage_on_every_sign_configuration():
         assert ok, (i, why)
 
 
+def test_lewiner_oracle_vertex_positions_close_to_the_iso_value():
+    """254 configurations x 6 magnitude sets in 1e-6 ... 1e-3: scikit-image's vertex POSITIONS to 2e-7 voxel -- its weights
+    1 / (eps + |value|) use eps = np.spacing(1.0), an exact linear interpolation; binary32's epsilon in its place moves these
+    vertices by up to 1e-2 voxel (the fixture's other cells have magnitudes >= 0.03 or compare edge ids only)."""
+    from oracle import marching_cubes_lewiner as ML
+    G = _mc_golden()
+    vals, gv, gnv, gf, gnf = G['near_values'], G['near_verts'], G['near_nverts'], G['near_faces'], G['near_nfaces']
+    assert len(vals) == 254 * 6 and float(np.abs(vals).max()) <= 1e-3
+    for i in range(len(vals)):
+        v, f = ML.marching_cubes(vals[i].reshape(2, 2, 2), 0.0)
+        ok, why = same_mesh(v, f, gv[i][:gnv[i]], gf[i][:gnf[i]], tol=2e-7)
+        assert ok, (i, why)
+
+
 def test_lewiner_oracle_equals_skimage_on_the_ambiguous_configurations():
     """50 000 cells of the configurations whose tiling depends on the magnitudes (Lewiner's cases 3, 4, 6, 7, 10, 12, 13; 4000 each
     for the two 'case 13' configurations), 5000 of them with TINY magnitudes (determinants of the face and interior tests on both sides

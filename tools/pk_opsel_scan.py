@@ -14,11 +14,15 @@ import tempfile
 
 OBJDUMP = '/opt/rocm/lib/llvm/bin/llvm-objdump'
 MAGIC = b'__CLANG_OFFLOAD_BUNDLE__'
-PK = re.compile(r'\b(v_pk_(?:mul|add|fma)_f32)\s+(.*)$')
+PK = re.compile(r'\b(v_pk_(?:mul|add|fma)_f32)\s+(.*)$')        # the packed-fp32 arithmetic forms of gfx950 (the ones the reproducer measured)
 
 
 def code_objects(lib_path):
+    """the gfx950 code objects of the library's (uncompressed) clang offload bundles; raises if the library holds no such bundle --
+    a compressed bundle (magic CCOB) or a changed layout must not read as 'nothing found'"""
     d = open(lib_path, 'rb').read()
+    if MAGIC not in d:
+        raise RuntimeError(f'{lib_path}: no uncompressed clang offload bundle' + (' (compressed bundle: CCOB)' if b'CCOB' in d else ''))
     pos = 0
     while True:
         i = d.find(MAGIC, pos)
@@ -43,29 +47,44 @@ def hazardous(operands):
     return any(sel[1:])
 
 
-def scan(lib_path):
-    """[(kernel symbol, instruction text)] of every hazardous instruction in the library's device code"""
+def scan(lib_path, stats=None):
+    """[(kernel symbol, instruction text)] of every hazardous instruction in the library's device code.  `stats` (a dict) receives
+    what was actually looked at -- code_objects, kernels, instructions, mfma, packed_f32 -- so that a caller can tell an empty result
+    from a scan that saw nothing."""
     hits = []
+    st = dict(code_objects=0, kernels=0, instructions=0, mfma=0, packed_f32=0)
     with tempfile.TemporaryDirectory() as tmp:
         for k, co in enumerate(code_objects(lib_path)):
             path = os.path.join(tmp, f'{k}.co')
             open(path, 'wb').write(co)
             txt = subprocess.run([OBJDUMP, '-d', '--no-show-raw-insn', path], capture_output=True, text=True, check=True).stdout
             sym = None
+            st['code_objects'] += 1
             for ln in txt.splitlines():
                 m = re.match(r'^[0-9a-f]+ <(\S+)>:', ln)
                 if m:
                     sym = m.group(1)
+                    st['kernels'] += 1
                     continue
+                if sym is None or not ln.startswith('\t'):
+                    continue
+                st['instructions'] += 1
+                st['mfma'] += 'v_mfma_' in ln
                 m = PK.search(ln)
-                if m and hazardous(m.group(2)):
-                    hits.append((sym, m.group(0).strip()))
+                if m:
+                    st['packed_f32'] += 1
+                    if hazardous(m.group(2)):
+                        hits.append((sym, m.group(0).strip()))
+    if stats is not None:
+        stats.update(st)
     return hits
 
 
 if __name__ == '__main__':
     lib = sys.argv[1] if len(sys.argv) > 1 else os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'bundlesdf_amd', 'libnof_hip.so')
-    hits = scan(lib)
+    st = {}
+    hits = scan(lib, st)
+    print(st)
     per = {}
     for sym, ins in hits:
         per.setdefault(sym, []).append(ins)
@@ -74,4 +93,4 @@ if __name__ == '__main__':
         for i in sorted(set(ins))[:4]:
             print('        ', i)
     print(f'{len(hits)} packed-fp32 instructions with op_sel on source 1 in {len(per)} kernels of {lib}')
-    sys.exit(1 if hits else 0)
+    sys.exit(1 if hits or not st['instructions'] else 0)
