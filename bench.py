@@ -187,19 +187,25 @@ def extra_configs():
                       '--precision', 'fp16']),
             # configs[0]'s shapes on the GPU: the same workload the cpu_baseline leg of a `--rays 1024 --log2_T 14 --mlp reference`
             # run times ("also run the GPU path at cfg1 shapes for an apples-to-apples ratio"); 4 keyframes as BASELINE says
-            ('cfg1_shapes', ['--rays', '1024', '--log2_T', '14', '--mlp', 'reference', '--keyframes', '4']),
+            # ... and the CPU leg at these shapes in the same sub-record (BASELINE configs[0] is "the reference's own CPU-runnable
+            # case"): `cpu_baseline` of the child = the oracle's step at 1024 rays, T = 2^14, 2+3 layers, for ~8 s
+            ('cfg1_shapes', ['--rays', '1024', '--log2_T', '14', '--mlp', 'reference', '--keyframes', '4', '--with-cpu-baseline',
+                             '--cpu-seconds', '8']),
             # configs[1] names bf16: the headline runs the reference's own autocast type (fp16, operands split hi + lo); the same
             # workload with bfloat16 operands split the same way (parity-tested at full size like fp16x3)
             ('cfg2_bf16', ['--precision', 'bf16x3'])]
     keep = ('value', 'unit', 'ms_per_step', 'steps', 'warmup', 'dtype', 'ms_per_step_dense_backward', 'zero_grad_sample_fraction',
-            'train_iters_per_sec', 'loss', 'flags', 'step_ms_spread', 'extraction')
+            'train_iters_per_sec', 'loss', 'flags', 'step_ms_spread', 'extraction', 'cpu_baseline', 'ms_per_step_p50_timed')
     out = []
     for name, extra in runs:
         try:
             r = subprocess.run([sys.executable, os.path.abspath(__file__)] + common + extra, capture_output=True, text=True, timeout=600)
             d = json.loads(r.stdout.strip().splitlines()[-1])
-            out.append({"name": name, **{k: d.get(k) for k in keep if k in d}, "workload": d['config']['workload'].split(';')[0],
-                        "roofline": {k: d['roofline'].get(k) for k in ('kernel', 'bound', 'frac', 'avg_ms')} if d.get('roofline') else None})
+            rec = {"name": name, **{k: d.get(k) for k in keep if k in d}, "workload": d['config']['workload'].split(';')[0],
+                   "roofline": {k: d['roofline'].get(k) for k in ('kernel', 'bound', 'frac', 'avg_ms')} if d.get('roofline') else None}
+            if d.get('cpu_baseline'):                 # SURVEY 8d's apples-to-apples ratio: the same shapes on both sides
+                rec["gpu_over_cpu"] = d['value'] / d['cpu_baseline']['value']
+            out.append(rec)
         except Exception as ex:                       # a sub-record must never cost the main line
             out.append({"name": name, "error": repr(ex)[:300]})
     return out
@@ -286,6 +292,7 @@ def main():
     ap.add_argument('--extract', type=int, default=0, help='after the timed steps: time the dense SDF query + marching cubes of an N^3 grid (BASELINE cfg4: 512)')
     ap.add_argument('--scatter-wgs', type=int, default=0, help='persistent workgroups per CU of the table scatter (0 = library default)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--with-cpu-baseline', action='store_true', help='overrides --no-cpu-baseline (the cfg1-shapes sub-record)')
     ap.add_argument('--trace-kernel', type=int, default=None, help='ray marcher of the step (NofSampleCfg.marcher): 0 = one lane per ray (walk), 1 = one wave per ray (the default)')
     ap.add_argument('--cpu-seconds', type=float, default=25.0)
     args = ap.parse_args()
@@ -405,15 +412,22 @@ def main():
         import gc
         gc.collect()
         gc.disable()
+        marks = []
         try:                                                           # (an exception in step() must not leave the collector off)
             barrier()
             t0 = time.perf_counter()
             for _ in range(n):
                 step()
+                marks.append(time.perf_counter())                      # (50 ns: when the host finished enqueueing the step)
             barrier()
             dt = time.perf_counter() - t0
         finally:
             gc.enable()
+        # the host enqueues a step in about the time the device needs for one, i.e. under the back-pressure of a full
+        # queue its per-step enqueue intervals follow the device's step times: their median and maximum make a one-off stall inside
+        # the region visible in the record itself (round 5: one driver-style run in eleven read a MEAN of 0.73 instead of 0.47)
+        iv = np.diff(np.array([t0] + marks)) * 1e3
+        timed.host_intervals = {"p50": float(np.median(iv)), "max": float(iv.max()), "n": int(len(iv))} if len(iv) else None
         if world > 1:
             t = torch.tensor([dt], device=device, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -427,7 +441,8 @@ def main():
     # (501 steps from a fresh field, config.yml:2) are reported beside it under their own names.
     zero_first = zero_fraction() if args.warmup > 0 else None
     dt = timed(args.steps)
-    log(f'timed region done: {dt / args.steps * 1e3:.3f} ms/step')
+    timed_intervals = timed.host_intervals
+    log(f'timed region done: {dt / args.steps * 1e3:.3f} ms/step; host enqueue intervals {timed_intervals}')
     # The parameters after exactly W + K steps: what the tests compare between the forms of the data-parallel step.  Taken HERE and
     # not at the end of the run: Adam with eps = 1e-15 (the reference's) turns the first rounding-noise gradient of a so far dead
     # weight into a full +-lr step, and an MLP weight that wakes up that way moves everything downstream -- 3 of 16 otherwise
@@ -668,6 +683,10 @@ def main():
                        "rays_per_step": R, "samples_per_ray": S, "keyframes_per_gpu": args.keyframes,
                        "pool_rays": int(runner.rays.shape[0]), "parallelism": f"dp{world}",
                        "forward": "fused encode+MLP (nof_encode_mlp_fwd)" if fld.fused_forward else "nof_hash_encode_fwd + nof_mlp_fwd"},
+            # the timed region's per-step HOST enqueue intervals (median / largest): a mean far above the median = a one-off stall
+            # inside the region, not the steady step
+            "ms_per_step_p50_timed": timed_intervals["p50"] if timed_intervals else None,
+            "ms_step_max_timed": timed_intervals["max"] if timed_intervals else None,
             "train_iters_per_sec": it_s * 1.0, "captured_step_ms_per_step": graph_ms, "captured_step_one_chain_ms_per_step": graph_alt_ms,
             # forward-only batches run before the warm-up steps (no parameter / optimiser / loader / RNG state touched)
             "preroll_forward_batches": args.preroll,
@@ -701,7 +720,7 @@ def main():
         default_workload = shape_key == (64, 4096, 19, 'baseline', 640, 480)
         if world == 1 and default_workload and not args.no_extra_configs and not dist.is_initialized():
             out["extra_configs"] = extra_configs()
-        if not args.no_cpu_baseline and world == 1:          # the CPU leg is timed on rank 0 at N = 1 only
+        if (not args.no_cpu_baseline or args.with_cpu_baseline) and world == 1:          # the CPU leg is timed on rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline(args.cpu_seconds, R, args.log2_T, args.mlp, args.finest)
         print(json.dumps(out), flush=True)
     if dist.is_initialized():

@@ -198,8 +198,12 @@ def build_variant(name, defines, sources=('nof_mlp.hip',), verbose=True):
 
 
 if __name__ == '__main__':
-    if '--variant' in sys.argv:                      # python -m bundlesdf_amd.build --variant NAME DEFINE[=V] ...
+    if '--variant' in sys.argv:                      # python -m bundlesdf_amd.build --variant NAME [--sources a.hip,b.hip] DEFINE[=V] ...
         i = sys.argv.index('--variant')
-        print(build_variant(sys.argv[i + 1], sys.argv[i + 2:]))
+        rest = sys.argv[i + 2:]
+        srcs = ('nof_mlp.hip',)
+        if rest and rest[0] == '--sources':
+            srcs, rest = tuple(rest[1].split(',')), rest[2:]
+        print(build_variant(sys.argv[i + 1], rest, sources=srcs))
     else:
         print(build(force='--force' in sys.argv))

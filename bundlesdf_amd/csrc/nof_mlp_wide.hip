@@ -61,6 +61,29 @@ __device__ __forceinline__ void relu_inplace(float (&h)[PN][16]) {
     }
 }
 
+// ---- ReLU and its derivative on PACKED 16-bit operands (round 6).  relu(round16(x)) == round16(relu(x)) for both operand types
+//      (rounding keeps sign and zero), so the backward kernel rounds first and clamps the packed halves: one v_pk_ashrrev_i16 +
+//      one v_and (v_bfi) per PAIR instead of a v_max + a v_alignbit per element, and no derivative bit words -- the recomputed
+//      activation itself (kept for the weight gradient anyway) says which units were on: a > 0 <=> the half's bits are non-zero.
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+template <class F>
+__device__ __forceinline__ F relu_pk(F x) {
+  asm volatile("" : "+v"(x));        // (no instruction: the packed conversion result as four registers -- otherwise the combiner converts
+                                     //  every half on its own and re-assembles the pairs with v_perm: 28 instead of 8 instructions per block)
+  const s16x8 b = __builtin_bit_cast(s16x8, x);
+  const s16x8 neg = b >> 15;                                             // 0xffff where the half is negative (incl. -0)
+  return __builtin_bit_cast(F, (s16x8)(b & ~neg));
+}
+// g where the (post-ReLU, non-negative) activation a is non-zero, else +0
+template <class F>
+__device__ __forceinline__ F mask_pk(F g, F a) {
+  asm volatile("" : "+v"(g));
+  const s16x8 ab = __builtin_bit_cast(s16x8, a);
+  // a in 0x0001 .. 0x7fff -> max(-a, -1) = -1 = 0xffff; a = 0 -> 0   (v_pk_sub_i16 + v_pk_max_i16 + v_and per pair)
+  const s16x8 on = __builtin_elementwise_max((s16x8)((s16x8)(0) - ab), (s16x8)(-1));
+  return __builtin_bit_cast(F, (s16x8)(__builtin_bit_cast(s16x8, g) & on));
+}
+
 #define WPAIR ((int)(16 * 64 * sizeof(typename P::elem)))
 
 // =====================================================================================================
@@ -179,7 +202,8 @@ struct WNet {
   static constexpr int SLOTB = slot_pairs() * 2048;                     // bytes of one ring slot
   static constexpr int XWAVE = 2 * HB * 2048;                           // exchange bytes per wave: HB delta blocks + HB input blocks
   static constexpr int XB = 2 * SLOTB, BIASB = XB + 4 * XWAVE, DBB = BIASB + (N - 1) * HB * 128;   // DBB: [wave][NDB][64] floats
-  static constexpr int LDS_BYTES = DBB + 4 * NDB * 256;
+  static constexpr int IDB = DBB + 4 * NDB * 256;                        // identity fragments of the MFMA transposes (2 KB)
+  static constexpr int LDS_BYTES = IDB + 2048;
 };
 
 // the scheduler of a 512-register kernel hoists every LDS read it can see (all blocks' weight fragments, all tiles' operands) in
@@ -279,13 +303,13 @@ __device__ __forceinline__ void pack_blk(const float (&x)[16], typename P::frag 
 // a sample-per-lane block (two operand fragments) -> slot-per-lane on the matrix core (transpose32 of nof_mlp_dev.h on packed
 // operands: x 1 + 0 is exact), as two operand fragments of the sample-contracted MFMA; returns the sum of the lane's 16 values
 // (lane = neuron: its bias gradient over the tile's samples)
-template <class P>
-__device__ __forceinline__ float transpose_pk(const Ident<P>& I, const typename P::frag (&x)[2], typename P::frag (&y)[2]) {
+template <class P, class ID>
+__device__ __forceinline__ float transpose_pk(const ID& I, const typename P::frag (&x)[2], typename P::frag (&y)[2]) {
   f32x16 t;
 #pragma unroll
   for (int r = 0; r < 16; ++r) t[r] = 0.0f;
-  t = P::mma(x[0], I.f[0], t);
-  t = P::mma(x[1], I.f[1], t);
+  t = P::mma(x[0], ident_frag<P>(I, 0), t);
+  t = P::mma(x[1], ident_frag<P>(I, 1), t);
   float v[16];
 #pragma unroll
   for (int r = 0; r < 16; ++r) v[r] = t[r];
@@ -309,8 +333,8 @@ __device__ __forceinline__ void wide_data_role(const NofMlpDesc& d, char* smem, 
   typedef WNet<HB, NET, N> W;
   typedef typename P::frag frag;
   const int hi = lane >> 5, j = lane & 31;
-  Ident<P> I;
-  I.init(lane);
+  IdentLds<P> I;                                                        // (in LDS, read where used: eight registers less across the pass)
+  I.base = reinterpret_cast<const typename P::frag*>(smem + W::IDB) + lane;
   const float gscale = d.grad_scale > 0.0f ? d.grad_scale : 1.0f, gunscale = 1.0f / gscale;
   // this wave's bias-gradient sums (its own tiles; lane = neuron): lane-private LDS words, no register across the passes
   float* const db = reinterpret_cast<float*>(smem + W::DBB) + wave_s * W::NDB * 64 + lane;
@@ -342,29 +366,22 @@ __device__ __forceinline__ void wide_data_role(const NofMlpDesc& d, char* smem, 
     };
     // ---------------- forward recompute: a[k] = relu(W_k a[k-1] + b_k), k < N - 1 ----------------
     frag a[N - 1][HB][2];
-    uint2 bits[N - 1];
     static_for<N - 1>([&](auto K) __attribute__((always_inline)) {
       constexpr int k = decltype(K)::value;
       frag x0[W::QN0][2];
       if constexpr (k == 0) load_x0(x0);
       __syncthreads();                                                  // chunk k is in its slot
       const char* wl = slot_of(k) + lane * 16;
-      uint32_t off[2] = {0u, 0u};
 #pragma unroll
       for (int p = 0; p < HB; ++p) {                                    // block by block: 16 fp32 values live, not 64
         float h[1][16];
         if constexpr (k == 0) dense_pk<P, W::QN0, 1>(wl + p * W::QN0 * 2048, bias_hi + (W::rel_oblk(k) + p) * 128, x0, h);
         else dense_pk<P, HB, 1>(wl + p * HB * 2048, bias_hi + (W::rel_oblk(k) + p) * 128, a[k - 1], h);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {                                  // relu_bits, one block
-          const int hb = __float_as_int(h[0][r]);
-          off[p >> 1] = __builtin_amdgcn_alignbit(off[p >> 1], (uint32_t)hb, 31);
-          h[0][r] = __int_as_float(hb > 0 ? hb : 0);
-        }
-        pack_blk<P>(h[0], a[k][p]);
+        pack_blk<P>(h[0], a[k][p]);                                     // round, then ReLU on the packed halves (relu_pk)
+        a[k][p][0] = relu_pk(a[k][p][0]);
+        a[k][p][1] = relu_pk(a[k][p][1]);
         WIDE_FENCE();
       }
-      bits[k] = make_uint2(~off[0], HB == 4 ? ~off[1] : 0u);
     });
     // ---------------- the head's gradient ----------------
     frag g[HB][2];                                                      // delta of the layer the walk is at (block 0 only for the head)
@@ -418,8 +435,9 @@ __device__ __forceinline__ void wide_data_role(const NofMlpDesc& d, char* smem, 
         for (int q = 0; q < HB; ++q) {
           float gq[16];
           bwd_pk<P, PN>(wl, q, g, gq);
-          apply_bits_blk(gq, bits[k - 1], q);
-          pack_blk<P>(gq, gn[q]);
+          pack_blk<P>(gq, gn[q]);                                       // round, then the ReLU derivative from the activation itself
+          gn[q][0] = mask_pk(gn[q][0], a[k - 1][q][0]);
+          gn[q][1] = mask_pk(gn[q][1], a[k - 1][q][1]);
           WIDE_FENCE();
         }
 #pragma unroll
@@ -576,6 +594,7 @@ __global__ __launch_bounds__(512, 2) void k_wide_bwd_net(NofMlpDesc d, const cha
 #ifndef NOF_WIDE_ROLES
 #define NOF_WIDE_ROLES 3                                  // (register-budget experiments: 1 = data role only, 2 = owner role only)
 #endif
+  { IdentLds<P> I0; I0.build(smem + W::IDB, lane); }                     // (wave 0 writes; the roles' first barrier publishes)
   if (wave_s < 4) {
     if (NOF_WIDE_ROLES & 1) wide_data_role<P, HB, NET, N>(d, smem, wave_s, lane, feat, featq, L, sig, view, S, draw, dsig, dfeat, dview, B, work, nbatch);
   } else {

@@ -676,6 +676,7 @@ class OracleField:
         if cfg.get('optimize_poses', 1):
             self.pose = (torch.zeros(n_frames, 6) if pose is None else torch.as_tensor(pose).float().clone()).requires_grad_(True)
         self.global_step = 0
+        self.pose_table = None      # optional [F,3,4]: trace_and_sample composes the world rays from it, in the product's float32 order
         self.N_iters = cfg['n_step'] + 1
         self._make_optimizer()
 
@@ -704,9 +705,23 @@ class OracleField:
             rays_d = batch[:, 0:3]
             viewdirs = rays_d / rays_d.norm(dim=-1, keepdim=True)
             fid = batch[:, 8].long()
-            tf = self.frame_tf()[fid]
-            rays_o_w = tf[:, :3, 3]
-            viewdirs_w = (tf[:, :3, :3] @ viewdirs[:, :, None])[:, :, 0]
+            if getattr(self, 'pose_table', None) is not None:
+                # The world-frame ray in the product's DOCUMENTED float32 order (csrc/nof_trace.hip: k_raymarch_wave / k_batch_trace),
+                # from a given pose table tf [F,3,4] = Delta(pose) c2w (the product's own, whose distance to frame_tf() the caller
+                # asserts): the reference composes the same quantities with a batched matmul whose summation order is the BLAS's;
+                # the index work that follows (cells, intervals, z) is discontinuous in the ray, so the two programs must agree on
+                # the ray's BITS before their indices can be compared one for one (tests/test_gpu_fullsize.py).
+                T = np.asarray(self.pose_table, dtype=f32).reshape(-1, 3, 4)[fid.numpy()]
+                r = batch[:, 0:3].numpy().astype(f32)
+                nrm = np.sqrt(((r[:, 0] * r[:, 0] + r[:, 1] * r[:, 1]).astype(f32) + r[:, 2] * r[:, 2]).astype(f32)).astype(f32)
+                v = (r / nrm[:, None]).astype(f32)
+                d = ((T[:, :, 0] * v[:, 0:1] + T[:, :, 1] * v[:, 1:2]).astype(f32) + T[:, :, 2] * v[:, 2:3]).astype(f32)
+                rays_o_w, viewdirs_w = torch.from_numpy(np.ascontiguousarray(T[:, :, 3])), torch.from_numpy(d)
+                viewdirs = torch.from_numpy(v)
+            else:
+                tf = self.frame_tf()[fid]
+                rays_o_w = tf[:, :3, 3]
+                viewdirs_w = (tf[:, :3, :3] @ viewdirs[:, :, None])[:, :, 0]
             tio, cid, nh = trace_rays(self.occ_l, rays_o_w.numpy(), viewdirs_w.numpy())
             trunc = get_truncation(cfg, self.global_step)
             z = sample_z(tio, viewdirs[:, 2].numpy(), batch[:, 6].numpy(), cfg, trunc,

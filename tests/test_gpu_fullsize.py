@@ -247,24 +247,32 @@ def test_fullsize_step_matches_oracle(nof, case, precision):
     plain16 = precision in ('fp16', 'bf16')
     orc = O.OracleField(cfg, geo, shape, F, pool['poses'], occ_l, table=table0, mlp=mlp, pose=pose0,
                         operand_dtype=ODT[PRECISIONS[precision]] if plain16 else None)
+    cpu = lambda t: t.detach().cpu().numpy()
+    # The index work is discontinuous in the ray, so both programs must start from the same ray BITS.  What the oracle is handed is
+    # the product's pose table -- F x 12 floats, tf = Delta(pose) c2w, asserted against the oracle's own (pytorch3d-style se3 exp in
+    # torch: libm's sin / cos / tanh differ from the device's in the last bit) -- and nothing per ray: the oracle composes the world
+    # rays itself, in the product's documented float32 order (OracleField.pose_table), and the rays' bits are then ASSERTED equal
+    # (round 5 allowed 0.1 % of the rays to differ with torch's batched matmul order and checked strictly only on the device's rays).
+    tf_dev = cpu(fld.tf).reshape(F, 3, 4)
+    with torch.no_grad():
+        tf_orc = orc.frame_tf()[:, :3, :4].numpy()
+    assert np.abs(tf_dev - tf_orc).max() < 2e-6, np.abs(tf_dev - tf_orc).max()
+    orc.pose_table = tf_dev
     ref = _oracle_step_chunked(orc, batch, u_occ, u_dep)
 
-    cpu = lambda t: t.detach().cpu().numpy()
-    # ---- index work: ray-hit cell lists (bit-identical except for rays whose fp32 pose transform grazes a cell face) ----
+    # ---- index work: every ray's hit count and cell list, bit for bit (north_star: "bit-identical occupancy/ray-hit indices") ----
+    ro, vd = cpu(b['rays_o_w']), cpu(b['viewdirs_w'])
+    assert np.array_equal(ro.view(np.uint32), ref['trace']['rays_o_w'].numpy().view(np.uint32))
+    assert np.array_equal(vd.view(np.uint32), ref['trace']['viewdirs_w'].numpy().view(np.uint32))
     nh_ref, cid_ref = ref['trace']['n_hits'], ref['trace']['cell_ids']
     H = cid_ref.shape[1]
     nh, cid = cpu(b['n_hits']), cpu(b['cell_ids'])[:, :H]
     same = (nh == nh_ref) & (cid == cid_ref).all(axis=1)
-    assert same.mean() > 0.999, same.mean()
+    assert same.all(), (int((~same).sum()), R)
     z, z_ref = cpu(b['z_vals']), ref['z_vals'].numpy()
-    assert np.abs(z - z_ref)[same].max() < 2e-5
-    # ---- STRICT, on identical rays (north_star: "bit-identical occupancy/ray-hit indices"): the allowance above exists because the
-    #      world-frame ray = (pose correction x keyframe pose) x pixel ray is composed in float32 by two different programs (the
-    #      device's fixed multiply-add order, torch's batched matmul on the host) and a last-bit difference of an origin flips a
-    #      cell for a ray that grazes a face.  Hand the oracle's tracer and sampler the DEVICE's world-frame rays, bit for bit, and
-    #      nothing is allowed: every ray's hit count, cell list and interval bits, and -- with the injected uniforms -- every z
-    #      value's bits equal the oracle's (Utils.py:443-475, common.cu:41-167, nerf_runner.py:67-87,979-1011).
-    ro, vd = cpu(b['rays_o_w']), cpu(b['viewdirs_w'])
+    assert np.array_equal(z.view(np.uint32), z_ref.view(np.uint32)), float(np.abs(z - z_ref).max())
+    # ---- the same once more with the tracer and the sampler called directly on the device's rays: interval bits too, and the
+    #      padding (Utils.py:443-475, common.cu:41-167, nerf_runner.py:67-87,979-1011).
     tio_s, cid_s, nh_s = O.trace_rays(occ_l, ro, vd)
     Hs = cid_s.shape[1]
     assert np.array_equal(nh, nh_s)
@@ -279,10 +287,8 @@ def test_fullsize_step_matches_oracle(nof, case, precision):
     z_s = np.asarray(O.sample_z(tio_s, vz, batch[:, 6], cfg, O.get_truncation(cfg, 0), u_occ, u_dep), np.float32)
     z_bad = z.view(np.uint32) != z_s.view(np.uint32)
     assert not z_bad.any(), (int(z_bad.sum()), int(z_bad.any(1).sum()), float(np.abs(z - z_s).max()))
-    # the two compositions themselves agree to float32 rounding (what the 0.1 % is made of)
-    assert np.abs(ro - ref['trace']['rays_o_w'].numpy()).max() < 2e-6 and np.abs(vd - ref['trace']['viewdirs_w'].numpy()).max() < 2e-6
-    print(f'fullsize {case} {precision}: rays with the oracle\'s own pose composition identical {same.mean():.5f}; on the device\'s rays: '
-          f'n_hits, cell ids, interval bits and z bits all identical ({R} rays, {int(nh.sum())} hits)')
+    print(f'fullsize {case} {precision}: world rays composed by the oracle from the pose table (max |tf - oracle tf| '
+          f'{np.abs(tf_dev - tf_orc).max():.1e}): ray bits, n_hits, cell ids, interval bits and z bits all identical ({R} rays, {int(nh.sum())} hits)')
     # ---- outputs: north_star's bar, SDF / colour within 1e-3 (max-norm) on the samples both sides call valid ----
     v_ref = ref['fwd']['valid_samples'].numpy()
     v_got = cpu(b['valid']).reshape(R, S).astype(bool)
