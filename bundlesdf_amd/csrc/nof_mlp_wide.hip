@@ -201,20 +201,24 @@ struct WNet {
   static constexpr int NDB = rel_oblk(N);                               // bias-gradient sums per wave (one register each)
   static constexpr int SLOTB = slot_pairs() * 2048;                     // bytes of one ring slot
   static constexpr int XWAVE = 2 * HB * 2048;                           // exchange bytes per wave: HB delta blocks + HB input blocks
-  static constexpr int XB = 2 * SLOTB, BIASB = XB + 4 * XWAVE, DBB = BIASB + (N - 1) * HB * 128;   // DBB: [wave][NDB][64] floats
-  static constexpr int IDB = DBB + 4 * NDB * 256;                        // identity fragments of the MFMA transposes (2 KB)
+  static constexpr int XB = 2 * SLOTB, BIASB = XB + 4 * XWAVE;
+  static constexpr int IDB = BIASB + (N - 1) * HB * 128;                 // identity fragments of the MFMA transposes (2 KB)
   static constexpr int LDS_BYTES = IDB + 2048;
+  static_assert(NDB <= 32 && HB <= 4, "one accumulator column per (layer, output block) of the bias gradient; block p belongs to owner p");
 };
 
 // the scheduler of a 512-register kernel hoists every LDS read it can see (all blocks' weight fragments, all tiles' operands) in
 // front of the first MFMA and then spills what it hoisted: a scheduling fence per block keeps a block's reads beside its MFMAs
 #ifndef NOF_WIDE_FENCE
-#define NOF_WIDE_FENCE 1
+#define NOF_WIDE_FENCE 1                                  // (without: the colour net's 4 x 128 data role spills five registers; 1.67 vs 1.70 ms at cfg5, r06_h)
 #endif
 #if NOF_WIDE_FENCE
 #define WIDE_FENCE() __builtin_amdgcn_sched_barrier(0)
 #else
 #define WIDE_FENCE() ((void)0)
+#endif
+#ifndef NOF_WIDE_DATA_PRIO
+#define NOF_WIDE_DATA_PRIO 2                               // s_setprio of the data waves (the owners stay at 0)
 #endif
 #ifndef NOF_WIDE_DMA
 #define NOF_WIDE_DMA 1                                    // weight chunks global -> LDS with global_load ... lds (0: through registers)
@@ -227,10 +231,14 @@ struct ChunkLoad {
 #if NOF_WIDE_DMA
   __device__ __forceinline__ void issue(const char* __restrict__ src, char* slot, int wave_s, int lane) {
     // a wave instruction moves one contiguous kilobyte: LDS address = M0 (wave-uniform) + 16 * lane
+    uint32_t lane16 = (uint32_t)lane * 16u;
+    asm volatile("" : "+v"(lane16));      // (no instruction: the lane offset re-enters here, so the per-chunk 64-bit addresses are formed on
+                                          //  the spot instead of being hoisted out of the persistent loop -- nine register pairs the colour
+                                          //  net's owners, at 176 accumulator registers, spilled to scratch)
 #pragma unroll
     for (int t = 0; t < BYTES / 4096; ++t) {
       const int piece = wave_s + 4 * t;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + piece * 1024 + lane * 16),
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + piece * 1024 + lane16),
                                        (__attribute__((address_space(3))) void*)(slot + piece * 1024), 16, 0, 0);
     }
   }
@@ -301,10 +309,9 @@ __device__ __forceinline__ void pack_blk(const float (&x)[16], typename P::frag 
   f[1] = P::pack(&x[8]);
 }
 // a sample-per-lane block (two operand fragments) -> slot-per-lane on the matrix core (transpose32 of nof_mlp_dev.h on packed
-// operands: x 1 + 0 is exact), as two operand fragments of the sample-contracted MFMA; returns the sum of the lane's 16 values
-// (lane = neuron: its bias gradient over the tile's samples)
+// operands: x 1 + 0 is exact), as two operand fragments of the sample-contracted MFMA
 template <class P, class ID>
-__device__ __forceinline__ float transpose_pk(const ID& I, const typename P::frag (&x)[2], typename P::frag (&y)[2]) {
+__device__ __forceinline__ void transpose_pk(const ID& I, const typename P::frag (&x)[2], typename P::frag (&y)[2]) {
   f32x16 t;
 #pragma unroll
   for (int r = 0; r < 16; ++r) t[r] = 0.0f;
@@ -313,13 +320,73 @@ __device__ __forceinline__ float transpose_pk(const ID& I, const typename P::fra
   float v[16];
 #pragma unroll
   for (int r = 0; r < 16; ++r) v[r] = t[r];
-  float s = 0.0f;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) s += v[r];
   y[0] = P::pack(&v[0]);
   y[1] = P::pack(&v[8]);
-  return s;
 }
+
+// The raw inputs of one tile as global memory delivers them -- the network's input block(s) and the head's gradient -- requested a
+// step of the walk AHEAD of the pass that uses them (nothing touches the registers until the next pass unpacks them, so the loads
+// stay in flight across the workgroup barriers; round 6's first form requested them at the top of the pass and waited right there,
+// and read the input a second time for layer 0's weight gradient).
+template <class P, int NET>
+struct WideIn {
+  typename P::frag q[2];                                                // NET 0: featq (two operand fragments); NET 1: q[0] = sigma head's output
+  float f[16];                                                          // NET 0: the fp32 embedding (feat path); NET 1: f[0..7] = view row half
+  typename P::frag hq;                                                  // NET 0: the head's gradient (dsig)
+  float4 hd;                                                            // NET 1: draw
+  __device__ __forceinline__ void fetch(const float2* __restrict__ feat, const typename P::elem* __restrict__ featq, int L,
+                                        const typename P::elem* __restrict__ sig, const float* __restrict__ view, int S,
+                                        const float4* __restrict__ draw, const typename P::elem* __restrict__ dsig, int64_t B,
+                                        int64_t b, int hi) {
+    typedef typename P::frag frag;
+    const bool ok = b < B;
+    frag z;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) z[t] = (typename P::elem)0.0f;
+    if constexpr (NET == 0) {
+      if (featq != nullptr) {
+        q[0] = z; q[1] = z;
+        if (ok) {
+          const frag* src = reinterpret_cast<const frag*>(featq + (b * 2 + hi) * 16);
+          q[0] = src[0]; q[1] = src[1];
+        }
+      } else {
+        float x[1][16];
+        load_feat_o1(feat, L, B, b, hi, x);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) f[r] = x[0][r];
+      }
+      hq = load_sig_raw<P>(dsig, B, b, hi);
+    } else {
+      q[0] = load_sig_raw<P>(sig, B, b, hi);
+      float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0;
+      if (ok) {                                                         // slot (hi, r < 8) = view column 8 hi + r (load_view_o1)
+        const float4* v = (const float4*)(view + (b / S) * NOF_VIEW_COLS + 8 * hi);
+        v0 = v[0]; v1 = v[1];
+      }
+      f[0] = v0.x; f[1] = v0.y; f[2] = v0.z; f[3] = v0.w; f[4] = v1.x; f[5] = v1.y; f[6] = v1.z; f[7] = v1.w;
+      hd = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (hi == 0 && ok) hd = draw[b];
+    }
+  }
+  // -> the input block(s) as MFMA operands (rounded where the forward kernel rounds them)
+  template <int QN0>
+  __device__ __forceinline__ void unpack(bool from_featq, typename P::frag (&x0)[QN0][2]) const {
+    if constexpr (NET == 0) {
+      if (from_featq) { x0[0][0] = q[0]; x0[0][1] = q[1]; }
+      else pack_blk<P>(f, x0[0]);
+    } else {
+      typename P::frag z;
+#pragma unroll
+      for (int t = 0; t < 8; ++t) z[t] = (typename P::elem)0.0f;
+      x0[0][0] = q[0]; x0[0][1] = z;                                    // the sigma head's 16 outputs: rows r < 8 of the block
+      float v[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) v[r] = r < 8 ? f[r] : 0.0f;
+      pack_blk<P>(v, x0[1]);
+    }
+  }
+};
 
 // ---- the DATA role (waves 0-3 of the workgroup): one 32-sample tile per wave and pass -- forward recompute, data gradients,
 //      the exchange operands.  Barriers: one per recomputed layer, two per layer of the walk -- the OWNER role runs the same sequence.
@@ -336,40 +403,28 @@ __device__ __forceinline__ void wide_data_role(const NofMlpDesc& d, char* smem, 
   IdentLds<P> I;                                                        // (in LDS, read where used: eight registers less across the pass)
   I.base = reinterpret_cast<const typename P::frag*>(smem + W::IDB) + lane;
   const float gscale = d.grad_scale > 0.0f ? d.grad_scale : 1.0f, gunscale = 1.0f / gscale;
-  // this wave's bias-gradient sums (its own tiles; lane = neuron): lane-private LDS words, no register across the passes
-  float* const db = reinterpret_cast<float*>(smem + W::DBB) + wave_s * W::NDB * 64 + lane;
-#pragma unroll
-  for (int a = 0; a < W::NDB; ++a) db[a * 64] = 0.0f;
   char* const xw = smem + W::XB + wave_s * W::XWAVE + lane * 16;        // this wave's exchange region (+ its lane)
   const char* const bias_hi = smem + W::BIASB + hi * 16;
   int par = 0;                                                          // ring slot of the pass's first chunk (see the kernel)
   auto slot_of = [&](int c) { return smem + ((par + c) & 1) * W::SLOTB; };
+  WideIn<P, NET> in;                                                    // the NEXT pass's raw inputs (in flight during the walk's last step)
+  in.fetch(feat, featq, L, sig, view, S, draw, dsig, B, work.at((int64_t)blockIdx.x * 4 + wave_s) * 32 + j, hi);
+  __builtin_amdgcn_s_setprio(NOF_WIDE_DATA_PRIO);                       // the data waves are the pass's critical path: they issue first
   for (int64_t bi = blockIdx.x; bi < nbatch; bi += gridDim.x) {
     asm volatile("" ::: "memory");
     const int64_t tile = work.at(bi * 4 + wave_s);                       // (past the end: a tile that does not exist -> zeros everywhere)
     const int64_t t0 = tile * 32, b = t0 + j;
     const bool ok = b < B;
-    // ---------------- inputs (read again for layer 0's exchange at the end of the walk: nothing of them lives through the pass) ----
-    auto load_x0 = [&](frag (&x0)[W::QN0][2]) __attribute__((always_inline)) {
-      if constexpr (NET == 0) {
-        float x[1][16];
-        if (featq != nullptr) load_featq_o1<P>(featq, B, b, hi, x);
-        else load_feat_o1(feat, L, B, b, hi, x);
-        pack_blk<P>(x[0], x0[0]);
-      } else {
-        float x[16];
-        load_sig_o1<P>(sig, B, b, hi, x);
-        pack_blk<P>(x, x0[0]);
-        load_view_o1(view, S, B, b, hi, x);
-        pack_blk<P>(x, x0[1]);
-      }
-    };
+    (void)ok;
+    // ---------------- inputs: unpacked once, kept for layer 0's exchange at the end of the walk ----------------
+    frag x0[W::QN0][2];
+    in.template unpack<W::QN0>(featq != nullptr, x0);
+    const float4 t_draw = in.hd;
+    const frag f_dsig = in.hq;
     // ---------------- forward recompute: a[k] = relu(W_k a[k-1] + b_k), k < N - 1 ----------------
     frag a[N - 1][HB][2];
     static_for<N - 1>([&](auto K) __attribute__((always_inline)) {
       constexpr int k = decltype(K)::value;
-      frag x0[W::QN0][2];
-      if constexpr (k == 0) load_x0(x0);
       __syncthreads();                                                  // chunk k is in its slot
       const char* wl = slot_of(k) + lane * 16;
 #pragma unroll
@@ -391,14 +446,11 @@ __device__ __forceinline__ void wide_data_role(const NofMlpDesc& d, char* smem, 
 #pragma unroll
       for (int r = 0; r < 16; ++r) gh[r] = 0.0f;
       if constexpr (NET == 1) {
-        float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (hi == 0 && ok) t = draw[b];
-        gh[0] = t.x * gscale; gh[1] = t.y * gscale; gh[2] = t.z * gscale;
-        dsdf1 = t.w * gscale;
+        gh[0] = t_draw.x * gscale; gh[1] = t_draw.y * gscale; gh[2] = t_draw.z * gscale;
+        dsdf1 = t_draw.w * gscale;
         pack_blk<P>(gh, g[0]);
       } else {
-        const frag f = load_sig_raw<P>(dsig, B, b, hi);
-        sig_to_o1<P>(f, gh);
+        sig_to_o1<P>(f_dsig, gh);
         pack_blk<P>(gh, g[0]);
       }
     }
@@ -410,23 +462,25 @@ __device__ __forceinline__ void wide_data_role(const NofMlpDesc& d, char* smem, 
 #pragma unroll
       for (int p = 0; p < PN; ++p) {
         frag y[2];
-        db[(W::rel_oblk(k) + p) * 64] += transpose_pk<P>(I, g[p], y);
+        transpose_pk<P>(I, g[p], y);
         *reinterpret_cast<frag*>(xw + (p * 2) * 1024) = y[0];
         *reinterpret_cast<frag*>(xw + (p * 2 + 1) * 1024) = y[1];
         WIDE_FENCE();
       }
-      frag x0[W::QN0][2];
-      if constexpr (k == 0) load_x0(x0);
 #pragma unroll
       for (int q = 0; q < QN; ++q) {
         frag y[2];
-        if constexpr (k == 0) (void)transpose_pk<P>(I, x0[q], y);
-        else (void)transpose_pk<P>(I, a[k - 1][q], y);
+        if constexpr (k == 0) transpose_pk<P>(I, x0[q], y);
+        else transpose_pk<P>(I, a[k - 1][q], y);
         *reinterpret_cast<frag*>(xw + ((HB + q) * 2) * 1024) = y[0];
         *reinterpret_cast<frag*>(xw + ((HB + q) * 2 + 1) * 1024) = y[1];
         WIDE_FENCE();
       }
       __syncthreads();                                                  // (A) the four tiles' operands are in place; chunk c too
+      if constexpr (k == 0) {                                           // the next pass's inputs: in flight from here
+        if (bi + gridDim.x < nbatch)
+          in.fetch(feat, featq, L, sig, view, S, draw, dsig, B, work.at((bi + gridDim.x) * 4 + wave_s) * 32 + j, hi);
+      }
       // the data gradient of the layer's input
       const char* wl = slot_of(c) + lane * 16;
       if constexpr (k > 0) {
@@ -448,9 +502,10 @@ __device__ __forceinline__ void wide_data_role(const NofMlpDesc& d, char* smem, 
         store_dfeat_o1(dfeat, L, B, b, hi, df1, gunscale);
       } else {
         float ds1[16], dv1[16], dv2[16];
-        bwd_pk<P, PN>(wl, 0, g, ds1);
         bwd_pk<P, PN>(wl, 1, g, dv1);
         transpose32<P>(I, dv1, dv2);
+        __builtin_amdgcn_sched_barrier(0);                              // (the view block first and done with, then the sigma block)
+        bwd_pk<P, PN>(wl, 0, g, ds1);
         // dview[ray][u] += sum over the tile's samples (lane = view slot, regs <-> samples; a tile may straddle two rays)
         const int64_t ray0 = t0 / S;
         const int64_t end0 = (ray0 + 1) * S, endB = end0 < B ? end0 : B;
@@ -491,6 +546,18 @@ __device__ __forceinline__ void wide_owner_role(const NofMlpDesc& d, char* smem,
   for (int a = 0; a < W::NACC; ++a)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[a][r] = 0.0f;
+  // The bias gradient db[m] = sum over samples of delta[m][sample] rides on the matrix core too: delta^T (the A operand of the dW
+  // MFMA, already in the exchange) times a ONE-HOT column selector gives D[m][c] = db[m] in column c = the (layer, block)'s number --
+  // one accumulator holds every block's sums side by side (NDB <= 32 columns), the data waves add nothing per tile (round 6: they
+  // summed 16 registers per delta block and kept lane-private LDS words: 208 v_add + 26 LDS read-modify-writes per tile on the
+  // critical path).  Block p of a layer belongs to owner p (PN <= 4).
+  f32x16 accb;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) accb[r] = 0.0f;
+  float one8[8];
+#pragma unroll
+  for (int t = 0; t < 8; ++t) one8[t] = 1.0f;
+  const frag ones = P::pack(one8);
   const char* const xr = smem + W::XB + lane * 16;                      // the exchange buffer as the owners read it
   int par = 0;
   auto slot_of = [&](int c) { return smem + ((par + c) & 1) * W::SLOTB; };
@@ -525,16 +592,25 @@ __device__ __forceinline__ void wide_owner_role(const NofMlpDesc& d, char* smem,
           xd[i] = xr + (p * 2) * 1024;
           xa[i] = xr + ((HB + q) * 2) * 1024;
         }
+        // bias gradient: the layer's block p = ow (PN <= 4: at most one per owner), in the same sweep over the exchange
+        constexpr bool HAS_DB = true;
+        const bool mine = ow < PN;                                      // (wave-uniform)
+        frag sel;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) sel[t] = j == W::rel_oblk(k) + ow ? ones[t] : (typename P::elem)0.0f;
+        const char* const xb = xr + (ow * 2) * 1024;
 #pragma unroll
         for (int w4 = 0; w4 < 4; ++w4) {
 #pragma unroll
-          for (int s = 0; s < 2; ++s)
+          for (int s = 0; s < 2; ++s) {
 #pragma unroll
             for (int i = 0; i < W::nb(k); ++i)
               if (ow + 4 * i < PN * QN)                                 // (wave-uniform)
                 acc[W::aoff(k) + i] = P::mma(*reinterpret_cast<const frag*>(xd[i] + w4 * W::XWAVE + s * 1024),
                                              *reinterpret_cast<const frag*>(xa[i] + w4 * W::XWAVE + s * 1024), acc[W::aoff(k) + i]);
-          WIDE_FENCE();
+            if (HAS_DB && mine) accb = P::mma(*reinterpret_cast<const frag*>(xb + w4 * W::XWAVE + s * 1024), sel, accb);
+          }
+          __builtin_amdgcn_sched_barrier(0);      // (the owners have time to spare and 176 + 16 accumulator registers: their reads stay beside their MFMAs)
         }
       }
       if (more) cl.commit(slot_of(c + 1), ow, lane);
@@ -562,6 +638,16 @@ __device__ __forceinline__ void wide_owner_role(const NofMlpDesc& d, char* smem,
         }
       }
     }
+    // bias gradients: column rel_oblk(k) + p of accb, rows = the block's neurons (lane j = column, hi = row half)
+#pragma unroll
+    for (int p = 0; p < PN; ++p)
+      if (p == ow && j == W::rel_oblk(k) + p) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int orow = 32 * p + nloc(hi, r);
+          if (orow < out_dim) dst[d.b_off[l] + orow] = accb[r] * gunscale;
+        }
+      }
   });
 }
 
@@ -604,24 +690,6 @@ __global__ __launch_bounds__(512, 2) void k_wide_bwd_net(NofMlpDesc d, const cha
       c0.commit(smem, wave_s - 4, lane);
     }
     if (NOF_WIDE_ROLES & 2) wide_owner_role<P, HB, NET, N>(d, smem, wave_s - 4, lane, fw_img, bw_img, dst, lbase, nbatch);
-  }
-  // bias gradients: the four data waves' lane-private sums, wave 0 writes
-  __syncthreads();
-  if (wave_s == 0) {
-    const int hi = lane >> 5, j = lane & 31;
-    const float gunscale = d.grad_scale > 0.0f ? 1.0f / d.grad_scale : 1.0f;
-    const float* red = reinterpret_cast<const float*>(smem + W::DBB) + lane;
-    static_for<N>([&](auto K) __attribute__((always_inline)) {
-      constexpr int k = decltype(K)::value;
-      const int l = lbase + k, out_dim = d.out_dim[l];
-#pragma unroll
-      for (int p = 0; p < W::pn(k); ++p) {
-        const int a = W::rel_oblk(k) + p;
-        float v = ((red[a * 64] + red[(W::NDB + a) * 64]) + red[(2 * W::NDB + a) * 64]) + red[(3 * W::NDB + a) * 64];
-        v += __shfl_xor(v, 32, 64);
-        if (hi == 0 && 32 * p + j < out_dim) dst[d.b_off[l] + 32 * p + j] = v * gunscale;
-      }
-    });
   }
 }
 
