@@ -328,9 +328,11 @@ def main():
 
     if args.unfused:
         fld.fused_forward = False
+        fld.fused_forward_wide = False
     if args.trace_kernel is not None:
         fld.marcher = 1 - int(args.trace_kernel)             # (the option's 1 = wave per ray = lib.MARCHER_WAVE = 0)
-    fwd_name = 'nof_encode_mlp_fwd' if fld.fused_forward else 'nof_hash_encode_fwd'     # the launch that holds the hash lookup
+    fwd_name = ('nof_encode_mlp_fwd' if fld.fused_forward else 'nof_encode_mlp_wide_fwd' if fld.wide and fld.fused_forward_wide
+                else 'nof_hash_encode_fwd')     # the launch that holds the hash lookup
 
     def zero_fraction():
         """ray-samples of the last batch whose loss gradient is exactly zero (one device reduction + host sync: outside timing)"""
@@ -547,6 +549,7 @@ def main():
         fld_r = runner.field
         fld_r.scatter_wgs_per_cu = args.scatter_wgs
         fld_r.fused_forward = fld.fused_forward
+        fld_r.fused_forward_wide = fld.fused_forward_wide
         barrier()
         t0 = time.perf_counter()
         for _ in range(args.round_steps):
@@ -682,7 +685,9 @@ def main():
                                    f"round from a fresh field: round_ms_per_step",
                        "rays_per_step": R, "samples_per_ray": S, "keyframes_per_gpu": args.keyframes,
                        "pool_rays": int(runner.rays.shape[0]), "parallelism": f"dp{world}",
-                       "forward": "fused encode+MLP (nof_encode_mlp_fwd)" if fld.fused_forward else "nof_hash_encode_fwd + nof_mlp_fwd"},
+                       "forward": ("fused encode+MLP (nof_encode_mlp_fwd)" if fld.fused_forward else
+                                   "encode + sigma net in one launch, colour net behind it (nof_encode_mlp_wide_fwd)" if fld.wide and fld.fused_forward_wide
+                                   else "nof_hash_encode_fwd + nof_mlp_fwd")},
             # the timed region's per-step HOST enqueue intervals (median / largest): a mean far above the median = a one-off stall
             # inside the region, not the steady step
             "ms_per_step_p50_timed": timed_intervals["p50"] if timed_intervals else None,

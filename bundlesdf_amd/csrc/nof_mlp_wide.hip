@@ -139,6 +139,104 @@ __global__ __launch_bounds__(WideFwdThreads<HB>::value) void k_wide_fwd_sigma(No
 }
 
 // =====================================================================================================
+// forward, sigma net WITH the hash encode in the launch (round 6; the narrow networks' k_enc_mlp_fwd, DESIGN 2.10, at width 128):
+// pts_w -> 16 levels gathered, lane = sample, the level wave-uniform -> a wave-private LDS stage, feature-major -> the chain of
+// two 32-sample tiles.  The fp32 embedding [L,B,2] (cfg5: 403 MB written by k_hash_fwd, read here, read again by the backward) is
+// gone; what the backward needs of it is its value in operand precision, featq [B][2][16] (64 B per sample).
+// =====================================================================================================
+template <class P, int HB>
+__global__ __launch_bounds__(WideFwdThreads<HB>::value) void k_wide_enc_fwd_sigma(NofMlpDesc d, const char* __restrict__ image,
+                                                             NofHashGrid g, const float2* __restrict__ table,
+                                                             const float* __restrict__ pts_w, float* __restrict__ out, int out_stride,
+                                                             int out_off, typename P::elem* __restrict__ sig,
+                                                             typename P::elem* __restrict__ featq, int64_t B) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int NS = d.n_sigma, NL = d.n_sigma + d.n_color;
+  const int bias_base = pair_base(d, NS) * WPAIR;
+  const int stage_base = (bias_base + oblk_base(d, NS) * 128 + 15) & ~15;
+  copy16(smem, image, (size_t)bias_base);
+  copy16(smem + bias_base, image + 2 * (size_t)pair_base(d, NL) * WPAIR, (size_t)oblk_base(d, NS) * 128);
+  const int NW = blockDim.x >> 6;
+  uint32_t* lvl = reinterpret_cast<uint32_t*>(smem + stage_base + NW * 8192);       // [16][8] words behind the stages (see k_enc_mlp_fwd)
+  if (threadIdx.x < NOF_MAX_LEVELS) {
+    const int l = threadIdx.x;
+    lvl[l * 8 + 0] = __float_as_uint(g.scale[l]); lvl[l * 8 + 1] = g.resolution[l]; lvl[l * 8 + 2] = g.offset[l];
+    lvl[l * 8 + 3] = g.size[l]; lvl[l * 8 + 4] = g.hashed[l];
+  }
+  const int n_levels = g.L;
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int hi = lane >> 5, j = lane & 31;
+  auto level_at = [&](int l) {                          // wave-uniform: the LDS words go through readfirstlane into SGPRs
+    HashLevel lv;
+    const uint4 q = *reinterpret_cast<const uint4*>(lvl + l * 8);
+    lv.scale = __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)q.x));
+    lv.res = (uint32_t)__builtin_amdgcn_readfirstlane((int)q.y);
+    lv.offset = (uint32_t)__builtin_amdgcn_readfirstlane((int)q.z);
+    lv.size = (uint32_t)__builtin_amdgcn_readfirstlane((int)q.w);
+    lv.hashed = (uint32_t)__builtin_amdgcn_readfirstlane((int)lvl[l * 8 + 4]);
+    return lv;
+  };
+  float* const stage = reinterpret_cast<float*>(smem + stage_base + wave * 8192);       // [32][64] floats
+  const int64_t npairs = (B + 63) / 64;
+  for (int64_t tp = (int64_t)blockIdx.x * NW + wave; tp < npairs; tp += (int64_t)gridDim.x * NW) {
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_setprio(3);                      // (the gather phase issues first: DESIGN 2.10)
+    const int64_t bs = tp * 64 + lane;
+    const int64_t bb = bs < B ? bs : B - 1;             // (a lane past the end encodes the last sample: nothing of it is stored)
+    const float p[3] = {pts_w[bb * 3], pts_w[bb * 3 + 1], pts_w[bb * 3 + 2]};
+#pragma unroll 1
+    for (int l0 = 0; l0 < NOF_MAX_LEVELS; ++l0) {
+      float2 a = make_float2(0.f, 0.f);
+      if (l0 < n_levels) {                              // (uniform)
+        const HashLevel lv = level_at(l0);
+        EncCell e = enc_prep(lv, p);
+        float2 v[8];
+        if (level_pairs(lv)) enc_load<true>(lv, table, e, v);
+        else enc_load<false>(lv, table, e, v);
+        enc_keep(e);
+        a = enc_blend(e, v);
+      }
+      stage[(2 * l0) * 64 + lane] = a.x;
+      stage[(2 * l0 + 1) * 64 + lane] = a.y;
+    }
+    __builtin_amdgcn_s_setprio(0);
+    // the two tiles through the chain: lane (j, hi) of tile t reads features 16 hi .. 16 hi + 15 of sample 32 t + j
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      asm volatile("" ::: "memory");
+      float x[1][16], h[HB][16], so[1][16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) x[0][r] = stage[(16 * hi + r) * 64 + 32 * t + j];
+      const int64_t b = tp * 64 + 32 * t + j;
+      const bool ok = b < B;
+      if (featq != nullptr && ok) {                     // the embedding as the backward reads it: rounded to the operand type, operand order
+        typename P::frag* q = reinterpret_cast<typename P::frag*>(featq + (b * 2 + hi) * 16);
+        q[0] = P::pack(&x[0][0]);
+        q[1] = P::pack(&x[0][8]);
+      }
+      dense_o1<P, 1, HB>(smem, 0, bias_base, x, h, lane);
+      relu_inplace<HB>(h);
+      int foff = HB * WPAIR, boff = bias_base + HB * 128;
+      for (int l = 1; l < NS - 1; ++l) {
+        float h2[HB][16];
+        dense_o1<P, HB, HB>(smem, foff, boff, h, h2, lane);
+        relu_inplace<HB>(h2);
+#pragma unroll
+        for (int pp = 0; pp < HB; ++pp)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) h[pp][r] = h2[pp][r];
+        foff += HB * HB * WPAIR;
+        boff += HB * 128;
+      }
+      dense_o1<P, HB, 1>(smem, foff, boff, h, so, lane);
+      if (sig != nullptr) store_sig_o1<P>(sig, B, b, hi, so[0]);
+      if (hi == 0 && ok) out[b * out_stride + out_off] = so[0][0];
+    }
+  }
+}
+
+// =====================================================================================================
 // forward, colour net: [sig | view] -> hidden layers -> rgb_raw -> raw[b].xyz
 // =====================================================================================================
 template <class P, int HB>
@@ -778,6 +876,47 @@ extern "C" int nof_mlp_wide_sdf(const NofMlpDesc* d, const void* packed, const f
   if (B == 0) return 0;
   WIDE_DISPATCH(wide_fwd_launch, d, packed, feat, L, (const float*)nullptr, 1, sdf, 1, 0, (const WideWs*)nullptr, true, B,
                 (hipStream_t)stream)
+  NOF_LAUNCH_OK();
+  return 0;
+}
+
+template <class P, int HB>
+static int wide_enc_fwd_launch(const NofHashGrid* g, const NofMlpDesc* d, const void* packed, const float* table, const float* pts_w,
+                               const float* view, int32_t S, float* raw, const WideWs* ws, void* featq, int64_t B, hipStream_t st) {
+  const int ns = d->n_sigma, nl = d->n_sigma + d->n_color;
+  const size_t pair_bytes = 16 * 64 * 2;
+  constexpr int NT = WideFwdThreads<HB>::value, NWV = NT / 64;
+  const size_t img_s = (((size_t)pair_base(*d, ns) * pair_bytes + (size_t)oblk_base(*d, ns) * 128) + 15) & ~(size_t)15;
+  const size_t shm_s = img_s + (size_t)NWV * 8192 + 512;               // fragments + biases | 8 KB of stage per wave | the level table
+  if (shm_s > 160 * 1024) return nof_set_error(-1, "nof_encode_mlp_wide_fwd: %zu bytes of LDS", shm_s);
+  const size_t shm_c = (size_t)(pair_base(*d, nl) - pair_base(*d, ns)) * pair_bytes + (size_t)(oblk_base(*d, nl) - oblk_base(*d, ns)) * 128;
+  typedef typename P::elem elem;
+  const int64_t npairs = (B + 63) / 64, ntiles = (B + 31) / 32;
+  const unsigned blocks_s = (unsigned)(nof_div_up(npairs, NWV) < (int64_t)nof_cu_count() ? nof_div_up(npairs, NWV) : nof_cu_count());
+  const unsigned blocks_c = (unsigned)(nof_div_up(ntiles, NWV) < (int64_t)nof_cu_count() ? nof_div_up(ntiles, NWV) : nof_cu_count());
+  auto ks = k_wide_enc_fwd_sigma<P, HB>;
+  if (int e = set_smem(ks, shm_s)) return e;
+  hipLaunchKernelGGL(ks, dim3(blocks_s), dim3(NT), shm_s, st, *d, (const char*)packed, *g, (const float2*)table, pts_w, raw, 4, 3,
+                     (elem*)ws->sig, (elem*)featq, B);
+  auto kc = k_wide_fwd_color<P, HB>;
+  if (int e = set_smem(kc, shm_c)) return e;
+  hipLaunchKernelGGL(kc, dim3(blocks_c), dim3(NT), shm_c, st, *d, (const char*)packed, (const elem*)ws->sig, view, (int)S, raw, B);
+  return 0;
+}
+
+/* Hash encode + both wide networks, the fp32 embedding never in HBM (the wide counterpart of nof_encode_mlp_fwd; replaces the pair
+ * nof_hash_encode_fwd + nof_mlp_wide_fwd of the training forward, reference nerf_runner.py:1255-1294): pts_w [B,3], table [rows,2],
+ * view [R,16] -> raw [B,4]; the sigma head's output stays in `workspace` (nof_mlp_wide_workspace_bytes); featq (may be NULL):
+ * [B][2][16] operand-type elements, the embedding as nof_mlp_wide_bwd_parts reads it. */
+extern "C" int nof_encode_mlp_wide_fwd(const NofHashGrid* g, const NofMlpDesc* d, const void* packed, const float* table,
+                                        const float* pts_w, const float* view, int32_t S, float* raw, void* workspace, void* featq,
+                                        int64_t B, void* stream) {
+  if (int e = check_wide(d)) return e;
+  NOF_ARG(g && g->C == 2 && g->L >= 1 && g->L <= NOF_MAX_LEVELS && g->L * 2 == d->in_feat);
+  NOF_ARG(packed && table && pts_w && view && raw && workspace && B >= 0 && S >= 1);
+  if (B == 0) return 0;
+  const WideWs ws = wide_ws(d, workspace, B);
+  WIDE_DISPATCH(wide_enc_fwd_launch, g, d, packed, table, pts_w, view, S, raw, &ws, featq, B, (hipStream_t)stream)
   NOF_LAUNCH_OK();
   return 0;
 }

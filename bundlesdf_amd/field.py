@@ -110,6 +110,9 @@ class NeuralObjectField:
         # the training forward as ONE launch with the embedding kept on chip (nof_encode_mlp_fwd; 64-wide networks, 16-bit operand
         # types); False: the two launches nof_hash_encode_fwd + nof_mlp_fwd with the fp32 [L,B,2] embedding in HBM between them
         self.fused_forward = not self.wide and self.desc.precision != 0
+        # the wide networks' counterpart (round 6): encode + sigma net in one launch, colour net behind it; the backward reads the
+        # operand-precision embedding `featq`.  False: nof_hash_encode_fwd + nof_mlp_wide_fwd with the fp32 embedding in HBM
+        self.fused_forward_wide = self.wide
         self.graph_fork = True            # a captured step (GraphedStep) keeps the backward's two branches (False: one chain)
         self.marcher = lib.MARCHER_WAVE   # NofSampleCfg.marcher: the ray marcher of nof_raymarch_sample (lib.MARCHER_WALK: the per-lane walk)
         self.scatter_wgs_per_cu = 0                  # persistent workgroups per CU of the table scatter (0 = the library's default)
@@ -394,6 +397,12 @@ class NeuralObjectField:
             self._call('nof_encode_mlp_fwd', C.byref(self.grid), C.byref(self.desc), self.packed, self.table, b['pts_w'], b['view'], S,
                        b['raw'], b['sig'], b['featq'], B)
             return b, S
+        if self.wide and self.fused_forward_wide:
+            if b['featq'] is None:
+                b['featq'] = torch.empty(B, 32, dtype=torch.int16, device=self.device)
+            self._call('nof_encode_mlp_wide_fwd', C.byref(self.grid), C.byref(self.desc), self.packed, self.table, b['pts_w'], b['view'], S,
+                       b['raw'], b['wide_ws'], b['featq'], B)
+            return b, S
         if b['feat'] is None:
             b['feat'] = torch.empty(self.L, B, 2, device=self.device)
         self._call('nof_hash_encode_fwd', C.byref(self.grid), b['pts_w'], self.table, b['feat'], B)
@@ -427,7 +436,9 @@ class NeuralObjectField:
         # wide networks (hidden 128 / 4 layers): one kernel per network, colour then sigma, forward recomputed and the weight
         # gradient accumulated on chip (round 6; rounds 3-5: two data kernels + eight weight-gradient passes on a third stream)
         if self.wide:
-            self._call('nof_mlp_wide_bwd_parts', C.byref(self.desc), self.packed, b['feat'], b['featq'], self.L, b['view'], S, b['draw'],
+            fused = self.fused_forward_wide                               # (the embedding the forward of THIS batch left: featq or feat)
+            self._call('nof_mlp_wide_bwd_parts', C.byref(self.desc), self.packed, None if fused else b['feat'],
+                       b['featq'] if fused else None, self.L, b['view'], S, b['draw'],
                        b['wide_ws'], b['dfeat'], b['dview'], b['partials'], tiles, 3, B, tag='nof_mlp_wide_bwd')
         elif self.fused_forward:
             self._call('nof_mlp_bwd_featq', C.byref(self.desc), self.packed, b['featq'], self.L, b['view'], S, b['draw'], b['sig'],

@@ -138,6 +138,7 @@ _SIGNATURES = {
     'nof_mlp_wide_sdf': ([C.POINTER(NofMlpDesc), _P, _P, _I32, _P, _I64, _P], C.c_int),
     'nof_mlp_wide_bwd': ([C.POINTER(NofMlpDesc), _P, _P, _I32, _P, _I32, _P, _P, _P, _P, _P, _I64, _P], C.c_int),
     'nof_mlp_wide_bwd_tiles': ([C.POINTER(NofMlpDesc), _P, _P, _I32, _P, _I32, _P, _P, _P, _P, _P, _P, _I64, _P], C.c_int),
+    'nof_encode_mlp_wide_fwd': ([C.POINTER(NofHashGrid), C.POINTER(NofMlpDesc), _P, _P, _P, _P, _I32, _P, _P, _P, _I64, _P], C.c_int),
     'nof_mlp_wide_bwd_parts': ([C.POINTER(NofMlpDesc), _P, _P, _P, _I32, _P, _I32, _P, _P, _P, _P, _P, _P, _I32, _I64, _P], C.c_int),
     'nof_texture_bake_frame': ([_P, _P, _I32, _I32, _P, _P, _I64, _P, _P, _P, _F, _I32, _P, _P, _P, _P, _P], C.c_int),
 }

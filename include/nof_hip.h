@@ -287,6 +287,13 @@ int nof_mlp_wide_bwd(const NofMlpDesc* h_desc, const void* packed, const float* 
 int nof_mlp_wide_bwd_tiles(const NofMlpDesc* h_desc, const void* packed, const float* feat, int32_t L, const float* view, int32_t S,
                            const float* draw, void* workspace, float* dfeat, float* dview, float* partials, const void* tile_list,
                            int64_t B, void* stream);
+/* Hash encode + both wide networks in two launches with the fp32 embedding never in HBM (the wide counterpart of nof_encode_mlp_fwd;
+ * replaces nof_hash_encode_fwd + nof_mlp_wide_fwd in the training forward; reference nerf_runner.py:1255-1294 materialises `embedded`).
+ * pts_w [B,3], table [rows,2], view [R,16] -> raw [B,4]; `workspace` as for nof_mlp_wide_fwd; featq (may be NULL): [B][2][16]
+ * operand-type elements (64 B per sample) = the embedding as nof_mlp_wide_bwd_parts reads it. */
+int nof_encode_mlp_wide_fwd(const NofHashGrid* h_grid, const NofMlpDesc* h_desc, const void* packed, const float* table,
+                            const float* pts_w, const float* view, int32_t S, float* raw, void* workspace, void* featq,
+                            int64_t B, void* stream);
 /* restricted to `parts` (all on `stream`): the colour net's kernel (needs draw; writes dview, the sigma head's gradient and the
  * colour layers' entries of every partial row) and / or the sigma net's (needs the colour part; writes dfeat and the sigma layers'
  * entries).  `featq` (may be NULL): the embedding in MFMA operand precision and order as nof_encode_mlp_wide_fwd leaves it

@@ -861,6 +861,75 @@ def test_fused_encode_mlp_forward_equals_the_two_launches(nof, ns, nc, ff, L, T,
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[0][2], outs[1][2])
 
 
+@pytest.mark.parametrize("ns,nc,hidden,ff,L,T,finest", [(4, 4, 128, 0, 16, 19, 512), (2, 3, 128, 2, 16, 14, 256), (4, 4, 64, 0, 16, 20, 512),
+                                                         (3, 4, 128, 2, 4, 14, 64)])
+@pytest.mark.parametrize("precision", [1, 2])
+def test_wide_fused_encode_forward_equals_the_two_launches(nof, ns, nc, hidden, ff, L, T, finest, precision):
+    """nof_encode_mlp_wide_fwd (round 6: hash encode inside the wide sigma forward, colour net behind it) against
+    nof_hash_encode_fwd + nof_mlp_wide_fwd on the same points: raw and the sigma hand-off in the workspace BIT-identical, featq =
+    the fp32 embedding rounded to the operand type in operand order, and nof_mlp_wide_bwd_parts fed from featq gives the bits of
+    the backward fed from the fp32 embedding.  Ragged B (not a multiple of 64 nor 32), dense + hashed levels, the 513 quirk, L < 8."""
+    torch.manual_seed(11)
+    n_view = 9 + ff
+    shape = O.FieldShape(input_ch=2 * L, input_ch_views=n_view, num_layers=ns, hidden_dim=hidden, num_layers_color=nc,
+                         hidden_dim_color=hidden)
+    params = O.init_mlp_params(shape)
+    for W, b in params:
+        b.add_(torch.randn_like(b) * 0.1)
+    desc, dims = nof.make_mlp_desc(ns, nc, 2 * L, n_view, precision, hidden=hidden)
+    flat = torch.cat([torch.cat([W.reshape(-1), b.reshape(-1)]) for W, b in params])
+    g, geo = U.make_grids(nof, L=L, T=T, finest=finest)
+    R, S = 37, 40
+    B = R * S
+    rng = np.random.default_rng(7)
+    pts = rng.uniform(-1, 1, size=(B, 3)).astype(np.float32)
+    pts[:6] = U.test_points(6)
+    pts[100:140] = pts[100] + np.linspace(0, 1e-3, 40, dtype=np.float32)[:, None]
+    table = (rng.uniform(-1, 1, size=(geo.n_entries, 2)) * 0.3).astype(np.float32)
+    view = torch.zeros(R, 16)
+    view[:, :n_view] = torch.randn(R, n_view)
+    d_pts, d_table, d_view = U.dev(pts), U.dev(table), view.cuda()
+    packed = _pack(nof, desc, flat)
+    nbytes = int(nof.load().nof_mlp_wide_workspace_bytes(C.byref(desc), B))
+    ws_a = torch.zeros(nbytes, dtype=torch.uint8, device='cuda')
+    ws_b = torch.full((nbytes,), 9, dtype=torch.uint8, device='cuda')
+    feat = torch.empty(L, B, 2, device='cuda')
+    raw_a, raw_b = torch.zeros(B, 4, device='cuda'), torch.ones(B, 4, device='cuda')
+    featq = torch.full((B, 32), 7, dtype=torch.int16, device='cuda')
+    nof.call('nof_hash_encode_fwd', C.byref(g), d_pts, d_table, feat, B)
+    nof.call('nof_mlp_wide_fwd', C.byref(desc), packed, feat, L, d_view, S, raw_a, ws_a, B)
+    nof.call('nof_encode_mlp_wide_fwd', C.byref(g), C.byref(desc), packed, d_table, d_pts, d_view, S, raw_b, ws_b, featq, B)
+    torch.cuda.synchronize()
+    assert torch.isfinite(raw_a).all()
+    assert torch.equal(raw_a, raw_b), (raw_a - raw_b).abs().max().item()
+    odt = torch.bfloat16 if precision == 1 else torch.float16
+    want = feat.permute(1, 0, 2).reshape(B, 2 * L)
+    if L < 16:
+        want = torch.cat([want, torch.zeros(B, 32 - 2 * L, device='cuda')], 1)
+    assert torch.equal(featq.view(odt), want.to(odt))
+    raw_c = torch.zeros(B, 4, device='cuda')
+    nof.call('nof_encode_mlp_wide_fwd', C.byref(g), C.byref(desc), packed, d_table, d_pts, d_view, S, raw_c, ws_b, None, B)
+    torch.cuda.synchronize()
+    assert torch.equal(raw_c, raw_a)
+    # the backward: from the fp32 embedding + the two-launch forward's workspace, and from featq + the fused forward's workspace
+    draw = torch.randn(B, 4, device='cuda')
+    draw[64:256] = 0
+    rows = nof.load().nof_mlp_wide_partial_rows()
+    outs = []
+    for use_q in (False, True):
+        dfeat = torch.full((L, B, 2), 3.0, device='cuda')
+        dview = torch.zeros(R, 16, device='cuda')
+        partials = torch.full((rows, desc.n_params), 5.0, device='cuda')
+        nof.call('nof_mlp_wide_bwd_parts', C.byref(desc), packed, None if use_q else feat, featq if use_q else None, L, d_view, S, draw,
+                 ws_b if use_q else ws_a, dfeat, dview, partials, None, 3, B)
+        gflat = torch.zeros(desc.n_params, device='cuda')
+        nof.call('nof_reduce_partials', partials, rows, desc.n_params, gflat, None)
+        torch.cuda.synchronize()
+        outs.append((dfeat, dview, gflat))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b), (a - b).abs().max().item()
+
+
 @pytest.mark.parametrize("precision", ['fp16x3', 'bf16x3'])
 def test_fused_forward_is_repeatable(nof, precision):
     """Round 4's fault (profiles/r04_fused_forward_race.txt): with more than one level's gathers in flight the fused forward returned,
