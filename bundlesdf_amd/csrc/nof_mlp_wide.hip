@@ -318,6 +318,9 @@ struct WNet {
 #ifndef NOF_WIDE_DATA_PRIO
 #define NOF_WIDE_DATA_PRIO 2                               // s_setprio of the data waves (the owners stay at 0)
 #endif
+#ifndef NOF_WIDE_X
+#define NOF_WIDE_X 0                                      // timing experiments only (results WRONG): 1 no weight stream after the first chunk,
+#endif                                                    // 2 owners skip their MFMAs, 4 data waves skip the transposes + exchange stores
 #ifndef NOF_WIDE_DMA
 #define NOF_WIDE_DMA 1                                    // weight chunks global -> LDS with global_load ... lds (0: through registers)
 #endif
@@ -558,7 +561,7 @@ __device__ __forceinline__ void wide_data_role(const NofMlpDesc& d, char* smem, 
       constexpr int PN = W::pn(k), QN = W::qn(k), c = 2 * N - 2 - k;
       // exchange: delta_k (PN blocks) and the layer's input (QN blocks), transposed on the matrix core
 #pragma unroll
-      for (int p = 0; p < PN; ++p) {
+      for (int p = 0; p < ((NOF_WIDE_X & 4) ? 0 : PN); ++p) {
         frag y[2];
         transpose_pk<P>(I, g[p], y);
         *reinterpret_cast<frag*>(xw + (p * 2) * 1024) = y[0];
@@ -566,7 +569,7 @@ __device__ __forceinline__ void wide_data_role(const NofMlpDesc& d, char* smem, 
         WIDE_FENCE();
       }
 #pragma unroll
-      for (int q = 0; q < QN; ++q) {
+      for (int q = 0; q < ((NOF_WIDE_X & 4) ? 0 : QN); ++q) {
         frag y[2];
         if constexpr (k == 0) transpose_pk<P>(I, x0[q], y);
         else transpose_pk<P>(I, a[k - 1][q], y);
@@ -666,8 +669,10 @@ __device__ __forceinline__ void wide_owner_role(const NofMlpDesc& d, char* smem,
       __syncthreads();                                                  // chunk k is published; the other slot's readers are done
       constexpr int kn = k + 1 < N - 1 ? k + 1 : N - 1;                 // next chunk: fw of layer k + 1, or bw of the head
       ChunkLoad<W::pn(kn) * W::qn(kn) * 2048> cl;
+      if (!(NOF_WIDE_X & 1)) {
       cl.issue((k + 1 < N - 1 ? fw_img : bw_img) + W::rel_pair(kn) * 2048, slot_of(k + 1), ow, lane);
       cl.commit(slot_of(k + 1), ow, lane);
+      }
     });
     static_for<N>([&](auto KK) __attribute__((always_inline)) {
       constexpr int k = N - 1 - decltype(KK)::value;
@@ -676,7 +681,7 @@ __device__ __forceinline__ void wide_owner_role(const NofMlpDesc& d, char* smem,
       // next chunk: bw of layer k - 1, or -- the last step -- fw of layer 0 for the workgroup's next pass
       constexpr int kn = k > 0 ? k - 1 : 0;
       ChunkLoad<W::pn(kn) * W::qn(kn) * 2048> cl;
-      const bool more = k > 0 || bi + gridDim.x < nbatch;
+      const bool more = !(NOF_WIDE_X & 1) && (k > 0 || bi + gridDim.x < nbatch);
       if (more) cl.issue((k > 0 ? bw_img : fw_img) + W::rel_pair(kn) * 2048, slot_of(c + 1), ow, lane);
       // idx = o + 4 i -> (p, q) = (idx / QN, idx % QN); the four tiles one after the other, the wave's blocks interleaved so that
       // consecutive MFMAs go to different accumulators
@@ -698,7 +703,7 @@ __device__ __forceinline__ void wide_owner_role(const NofMlpDesc& d, char* smem,
         for (int t = 0; t < 8; ++t) sel[t] = j == W::rel_oblk(k) + ow ? ones[t] : (typename P::elem)0.0f;
         const char* const xb = xr + (ow * 2) * 1024;
 #pragma unroll
-        for (int w4 = 0; w4 < 4; ++w4) {
+        for (int w4 = 0; w4 < ((NOF_WIDE_X & 2) ? 0 : 4); ++w4) {
 #pragma unroll
           for (int s = 0; s < 2; ++s) {
 #pragma unroll
