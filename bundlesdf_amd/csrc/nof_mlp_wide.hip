@@ -318,9 +318,6 @@ struct WNet {
 #ifndef NOF_WIDE_DATA_PRIO
 #define NOF_WIDE_DATA_PRIO 2                               // s_setprio of the data waves (the owners stay at 0)
 #endif
-#ifndef NOF_WIDE_X
-#define NOF_WIDE_X 0                                      // timing experiments only (results WRONG): 1 no weight stream after the first chunk,
-#endif                                                    // 2 owners skip their MFMAs, 4 data waves skip the transposes + exchange stores
 #ifndef NOF_WIDE_DMA
 #define NOF_WIDE_DMA 1                                    // weight chunks global -> LDS with global_load ... lds (0: through registers)
 #endif
@@ -489,6 +486,121 @@ struct WideIn {
   }
 };
 
+// ---- software-pipelined block loops (round 6, second form).  The first on-chip form ran every block as read -> wait -> MFMA
+//      chain -> wait -> pack, fenced block by block: the matrix pipe idled through every LDS latency and every result drain (the
+//      data role alone, no owners and no exchange, ran at 42 % of its MFMA time; profiles/r06_l_wide_x.txt).  Here block p + 1's
+//      fragments are requested BEFORE block p's chain and block p - 1's packing sits behind it, inside one fenced region, so the
+//      reads land and the VALU work issues in the chain's shadow; two fragment sets and two accumulators alive (+ 48 registers).
+template <class P, int T>
+struct FragSet { typename P::frag a[T]; };
+template <class P, int T>
+__device__ __forceinline__ void load_frags(const char* base, FragSet<P, T>& w) {
+#pragma unroll
+  for (int t = 0; t < T; ++t) w.a[t] = *(const typename P::frag*)(base + t * 1024);
+}
+__device__ __forceinline__ f32x16 zero16() {
+  f32x16 z;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) z[r] = 0.0f;
+  return z;
+}
+template <class P>
+__device__ __forceinline__ void pack_acc(const f32x16& acc, typename P::frag (&f)[2]) {
+  float v[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) v[r] = acc[r];
+  f[0] = P::pack(&v[0]);
+  f[1] = P::pack(&v[8]);
+}
+
+// out[p] = relu(round16(bias_p + W[p][:] in)), p < PN: the recompute of one hidden layer (fragments of the layer at `wl` = slot +
+// 16 * lane, block p's QN * 2 fragments contiguous; `bias_hi` = the layer's first bias block + 16 * hi).  Same MFMA sequence per
+// block as dense_pk (one accumulator chain over q, s): the same bits.
+template <class P, int QN, int PN>
+__device__ __forceinline__ void dense_relu_pipe(const char* wl, const char* bias_hi, const typename P::frag (&in)[QN][2],
+                                                typename P::frag (&out)[PN][2]) {
+  FragSet<P, QN * 2> w[2];
+  float4 bv[2][4];
+  f32x16 acc[2];
+  auto load = [&](auto PC, auto BC) __attribute__((always_inline)) {
+    constexpr int p = decltype(PC)::value, bf = decltype(BC)::value;
+    load_frags<P, QN * 2>(wl + p * QN * 2048, w[bf]);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) bv[bf][g] = *(const float4*)(bias_hi + p * 128 + 32 * g);
+  };
+  auto finish = [&](auto PC, auto BC) __attribute__((always_inline)) {
+    constexpr int p = decltype(PC)::value, bf = decltype(BC)::value;
+    pack_acc<P>(acc[bf], out[p]);                                       // round, then ReLU on the packed halves (relu_pk)
+    out[p][0] = relu_pk(out[p][0]);
+    out[p][1] = relu_pk(out[p][1]);
+  };
+  load(std::integral_constant<int, 0>(), std::integral_constant<int, 0>());
+  static_for<PN>([&](auto PC) __attribute__((always_inline)) {
+    constexpr int p = decltype(PC)::value, cur = p & 1, nxt = cur ^ 1;
+    if constexpr (p + 1 < PN) load(std::integral_constant<int, p + 1>(), std::integral_constant<int, nxt>());
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      acc[cur][4 * g] = bv[cur][g].x; acc[cur][4 * g + 1] = bv[cur][g].y; acc[cur][4 * g + 2] = bv[cur][g].z; acc[cur][4 * g + 3] = bv[cur][g].w;
+    }
+#pragma unroll
+    for (int q = 0; q < QN; ++q)
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) acc[cur] = P::mma(w[cur].a[q * 2 + s2], in[q][s2], acc[cur]);
+    if constexpr (p > 0) finish(std::integral_constant<int, p - 1>(), std::integral_constant<int, nxt>());
+    WIDE_FENCE();
+  });
+  finish(std::integral_constant<int, PN - 1>(), std::integral_constant<int, (PN - 1) & 1>());
+  WIDE_FENCE();
+}
+
+// din[q] = W^T[q][:] dout for q = Q0 .. Q0 + NQ - 1 (bw fragments of the layer at `wl`, block q's PN * 2 fragments contiguous);
+// done(q, acc) consumes block q's sums one region later.  Same chain per block as bwd_pk.
+template <class P, int PN, int Q0, int NQ, int GB, class DONE>
+__device__ __forceinline__ void bwd_pipe(const char* wl, const typename P::frag (&dout)[GB][2], DONE&& done) {
+  static_assert(PN <= GB, "the layer's output blocks are the first PN of the array");
+  FragSet<P, PN * 2> w[2];
+  f32x16 acc[2];
+  load_frags<P, PN * 2>(wl + Q0 * PN * 2048, w[0]);
+  static_for<NQ>([&](auto QC) __attribute__((always_inline)) {
+    constexpr int i = decltype(QC)::value, cur = i & 1, nxt = cur ^ 1;
+    if constexpr (i + 1 < NQ) load_frags<P, PN * 2>(wl + (Q0 + i + 1) * PN * 2048, w[nxt]);
+    acc[cur] = zero16();
+#pragma unroll
+    for (int p = 0; p < PN; ++p)
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) acc[cur] = P::mma(w[cur].a[p * 2 + s2], dout[p][s2], acc[cur]);
+    if constexpr (i > 0) done(std::integral_constant<int, Q0 + i - 1>(), acc[nxt]);
+    WIDE_FENCE();
+  });
+  done(std::integral_constant<int, Q0 + NQ - 1>(), acc[(NQ - 1) & 1]);
+  WIDE_FENCE();
+}
+
+// NB sample-per-lane blocks -> slot-per-lane (x 1 + 0 on the matrix core, exact: transpose_pk) -> the exchange region:
+// src(i) = block i's two operand fragments, dst(i) = where its two transposed fragments go (+ 0 and + 1024)
+template <class P, int NB, class SRC, class DST>
+__device__ __forceinline__ void transpose_pipe(const typename P::frag (&I)[2], SRC&& src, DST&& dst) {
+  typedef typename P::frag frag;
+  f32x16 t[2];
+  auto run = [&](auto IC, auto BC) __attribute__((always_inline)) {
+    constexpr int bf = decltype(BC)::value;
+    const frag (&x)[2] = src(IC);
+    t[bf] = P::mma(x[0], I[0], zero16());
+    t[bf] = P::mma(x[1], I[1], t[bf]);
+  };
+  run(std::integral_constant<int, 0>(), std::integral_constant<int, 0>());
+  static_for<NB>([&](auto IC) __attribute__((always_inline)) {
+    constexpr int i = decltype(IC)::value, cur = i & 1, nxt = cur ^ 1;
+    if constexpr (i + 1 < NB) run(std::integral_constant<int, i + 1>(), std::integral_constant<int, nxt>());
+    frag y[2];
+    pack_acc<P>(t[cur], y);
+    char* d = dst(IC);
+    *reinterpret_cast<frag*>(d) = y[0];
+    *reinterpret_cast<frag*>(d + 1024) = y[1];
+    WIDE_FENCE();
+  });
+}
+
 // ---- the DATA role (waves 0-3 of the workgroup): one 32-sample tile per wave and pass -- forward recompute, data gradients,
 //      the exchange operands.  Barriers: one per recomputed layer, two per layer of the walk -- the OWNER role runs the same sequence.
 template <class P, int HB, int NET, int N>
@@ -501,7 +613,7 @@ __device__ __forceinline__ void wide_data_role(const NofMlpDesc& d, char* smem, 
   typedef WNet<HB, NET, N> W;
   typedef typename P::frag frag;
   const int hi = lane >> 5, j = lane & 31;
-  IdentLds<P> I;                                                        // (in LDS, read where used: eight registers less across the pass)
+  IdentLds<P> I;                                                        // (in LDS: read once per step of the walk)
   I.base = reinterpret_cast<const typename P::frag*>(smem + W::IDB) + lane;
   const float gscale = d.grad_scale > 0.0f ? d.grad_scale : 1.0f, gunscale = 1.0f / gscale;
   char* const xw = smem + W::XB + wave_s * W::XWAVE + lane * 16;        // this wave's exchange region (+ its lane)
@@ -528,16 +640,8 @@ __device__ __forceinline__ void wide_data_role(const NofMlpDesc& d, char* smem, 
       constexpr int k = decltype(K)::value;
       __syncthreads();                                                  // chunk k is in its slot
       const char* wl = slot_of(k) + lane * 16;
-#pragma unroll
-      for (int p = 0; p < HB; ++p) {                                    // block by block: 16 fp32 values live, not 64
-        float h[1][16];
-        if constexpr (k == 0) dense_pk<P, W::QN0, 1>(wl + p * W::QN0 * 2048, bias_hi + (W::rel_oblk(k) + p) * 128, x0, h);
-        else dense_pk<P, HB, 1>(wl + p * HB * 2048, bias_hi + (W::rel_oblk(k) + p) * 128, a[k - 1], h);
-        pack_blk<P>(h[0], a[k][p]);                                     // round, then ReLU on the packed halves (relu_pk)
-        a[k][p][0] = relu_pk(a[k][p][0]);
-        a[k][p][1] = relu_pk(a[k][p][1]);
-        WIDE_FENCE();
-      }
+      if constexpr (k == 0) dense_relu_pipe<P, W::QN0, HB>(wl, bias_hi + W::rel_oblk(k) * 128, x0, a[k]);
+      else dense_relu_pipe<P, HB, HB>(wl, bias_hi + W::rel_oblk(k) * 128, a[k - 1], a[k]);
     });
     // ---------------- the head's gradient ----------------
     frag g[HB][2];                                                      // delta of the layer the walk is at (block 0 only for the head)
@@ -560,22 +664,19 @@ __device__ __forceinline__ void wide_data_role(const NofMlpDesc& d, char* smem, 
       constexpr int k = N - 1 - decltype(KK)::value;
       constexpr int PN = W::pn(k), QN = W::qn(k), c = 2 * N - 2 - k;
       // exchange: delta_k (PN blocks) and the layer's input (QN blocks), transposed on the matrix core
-#pragma unroll
-      for (int p = 0; p < ((NOF_WIDE_X & 4) ? 0 : PN); ++p) {
-        frag y[2];
-        transpose_pk<P>(I, g[p], y);
-        *reinterpret_cast<frag*>(xw + (p * 2) * 1024) = y[0];
-        *reinterpret_cast<frag*>(xw + (p * 2 + 1) * 1024) = y[1];
-        WIDE_FENCE();
-      }
-#pragma unroll
-      for (int q = 0; q < ((NOF_WIDE_X & 4) ? 0 : QN); ++q) {
-        frag y[2];
-        if constexpr (k == 0) transpose_pk<P>(I, x0[q], y);
-        else transpose_pk<P>(I, a[k - 1][q], y);
-        *reinterpret_cast<frag*>(xw + ((HB + q) * 2) * 1024) = y[0];
-        *reinterpret_cast<frag*>(xw + ((HB + q) * 2 + 1) * 1024) = y[1];
-        WIDE_FENCE();
+      {
+        const frag Id[2] = {I.get(0), I.get(1)};
+        transpose_pipe<P, PN + QN>(Id,
+          [&](auto IC) __attribute__((always_inline)) -> const frag (&)[2] {
+            constexpr int i = decltype(IC)::value;
+            if constexpr (i < PN) return g[i];
+            else if constexpr (k == 0) return x0[i - PN];
+            else return a[k > 0 ? k - 1 : 0][i - PN];
+          },
+          [&](auto IC) __attribute__((always_inline)) -> char* {
+            constexpr int i = decltype(IC)::value;
+            return xw + ((i < PN ? i : HB + i - PN) * 2) * 1024;
+          });
       }
       __syncthreads();                                                  // (A) the four tiles' operands are in place; chunk c too
       if constexpr (k == 0) {                                           // the next pass's inputs: in flight from here
@@ -586,15 +687,12 @@ __device__ __forceinline__ void wide_data_role(const NofMlpDesc& d, char* smem, 
       const char* wl = slot_of(c) + lane * 16;
       if constexpr (k > 0) {
         frag gn[HB][2];
-#pragma unroll
-        for (int q = 0; q < HB; ++q) {
-          float gq[16];
-          bwd_pk<P, PN>(wl, q, g, gq);
-          pack_blk<P>(gq, gn[q]);                                       // round, then the ReLU derivative from the activation itself
-          gn[q][0] = mask_pk(gn[q][0], a[k - 1][q][0]);
-          gn[q][1] = mask_pk(gn[q][1], a[k - 1][q][1]);
-          WIDE_FENCE();
-        }
+        bwd_pipe<P, PN, 0, HB>(wl, g, [&](auto QC, const f32x16& acc) __attribute__((always_inline)) {
+          constexpr int q = decltype(QC)::value;
+          pack_acc<P>(acc, gn[q]);                                      // round, then the ReLU derivative from the activation itself
+          gn[q][0] = mask_pk(gn[q][0], a[k > 0 ? k - 1 : 0][q][0]);
+          gn[q][1] = mask_pk(gn[q][1], a[k > 0 ? k - 1 : 0][q][1]);
+        });
 #pragma unroll
         for (int q = 0; q < HB; ++q) { g[q][0] = gn[q][0]; g[q][1] = gn[q][1]; }
       } else if constexpr (NET == 0) {
@@ -633,28 +731,26 @@ __device__ __forceinline__ void wide_data_role(const NofMlpDesc& d, char* smem, 
   }
 }
 
-// ---- the OWNER role (waves 4-7): owner o = wave - 4 holds the dW blocks idx = o + 4 i of every layer, adds the four tiles' products
+// ---- the OWNER role (waves 4-7): owner OW = wave - 4 (a template argument: which blocks a wave owns folds at compile time, no
+//      wave-uniform branches around single MFMAs) holds the dW blocks idx = OW + 4 i of every layer, adds the four tiles' products
 //      between the barriers (A) and (B) of a layer's step, and streams the weight chunks into the ring for everybody.
-template <class P, int HB, int NET, int N>
-__device__ __forceinline__ void wide_owner_role(const NofMlpDesc& d, char* smem, int ow, int lane, const char* __restrict__ fw_img,
+template <class P, int HB, int NET, int N, int OW>
+__device__ __forceinline__ void wide_owner_role(const NofMlpDesc& d, char* smem, int lane, const char* __restrict__ fw_img,
                                                 const char* __restrict__ bw_img, float* __restrict__ dst, int lbase, int64_t nbatch) {
   typedef WNet<HB, NET, N> W;
   typedef typename P::frag frag;
+  constexpr int ow = OW;
   const int hi = lane >> 5, j = lane & 31;
   const float gunscale = d.grad_scale > 0.0f ? 1.0f / d.grad_scale : 1.0f;
   f32x16 acc[W::NACC];                                                  // the dW blocks this wave owns, all layers
 #pragma unroll
-  for (int a = 0; a < W::NACC; ++a)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[a][r] = 0.0f;
+  for (int a = 0; a < W::NACC; ++a) acc[a] = zero16();
   // The bias gradient db[m] = sum over samples of delta[m][sample] rides on the matrix core too: delta^T (the A operand of the dW
   // MFMA, already in the exchange) times a ONE-HOT column selector gives D[m][c] = db[m] in column c = the (layer, block)'s number --
   // one accumulator holds every block's sums side by side (NDB <= 32 columns), the data waves add nothing per tile (round 6: they
   // summed 16 registers per delta block and kept lane-private LDS words: 208 v_add + 26 LDS read-modify-writes per tile on the
   // critical path).  Block p of a layer belongs to owner p (PN <= 4).
-  f32x16 accb;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) accb[r] = 0.0f;
+  f32x16 accb = zero16();
   float one8[8];
 #pragma unroll
   for (int t = 0; t < 8; ++t) one8[t] = 1.0f;
@@ -669,10 +765,8 @@ __device__ __forceinline__ void wide_owner_role(const NofMlpDesc& d, char* smem,
       __syncthreads();                                                  // chunk k is published; the other slot's readers are done
       constexpr int kn = k + 1 < N - 1 ? k + 1 : N - 1;                 // next chunk: fw of layer k + 1, or bw of the head
       ChunkLoad<W::pn(kn) * W::qn(kn) * 2048> cl;
-      if (!(NOF_WIDE_X & 1)) {
       cl.issue((k + 1 < N - 1 ? fw_img : bw_img) + W::rel_pair(kn) * 2048, slot_of(k + 1), ow, lane);
       cl.commit(slot_of(k + 1), ow, lane);
-      }
     });
     static_for<N>([&](auto KK) __attribute__((always_inline)) {
       constexpr int k = N - 1 - decltype(KK)::value;
@@ -681,39 +775,40 @@ __device__ __forceinline__ void wide_owner_role(const NofMlpDesc& d, char* smem,
       // next chunk: bw of layer k - 1, or -- the last step -- fw of layer 0 for the workgroup's next pass
       constexpr int kn = k > 0 ? k - 1 : 0;
       ChunkLoad<W::pn(kn) * W::qn(kn) * 2048> cl;
-      const bool more = !(NOF_WIDE_X & 1) && (k > 0 || bi + gridDim.x < nbatch);
+      const bool more = k > 0 || bi + gridDim.x < nbatch;
       if (more) cl.issue((k > 0 ? bw_img : fw_img) + W::rel_pair(kn) * 2048, slot_of(c + 1), ow, lane);
-      // idx = o + 4 i -> (p, q) = (idx / QN, idx % QN); the four tiles one after the other, the wave's blocks interleaved so that
-      // consecutive MFMAs go to different accumulators
+      // idx = OW + 4 i -> (p, q) = (idx / QN, idx % QN).  One unit of work = one (tile, K half): the wave's NBK blocks' products
+      // (consecutive MFMAs go to different accumulators) + the bias selector; unit u + 1's operands are requested before unit
+      // u's MFMAs (two operand sets alive).
       {
-        const char* xd[W::nb(k)];
-        const char* xa[W::nb(k)];
-#pragma unroll
-        for (int i = 0; i < W::nb(k); ++i) {
-          const int idx = ow + 4 * i;
-          const int p = idx / QN, q = idx % QN;
-          xd[i] = xr + (p * 2) * 1024;
-          xa[i] = xr + ((HB + q) * 2) * 1024;
-        }
-        // bias gradient: the layer's block p = ow (PN <= 4: at most one per owner), in the same sweep over the exchange
-        constexpr bool HAS_DB = true;
-        const bool mine = ow < PN;                                      // (wave-uniform)
+        constexpr int NBK = (PN * QN - ow + 3) / 4 > 0 ? (PN * QN - ow + 3) / 4 : 0;      // blocks of this layer the wave owns
+        constexpr bool mine = ow < PN;                                  // the bias block p = OW
         frag sel;
 #pragma unroll
         for (int t = 0; t < 8; ++t) sel[t] = j == W::rel_oblk(k) + ow ? ones[t] : (typename P::elem)0.0f;
-        const char* const xb = xr + (ow * 2) * 1024;
+        struct Ops { frag dl[NBK > 0 ? NBK : 1], av[NBK > 0 ? NBK : 1], db; };
+        Ops op[2];
+        auto fetch = [&](auto UC, auto BC) __attribute__((always_inline)) {
+          constexpr int u = decltype(UC)::value, bf = decltype(BC)::value, w4 = u >> 1, s2 = u & 1;
+          const char* base = xr + w4 * W::XWAVE + s2 * 1024;
 #pragma unroll
-        for (int w4 = 0; w4 < ((NOF_WIDE_X & 2) ? 0 : 4); ++w4) {
-#pragma unroll
-          for (int s = 0; s < 2; ++s) {
-#pragma unroll
-            for (int i = 0; i < W::nb(k); ++i)
-              if (ow + 4 * i < PN * QN)                                 // (wave-uniform)
-                acc[W::aoff(k) + i] = P::mma(*reinterpret_cast<const frag*>(xd[i] + w4 * W::XWAVE + s * 1024),
-                                             *reinterpret_cast<const frag*>(xa[i] + w4 * W::XWAVE + s * 1024), acc[W::aoff(k) + i]);
-            if (HAS_DB && mine) accb = P::mma(*reinterpret_cast<const frag*>(xb + w4 * W::XWAVE + s * 1024), sel, accb);
+          for (int i = 0; i < NBK; ++i) {
+            const int idx = ow + 4 * i;
+            op[bf].dl[i] = *reinterpret_cast<const frag*>(base + ((idx / QN) * 2) * 1024);
+            op[bf].av[i] = *reinterpret_cast<const frag*>(base + ((HB + idx % QN) * 2) * 1024);
           }
-          __builtin_amdgcn_sched_barrier(0);      // (the owners have time to spare and 176 + 16 accumulator registers: their reads stay beside their MFMAs)
+          if constexpr (mine) op[bf].db = *reinterpret_cast<const frag*>(base + (ow * 2) * 1024);
+        };
+        if constexpr (NBK > 0 || mine) {
+          fetch(std::integral_constant<int, 0>(), std::integral_constant<int, 0>());
+          static_for<8>([&](auto UC) __attribute__((always_inline)) {
+            constexpr int u = decltype(UC)::value, cur = u & 1, nxt = cur ^ 1;
+            if constexpr (u + 1 < 8) fetch(std::integral_constant<int, u + 1>(), std::integral_constant<int, nxt>());
+#pragma unroll
+            for (int i = 0; i < NBK; ++i) acc[W::aoff(k) + i] = P::mma(op[cur].dl[i], op[cur].av[i], acc[W::aoff(k) + i]);
+            if constexpr (mine) accb = P::mma(op[cur].db, sel, accb);
+            __builtin_amdgcn_sched_barrier(0);
+          });
         }
       }
       if (more) cl.commit(slot_of(c + 1), ow, lane);
@@ -730,6 +825,7 @@ __device__ __forceinline__ void wide_owner_role(const NofMlpDesc& d, char* smem,
     const int in_dim = d.in_dim[l], out_dim = d.out_dim[l];
 #pragma unroll
     for (int i = 0; i < W::nb(k); ++i) {
+      constexpr int dummy = 0; (void)dummy;
       const int idx = ow + 4 * i;
       if (idx < PN * QN) {
         const int p = idx / QN, q = idx % QN;
@@ -742,15 +838,13 @@ __device__ __forceinline__ void wide_owner_role(const NofMlpDesc& d, char* smem,
       }
     }
     // bias gradients: column rel_oblk(k) + p of accb, rows = the block's neurons (lane j = column, hi = row half)
+    if (ow < PN && j == W::rel_oblk(k) + ow) {
 #pragma unroll
-    for (int p = 0; p < PN; ++p)
-      if (p == ow && j == W::rel_oblk(k) + p) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int orow = 32 * p + nloc(hi, r);
-          if (orow < out_dim) dst[d.b_off[l] + orow] = accb[r] * gunscale;
-        }
+      for (int r = 0; r < 16; ++r) {
+        const int orow = 32 * ow + nloc(hi, r);
+        if (orow < out_dim) dst[d.b_off[l] + orow] = accb[r] * gunscale;
       }
+    }
   });
 }
 
@@ -792,7 +886,14 @@ __global__ __launch_bounds__(512, 2) void k_wide_bwd_net(NofMlpDesc d, const cha
       c0.issue(fw_img, smem, wave_s - 4, lane);
       c0.commit(smem, wave_s - 4, lane);
     }
-    if (NOF_WIDE_ROLES & 2) wide_owner_role<P, HB, NET, N>(d, smem, wave_s - 4, lane, fw_img, bw_img, dst, lbase, nbatch);
+    if (NOF_WIDE_ROLES & 2) {
+      switch (wave_s) {                                                 // (wave-uniform)
+        case 4: wide_owner_role<P, HB, NET, N, 0>(d, smem, lane, fw_img, bw_img, dst, lbase, nbatch); break;
+        case 5: wide_owner_role<P, HB, NET, N, 1>(d, smem, lane, fw_img, bw_img, dst, lbase, nbatch); break;
+        case 6: wide_owner_role<P, HB, NET, N, 2>(d, smem, lane, fw_img, bw_img, dst, lbase, nbatch); break;
+        default: wide_owner_role<P, HB, NET, N, 3>(d, smem, lane, fw_img, bw_img, dst, lbase, nbatch); break;
+      }
+    }
   }
 }
 
