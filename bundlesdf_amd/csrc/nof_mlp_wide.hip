@@ -26,41 +26,6 @@
 #include "nof_mlp_dev.h"
 #include <utility>
 
-// ReLU in place + the 16 PN derivative bits of the lane (relu_mask of nof_mlp_dev.h, two blocks per 32-bit word)
-template <int HB>
-__device__ __forceinline__ uint2 relu_bits(float (&h)[HB][16]) {
-  static_assert(HB == 2 || HB == 4, "hidden width 64 or 128");
-  uint32_t off[2] = {0u, 0u};
-#pragma unroll
-  for (int p = 0; p < HB; ++p)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {                                     // (plain indexing: a reinterpret_cast of the array sent it to scratch)
-      const int bits = __float_as_int(h[p][r]);
-      off[p >> 1] = __builtin_amdgcn_alignbit(off[p >> 1], (uint32_t)bits, 31);
-      h[p][r] = __int_as_float(bits > 0 ? bits : 0);
-    }
-  return make_uint2(~off[0], HB == 4 ? ~off[1] : 0u);
-}
-// element r of block p sits in word p >> 1 at bit 31 - (16 (p & 1) + r), 1 = the unit was on
-__device__ __forceinline__ void apply_bits_blk(float (&g)[16], uint2 m, int p) {
-#pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const uint32_t keep = (uint32_t)__builtin_amdgcn_sbfe((int)(p < 2 ? m.x : m.y), 31 - (16 * (p & 1) + r), 1);
-    g[r] = __uint_as_float(__float_as_uint(g[r]) & keep);
-  }
-}
-
-template <int PN>
-__device__ __forceinline__ void relu_inplace(float (&h)[PN][16]) {
-#pragma unroll
-  for (int p = 0; p < PN; ++p)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {                                     // signed-integer max on the bits: one instruction (see relu_mask)
-      const int bits = __float_as_int(h[p][r]);
-      h[p][r] = __int_as_float(bits > 0 ? bits : 0);
-    }
-}
-
 // ---- ReLU and its derivative on PACKED 16-bit operands (round 6).  relu(round16(x)) == round16(relu(x)) for both operand types
 //      (rounding keeps sign and zero), so the backward kernel rounds first and clamps the packed halves: one v_pk_ashrrev_i16 +
 //      one v_and (v_bfi) per PAIR instead of a v_max + a v_alignbit per element, and no derivative bit words -- the recomputed
@@ -85,200 +50,6 @@ __device__ __forceinline__ F mask_pk(F g, F a) {
 }
 
 #define WPAIR ((int)(16 * 64 * sizeof(typename P::elem)))
-
-// =====================================================================================================
-// forward, sigma net: features -> hidden layers -> head: sdf -> raw[b].w (or sdf[b]), sig[b] = 16 head outputs
-// =====================================================================================================
-// threads per workgroup of the forward kernels: 768 (3 waves per SIMD, 168 registers) where that fits without scratch (hidden 64);
-// hidden 128 needs ~190 (two 64-register activation sets + the operand and weight fragments of a chain): 512 threads
-template <int HB> struct WideFwdThreads { static constexpr int value = HB >= 4 ? 512 : 768; };
-
-template <class P, int HB>
-__global__ __launch_bounds__(WideFwdThreads<HB>::value) void k_wide_fwd_sigma(NofMlpDesc d, const char* __restrict__ image,
-                                                         const float2* __restrict__ feat, int L,
-                                                         float* __restrict__ out, int out_stride, int out_off,
-                                                         typename P::elem* __restrict__ sig, int64_t B) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int NS = d.n_sigma, NL = d.n_sigma + d.n_color;
-  const int bias_base = pair_base(d, NS) * WPAIR;
-  copy16(smem, image, (size_t)bias_base);
-  copy16(smem + bias_base, image + 2 * (size_t)pair_base(d, NL) * WPAIR, (size_t)oblk_base(d, NS) * 128);
-  __syncthreads();
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
-  const int hi = lane >> 5, j = lane & 31;
-  const int64_t ntiles = (B + 31) / 32, tstride = (int64_t)gridDim.x * nw;
-  float xn[1][16];                                                      // the NEXT tile's features, a whole tile ahead
-  load_feat_o1(feat, L, B, ((int64_t)blockIdx.x * nw + wave) * 32 + j, hi, xn);
-  for (int64_t tile = (int64_t)blockIdx.x * nw + wave; tile < ntiles; tile += tstride) {
-    asm volatile("" ::: "memory");
-    const int64_t b = tile * 32 + j;
-    const bool ok = b < B;
-    float x[1][16], h[HB][16], so[1][16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) x[0][r] = xn[0][r];
-    pin16(x[0]);
-    load_feat_o1(feat, L, B, (tile + tstride) * 32 + j, hi, xn);
-    dense_o1<P, 1, HB>(smem, 0, bias_base, x, h, lane);
-    relu_inplace<HB>(h);
-    int foff = HB * WPAIR, boff = bias_base + HB * 128;
-    for (int l = 1; l < NS - 1; ++l) {
-      float h2[HB][16];
-      dense_o1<P, HB, HB>(smem, foff, boff, h, h2, lane);
-      relu_inplace<HB>(h2);
-#pragma unroll
-      for (int p = 0; p < HB; ++p)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) h[p][r] = h2[p][r];
-      foff += HB * HB * WPAIR;
-      boff += HB * 128;
-    }
-    dense_o1<P, HB, 1>(smem, foff, boff, h, so, lane);
-    if (sig != nullptr) store_sig_o1<P>(sig, B, b, hi, so[0]);
-    if (hi == 0 && ok) out[b * out_stride + out_off] = so[0][0];
-  }
-}
-
-// =====================================================================================================
-// forward, sigma net WITH the hash encode in the launch (round 6; the narrow networks' k_enc_mlp_fwd, DESIGN 2.10, at width 128):
-// pts_w -> 16 levels gathered, lane = sample, the level wave-uniform -> a wave-private LDS stage, feature-major -> the chain of
-// two 32-sample tiles.  The fp32 embedding [L,B,2] (cfg5: 403 MB written by k_hash_fwd, read here, read again by the backward) is
-// gone; what the backward needs of it is its value in operand precision, featq [B][2][16] (64 B per sample).
-// =====================================================================================================
-template <class P, int HB>
-__global__ __launch_bounds__(WideFwdThreads<HB>::value) void k_wide_enc_fwd_sigma(NofMlpDesc d, const char* __restrict__ image,
-                                                             NofHashGrid g, const float2* __restrict__ table,
-                                                             const float* __restrict__ pts_w, float* __restrict__ out, int out_stride,
-                                                             int out_off, typename P::elem* __restrict__ sig,
-                                                             typename P::elem* __restrict__ featq, int64_t B) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int NS = d.n_sigma, NL = d.n_sigma + d.n_color;
-  const int bias_base = pair_base(d, NS) * WPAIR;
-  const int stage_base = (bias_base + oblk_base(d, NS) * 128 + 15) & ~15;
-  copy16(smem, image, (size_t)bias_base);
-  copy16(smem + bias_base, image + 2 * (size_t)pair_base(d, NL) * WPAIR, (size_t)oblk_base(d, NS) * 128);
-  const int NW = blockDim.x >> 6;
-  uint32_t* lvl = reinterpret_cast<uint32_t*>(smem + stage_base + NW * 8192);       // [16][8] words behind the stages (see k_enc_mlp_fwd)
-  if (threadIdx.x < NOF_MAX_LEVELS) {
-    const int l = threadIdx.x;
-    lvl[l * 8 + 0] = __float_as_uint(g.scale[l]); lvl[l * 8 + 1] = g.resolution[l]; lvl[l * 8 + 2] = g.offset[l];
-    lvl[l * 8 + 3] = g.size[l]; lvl[l * 8 + 4] = g.hashed[l];
-  }
-  const int n_levels = g.L;
-  __syncthreads();
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int hi = lane >> 5, j = lane & 31;
-  auto level_at = [&](int l) {                          // wave-uniform: the LDS words go through readfirstlane into SGPRs
-    HashLevel lv;
-    const uint4 q = *reinterpret_cast<const uint4*>(lvl + l * 8);
-    lv.scale = __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)q.x));
-    lv.res = (uint32_t)__builtin_amdgcn_readfirstlane((int)q.y);
-    lv.offset = (uint32_t)__builtin_amdgcn_readfirstlane((int)q.z);
-    lv.size = (uint32_t)__builtin_amdgcn_readfirstlane((int)q.w);
-    lv.hashed = (uint32_t)__builtin_amdgcn_readfirstlane((int)lvl[l * 8 + 4]);
-    return lv;
-  };
-  float* const stage = reinterpret_cast<float*>(smem + stage_base + wave * 8192);       // [32][64] floats
-  const int64_t npairs = (B + 63) / 64;
-  for (int64_t tp = (int64_t)blockIdx.x * NW + wave; tp < npairs; tp += (int64_t)gridDim.x * NW) {
-    asm volatile("" ::: "memory");
-    __builtin_amdgcn_s_setprio(3);                      // (the gather phase issues first: DESIGN 2.10)
-    const int64_t bs = tp * 64 + lane;
-    const int64_t bb = bs < B ? bs : B - 1;             // (a lane past the end encodes the last sample: nothing of it is stored)
-    const float p[3] = {pts_w[bb * 3], pts_w[bb * 3 + 1], pts_w[bb * 3 + 2]};
-#pragma unroll 1
-    for (int l0 = 0; l0 < NOF_MAX_LEVELS; ++l0) {
-      float2 a = make_float2(0.f, 0.f);
-      if (l0 < n_levels) {                              // (uniform)
-        const HashLevel lv = level_at(l0);
-        EncCell e = enc_prep(lv, p);
-        float2 v[8];
-        if (level_pairs(lv)) enc_load<true>(lv, table, e, v);
-        else enc_load<false>(lv, table, e, v);
-        enc_keep(e);
-        a = enc_blend(e, v);
-      }
-      stage[(2 * l0) * 64 + lane] = a.x;
-      stage[(2 * l0 + 1) * 64 + lane] = a.y;
-    }
-    __builtin_amdgcn_s_setprio(0);
-    // the two tiles through the chain: lane (j, hi) of tile t reads features 16 hi .. 16 hi + 15 of sample 32 t + j
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      asm volatile("" ::: "memory");
-      float x[1][16], h[HB][16], so[1][16];
-#pragma unroll
-      for (int r = 0; r < 16; ++r) x[0][r] = stage[(16 * hi + r) * 64 + 32 * t + j];
-      const int64_t b = tp * 64 + 32 * t + j;
-      const bool ok = b < B;
-      if (featq != nullptr && ok) {                     // the embedding as the backward reads it: rounded to the operand type, operand order
-        typename P::frag* q = reinterpret_cast<typename P::frag*>(featq + (b * 2 + hi) * 16);
-        q[0] = P::pack(&x[0][0]);
-        q[1] = P::pack(&x[0][8]);
-      }
-      dense_o1<P, 1, HB>(smem, 0, bias_base, x, h, lane);
-      relu_inplace<HB>(h);
-      int foff = HB * WPAIR, boff = bias_base + HB * 128;
-      for (int l = 1; l < NS - 1; ++l) {
-        float h2[HB][16];
-        dense_o1<P, HB, HB>(smem, foff, boff, h, h2, lane);
-        relu_inplace<HB>(h2);
-#pragma unroll
-        for (int pp = 0; pp < HB; ++pp)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) h[pp][r] = h2[pp][r];
-        foff += HB * HB * WPAIR;
-        boff += HB * 128;
-      }
-      dense_o1<P, HB, 1>(smem, foff, boff, h, so, lane);
-      if (sig != nullptr) store_sig_o1<P>(sig, B, b, hi, so[0]);
-      if (hi == 0 && ok) out[b * out_stride + out_off] = so[0][0];
-    }
-  }
-}
-
-// =====================================================================================================
-// forward, colour net: [sig | view] -> hidden layers -> rgb_raw -> raw[b].xyz
-// =====================================================================================================
-template <class P, int HB>
-__global__ __launch_bounds__(WideFwdThreads<HB>::value) void k_wide_fwd_color(NofMlpDesc d, const char* __restrict__ image,
-                                                         const typename P::elem* __restrict__ sig,
-                                                         const float* __restrict__ view, int S,
-                                                         float* __restrict__ raw, int64_t B) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int NS = d.n_sigma, NC = d.n_color, NL = NS + NC;
-  const int PA = pair_base(d, NS), PB = pair_base(d, NL), OA = oblk_base(d, NS), OB = oblk_base(d, NL);
-  const int bias_base = (PB - PA) * WPAIR;
-  copy16(smem, image + (size_t)PA * WPAIR, (size_t)bias_base);
-  copy16(smem + bias_base, image + 2 * (size_t)PB * WPAIR + OA * 128, (size_t)(OB - OA) * 128);
-  __syncthreads();
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
-  const int hi = lane >> 5, j = lane & 31;
-  const int64_t ntiles = (B + 31) / 32;
-  for (int64_t tile = (int64_t)blockIdx.x * nw + wave; tile < ntiles; tile += (int64_t)gridDim.x * nw) {
-    asm volatile("" ::: "memory");
-    const int64_t b = tile * 32 + j;
-    const bool ok = b < B;
-    float cin[2][16], h[HB][16], co[1][16];
-    load_sig_o1<P>(sig, B, b, hi, cin[0]);            // (requested a tile ahead: 4-10 % slower at cfg5, measured twice)
-    load_view_o1(view, S, B, b, hi, cin[1]);
-    dense_o1<P, 2, HB>(smem, 0, bias_base, cin, h, lane);
-    relu_inplace<HB>(h);
-    int foff = 2 * HB * WPAIR, boff = bias_base + HB * 128;
-    for (int l = 1; l < NC - 1; ++l) {
-      float h2[HB][16];
-      dense_o1<P, HB, HB>(smem, foff, boff, h, h2, lane);
-      relu_inplace<HB>(h2);
-#pragma unroll
-      for (int p = 0; p < HB; ++p)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) h[p][r] = h2[p][r];
-      foff += HB * HB * WPAIR;
-      boff += HB * 128;
-    }
-    dense_o1<P, HB, 1>(smem, foff, boff, h, co, lane);
-    if (hi == 0 && ok) { raw[b * 4] = co[0][0]; raw[b * 4 + 1] = co[0][1]; raw[b * 4 + 2] = co[0][2]; }
-  }
-}
 
 // =====================================================================================================
 // backward of ONE network, everything on chip (header).  NET: 0 = sigma net (x0 = hash features, head gradient = dsig, input
@@ -599,6 +370,187 @@ __device__ __forceinline__ void transpose_pipe(const typename P::frag (&I)[2], S
     *reinterpret_cast<frag*>(d + 1024) = y[1];
     WIDE_FENCE();
   });
+}
+
+// =====================================================================================================
+// forward, sigma net: features -> hidden layers -> head: sdf -> raw[b].w (or sdf[b]), sig[b] = 16 head outputs
+// =====================================================================================================
+// threads per workgroup of the forward kernels: 768 (3 waves per SIMD, 168 registers) where that fits without scratch (hidden 64);
+// hidden 128 needs ~190 (two 64-register activation sets + the operand and weight fragments of a chain): 512 threads
+template <int HB> struct WideFwdThreads { static constexpr int value = HB >= 4 ? 512 : 768; };
+
+// One network's chain on PACKED operands (round 6: the forward kernels ran dense_o1 block by block on fp32 arrays -- read, wait,
+// chain, drain, ReLU -- at 52-55 % matrix-pipe busy): hidden layers through dense_relu_pipe (the backward's recompute: the same
+// bits by construction), then the head's single block.  `wl0` = the network's first fragment + 16 * lane, `bias_hi` = its first
+// bias block + 16 * hi.
+template <class P, int HB, int QN0>
+__device__ __forceinline__ void wide_chain(const char* wl0, const char* bias_hi, int nlayers, const typename P::frag (&x0)[QN0][2],
+                                           float (&out)[1][16]) {
+  typename P::frag h[HB][2];
+  dense_relu_pipe<P, QN0, HB>(wl0, bias_hi, x0, h);
+  int foff = QN0 * HB * 2048, boff = HB * 128;
+  for (int l = 1; l < nlayers - 1; ++l) {
+    typename P::frag h2[HB][2];
+    dense_relu_pipe<P, HB, HB>(wl0 + foff, bias_hi + boff, h, h2);
+#pragma unroll
+    for (int p = 0; p < HB; ++p) { h[p][0] = h2[p][0]; h[p][1] = h2[p][1]; }
+    foff += HB * HB * 2048;
+    boff += HB * 128;
+  }
+  dense_pk<P, HB, 1>(wl0 + foff, bias_hi + boff, h, out);
+}
+
+template <class P, int HB>
+__global__ __launch_bounds__(WideFwdThreads<HB>::value) void k_wide_fwd_sigma(NofMlpDesc d, const char* __restrict__ image,
+                                                         const float2* __restrict__ feat, int L,
+                                                         float* __restrict__ out, int out_stride, int out_off,
+                                                         typename P::elem* __restrict__ sig, int64_t B) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int NS = d.n_sigma, NL = d.n_sigma + d.n_color;
+  const int bias_base = pair_base(d, NS) * WPAIR;
+  copy16(smem, image, (size_t)bias_base);
+  copy16(smem + bias_base, image + 2 * (size_t)pair_base(d, NL) * WPAIR, (size_t)oblk_base(d, NS) * 128);
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  const int hi = lane >> 5, j = lane & 31;
+  const int64_t ntiles = (B + 31) / 32, tstride = (int64_t)gridDim.x * nw;
+  float xn[1][16];                                                      // the NEXT tile's features, a whole tile ahead
+  load_feat_o1(feat, L, B, ((int64_t)blockIdx.x * nw + wave) * 32 + j, hi, xn);
+  for (int64_t tile = (int64_t)blockIdx.x * nw + wave; tile < ntiles; tile += tstride) {
+    asm volatile("" ::: "memory");
+    const int64_t b = tile * 32 + j;
+    const bool ok = b < B;
+    float x[1][16], so[1][16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) x[0][r] = xn[0][r];
+    pin16(x[0]);
+    load_feat_o1(feat, L, B, (tile + tstride) * 32 + j, hi, xn);
+    typename P::frag x0[1][2];
+    pack_blk<P>(x[0], x0[0]);
+    wide_chain<P, HB, 1>(smem + lane * 16, smem + bias_base + hi * 16, NS, x0, so);
+    if (sig != nullptr) store_sig_o1<P>(sig, B, b, hi, so[0]);
+    if (hi == 0 && ok) out[b * out_stride + out_off] = so[0][0];
+  }
+}
+
+// =====================================================================================================
+// forward, sigma net WITH the hash encode in the launch (round 6; the narrow networks' k_enc_mlp_fwd, DESIGN 2.10, at width 128):
+// pts_w -> 16 levels gathered, lane = sample, the level wave-uniform -> a wave-private LDS stage, feature-major -> the chain of
+// two 32-sample tiles.  The fp32 embedding [L,B,2] (cfg5: 403 MB written by k_hash_fwd, read here, read again by the backward) is
+// gone; what the backward needs of it is its value in operand precision, featq [B][2][16] (64 B per sample).
+// =====================================================================================================
+template <class P, int HB>
+__global__ __launch_bounds__(WideFwdThreads<HB>::value) void k_wide_enc_fwd_sigma(NofMlpDesc d, const char* __restrict__ image,
+                                                             NofHashGrid g, const float2* __restrict__ table,
+                                                             const float* __restrict__ pts_w, float* __restrict__ out, int out_stride,
+                                                             int out_off, typename P::elem* __restrict__ sig,
+                                                             typename P::elem* __restrict__ featq, int64_t B) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int NS = d.n_sigma, NL = d.n_sigma + d.n_color;
+  const int bias_base = pair_base(d, NS) * WPAIR;
+  const int stage_base = (bias_base + oblk_base(d, NS) * 128 + 15) & ~15;
+  copy16(smem, image, (size_t)bias_base);
+  copy16(smem + bias_base, image + 2 * (size_t)pair_base(d, NL) * WPAIR, (size_t)oblk_base(d, NS) * 128);
+  const int NW = blockDim.x >> 6;
+  uint32_t* lvl = reinterpret_cast<uint32_t*>(smem + stage_base + NW * 8192);       // [16][8] words behind the stages (see k_enc_mlp_fwd)
+  if (threadIdx.x < NOF_MAX_LEVELS) {
+    const int l = threadIdx.x;
+    lvl[l * 8 + 0] = __float_as_uint(g.scale[l]); lvl[l * 8 + 1] = g.resolution[l]; lvl[l * 8 + 2] = g.offset[l];
+    lvl[l * 8 + 3] = g.size[l]; lvl[l * 8 + 4] = g.hashed[l];
+  }
+  const int n_levels = g.L;
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int hi = lane >> 5, j = lane & 31;
+  auto level_at = [&](int l) {                          // wave-uniform: the LDS words go through readfirstlane into SGPRs
+    HashLevel lv;
+    const uint4 q = *reinterpret_cast<const uint4*>(lvl + l * 8);
+    lv.scale = __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)q.x));
+    lv.res = (uint32_t)__builtin_amdgcn_readfirstlane((int)q.y);
+    lv.offset = (uint32_t)__builtin_amdgcn_readfirstlane((int)q.z);
+    lv.size = (uint32_t)__builtin_amdgcn_readfirstlane((int)q.w);
+    lv.hashed = (uint32_t)__builtin_amdgcn_readfirstlane((int)lvl[l * 8 + 4]);
+    return lv;
+  };
+  float* const stage = reinterpret_cast<float*>(smem + stage_base + wave * 8192);       // [32][64] floats
+  const int64_t npairs = (B + 63) / 64;
+  for (int64_t tp = (int64_t)blockIdx.x * NW + wave; tp < npairs; tp += (int64_t)gridDim.x * NW) {
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_setprio(3);                      // (the gather phase issues first: DESIGN 2.10)
+    const int64_t bs = tp * 64 + lane;
+    const int64_t bb = bs < B ? bs : B - 1;             // (a lane past the end encodes the last sample: nothing of it is stored)
+    const float p[3] = {pts_w[bb * 3], pts_w[bb * 3 + 1], pts_w[bb * 3 + 2]};
+#pragma unroll 1
+    for (int l0 = 0; l0 < NOF_MAX_LEVELS; ++l0) {
+      float2 a = make_float2(0.f, 0.f);
+      if (l0 < n_levels) {                              // (uniform)
+        const HashLevel lv = level_at(l0);
+        EncCell e = enc_prep(lv, p);
+        float2 v[8];
+        if (level_pairs(lv)) enc_load<true>(lv, table, e, v);
+        else enc_load<false>(lv, table, e, v);
+        enc_keep(e);
+        a = enc_blend(e, v);
+      }
+      stage[(2 * l0) * 64 + lane] = a.x;
+      stage[(2 * l0 + 1) * 64 + lane] = a.y;
+    }
+    __builtin_amdgcn_s_setprio(0);
+    // the two tiles through the chain: lane (j, hi) of tile t reads features 16 hi .. 16 hi + 15 of sample 32 t + j
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      asm volatile("" ::: "memory");
+      float x[1][16], so[1][16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) x[0][r] = stage[(16 * hi + r) * 64 + 32 * t + j];
+      const int64_t b = tp * 64 + 32 * t + j;
+      const bool ok = b < B;
+      typename P::frag x0[1][2];
+      pack_blk<P>(x[0], x0[0]);
+      if (featq != nullptr && ok) {                     // the embedding as the backward reads it: rounded to the operand type, operand order
+        typename P::frag* q = reinterpret_cast<typename P::frag*>(featq + (b * 2 + hi) * 16);
+        q[0] = x0[0][0];
+        q[1] = x0[0][1];
+      }
+      wide_chain<P, HB, 1>(smem + lane * 16, smem + bias_base + hi * 16, NS, x0, so);
+      if (sig != nullptr) store_sig_o1<P>(sig, B, b, hi, so[0]);
+      if (hi == 0 && ok) out[b * out_stride + out_off] = so[0][0];
+    }
+  }
+}
+
+// =====================================================================================================
+// forward, colour net: [sig | view] -> hidden layers -> rgb_raw -> raw[b].xyz
+// =====================================================================================================
+template <class P, int HB>
+__global__ __launch_bounds__(WideFwdThreads<HB>::value) void k_wide_fwd_color(NofMlpDesc d, const char* __restrict__ image,
+                                                         const typename P::elem* __restrict__ sig,
+                                                         const float* __restrict__ view, int S,
+                                                         float* __restrict__ raw, int64_t B) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int NS = d.n_sigma, NC = d.n_color, NL = NS + NC;
+  const int PA = pair_base(d, NS), PB = pair_base(d, NL), OA = oblk_base(d, NS), OB = oblk_base(d, NL);
+  const int bias_base = (PB - PA) * WPAIR;
+  copy16(smem, image + (size_t)PA * WPAIR, (size_t)bias_base);
+  copy16(smem + bias_base, image + 2 * (size_t)PB * WPAIR + OA * 128, (size_t)(OB - OA) * 128);
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  const int hi = lane >> 5, j = lane & 31;
+  const int64_t ntiles = (B + 31) / 32;
+  for (int64_t tile = (int64_t)blockIdx.x * nw + wave; tile < ntiles; tile += (int64_t)gridDim.x * nw) {
+    asm volatile("" ::: "memory");
+    const int64_t b = tile * 32 + j;
+    const bool ok = b < B;
+    float vw[16], co[1][16];
+    typename P::frag x0[2][2];                         // [sigma head | view] as the backward's WideIn<P, 1>::unpack builds them
+    x0[0][0] = load_sig_raw<P>(sig, B, b, hi);        // (requested a tile ahead: 4-10 % slower at cfg5, measured twice)
+#pragma unroll
+    for (int t = 0; t < 8; ++t) x0[0][1][t] = (typename P::elem)0.0f;
+    load_view_o1(view, S, B, b, hi, vw);
+    pack_blk<P>(vw, x0[1]);
+    wide_chain<P, HB, 2>(smem + lane * 16, smem + bias_base + hi * 16, NC, x0, co);
+    if (hi == 0 && ok) { raw[b * 4] = co[0][0]; raw[b * 4 + 1] = co[0][1]; raw[b * 4 + 2] = co[0][2]; }
+  }
 }
 
 // ---- the DATA role (waves 0-3 of the workgroup): one 32-sample tile per wave and pass -- forward recompute, data gradients,
