@@ -378,6 +378,11 @@ __device__ __forceinline__ void transpose_pipe(const typename P::frag (&I)[2], S
 // threads per workgroup of the forward kernels: 768 (3 waves per SIMD, 168 registers) where that fits without scratch (hidden 64);
 // hidden 128 needs ~190 (two 64-register activation sets + the operand and weight fragments of a chain): 512 threads
 template <int HB> struct WideFwdThreads { static constexpr int value = HB >= 4 ? 512 : 768; };
+#ifndef NOF_WIDE_COLOR_T4
+#define NOF_WIDE_COLOR_T4 768
+#endif
+// the colour forward (no stage buffers, 161 registers on packed operands) has room for a third wave per SIMD
+template <int HB> struct WideColorThreads { static constexpr int value = HB >= 4 ? NOF_WIDE_COLOR_T4 : 768; };
 
 // One network's chain on PACKED operands (round 6: the forward kernels ran dense_o1 block by block on fp32 arrays -- read, wait,
 // chain, drain, ReLU -- at 52-55 % matrix-pipe busy): hidden layers through dense_relu_pipe (the backward's recompute: the same
@@ -523,7 +528,7 @@ __global__ __launch_bounds__(WideFwdThreads<HB>::value) void k_wide_enc_fwd_sigm
 // forward, colour net: [sig | view] -> hidden layers -> rgb_raw -> raw[b].xyz
 // =====================================================================================================
 template <class P, int HB>
-__global__ __launch_bounds__(WideFwdThreads<HB>::value) void k_wide_fwd_color(NofMlpDesc d, const char* __restrict__ image,
+__global__ __launch_bounds__(WideColorThreads<HB>::value) void k_wide_fwd_color(NofMlpDesc d, const char* __restrict__ image,
                                                          const typename P::elem* __restrict__ sig,
                                                          const float* __restrict__ view, int S,
                                                          float* __restrict__ raw, int64_t B) {
@@ -895,9 +900,11 @@ static int wide_fwd_launch(const NofMlpDesc* d, const void* packed, const float*
   hipLaunchKernelGGL(ks, dim3(blocks), dim3(NT), shm_s, st, *d, (const char*)packed, (const float2*)feat, (int)L, out, out_stride,
                      out_off, sdf_only ? (elem*)nullptr : (elem*)ws->sig, B);
   if (!sdf_only) {
+    constexpr int NTC = WideColorThreads<HB>::value;
+    const unsigned blocks_c = (unsigned)(nof_div_up(ntiles, NTC / 64) < (int64_t)nof_cu_count() ? nof_div_up(ntiles, NTC / 64) : nof_cu_count());
     auto kc = k_wide_fwd_color<P, HB>;
     if (int e = set_smem(kc, shm_c)) return e;
-    hipLaunchKernelGGL(kc, dim3(blocks), dim3(NT), shm_c, st, *d, (const char*)packed, (const elem*)ws->sig, view, (int)S, out, B);
+    hipLaunchKernelGGL(kc, dim3(blocks_c), dim3(NTC), shm_c, st, *d, (const char*)packed, (const elem*)ws->sig, view, (int)S, out, B);
   }
   return 0;
 }
@@ -951,14 +958,15 @@ static int wide_enc_fwd_launch(const NofHashGrid* g, const NofMlpDesc* d, const 
   typedef typename P::elem elem;
   const int64_t npairs = (B + 63) / 64, ntiles = (B + 31) / 32;
   const unsigned blocks_s = (unsigned)(nof_div_up(npairs, NWV) < (int64_t)nof_cu_count() ? nof_div_up(npairs, NWV) : nof_cu_count());
-  const unsigned blocks_c = (unsigned)(nof_div_up(ntiles, NWV) < (int64_t)nof_cu_count() ? nof_div_up(ntiles, NWV) : nof_cu_count());
+  constexpr int NTC = WideColorThreads<HB>::value;
+  const unsigned blocks_c = (unsigned)(nof_div_up(ntiles, NTC / 64) < (int64_t)nof_cu_count() ? nof_div_up(ntiles, NTC / 64) : nof_cu_count());
   auto ks = k_wide_enc_fwd_sigma<P, HB>;
   if (int e = set_smem(ks, shm_s)) return e;
   hipLaunchKernelGGL(ks, dim3(blocks_s), dim3(NT), shm_s, st, *d, (const char*)packed, *g, (const float2*)table, pts_w, raw, 4, 3,
                      (elem*)ws->sig, (elem*)featq, B);
   auto kc = k_wide_fwd_color<P, HB>;
   if (int e = set_smem(kc, shm_c)) return e;
-  hipLaunchKernelGGL(kc, dim3(blocks_c), dim3(NT), shm_c, st, *d, (const char*)packed, (const elem*)ws->sig, view, (int)S, raw, B);
+  hipLaunchKernelGGL(kc, dim3(blocks_c), dim3(NTC), shm_c, st, *d, (const char*)packed, (const elem*)ws->sig, view, (int)S, raw, B);
   return 0;
 }
 
