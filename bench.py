@@ -718,6 +718,8 @@ def main():
             "allreduce_bytes_per_step": (sync.bytes_step if sync is not None else (fld.n_total * 4 if runner.grad_sync is not None else 0)),
             "collectives_per_step": (sync.collectives_step if sync is not None else (1 if runner.grad_sync is not None else 0)),
             "exposed_comm_ms": exposed_comm_ms, "dp_payload": getattr(sync, 'payload', None), "dp_mode": dp_mode,
+            # GradSync mode 'rows': table rows that travelled in the last step (the union of the ranks' non-zero rows) of how many
+            "dp_rows_per_step": getattr(sync, 'rows_step', None), "dp_table_rows": int(fld.n_table // 2),
             "roofline": roof,
         }
         if extraction is not None:

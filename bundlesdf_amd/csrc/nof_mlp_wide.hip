@@ -22,7 +22,8 @@
 //   * per workgroup ONE partial row of dW / db -> nof_reduce_partials, like the narrow path.
 // Per tile and 128x128 layer: 32 (forward) + 32 (data gradient) + 16 (transposes) + 32 (dW) MFMAs against 64 KB of weight reads,
 // 16 KB of exchange writes and 40 KB of exchange reads from LDS: matrix-pipe-bound on paper.
-// 16-bit operand types only; precisions 3 / 4 run as 2 / 1 here (no operand split).
+// 16-bit operand types only, no operand split: precisions 3 / 4 are refused (the Python host maps fp16x3 / bf16x3 to fp16 / bf16
+// for these shapes and says so: NeuralObjectField.precision_effective).
 #include "nof_mlp_dev.h"
 #include <utility>
 
@@ -862,6 +863,9 @@ static int check_wide(const NofMlpDesc* d) {
   if (d->precision == 0)
     return nof_set_error(-1, "mlp (wide path, hidden %d depths %d,%d): 16-bit operand types only (fp32 fragments do not fit LDS)",
                          d->hidden, d->n_sigma, d->n_color);
+  if (d->precision != 1 && d->precision != 2)      // (rounds 3-5 ran 3 / 4 silently as 2 / 1: the name promised a split that was not there)
+    return nof_set_error(-1, "mlp (wide path, hidden %d depths %d,%d): no hi+lo operand split here -- precision %d is not available, "
+                         "pass 2 (fp16) or 1 (bf16)", d->hidden, d->n_sigma, d->n_color, d->precision);
   return 0;
 }
 

@@ -46,7 +46,15 @@ class GradSync:
     element-wise, so bucketing does not change a single bit of the result."""
 
     def __init__(self, payload='fp32', mode='allreduce'):
-        assert payload in ('fp32', 'bf16') and mode in ('allreduce', 'zero1')
+        assert payload in ('fp32', 'bf16') and mode in ('allreduce', 'zero1', 'rows')
+        # 'rows' (round 6; SURVEY 8e "per level"): only the table rows SOME rank touched in this step travel.  A step's table
+        # gradient is zero except in the rows its samples' corners hit (cfg2, settled: one row in ten on a rank); the ranks
+        # all-gather a bitmap of their non-zero rows (1 bit per row), OR them, and all-reduce the union's rows only -- the other
+        # rows are zero on every rank, so the result equals the dense all-reduce's entry for entry (at world size 2 bit for bit: a
+        # two-term sum does not depend on its order; beyond that up to the ring's summation order, like any all-reduce).  Everything
+        # behind the table (MLP, frame features, poses) goes dense in a second call.  One host sync per step (the union's size is
+        # the collective's size); nothing overlaps the backward.  Opt-in like the other two: the union grows with the world size
+        # (1 - 0.9^N: 19 % of the rows at N = 2, 57 % at N = 8), so what it saves shrinks where the wire matters most (DESIGN 6).
         # 'zero1' (SURVEY 8e): reduce-scatter of the flat gradient -> every rank runs Adam on ITS 1/world of the flat buffers ->
         # all-gather of the parameters.  The same bytes on the wire as the all-reduce (which is a reduce-scatter + an all-gather
         # of GRADIENTS), the optimiser pass cut to 1/world per rank; the exchange sits between the backward and the next forward
@@ -97,6 +105,62 @@ class GradSync:
         self._ev1(ev)
         self._bytes += padded.numel() * padded.element_size()
         self._n += 1
+
+    # ---- 'rows' -------------------------------------------------------------------------------------------------------
+    @staticmethod
+    def _row_bitmap(rows):
+        """[n, w] float rows -> uint8 [ceil(n / 8)]: bit (i & 7) of byte (i >> 3) = row i has a non-zero entry"""
+        nz = (rows != 0).any(1)
+        n = nz.numel()
+        pad = (-n) % 8
+        if pad:
+            nz = torch.cat([nz, nz.new_zeros(pad)])
+        w = torch.tensor([1, 2, 4, 8, 16, 32, 64, 128], dtype=torch.uint8, device=rows.device)
+        return (nz.view(-1, 8).to(torch.uint8) * w).sum(1, dtype=torch.uint8)
+
+    @staticmethod
+    def _bitmap_rows(bits, n):
+        """the inverse: indices (int64, ascending) of the set bits among the first n"""
+        sh = torch.arange(8, dtype=torch.uint8, device=bits.device)
+        on = ((bits[:, None] >> sh) & 1).reshape(-1)[:n]
+        return torch.nonzero(on).reshape(-1)
+
+    def exchange_rows_(self, table_grad, width=2):
+        """in place: `table_grad` (flat fp32, rows of `width` entries) becomes the sum over the ranks, moving only the rows that are
+        non-zero on at least one rank.  Blocking; returns the number of rows that travelled."""
+        rows = table_grad.view(-1, width)
+        n = rows.shape[0]
+        world = dist.get_world_size()
+        ev = self._ev0()
+        mine = self._row_bitmap(rows)
+        every = torch.empty(world * mine.numel(), dtype=torch.uint8, device=mine.device)
+        dist.all_gather_into_tensor(every, mine)
+        every = every.view(world, -1)
+        union = every[0]
+        for r in range(1, world):
+            union = union | every[r]
+        idx = self._bitmap_rows(union, n)                       # (torch.nonzero: the step's one host sync in this mode)
+        k = int(idx.numel())
+        self._bytes += mine.numel()                             # (payload handed to the collectives per rank, like the other modes)
+        self._n += 1
+        if k:
+            vals = rows.index_select(0, idx)
+            dist.all_reduce(vals, op=dist.ReduceOp.SUM)
+            rows.index_copy_(0, idx, vals)
+            self._bytes += vals.numel() * vals.element_size()
+            self._n += 1
+        self._ev1(ev)
+        self.rows_step = k
+        return k
+
+    def exchange_dense_(self, part):
+        """blocking all-reduce of a slice, counted into the step's totals (the 'rows' mode's second call: everything behind the table)"""
+        if part.numel():
+            ev = self._ev0()
+            dist.all_reduce(part, op=dist.ReduceOp.SUM)
+            self._ev1(ev)
+            self._bytes += part.numel() * part.element_size()
+            self._n += 1
 
     def max_flags_(self, flags):
         """the ranks agree on the SKIP predicate of the device flag word (bit 2 of flags[0]: this step's gradient is not finite -- a
@@ -176,7 +240,7 @@ def make_grad_sync(overlap=True, payload='fp32', mode='allreduce'):
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return None
     g = GradSync(payload, mode)
-    return g if overlap or mode == 'zero1' else g.__call__
+    return g if overlap or mode in ('zero1', 'rows') else g.__call__
 
 
 def shard_frames(n_total, rank, world):

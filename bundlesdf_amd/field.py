@@ -46,12 +46,19 @@ class NeuralObjectField:
         self.grid, self.offsets, self.n_entries, self.per_level_scale = lib.make_hash_grid(
             cfg['num_levels'], cfg['feature_grid_dim'], cfg['base_res'], cfg['log2_hashmap_size'], cfg['finest_res'])
         self.L = int(cfg['num_levels'])
-        self.desc, self.layer_dims = lib.make_mlp_desc(n_sigma, n_color, 2 * self.L, self.n_view,
-                                                       PRECISIONS[precision] if isinstance(precision, str) else precision,
-                                                       hidden=hidden)
         self.n_sigma, self.n_color, self.hidden = n_sigma, n_color, int(hidden)
-        # hidden 128 / 4 layers per network (BASELINE cfg5) run through the nof_mlp_wide_* kernels (staged activations)
+        # hidden 128 / 4 layers per network (BASELINE cfg5) run through the nof_mlp_wide_* kernels (everything on chip since round 6)
         self.wide = hidden != 64 or n_sigma > 3 or n_color > 3
+        prec = PRECISIONS[precision] if isinstance(precision, str) else int(precision)
+        if self.wide and prec in (3, 4):
+            # the wide kernels have no hi + lo operand split (the C ABI refuses 3 / 4 for these shapes): the step runs in the plain
+            # 16-bit type -- the reference's own autocast arithmetic -- and says so (rounds 3-5 downgraded silently inside the library)
+            import warnings
+            prec = {3: 2, 4: 1}[prec]
+            warnings.warn(f"NeuralObjectField: hidden {hidden} / depths ({n_sigma},{n_color}) run without the operand split: precision "
+                          f"'{precision}' -> '{ {1: 'bf16', 2: 'fp16'}[prec] }'", stacklevel=2)
+        self.precision_effective = {v: k for k, v in PRECISIONS.items()}[prec]
+        self.desc, self.layer_dims = lib.make_mlp_desc(n_sigma, n_color, 2 * self.L, self.n_view, prec, hidden=hidden)
         self.eikonal = float(cfg.get('eikonal_weight', 0)) > 0
         if self.eikonal:
             if self.wide:
@@ -582,7 +589,13 @@ class NeuralObjectField:
                 self._zero1_shard = (lo, hi)
             grad_sync.end_step()
             return b
-        if bucketed:
+        if grad_sync is not None and getattr(grad_sync, 'mode', '') == 'rows':
+            # touched-row exchange (dist.GradSync mode 'rows'): the table as the union of the ranks' non-zero rows, the rest dense
+            with torch.cuda.stream(self._st):
+                grad_sync.exchange_rows_(self.grads[:self.n_table], 2)
+                grad_sync.exchange_dense_(self.grads[self.n_table:])
+            grad_sync.end_step()
+        elif bucketed:
             # ONE more collective: everything that is not in flight yet.  [0, a) and what lies behind the first slice are not
             # contiguous in the flat buffer, so a copy of the latter (tens of KB) rides in the headroom in front of it
             h = self._head

@@ -125,6 +125,37 @@ def _worker(rank, world, port, R, out):
     sz.end_step()
     assert torch.equal(pz[:n], torch.from_numpy(pa))
     assert sz.collectives_step == 2 and sz.bytes_step == 2 * 4 * n_pad and sz.timed_steps == 1
+    # touched-row exchange (GradSync mode 'rows'): a table gradient that is zero except in the rows a rank's samples hit -- bitmap
+    # all-gather, OR, all-reduce of the union's rows -- equals the dense all-reduce BIT for bit, and moves the union's rows only
+    nrow = 1003                                          # (not a multiple of 8: the bitmap's last byte is partial)
+    gens = [torch.Generator().manual_seed(100 + r) for r in range(world)]
+    tabs = []
+    for r in range(world):
+        t = torch.zeros(nrow, 2)
+        hit = torch.randperm(nrow, generator=gens[r])[:nrow // 10]
+        t[hit] = torch.randn(hit.numel(), 2, generator=gens[r])
+        t[hit[:5], 1] = 0.0                              # rows with one zero entry still count as touched
+        t[hit[5:8]] = 0.0                                # ... and a hit that summed to exactly zero is simply not sent
+        tabs.append(t)
+    tail = [torch.randn(37, generator=gens[r]) for r in range(world)]
+    mine = torch.cat([tabs[rank].reshape(-1), tail[rank]])
+    dense = mine.clone()
+    dist.all_reduce(dense)
+    sr = D.make_grad_sync(mode='rows')
+    assert sr.mode == 'rows'
+    k = sr.exchange_rows_(mine[:2 * nrow], 2)
+    sr.exchange_dense_(mine[2 * nrow:])
+    sr.end_step()
+    union = torch.zeros(nrow, dtype=torch.bool)
+    for t in tabs:
+        union |= (t != 0).any(1)
+    assert k == int(union.sum()) == sr.rows_step and 0 < k < nrow // 4
+    assert torch.equal(mine, dense)
+    assert sr.collectives_step == 3 and sr.bytes_step == (nrow + 7) // 8 + 8 * k + 4 * 37
+    empty = torch.zeros(2 * 64)                          # nothing touched anywhere: the bitmap travels, no row does
+    assert sr.exchange_rows_(empty, 2) == 0 and not empty.any()
+    sr.end_step()
+    assert sr.collectives_step == 1
     # only the skip bit (4) travels; a rank's other bits -- 1: a ray exceeded max_hits, 8: the sticky mark of an EARLIER skipped step
     # -- neither hide another rank's skip bit (MAX over the whole word would let 9 beat 4) nor spread
     fl = torch.tensor([4 if rank == 1 else 9, 7, 0, 0], dtype=torch.int32)

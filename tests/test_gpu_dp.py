@@ -60,15 +60,30 @@ def test_bench_two_ranks_one_gpu_gloo(nof):
     assert d['allreduce_bytes_per_step'] >= d0['allreduce_bytes_per_step'] > 4 * 9_000_000
 
 
+def test_touched_row_exchange_two_ranks_one_gpu_gloo(nof):
+    """GradSync mode 'rows' (round 6) through bench.py's own launch path, two ranks sharing the one GPU: only the
+    table rows some rank touched travel (bitmap all-gather + all-reduce of the union's rows), everything behind the table dense.
+    Replicas bit-identical, parameters equal to the dense all-reduce form's, and far fewer bytes handed to the collectives."""
+    d = _run('1', 29543, mode='rows', steps=8)
+    d0 = _run('0', 29544, steps=8)
+    assert d['dp_mode'] == 'rows' and d['dp_param_checksum_spread'] == 0.0 and d['flags'] == 0
+    assert abs(d['param_checksum'] - d0['param_checksum']) <= 2e-5 * d0['param_checksum']
+    assert d['collectives_per_step'] == 3                              # bitmap all-gather, the union's rows, the dense tail
+    assert 0 < d['dp_rows_per_step'] < 0.6 * d['dp_table_rows']
+    assert d['allreduce_bytes_per_step'] < 0.6 * d0['allreduce_bytes_per_step']
+    print(f"touched-row exchange, 2 ranks: {d['dp_rows_per_step']} of {d['dp_table_rows']} rows, {d['allreduce_bytes_per_step'] / 1e6:.2f} MB "
+          f"per step vs {d0['allreduce_bytes_per_step'] / 1e6:.2f} MB dense; {d['ms_per_step']:.3f} vs {d0['ms_per_step']:.3f} ms/step")
+
+
 @pytest.mark.parametrize("overlap,payload,mode", [('1', 'fp32', 'allreduce'), ('1', 'bf16', 'allreduce'), ('0', 'fp32', 'allreduce'),
-                                                  ('1', 'fp32', 'zero1')])
+                                                  ('1', 'fp32', 'zero1'), ('1', 'fp32', 'rows')])
 def test_overflow_on_one_rank_is_skipped_by_both(nof, overlap, payload, mode):
     """the bucketed step ran the first slice's share of Adam before the ranks had agreed on the step's overflow flag -- a
     rank that overflowed alone skipped the slice while the other applied a summed gradient that held its inf (NaN weights, replicas
     apart).  Rank 1's fp16 loss scale is raised by 2^40 for step 3 (bench.py: NOF_DP_INJECT_OVERFLOW): its MLP weight gradient is not
     finite in that step, rank 0's is.  Every form of the exchange must end with bit-identical, finite replicas that both skipped
     that step (the skipped step's mark is the sticky bit the host polls: it must be up on rank 0, which did not overflow itself)."""
-    port = 29550 + 4 * ['allreduce', 'zero1'].index(mode) + 2 * int(overlap) + (payload == 'bf16')
+    port = 29550 + 4 * ['allreduce', 'zero1', 'rows'].index(mode) + 2 * int(overlap) + (payload == 'bf16')
     d = _run(overlap, port, payload=payload, mode=mode, inject='1:3', precision='fp16x3')
     assert d['dp_param_checksum_spread'] == 0.0, d['dp_param_checksum_spread']
     assert d['param_checksum'] == d['param_checksum'] and d['param_checksum'] < 1e30 and d['loss'] == d['loss']

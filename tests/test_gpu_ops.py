@@ -573,6 +573,9 @@ def test_mlp_wide_forward_backward(nof, ns, nc, hidden, ff, L, precision):
     nof.call('nof_mlp_wide_sdf', C.byref(desc), packed, d_feat, L, sdf, B)
     with pytest.raises(nof.NofError):                    # the narrow entry points name the wide ones instead of mis-computing
         nof.call('nof_mlp_fwd', C.byref(desc), packed, d_feat, L, view.cuda(), S, raw, None, B)
+    desc3, _ = nof.make_mlp_desc(ns, nc, 2 * L, n_view, {1: 4, 2: 3}[precision], hidden=hidden)
+    with pytest.raises(nof.NofError, match='operand split'):     # 'fp16x3' / 'bf16x3' do not exist on the wide path: refused, not downgraded
+        nof.call('nof_mlp_wide_fwd', C.byref(desc3), packed, d_feat, L, view.cuda(), S, raw, ws, B)
     rows = nof.load().nof_mlp_wide_partial_rows()
     dfeat = torch.full((L, B, 2), 3.0, device='cuda')
     dview = torch.zeros(R, 16, device='cuda')
