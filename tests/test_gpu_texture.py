@@ -49,6 +49,18 @@ def test_bary_uv_matches_reference_kernel(nof):
     assert np.abs(uvs.cpu().numpy() - want).max() < 2e-3             # texel units (|uv| up to 511): float32 rounding of the blend
 
 
+def _ray_bary(o, d, A, B, Cc):
+    """float64 barycentric coordinates (and the ray parameter) of the ray o + t d on the plane of triangle A B C"""
+    e1, e2 = B - A, Cc - A
+    p = np.cross(d, e2)
+    det = p @ e1
+    tv = o - A
+    u = (p @ tv) / det
+    q = np.cross(tv, e1)
+    w = (d @ q) / det
+    return min(u, w, 1 - u - w), (e2 @ q) / det
+
+
 def test_texture_bake_frame_matches_oracle(nof):
     from bundlesdf_amd.mesh import Mesh
     from bundlesdf_amd.synthetic import look_at_cv
@@ -65,6 +77,7 @@ def test_texture_bake_frame_matches_oracle(nof):
     owner = torch.empty(T * T, dtype=torch.int32, device='cuda')
     tex_o, wtex_o = np.zeros((T, T, 3)), np.zeros((T, T))
     K4 = (C.c_float * 4)(90.0, 90.0, 40.0, 30.0)
+    n_edge_pixels = 0
     for cam in ([1.6, 0.2, 0.3], [-0.4, 1.5, -0.5]):
         cam_in_ob = look_at_cv(np.array(cam))
         ob_in_cam = np.linalg.inv(cam_in_ob)
@@ -79,13 +92,29 @@ def test_texture_bake_frame_matches_oracle(nof):
         got_tri = np.where(z == np.uint64(0xFFFFFFFFFFFFFFFF), -1, (z & np.uint64(0xFFFFFFFF)).astype(np.int64)).reshape(H, W)
         got_depth = (z >> np.uint64(32)).astype(np.uint32).view(np.float32).reshape(H, W)
         same = got_tri == tri
-        assert same.mean() > 0.985, same.mean()                      # pixels on a triangle edge may fall to the neighbour
+        # Round 6 ("passes at 97 %, the 3 % never characterised"): measured, the float32 rasteriser and the
+        # float64 ray caster agree on EVERY pixel of both views (tools/texture_edge_probe.py, profiles/r06_q_texture_probe.txt).
+        # What may legitimately differ is a pixel whose ray passes within float32 rounding of a triangle edge: any such pixel must
+        # be exactly that -- on the triangle the device chose, the float64 ray lies within 1e-4 (barycentric) of the boundary at
+        # the oracle's depth -- and there may be at most a handful.
+        n_edge_pixels += int((~same).sum())
+        assert (~same).sum() <= 4, int((~same).sum())
+        o64 = -ob_in_cam[:3, :3].T @ ob_in_cam[:3, 3]
+        for (y, x) in np.argwhere(~same):
+            d64 = ob_in_cam[:3, :3].T @ np.array([(x - K[0, 2]) / K[0, 0], (y - K[1, 2]) / K[1, 1], 1.0])
+            f_dev, f_orc = got_tri[y, x], tri[y, x]
+            f = f_dev if f_dev >= 0 else f_orc                       # (the device saw nothing: the ray grazes the oracle's triangle)
+            mb, tt = _ray_bary(o64, d64, *(verts[faces[f, k]].astype(np.float64) for k in range(3)))
+            assert abs(mb) < 1e-4, (y, x, f_dev, f_orc, mb)
+            if f_dev >= 0 and f_orc >= 0:
+                assert abs(tt - depth[y, x]) < 1e-3, (y, x, tt, depth[y, x])
         hit = same & (tri >= 0)
         assert hit.sum() > 500 and np.abs(got_depth[hit] - depth[hit]).max() < 1e-4
     w_got, t_got = wtex.cpu().numpy(), tex.cpu().numpy()
     cover = (w_got > 0) | (wtex_o > 0)
     agree = (w_got == wtex_o) & (np.abs(t_got - tex_o).max(-1) < 1e-3)
-    assert cover.sum() > 800 and agree[cover].mean() > 0.97, (cover.sum(), agree[cover].mean())
+    # every texel's weight and colour equal the oracle's, except the (at most four) texels an edge pixel above would have painted
+    assert cover.sum() > 800 and int((~agree[cover]).sum()) <= 2 * n_edge_pixels, (cover.sum(), int((~agree[cover]).sum()), n_edge_pixels)
 
 
 def test_runner_texture_bake_end_to_end(nof):
