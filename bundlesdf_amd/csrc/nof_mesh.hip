@@ -13,10 +13,12 @@
 
 __device__ __constant__ int kTets[6][4] = {{0, 1, 3, 7}, {0, 1, 5, 7}, {0, 2, 3, 7}, {0, 2, 6, 7}, {0, 4, 5, 7}, {0, 4, 6, 7}};
 
+typedef float mt_f32x8 __attribute__((ext_vector_type(8)));
 struct MtCell {
-  float f[8];
-  int64_t id[8];
+  mt_f32x8 f;                                                         // corner values: ONE vector value (a run-time element pick is a register
+  int64_t base, si, sj;                                               //  move; as float f[8] + int64 id[8] the record lived in scratch: 112 B)
   uint32_t in;                                                        // bit c: corner c is inside (value < iso)
+  __device__ __forceinline__ int64_t id(int c) const { return base + (c & 1) * si + ((c >> 1) & 1) * sj + (c >> 2); }
 };
 
 // corner c = (dx, dy, dz) = (c & 1, (c >> 1) & 1, c >> 2)
@@ -26,13 +28,16 @@ __device__ __forceinline__ bool mt_load(const float* __restrict__ vol, int nx, i
   const int64_t t = cell / cz;
   const int j = (int)(t % cy), i = (int)(t / cy);
   m.in = 0;
+  m.base = ((int64_t)i * ny + j) * nz + k;
+  m.si = (int64_t)ny * nz;
+  m.sj = nz;
+  mt_f32x8 f;
 #pragma unroll
   for (int c = 0; c < 8; ++c) {
-    const int64_t id = ((int64_t)(i + (c & 1)) * ny + (j + ((c >> 1) & 1))) * nz + (k + (c >> 2));
-    m.id[c] = id;
-    m.f[c] = vol[id];
-    if (m.f[c] < iso) m.in |= 1u << c;
+    f[c] = vol[m.id(c)];
+    if (f[c] < iso) m.in |= 1u << c;
   }
+  m.f = f;
   return m.in != 0u && m.in != 0xFFu;
 }
 
@@ -79,7 +84,7 @@ __device__ __forceinline__ void mt_write_tri(const MtCell& m, const int (&ea)[3]
   int64_t key[3];
 #pragma unroll
   for (int e = 0; e < 3; ++e) {
-    const int64_t a = m.id[ea[e]], b = m.id[eb[e]];
+    const int64_t a = m.id(ea[e]), b = m.id(eb[e]);
     mt_edge_vertex(a, b, m.f[ea[e]], m.f[eb[e]], iso, ny, nz, p[e]);
     key[e] = (a < b ? a : b) * npts + (a < b ? b : a);
   }
@@ -113,7 +118,7 @@ __global__ __launch_bounds__(256) void k_mt_emit(const float* __restrict__ vol, 
     if (cnt == 0 || cnt == 4) continue;
     double pos[4][3];
 #pragma unroll
-    for (int v = 0; v < 4; ++v) mt_point(m.id[c[v]], ny, nz, pos[v]);
+    for (int v = 0; v < 4; ++v) mt_point(m.id(c[v]), ny, nz, pos[v]);
     if (cnt == 1 || cnt == 3) {                                       // one vertex on its own side -> one triangle
       int lone = 0;
 #pragma unroll
@@ -192,7 +197,7 @@ __global__ __launch_bounds__(256) void k_mc_emit(const float* __restrict__ vol, 
   int64_t* out = keys + offsets[cell] * 3;
   for (int t = 0; t < 3 * n; ++t) {
     const int e = row[1 + t];
-    out[t] = m.id[kMcEdge[e][0]] * npts + m.id[kMcEdge[e][1]];        // the lower corner has the lower grid id
+    out[t] = m.id(kMcEdge[e][0]) * npts + m.id(kMcEdge[e][1]);        // the lower corner has the lower grid id
   }
 }
 
@@ -257,7 +262,7 @@ extern "C" int nof_mt_vertices(const float* vol, int32_t nx, int32_t ny, int32_t
 // -(cell + 1), placed like scikit-image places it (the corners weighted by 1 / (eps + |value - iso|)).  The tests run in double
 // like scikit-image's.  oracle/marching_cubes_lewiner.py is the restatement this is checked against, itself pinned on scikit-image's
 // outputs (tests/golden/mc_skimage_vectors.npz).
-// Lewiner's cube: corner p at array offset kMclCorner[p] = (di, dj, dk) -- x = the last array axis --, edge e = kMclEdge[e].
+// Lewiner's cube: corner p at array offset kMclCorner[p] = (di, dj, dk) -- x = the last array axis --, edge e joins the corner pair mcl_write spells out.
 // =====================================================================================================
 enum { L_CASES, L_T1, L_T2, L_T3_1, L_T3_2, L_T4_1, L_T4_2, L_T5, L_T6_1_1, L_T6_1_2, L_T6_2, L_T7_1, L_T7_2, L_T7_3, L_T7_4_1, L_T7_4_2,
        L_T8, L_T9, L_T10_1_1, L_T10_1_1_, L_T10_1_2, L_T10_2, L_T10_2_, L_T11, L_T12_1_1, L_T12_1_1_, L_T12_1_2, L_T12_2, L_T12_2_,
@@ -265,25 +270,31 @@ enum { L_CASES, L_T1, L_T2, L_T3_1, L_T3_2, L_T4_1, L_T4_2, L_T5, L_T6_1_1, L_T6
        L_TEST7, L_TEST10, L_TEST12, L_TEST13, L_SUB13, L_COUNT };
 static_assert(L_COUNT == NOF_MCL_TABLES, "table order of include/nof_hip.h");
 __device__ __constant__ int kMclCorner[8][3] = {{0, 0, 0}, {0, 0, 1}, {0, 1, 1}, {0, 1, 0}, {1, 0, 0}, {1, 0, 1}, {1, 1, 1}, {1, 1, 0}};
-__device__ __constant__ int kMclEdge[12][2] = {{0, 1}, {1, 2}, {2, 3}, {3, 0}, {4, 5}, {5, 6}, {6, 7}, {7, 4}, {0, 4}, {1, 5}, {2, 6}, {3, 7}};
 // interior test: the reference edge (p, q) and the three edges parallel to it in the order the paper's code walks them
 __device__ __constant__ int kMclPar[12][8] = {{0, 1, 3, 2, 7, 6, 4, 5}, {1, 2, 0, 3, 4, 7, 5, 6}, {2, 3, 1, 0, 5, 4, 6, 7}, {3, 0, 2, 1, 6, 5, 7, 4},
                                              {4, 5, 0, 1, 3, 2, 7, 6}, {5, 6, 1, 2, 0, 3, 4, 7}, {6, 7, 2, 3, 1, 0, 5, 4}, {7, 4, 3, 0, 2, 1, 6, 5},
                                              {0, 4, 3, 7, 2, 6, 1, 5}, {1, 5, 0, 4, 3, 7, 2, 6}, {2, 6, 1, 5, 0, 4, 3, 7}, {3, 7, 2, 6, 1, 5, 0, 4}};
 #define MCL_EPS 2.220446049250313e-16   /* scikit-image's 'FLT_EPSILON' = np.spacing(1.0): the weights 1 / (eps + |value|) are an exact linear interpolation */
 
+typedef double mcl_f64x8 __attribute__((ext_vector_type(8)));
 struct MclCell {
-  double c[8];                                                         // corner values minus the iso value, Lewiner's corner order
-  int64_t id[8];
-  int idx;                                                             // bit p: c[p] > 0
+  mcl_f64x8 c;                                                         // corner values minus the iso value, Lewiner's corner order
+  int64_t base;                                                        // array index of corner 0; corner p sits at base + mcl_corner_off(p)
+  int idx;                                                             // bit p: c_p > 0
 };
+// array offset of Lewiner's corner p from corner 0 (kMclCorner as arithmetic).  The corner values are ONE vector value (a run-time
+// element pick of a register vector is a register move, not a memory access): round 5's record -- c[8], id[8] in private memory,
+// picked by table entries -- cost 144 B of scratch (or 20 KB of LDS where the compiler promoted it); as eight named fields behind a
+// select chain the compiler re-merged the loads into one load through a selected POINTER and kept the record in scratch
+__device__ __forceinline__ int64_t mcl_corner_off(int p, int64_t si, int64_t sj) {
+  return ((p & 4) ? si : 0) + (((p & 3) == 2 || (p & 3) == 3) ? sj : 0) + (((p & 3) == 1 || (p & 3) == 2) ? 1 : 0);
+}
 __device__ __forceinline__ bool mcl_load(const float* __restrict__ vol, int nx, int ny, int nz, float iso, int64_t cell, MclCell& m) {
   const int cz = nz - 1, cy = ny - 1;
   const int k = (int)(cell % cz);
   const int64_t t = cell / cz;
   const int j = (int)(t % cy), i = (int)(t / cy);
-  // first the signs alone ((double)v - (double)iso > 0 <=> v > iso): 99 % of the cells of a dense grid end here, before anything of
-  // the cell record is written (the record lives in private memory: the tests pick corners by table entries)
+  // first the signs alone ((double)v - (double)iso > 0 <=> v > iso): 99 % of the cells of a dense grid end here
   const int64_t base = ((int64_t)i * ny + j) * nz + k;
   const int64_t sj = nz, si = (int64_t)ny * nz;
   const float v0 = vol[base], v1 = vol[base + 1], v2 = vol[base + sj + 1], v3 = vol[base + sj];
@@ -292,20 +303,13 @@ __device__ __forceinline__ bool mcl_load(const float* __restrict__ vol, int nx, 
                   (v5 > iso ? 32 : 0) | (v6 > iso ? 64 : 0) | (v7 > iso ? 128 : 0);
   m.idx = idx;
   if (idx == 0 || idx == 0xFF) return false;
-  const float v[8] = {v0, v1, v2, v3, v4, v5, v6, v7};
-#pragma unroll
-  for (int p = 0; p < 8; ++p) {
-    m.id[p] = base + kMclCorner[p][0] * si + kMclCorner[p][1] * sj + kMclCorner[p][2];
-    m.c[p] = (double)v[p] - (double)iso;
-  }
+  m.base = base;
+  const double d = (double)iso;
+  const mcl_f64x8 c = {(double)v0 - d, (double)v1 - d, (double)v2 - d, (double)v3 - d, (double)v4 - d, (double)v5 - d, (double)v6 - d, (double)v7 - d};
+  m.c = c;
   return true;
 }
-__device__ __forceinline__ double mcl_pick(const MclCell& m, int p) {   // (a select chain: no run-time index into registers)
-  double v = m.c[0];
-#pragma unroll
-  for (int q = 1; q < 8; ++q) v = p == q ? m.c[q] : v;
-  return v;
-}
+__device__ __forceinline__ double mcl_pick(const MclCell& m, int p) { return m.c[p & 7]; }
 __device__ __forceinline__ bool mcl_test_face(const MclCell& m, int face) {
   const int f = face < 0 ? -face : face;
   const int a = f == 1 ? 0 : f == 2 ? 1 : f == 3 ? 2 : f == 4 ? 3 : f == 5 ? 0 : 4;
@@ -318,16 +322,16 @@ __device__ __forceinline__ bool mcl_test_face(const MclCell& m, int face) {
 __device__ __forceinline__ bool mcl_test_interior(const MclCell& m, int s, int cs, int edge) {
   double At, Bt, Ct, Dt;
   if (cs == 4 || cs == 10) {
-    const double* c = m.c;
-    const double a = (c[4] - c[0]) * (c[6] - c[2]) - (c[7] - c[3]) * (c[5] - c[1]);
-    const double b = c[2] * (c[4] - c[0]) + c[0] * (c[6] - c[2]) - c[1] * (c[7] - c[3]) - c[3] * (c[5] - c[1]);
+    const double c0 = m.c[0], c1 = m.c[1], c2 = m.c[2], c3 = m.c[3], c4 = m.c[4], c5 = m.c[5], c6 = m.c[6], c7 = m.c[7];
+    const double a = (c4 - c0) * (c6 - c2) - (c7 - c3) * (c5 - c1);
+    const double b = c2 * (c4 - c0) + c0 * (c6 - c2) - c1 * (c7 - c3) - c3 * (c5 - c1);
     if (a == 0.0) return s > 0;
     const double t = -b / (2.0 * a);
     if (!(t >= 0.0 && t <= 1.0)) return s > 0;
-    At = c[0] + (c[4] - c[0]) * t;
-    Bt = c[3] + (c[7] - c[3]) * t;
-    Ct = c[2] + (c[6] - c[2]) * t;
-    Dt = c[1] + (c[5] - c[1]) * t;
+    At = c0 + (c4 - c0) * t;
+    Bt = c3 + (c7 - c3) * t;
+    Ct = c2 + (c6 - c2) * t;
+    Dt = c1 + (c5 - c1) * t;
   } else {
     const int* q = kMclPar[edge];
     const double cp = mcl_pick(m, q[0]), cq = mcl_pick(m, q[1]);
@@ -441,6 +445,26 @@ __global__ __launch_bounds__(256) void k_mcl_count(const float* __restrict__ vol
   counts[cell] = n;
 }
 
+// the n triangles of a cell's tiling as vertex keys
+__device__ __forceinline__ void mcl_write(const MclCell& m, const int8_t* __restrict__ row, int n, int64_t cell, int ny, int nz,
+                                          int64_t npts, int64_t* __restrict__ out) {
+  const int64_t sj = nz, si = (int64_t)ny * nz;
+  for (int t = 0; t < n; ++t) {
+#pragma unroll
+    for (int v = 0; v < 3; ++v) {
+      const int e = row[3 * t + v];
+      int64_t key = -(cell + 1);                                       // the centre vertex of the cell
+      if (e < 12) {
+        // Lewiner's edge e joins corners (e, e + 1 mod 4) on the bottom face, (e, 4 + (e + 1) mod 4) on the top, (e - 8, e - 4) upright
+        const int p0 = e < 8 ? e : e - 8, p1 = e < 4 ? ((e + 1) & 3) : e < 8 ? 4 + ((e + 1) & 3) : e - 4;
+        const int64_t a = m.base + mcl_corner_off(p0, si, sj), b = m.base + mcl_corner_off(p1, si, sj);
+        key = a < b ? a * npts + b : b * npts + a;
+      }
+      out[3 * t + (2 - v)] = key;                                      // scikit-image's default winding (gradient_direction='descent')
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void k_mcl_emit(const float* __restrict__ vol, int nx, int ny, int nz, float iso,
                                                    const int8_t* __restrict__ luts, NofMclLuts offs, int64_t ncell,
                                                    const int64_t* __restrict__ offsets, int64_t* __restrict__ keys) {
@@ -450,22 +474,61 @@ __global__ __launch_bounds__(256) void k_mcl_emit(const float* __restrict__ vol,
   if (!mcl_load(vol, nx, ny, nz, iso, cell, m)) return;
   int n = 0;
   const int8_t* row = mcl_tiling(m, luts, offs, n);
-  const int64_t npts = (int64_t)nx * ny * nz;
-  int64_t* out = keys + offsets[cell] * 3;
-  for (int t = 0; t < n; ++t) {
+  mcl_write(m, row, n, cell, ny, nz, (int64_t)nx * ny * nz, keys + offsets[cell] * 3);
+}
+
+// ---- the two-level form (round 6): at 512^3 the per-cell counts (0.5 GB), their 64-bit inclusive scan (1 GB) and the exclusive offsets
+//      (1 GB) cost 2.1 of the extraction's 4.9 ms in torch launches -- for 99.5 % cells that emit nothing.  Here the first launch
+//      leaves ONE number per 256 cells (the workgroup's triangle count), the host scans those (0.5 M entries), and the second launch
+//      -- workgroups without surface return at once -- recomputes its cells' tilings and places them with a workgroup-local scan.
+__device__ __forceinline__ int mcl_block_scan(int n, int* total) {       // exclusive prefix of n over the workgroup's 256 threads
+  __shared__ int wsum[4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int incl = n;
 #pragma unroll
-    for (int v = 0; v < 3; ++v) {
-      const int e = row[3 * t + v];
-      int64_t key = -(cell + 1);                                       // the centre vertex of the cell
-      if (e < 12) {
-        int64_t a = m.id[0], b = m.id[0];
-#pragma unroll
-        for (int p = 1; p < 8; ++p) { a = kMclEdge[e][0] == p ? m.id[p] : a; b = kMclEdge[e][1] == p ? m.id[p] : b; }
-        key = a < b ? a * npts + b : b * npts + a;
-      }
-      out[3 * t + (2 - v)] = key;                                      // scikit-image's default winding (gradient_direction='descent')
-    }
+  for (int d = 1; d < 64; d <<= 1) {
+    const int up = __shfl_up(incl, d, 64);
+    if (lane >= d) incl += up;
   }
+  if (lane == 63) wsum[wave] = incl;
+  __syncthreads();
+  int before = 0, all = 0;
+#pragma unroll
+  for (int w = 0; w < 4; ++w) { before += w < wave ? wsum[w] : 0; all += wsum[w]; }
+  *total = all;
+  return before + incl - n;
+}
+
+__global__ __launch_bounds__(256) void k_mcl_count_blocks(const float* __restrict__ vol, int nx, int ny, int nz, float iso,
+                                                           const int8_t* __restrict__ luts, NofMclLuts offs, int64_t ncell,
+                                                           int32_t* __restrict__ block_counts) {
+  const int64_t cell = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  MclCell m;
+  int n = 0;
+  if (cell < ncell && mcl_load(vol, nx, ny, nz, iso, cell, m)) (void)mcl_tiling(m, luts, offs, n);
+  if (__syncthreads_or(n) == 0) {                                      // (the common case: no cell of the workgroup meets the surface)
+    if (threadIdx.x == 0) block_counts[blockIdx.x] = 0;
+    return;
+  }
+  int total;
+  (void)mcl_block_scan(n, &total);
+  if (threadIdx.x == 0) block_counts[blockIdx.x] = total;
+}
+
+__global__ __launch_bounds__(256) void k_mcl_emit_blocks(const float* __restrict__ vol, int nx, int ny, int nz, float iso,
+                                                          const int8_t* __restrict__ luts, NofMclLuts offs, int64_t ncell,
+                                                          const int64_t* __restrict__ block_end, int64_t* __restrict__ keys) {
+  // block_end = the INCLUSIVE scan of block_counts: this workgroup's triangles are [block_end[b - 1], block_end[b])
+  const int64_t first = blockIdx.x == 0 ? 0 : block_end[blockIdx.x - 1];
+  if (block_end[blockIdx.x] == first) return;                          // (uniform)
+  const int64_t cell = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  MclCell m;
+  int n = 0;
+  const int8_t* row = luts;
+  if (cell < ncell && mcl_load(vol, nx, ny, nz, iso, cell, m)) row = mcl_tiling(m, luts, offs, n);
+  int total;
+  const int before = mcl_block_scan(n, &total);
+  if (n > 0) mcl_write(m, row, n, cell, ny, nz, (int64_t)nx * ny * nz, keys + (first + before) * 3);
 }
 
 __global__ __launch_bounds__(256) void k_mcl_vertices(const float* __restrict__ vol, int nx, int ny, int nz, float iso,
@@ -525,6 +588,26 @@ extern "C" int nof_mcl_emit(const float* vol, int32_t nx, int32_t ny, int32_t nz
   const int64_t ncell = (int64_t)(nx - 1) * (ny - 1) * (nz - 1);
   hipLaunchKernelGGL(k_mcl_emit, dim3((unsigned)nof_div_up(ncell, 256)), dim3(256), 0, (hipStream_t)stream, vol, nx, ny, nz, iso,
                      luts, *offs, ncell, offsets, keys);
+  NOF_LAUNCH_OK();
+  return 0;
+}
+
+extern "C" int nof_mcl_count_blocks(const float* vol, int32_t nx, int32_t ny, int32_t nz, float iso, const int8_t* luts,
+                                     const NofMclLuts* offs, int32_t* block_counts, void* stream) {
+  NOF_ARG(vol && block_counts && luts && offs && mt_dims_ok(nx, ny, nz));
+  const int64_t ncell = (int64_t)(nx - 1) * (ny - 1) * (nz - 1);
+  hipLaunchKernelGGL(k_mcl_count_blocks, dim3((unsigned)nof_div_up(ncell, 256)), dim3(256), 0, (hipStream_t)stream, vol, nx, ny, nz, iso,
+                     luts, *offs, ncell, block_counts);
+  NOF_LAUNCH_OK();
+  return 0;
+}
+
+extern "C" int nof_mcl_emit_blocks(const float* vol, int32_t nx, int32_t ny, int32_t nz, float iso, const int8_t* luts,
+                                    const NofMclLuts* offs, const int64_t* block_end, int64_t* keys, void* stream) {
+  NOF_ARG(vol && block_end && keys && luts && offs && mt_dims_ok(nx, ny, nz));
+  const int64_t ncell = (int64_t)(nx - 1) * (ny - 1) * (nz - 1);
+  hipLaunchKernelGGL(k_mcl_emit_blocks, dim3((unsigned)nof_div_up(ncell, 256)), dim3(256), 0, (hipStream_t)stream, vol, nx, ny, nz, iso,
+                     luts, *offs, ncell, block_end, keys);
   NOF_LAUNCH_OK();
   return 0;
 }

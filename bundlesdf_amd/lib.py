@@ -124,6 +124,8 @@ _SIGNATURES = {
     'nof_mt_vertices': ([_P, _I32, _I32, _I32, _F, _P, _I64, _P, _P], C.c_int),
     'nof_mcl_count': ([_P, _I32, _I32, _I32, _F, _P, _P, _P, _P], C.c_int),
     'nof_mcl_emit': ([_P, _I32, _I32, _I32, _F, _P, _P, _P, _P, _P], C.c_int),
+    'nof_mcl_count_blocks': ([_P, _I32, _I32, _I32, _F, _P, _P, _P, _P], C.c_int),
+    'nof_mcl_emit_blocks': ([_P, _I32, _I32, _I32, _F, _P, _P, _P, _P, _P], C.c_int),
     'nof_mcl_vertices': ([_P, _I32, _I32, _I32, _F, _P, _I64, _P, _P], C.c_int),
     'nof_mask_dilate': ([_P, _I32, _I32, _I32, _P, _P, _P], C.c_int),
     'nof_frame_rays': ([C.POINTER(NofFrameRaysCfg), _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _P, _P, _P], C.c_int),
@@ -143,7 +145,7 @@ _SIGNATURES = {
     'nof_texture_bake_frame': ([_P, _P, _I32, _I32, _P, _P, _I64, _P, _P, _P, _F, _I32, _P, _P, _P, _P, _P], C.c_int),
 }
 OPTIONAL = set()
-ABI_VERSION = 120           # include/nof_hip.h: NOF_ABI_VERSION
+ABI_VERSION = 121           # include/nof_hip.h: NOF_ABI_VERSION
 
 _lib = None
 

@@ -100,16 +100,19 @@ def marching_cubes_lewiner_gpu(vol, iso=0.0):
     nx, ny, nz = vol.shape
     ncell = (nx - 1) * (ny - 1) * (nz - 1)
     iso32 = C.c_float(float(np.float32(iso)))
-    counts = torch.empty(ncell, dtype=torch.int32, device=vol.device)
-    lib.call('nof_mcl_count', vol, nx, ny, nz, iso32, luts, C.byref(offs), counts)
-    incl = torch.cumsum(counts, 0, dtype=torch.int64)
-    T = int(incl[-1].item()) if ncell > 0 else 0
+    # two-level scan (round 6): one count per workgroup of 256 cells, their scan here, placement inside the emit launch -- the
+    # per-cell counts / scan / offsets of the three-launch scheme (2.5 GB at 512^3, 2.1 of 4.9 ms) are gone
+    nblk = (ncell + 255) // 256
+    block_counts = torch.empty(max(nblk, 1), dtype=torch.int32, device=vol.device)
+    if ncell > 0:
+        lib.call('nof_mcl_count_blocks', vol, nx, ny, nz, iso32, luts, C.byref(offs), block_counts)
+    block_end = torch.cumsum(block_counts, 0, dtype=torch.int64)
+    T = int(block_end[-1].item()) if ncell > 0 else 0
     if T == 0:
         raise ValueError('Surface level must be within volume data range.')
-    offsets = (incl - counts).contiguous()
     keys = torch.empty(T, 3, dtype=torch.int64, device=vol.device)
-    lib.call('nof_mcl_emit', vol, nx, ny, nz, iso32, luts, C.byref(offs), offsets, keys)
-    del offsets, incl, counts
+    lib.call('nof_mcl_emit_blocks', vol, nx, ny, nz, iso32, luts, C.byref(offs), block_end, keys)
+    del block_end, block_counts
     uniq, inv = torch.unique(keys.view(-1), sorted=True, return_inverse=True)
     faces = inv.view(-1, 3)
     verts = torch.empty(uniq.numel(), 3, dtype=torch.float64, device=vol.device)

@@ -37,8 +37,10 @@ const char* nof_last_error(void);
  * an out-of-tree caller built against another header can refuse to run instead of passing misaligned arguments.
  *   100  rounds 1-4
  *   110  round 5: nof_batch_trace gained `marcher` (in the middle of its argument list); NofSampleCfg gained `marcher` (trailing)
- *   120  round 6: nof_mlp_wide_bwd_parts gained `featq`; the wide networks' workspace holds the sigma head's hand-off only */
-#define NOF_ABI_VERSION 120
+ *   120  round 6: nof_mlp_wide_bwd_parts gained `featq`; the wide networks' workspace holds the sigma head's hand-off only
+ *   121  round 6: new entry points nof_encode_mlp_wide_fwd, nof_mcl_count_blocks, nof_mcl_emit_blocks (nothing existing changed);
+ *        the wide entry points refuse precisions 3 / 4 instead of running them as 2 / 1 */
+#define NOF_ABI_VERSION 121
 int nof_version(void);
 
 /* ---- multires hash grid (replaces gridencoder.*) --------------------------------------------- */
@@ -369,6 +371,14 @@ int nof_mcl_count(const float* vol, int32_t nx, int32_t ny, int32_t nz, float is
                   int32_t* counts, void* stream);
 int nof_mcl_emit(const float* vol, int32_t nx, int32_t ny, int32_t nz, float iso, const int8_t* luts, const NofMclLuts* offs,
                  const int64_t* offsets, int64_t* keys, void* stream);
+/* The two-level form of count / emit (what bundlesdf_amd/mesh_gpu.py calls): ONE triangle count per workgroup of 256 consecutive
+ * cells -- block_counts [ceil(ncell / 256)] --, the host's inclusive 64-bit scan of those (block_end), and an emit launch in which
+ * every workgroup with surface recomputes its cells' tilings and places them behind block_end[b - 1] with a workgroup-local scan:
+ * the same keys in the same order as nof_mcl_count -> scan -> nof_mcl_emit, without the per-cell arrays (2.5 GB at 512^3). */
+int nof_mcl_count_blocks(const float* vol, int32_t nx, int32_t ny, int32_t nz, float iso, const int8_t* luts, const NofMclLuts* offs,
+                         int32_t* block_counts, void* stream);
+int nof_mcl_emit_blocks(const float* vol, int32_t nx, int32_t ny, int32_t nz, float iso, const int8_t* luts, const NofMclLuts* offs,
+                        const int64_t* block_end, int64_t* keys, void* stream);
 int nof_mcl_vertices(const float* vol, int32_t nx, int32_t ny, int32_t nz, float iso, const int64_t* keys, int64_t V,
                      double* verts, void* stream);
 

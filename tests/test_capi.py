@@ -231,10 +231,9 @@ def test_hot_kernels_have_no_scratch():
     s_waitcnt vmcnt(0)), and a run-time index into a small local array does the same silently (the ray marcher's DDA loop did,
     until round 3).  The compiler's own metadata says which kernels use private memory: none of the kernels a default step or a
     wide-network step launches may.  Known exceptions, listed so that a new one is noticed: the one-kernel MLP backward
-    (`k_mlp_bwd`: fp32 mode and the entry point without a split workspace; 512 registers + AGPRs by design), the bf16 colour
-    backward at hidden 128 (2 registers = 12 bytes; the fp16 variant, cfg5's, is clean), and the mesh extractors' emit kernels
-    (renderer side: the case table indexes the cell's corner values at run time; likewise the Lewiner extractor's count / emit
-    kernels, whose face and interior tests pick corners by table entries).  The colour backward with THREE colour layers --
+    (`k_mlp_bwd`: fp32 mode and the entry point without a split workspace; 512 registers + AGPRs by design).  Until round 6 the mesh
+    extractors' kernels were exceptions too (the case tables index the cell's corner values at run time: 112-144 B of scratch);
+    their cell records are register vectors now.  The colour backward with THREE colour layers --
     the reference's own shape, nerf_runner.py:221 -- was an exception until round 4 (148 B): its first layer's weight gradient is
     accumulated transposed (32 instead of 64 registers).  Round 5: the library is built without clang's SLP vectoriser (a
     correctness matter on gfx950: test_no_packed_fp32_instruction_reads_source_1_through_op_sel), which had packed a few of that
@@ -243,7 +242,7 @@ def test_hot_kernels_have_no_scratch():
     from a lane id that is re-derived on the spot (lane_id_here): nothing to hoist, nothing spilled -- guarded like every other
     shape again.  The eikonal kernel's two spilled registers (three sigma layers) go to AGPRs: no private memory."""
     import re
-    allowed = (r'^k_mlp_bwd<', r'^k_wide_bwd_color<PrecBF16, 4>', r'^k_m[ct]_emit$', r'^k_mcl_(count|emit)$')
+    allowed = (r'^k_mlp_bwd<',)
     bad = []
     seen = set()
     for name, md in _kernel_metadata():
