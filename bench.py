@@ -183,8 +183,10 @@ def extra_configs():
     common = ['--keyframes', '16', '--steps', '20', '--warmup', '10', '--settle', '0', '--round-steps', '0', '--no-cpu-baseline',
               '--no-extra-configs']
     runs = [('cfg4', ['--rays', '8192', '--finest', '512', '--extract', '512']),
+            # (cfg5 also times the same 20 steps again 100 steps into the run -- `ms_per_step_settled` -- where the zero-gradient
+            # fraction has stopped moving: steps 10-30 from a fresh field still scatter 1.5x the settled number of rows)
             ('cfg5', ['--mlp', 'cfg5', '--rays', '16384', '--log2_T', '22', '--finest', '512', '--width', '1280', '--height', '720',
-                      '--precision', 'fp16']),
+                      '--precision', 'fp16', '--settle', '100']),
             # configs[0]'s shapes on the GPU: the same workload the cpu_baseline leg of a `--rays 1024 --log2_T 14 --mlp reference`
             # run times ("also run the GPU path at cfg1 shapes for an apples-to-apples ratio"); 4 keyframes as BASELINE says
             # ... and the CPU leg at these shapes in the same sub-record (BASELINE configs[0] is "the reference's own CPU-runnable
@@ -195,6 +197,7 @@ def extra_configs():
             # workload with bfloat16 operands split the same way (parity-tested at full size like fp16x3)
             ('cfg2_bf16', ['--precision', 'bf16x3'])]
     keep = ('value', 'unit', 'ms_per_step', 'steps', 'warmup', 'dtype', 'ms_per_step_dense_backward', 'zero_grad_sample_fraction',
+            'ms_per_step_settled', 'settled_after_steps', 'zero_grad_sample_fraction_settled',
             'train_iters_per_sec', 'loss', 'flags', 'step_ms_spread', 'extraction', 'cpu_baseline', 'ms_per_step_p50_timed')
     out = []
     for name, extra in runs:
@@ -415,19 +418,25 @@ def main():
         gc.collect()
         gc.disable()
         marks = []
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(n + 1)]      # (created outside the timed region)
         try:                                                           # (an exception in step() must not leave the collector off)
             barrier()
             t0 = time.perf_counter()
-            for _ in range(n):
+            evs[0].record()
+            for i in range(n):
                 step()
+                evs[i + 1].record()                                    # (a marker on the step's stream: ~1 us of host time, no device work)
                 marks.append(time.perf_counter())                      # (50 ns: when the host finished enqueueing the step)
             barrier()
             dt = time.perf_counter() - t0
         finally:
             gc.enable()
-        # the host enqueues a step in about the time the device needs for one, i.e. under the back-pressure of a full
-        # queue its per-step enqueue intervals follow the device's step times: their median and maximum make a one-off stall inside
-        # the region visible in the record itself (round 5: one driver-style run in eleven read a MEAN of 0.73 instead of 0.47)
+        # DEVICE-side duration of every step of the timed region (event to event on the step's stream): their median and maximum
+        # make a one-off stall inside the region visible in the record itself (round 5: one driver-style run in eleven read a MEAN of
+        # 0.73 instead of 0.47 ms)
+        dv = np.array([evs[i].elapsed_time(evs[i + 1]) for i in range(n)]) if n else np.zeros(0)
+        timed.device_intervals = {"p50": float(np.median(dv)), "max": float(dv.max()), "n": int(len(dv))} if len(dv) else None
+        # ... and the HOST's enqueue intervals (the host runs ahead of the device: these say how long a step takes to ENQUEUE)
         iv = np.diff(np.array([t0] + marks)) * 1e3
         timed.host_intervals = {"p50": float(np.median(iv)), "max": float(iv.max()), "n": int(len(iv))} if len(iv) else None
         if world > 1:
@@ -443,8 +452,8 @@ def main():
     # (501 steps from a fresh field, config.yml:2) are reported beside it under their own names.
     zero_first = zero_fraction() if args.warmup > 0 else None
     dt = timed(args.steps)
-    timed_intervals = timed.host_intervals
-    log(f'timed region done: {dt / args.steps * 1e3:.3f} ms/step; host enqueue intervals {timed_intervals}')
+    timed_intervals, host_intervals = timed.device_intervals, timed.host_intervals
+    log(f'timed region done: {dt / args.steps * 1e3:.3f} ms/step; device step intervals {timed_intervals}; host enqueue intervals {host_intervals}')
     # The parameters after exactly W + K steps: what the tests compare between the forms of the data-parallel step.  Taken HERE and
     # not at the end of the run: Adam with eps = 1e-15 (the reference's) turns the first rounding-noise gradient of a so far dead
     # weight into a full +-lr step, and an MLP weight that wakes up that way moves everything downstream -- 3 of 16 otherwise
@@ -688,10 +697,11 @@ def main():
                        "forward": ("fused encode+MLP (nof_encode_mlp_fwd)" if fld.fused_forward else
                                    "encode + sigma net in one launch, colour net behind it (nof_encode_mlp_wide_fwd)" if fld.wide and fld.fused_forward_wide
                                    else "nof_hash_encode_fwd + nof_mlp_fwd")},
-            # the timed region's per-step HOST enqueue intervals (median / largest): a mean far above the median = a one-off stall
-            # inside the region, not the steady step
+            # the timed region's per-step DEVICE durations (event to event; median / largest): a mean far above the median = a one-off
+            # stall inside the region, not the steady step.  host_enqueue_ms_p50: how long the host takes to enqueue a step
             "ms_per_step_p50_timed": timed_intervals["p50"] if timed_intervals else None,
             "ms_step_max_timed": timed_intervals["max"] if timed_intervals else None,
+            "host_enqueue_ms_p50": host_intervals["p50"] if host_intervals else None,
             "train_iters_per_sec": it_s * 1.0, "captured_step_ms_per_step": graph_ms, "captured_step_one_chain_ms_per_step": graph_alt_ms,
             # forward-only batches run before the warm-up steps (no parameter / optimiser / loader / RNG state touched)
             "preroll_forward_batches": args.preroll,
