@@ -385,78 +385,112 @@ __global__ __launch_bounds__(64 * NOF_ENC_WAVES, (NOF_ENC_WAVES + 3) / 4) void k
 // dense SDF grid for mesh extraction (extract_mesh + run_network_density, nerf_runner.py:1307-1386), fused:
 // voxel centre -> octree mask -> hash encode in registers -> sigma net on MFMA -> sdf[nx,ny,nz].  Nothing per point ever goes
 // to HBM except the 4-byte result (the reference materialises query_pts, the [N,32] embedding and every activation).
-// A wave owns 32 consecutive voxels of one z column (lane = (voxel, hi), hi picks which 8 levels the lane encodes = exactly
-// the B-operand layout of the first layer); occupancy is spatially coherent (level <= 6 cells vs 1/512 voxels), so a
-// wave-uniform skip of all-empty tiles is the whole compaction that is needed.
+// Round 6: the encode of the TRAINING forward (k_enc_mlp_fwd) -- lane = voxel, the level wave-uniform (its constants in SGPRs, one
+// saddr gather instruction per corner row for 64 voxels), the features parked feature-major in a wave-private 8 KB LDS stage -- then
+// the sigma net over the stage's two 32-voxel tiles.  Rounds 2-5 put (voxel, 8 of the 16 levels) on a lane: 32 voxels per wave pass,
+// every level's constants per lane, 64 gathers per lane; 5.5 ms for 512^3 against the 2.2 ms the training forward needs for as many
+// points.  A wave owns 64 consecutive voxels of one z column; occupancy is spatially coherent (level <= 6 cells vs 1/512 voxels), so a
+// wave-uniform skip of all-empty columns (and of an empty half) is the whole compaction that is needed; voxels outside the octree
+// issue no gathers (their lanes are masked).
 // =====================================================================================================
 template <class P, int NS, int NC, bool SPLIT>
-__global__ __launch_bounds__(256, 2) void k_sdf_grid(NofMlpDesc d, const char* __restrict__ image, NofHashGrid g,
-                                                      const float2* __restrict__ table, const uint32_t* __restrict__ occ_bits,
-                                                      int occ_n, const float* __restrict__ tx, const float* __restrict__ ty,
-                                                      const float* __restrict__ tz, int nx, int ny, int nz, float outside,
-                                                      float* __restrict__ sdf) {
+__global__ __launch_bounds__(64 * NOF_ENC_WAVES, (NOF_ENC_WAVES + 3) / 4) void k_sdf_grid(
+    NofMlpDesc d, const char* __restrict__ image, NofHashGrid g, const float2* __restrict__ table, const uint32_t* __restrict__ occ_bits,
+    int occ_n, const float* __restrict__ tx, const float* __restrict__ ty, const float* __restrict__ tz, int nx, int ny, int nz,
+    float outside, float* __restrict__ sdf) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   typedef Shp<NS, NC> SH;
   constexpr int BIAS_BASE = SH::pair_base(NS) * PAIR_BYTES;
   constexpr int LO_BASE = BIAS_BASE + SH::oblk_base(NS) * 32 * 4;
+  constexpr int PARK_BASE = (LO_BASE + (SPLIT ? BIAS_BASE : 0) + 15) & ~15;     // [wave][32][64] floats: the wave's feature stage
   copy16(smem, image, (size_t)BIAS_BASE);
   copy16(smem + BIAS_BASE, image + 2 * (size_t)SH::pair_base(NS + NC) * PAIR_BYTES, (size_t)SH::oblk_base(NS) * 32 * 4);
   if constexpr (SPLIT)
     copy16(smem + LO_BASE, image + 2 * (size_t)SH::pair_base(NS + NC) * PAIR_BYTES + (size_t)SH::oblk_base(NS + NC) * 32 * 4,
            (size_t)BIAS_BASE);
+  const int NW = blockDim.x >> 6;
+  uint32_t* lvl = reinterpret_cast<uint32_t*>(smem + PARK_BASE + NW * 8192);    // [16][8] words behind the stages (see k_enc_mlp_fwd)
+  if (threadIdx.x < NOF_MAX_LEVELS) {
+    const int l = threadIdx.x;
+    lvl[l * 8 + 0] = __float_as_uint(g.scale[l]); lvl[l * 8 + 1] = g.resolution[l]; lvl[l * 8 + 2] = g.offset[l];
+    lvl[l * 8 + 3] = g.size[l]; lvl[l * 8 + 4] = g.hashed[l];
+  }
+  const int n_levels = g.L;
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int hi = lane >> 5, j = lane & 31;
-  const int ntz = (nz + 31) / 32;
+  auto level_at = [&](int l) {                          // wave-uniform: the LDS words go through readfirstlane into SGPRs
+    HashLevel lv;
+    const uint4 q = *reinterpret_cast<const uint4*>(lvl + l * 8);
+    lv.scale = __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)q.x));
+    lv.res = (uint32_t)__builtin_amdgcn_readfirstlane((int)q.y);
+    lv.offset = (uint32_t)__builtin_amdgcn_readfirstlane((int)q.z);
+    lv.size = (uint32_t)__builtin_amdgcn_readfirstlane((int)q.w);
+    lv.hashed = (uint32_t)__builtin_amdgcn_readfirstlane((int)lvl[l * 8 + 4]);
+    return lv;
+  };
+  float* const stage = reinterpret_cast<float*>(smem + PARK_BASE + wave * 8192);       // [32][64] floats
+  const int ntz = (nz + 63) / 64;
   const int64_t ntiles = (int64_t)nx * ny * ntz;
-  for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < ntiles; tile += (int64_t)gridDim.x * 4) {
+  for (int64_t tile = (int64_t)blockIdx.x * NW + wave; tile < ntiles; tile += (int64_t)gridDim.x * NW) {
     asm volatile("" ::: "memory");
     const int64_t col = tile / ntz;
-    const int k = (int)(tile - col * ntz) * 32 + j;
+    const int k0 = (int)(tile - col * ntz) * 64;
+    const int k = k0 + lane;
     const int ix = (int)(col / ny), iy = (int)(col - (int64_t)ix * ny);
     const bool in_range = k < nz;
     float p[3] = {tx[ix], ty[iy], in_range ? tz[k] : 0.0f};
     const bool inside = in_range && (occ_bits == nullptr || occ_point_test(occ_bits, occ_n, p[0], p[1], p[2]));
-    const int64_t vox = col * nz + k;
-    if (__ballot(inside) == 0ull) {
-      if (hi == 0 && in_range) sdf[vox] = outside;
+    const uint64_t mask = __ballot(inside);
+    if (mask == 0ull) {
+      if (in_range) sdf[col * nz + k] = outside;
       continue;
     }
 #pragma unroll
     for (int dd = 0; dd < 3; ++dd) p[dd] = fminf(fmaxf(p[dd], -1.0f), 1.0f);      // run_network_density clips (nerf_runner.py:1313)
-    float x[1][16];
-#if NOF_GRID_PRIO
-    __builtin_amdgcn_s_setprio(3);                     // (as in k_enc_mlp_fwd: the gather phase issues first)
-#endif
-#pragma unroll
-    for (int kk = 0; kk < 8; ++kk) {
-      const int level = 8 * hi + kk;
-      float2 v = make_float2(0.f, 0.f);
-      if (inside && level < g.L) {
-        const HashLevel lv = load_level(g, level);
-        v = encode_level(lv, table, locate3(p, lv.scale));
+#pragma unroll 1
+    for (int l0 = 0; l0 < NOF_MAX_LEVELS; ++l0) {
+      float2 a = make_float2(0.f, 0.f);
+      if (l0 < n_levels && inside) {                    // (the level test is uniform; lanes outside the octree gather nothing)
+        const HashLevel lv = level_at(l0);
+        EncCell e = enc_prep(lv, p);
+        float2 v[8];
+        if (level_pairs(lv)) enc_load<true>(lv, table, e, v);
+        else enc_load<false>(lv, table, e, v);
+        enc_keep(e);
+        a = enc_blend(e, v);
       }
-      x[0][2 * kk] = v.x;
-      x[0][2 * kk + 1] = v.y;
+      stage[(2 * l0) * 64 + lane] = a.x;
+      stage[(2 * l0 + 1) * 64 + lane] = a.y;
     }
-#if NOF_GRID_PRIO
-    __builtin_amdgcn_s_setprio(0);
-#endif
-    float h[2][16], so[1][16];
-    dense_o1<P, 1, 2, SPLIT>(smem, FW_OFF(0), BIAS_OFF(0), x, h, lane, LO_OFF(0));
-    relu_mask<2>(h);
 #pragma unroll
-    for (int l = 1; l < NS - 1; ++l) {
-      float h2[2][16];
-      dense_o1<P, 2, 2, SPLIT>(smem, FW_OFF(l), BIAS_OFF(l), h, h2, lane, LO_OFF(l));
-      relu_mask<2>(h2);
+    for (int t = 0; t < 2; ++t) {
+      asm volatile("" ::: "memory");
+      const int kt = k0 + 32 * t + j;                   // the voxel of lane (j, hi) in tile t
+      const uint32_t mt = (uint32_t)(mask >> (32 * t));
+      if (mt == 0u) {                                   // (uniform) nothing of this half is inside
+        if (hi == 0 && kt < nz) sdf[col * nz + kt] = outside;
+        continue;
+      }
+      float x[1][16];
 #pragma unroll
-      for (int pp = 0; pp < 2; ++pp)
+      for (int r = 0; r < 16; ++r) x[0][r] = stage[(16 * hi + r) * 64 + 32 * t + j];
+      float h[2][16], so[1][16];
+      dense_o1<P, 1, 2, SPLIT>(smem, FW_OFF(0), BIAS_OFF(0), x, h, lane, LO_OFF(0));
+      relu_mask<2>(h);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) h[pp][r] = h2[pp][r];
+      for (int l = 1; l < NS - 1; ++l) {
+        float h2[2][16];
+        dense_o1<P, 2, 2, SPLIT>(smem, FW_OFF(l), BIAS_OFF(l), h, h2, lane, LO_OFF(l));
+        relu_mask<2>(h2);
+#pragma unroll
+        for (int pp = 0; pp < 2; ++pp)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) h[pp][r] = h2[pp][r];
+      }
+      dense_o1<P, 2, 1, SPLIT>(smem, FW_OFF(NS - 1), BIAS_OFF(NS - 1), h, so, lane, LO_OFF(NS - 1));
+      if (hi == 0 && kt < nz) sdf[col * nz + kt] = ((mt >> j) & 1u) ? so[0][0] : outside;
     }
-    dense_o1<P, 2, 1, SPLIT>(smem, FW_OFF(NS - 1), BIAS_OFF(NS - 1), h, so, lane, LO_OFF(NS - 1));
-    if (hi == 0 && in_range) sdf[vox] = inside ? so[0][0] : outside;
   }
 }
 
@@ -1619,15 +1653,20 @@ extern "C" int nof_sdf_grid_query(const NofHashGrid* g, const NofMlpDesc* d, con
   NOF_ARG(packed && table && tx && ty && tz && sdf && nx >= 0 && ny >= 0 && nz >= 0 && level >= 0 && level <= 8);
   if (nx == 0 || ny == 0 || nz == 0) return 0;
   const int nl = d->n_sigma;
-  const size_t shm = (is_split(d->precision) ? 2 : 1) * (size_t)n_pairs(*d, nl) * 16 * 64 * elem_size(d->precision) +
-                     (size_t)n_oblk(*d, nl) * 32 * 4;
-  const int64_t ntiles = (int64_t)nx * ny * ((nz + 31) / 32);
-  const unsigned blocks = (unsigned)(nof_div_up(ntiles, 4) < 2048 ? nof_div_up(ntiles, 4) : 2048);
+  const size_t img = ((is_split(d->precision) ? 2 : 1) * (size_t)n_pairs(*d, nl) * 16 * 64 * elem_size(d->precision) +
+                      (size_t)n_oblk(*d, nl) * 32 * 4 + 15) & ~(size_t)15;
+  int waves = (int)((160 * 1024 - img - 512) / 8192);                   // one workgroup per CU: the sigma image + 8 KB of stage per wave + the level table
+  if (waves > NOF_ENC_WAVES) waves = NOF_ENC_WAVES;
+  NOF_ARG(waves >= 4);
+  const size_t shm = img + (size_t)waves * 8192 + 512;
+  const int64_t ntiles = (int64_t)nx * ny * ((nz + 63) / 64);
+  const int64_t want = nof_div_up(ntiles, waves), cap = (int64_t)nof_cu_count();
+  const unsigned blocks = (unsigned)(want < cap ? want : cap);
 #define LAUNCH_GRID(P, NS_, NC_, SPLIT_)                                                                  \
   {                                                                                                       \
     auto kern = k_sdf_grid<P, NS_, NC_, SPLIT_>;                                                          \
     if (int e = set_smem(kern, shm)) return e;                                                            \
-    hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), shm, (hipStream_t)stream, *d, (const char*)packed, *g, \
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(64 * waves), shm, (hipStream_t)stream, *d, (const char*)packed, *g, \
                        (const float2*)table, occ_bits, 1 << level, tx, ty, tz, (int)nx, (int)ny, (int)nz, \
                        outside_value, sdf);                                                               \
   }
