@@ -1,6 +1,6 @@
 """profiles/pmc_traffic.json from the FETCH_SIZE / WRITE_SIZE passes of tools/gpu_evidence.sh (leg "traffic") (run on the GPU box, where the
 rocprofv3 databases are): HBM-side bytes per launch of every C-ABI entry point bench.py can name as dominant."""
-import glob, json, sqlite3, sys
+import glob, json, os, sqlite3, sys
 
 out_path = sys.argv[1] if len(sys.argv) > 1 else 'gpurun_out/pmc_traffic.json'
 source = sys.argv[2] if len(sys.argv) > 2 else 'the FETCH_SIZE / WRITE_SIZE summary of the same round in profiles/'
@@ -28,7 +28,7 @@ out = {'_note': 'HBM-side bytes per launch from rocprofv3 --pmc FETCH_SIZE / WRI
                 'on gfx950 FETCH_SIZE under-reports wide coalesced streaming reads by 2x (MI355X_MICROARCH.md, HBM section); for '
                 '8-byte gathers and atomics it is uncalibrated. Source: profiles/' + source + ' (backward over the work list of non-zero '
                 'tiles, 200 warm-up steps)',
-       'workload': 'cfg2 batch, bench.py default precision (fp16x3), 16-keyframe pool'}
+       'workload': f"cfg2 batch, bench.py default precision (fp16x3), {os.environ.get('KF', '64')}-keyframe pool"}
 for k, names in groups.items():
     f = total(fetch, names) * 1024
     w = total(write, names) * 1024
