@@ -226,7 +226,9 @@ def time_extraction(runner, n):
     rec = None
     for attempt in range(3):
         try:
-            for rep in range(2):
+            v = f = None
+            for rep in range(3):                      # (the third call re-uses the first call's pinned staging buffers, released here)
+                v = f = None
                 torch.cuda.synchronize(); t0 = _t.perf_counter()
                 vol = fld.query_sdf_grid(*axes)
                 torch.cuda.synchronize(); t1 = _t.perf_counter()
