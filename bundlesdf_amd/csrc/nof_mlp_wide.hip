@@ -379,6 +379,12 @@ __device__ __forceinline__ void transpose_pipe(const typename P::frag (&I)[2], S
 // threads per workgroup of the forward kernels: 768 (3 waves per SIMD, 168 registers) where that fits without scratch (hidden 64);
 // hidden 128 needs ~190 (two 64-register activation sets + the operand and weight fragments of a chain): 512 threads
 template <int HB> struct WideFwdThreads { static constexpr int value = HB >= 4 ? 512 : 768; };
+#ifndef NOF_WIDE_ENC_T
+#define NOF_WIDE_ENC_T 768
+#endif
+// the fused-encode forward: its stage holds the features in OPERAND precision (4 KB per wave: what the chain's first layer and
+// featq take anyway), so twelve waves fit beside the 78 KB sigma image -- a third wave per SIMD to hide the gathers of a 236 MB table
+template <int HB> struct WideEncThreads { static constexpr int value = NOF_WIDE_ENC_T; };
 #ifndef NOF_WIDE_COLOR_T4
 #define NOF_WIDE_COLOR_T4 768
 #endif
@@ -446,7 +452,7 @@ __global__ __launch_bounds__(WideFwdThreads<HB>::value) void k_wide_fwd_sigma(No
 // gone; what the backward needs of it is its value in operand precision, featq [B][2][16] (64 B per sample).
 // =====================================================================================================
 template <class P, int HB>
-__global__ __launch_bounds__(WideFwdThreads<HB>::value) void k_wide_enc_fwd_sigma(NofMlpDesc d, const char* __restrict__ image,
+__global__ __launch_bounds__(WideEncThreads<HB>::value) void k_wide_enc_fwd_sigma(NofMlpDesc d, const char* __restrict__ image,
                                                              NofHashGrid g, const float2* __restrict__ table,
                                                              const float* __restrict__ pts_w, float* __restrict__ out, int out_stride,
                                                              int out_off, typename P::elem* __restrict__ sig,
@@ -458,7 +464,7 @@ __global__ __launch_bounds__(WideFwdThreads<HB>::value) void k_wide_enc_fwd_sigm
   copy16(smem, image, (size_t)bias_base);
   copy16(smem + bias_base, image + 2 * (size_t)pair_base(d, NL) * WPAIR, (size_t)oblk_base(d, NS) * 128);
   const int NW = blockDim.x >> 6;
-  uint32_t* lvl = reinterpret_cast<uint32_t*>(smem + stage_base + NW * 8192);       // [16][8] words behind the stages (see k_enc_mlp_fwd)
+  uint32_t* lvl = reinterpret_cast<uint32_t*>(smem + stage_base + NW * 4096);       // [16][8] words behind the stages (see k_enc_mlp_fwd)
   if (threadIdx.x < NOF_MAX_LEVELS) {
     const int l = threadIdx.x;
     lvl[l * 8 + 0] = __float_as_uint(g.scale[l]); lvl[l * 8 + 1] = g.resolution[l]; lvl[l * 8 + 2] = g.offset[l];
@@ -478,7 +484,10 @@ __global__ __launch_bounds__(WideFwdThreads<HB>::value) void k_wide_enc_fwd_sigm
     lv.hashed = (uint32_t)__builtin_amdgcn_readfirstlane((int)lvl[l * 8 + 4]);
     return lv;
   };
-  float* const stage = reinterpret_cast<float*>(smem + stage_base + wave * 8192);       // [32][64] floats
+  // [16 levels][64 samples] words: a level's two features of a sample, rounded to the operand type where they are parked (the
+  // rounding the chain's first operand and featq apply anyway: same bits), one conflict-free ds_write_b32 per level
+  uint32_t* const stage = reinterpret_cast<uint32_t*>(smem + stage_base + wave * 4096);
+  typedef typename P::elem elem2 __attribute__((ext_vector_type(2)));
   const int64_t npairs = (B + 63) / 64;
   for (int64_t tp = (int64_t)blockIdx.x * NW + wave; tp < npairs; tp += (int64_t)gridDim.x * NW) {
     asm volatile("" ::: "memory");
@@ -498,21 +507,26 @@ __global__ __launch_bounds__(WideFwdThreads<HB>::value) void k_wide_enc_fwd_sigm
         enc_keep(e);
         a = enc_blend(e, v);
       }
-      stage[(2 * l0) * 64 + lane] = a.x;
-      stage[(2 * l0 + 1) * 64 + lane] = a.y;
+      elem2 pr;
+      pr[0] = (typename P::elem)a.x;
+      pr[1] = (typename P::elem)a.y;
+      stage[l0 * 64 + lane] = __builtin_bit_cast(uint32_t, pr);
     }
     __builtin_amdgcn_s_setprio(0);
     // the two tiles through the chain: lane (j, hi) of tile t reads features 16 hi .. 16 hi + 15 of sample 32 t + j
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
       asm volatile("" ::: "memory");
-      float x[1][16], so[1][16];
+      float so[1][16];
+      // lane (j, hi) of tile t: features 16 hi .. 16 hi + 15 of sample 32 t + j = the words of levels 8 hi .. 8 hi + 7 (operand order)
+      uint32_t w[8];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) x[0][r] = stage[(16 * hi + r) * 64 + 32 * t + j];
+      for (int r = 0; r < 8; ++r) w[r] = stage[(8 * hi + r) * 64 + 32 * t + j];
       const int64_t b = tp * 64 + 32 * t + j;
       const bool ok = b < B;
       typename P::frag x0[1][2];
-      pack_blk<P>(x[0], x0[0]);
+      x0[0][0] = __builtin_bit_cast(typename P::frag, make_uint4(w[0], w[1], w[2], w[3]));
+      x0[0][1] = __builtin_bit_cast(typename P::frag, make_uint4(w[4], w[5], w[6], w[7]));
       if (featq != nullptr && ok) {                     // the embedding as the backward reads it: rounded to the operand type, operand order
         typename P::frag* q = reinterpret_cast<typename P::frag*>(featq + (b * 2 + hi) * 16);
         q[0] = x0[0][0];
@@ -954,9 +968,9 @@ static int wide_enc_fwd_launch(const NofHashGrid* g, const NofMlpDesc* d, const 
                                const float* view, int32_t S, float* raw, const WideWs* ws, void* featq, int64_t B, hipStream_t st) {
   const int ns = d->n_sigma, nl = d->n_sigma + d->n_color;
   const size_t pair_bytes = 16 * 64 * 2;
-  constexpr int NT = WideFwdThreads<HB>::value, NWV = NT / 64;
+  constexpr int NT = WideEncThreads<HB>::value, NWV = NT / 64;
   const size_t img_s = (((size_t)pair_base(*d, ns) * pair_bytes + (size_t)oblk_base(*d, ns) * 128) + 15) & ~(size_t)15;
-  const size_t shm_s = img_s + (size_t)NWV * 8192 + 512;               // fragments + biases | 8 KB of stage per wave | the level table
+  const size_t shm_s = img_s + (size_t)NWV * 4096 + 512;               // fragments + biases | 4 KB of stage per wave | the level table
   if (shm_s > 160 * 1024) return nof_set_error(-1, "nof_encode_mlp_wide_fwd: %zu bytes of LDS", shm_s);
   const size_t shm_c = (size_t)(pair_base(*d, nl) - pair_base(*d, ns)) * pair_bytes + (size_t)(oblk_base(*d, nl) - oblk_base(*d, ns)) * 128;
   typedef typename P::elem elem;
