@@ -452,3 +452,26 @@ def test_scatter_request_counter_zero_gradient_rules():
     only = SR.count_requests(pts.reshape(n_rays, S, 3)[1::2].reshape(-1, 3), *args[1:])
     assert half == only
     assert 0 < sum(half.values()) < sum(base.values())
+
+
+def test_row_bitmap_round_trip():
+    """GradSync mode 'rows' (bundlesdf_amd/dist.py): the bitmap of a table gradient's non-zero rows and its inverse -- rows with one
+    zero entry, NaN / inf rows (a non-finite gradient must travel: the ranks agree on the skipped step from the SUMMED gradient), sizes
+    that are not a multiple of 8."""
+    import torch
+    from bundlesdf_amd.dist import GradSync
+    for n in (1, 7, 8, 9, 64, 1003):
+        g = torch.Generator().manual_seed(n)
+        rows = torch.zeros(n, 2)
+        hit = torch.randperm(n, generator=g)[:max(1, n // 3)]
+        rows[hit] = torch.randn(hit.numel(), 2, generator=g)
+        rows[hit[0], 1] = 0.0
+        if hit.numel() >= 3:
+            rows[hit[1]] = torch.tensor([float('nan'), 0.0])
+            rows[hit[2]] = torch.tensor([0.0, float('inf')])
+        bits = GradSync._row_bitmap(rows)
+        assert bits.dtype == torch.uint8 and bits.numel() == (n + 7) // 8
+        idx = GradSync._bitmap_rows(bits, n)
+        want = torch.nonzero((rows != 0).any(1)).reshape(-1)
+        assert torch.equal(idx, want)
+        assert set(want.tolist()) <= set(hit.tolist())
