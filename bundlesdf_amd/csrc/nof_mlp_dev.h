@@ -72,6 +72,9 @@ struct Shp {                                       // compile-time layer table (
 // residual, and the product is the three MFMAs hi*hi + hi*lo + lo*hi (the lo*lo term is below fp32 rounding): twice the
 // operand mantissa (fp16: 22 bits), i.e. fp32-class outputs from the 16-bit matrix cores at 3x the (idle) MFMA work.
 // `lo_off` = byte offset of the layer's residual fragments (same layout as the main ones).
+#ifndef NOF_SPLIT_FMA_MIX
+#define NOF_SPLIT_FMA_MIX 1
+#endif
 template <class P, int QN, int PN, bool SPLIT = false>
 __device__ __forceinline__ void dense_o1(const char* smem, int frag_off, int bias_off, const float (&in)[QN][16],
                                          float (&out)[PN][16], int lane, int lo_off = 0) {
@@ -81,6 +84,8 @@ __device__ __forceinline__ void dense_o1(const char* smem, int frag_off, int bia
   const int hi = lane >> 5;
   typename P::frag bop[QN][NSTEP];
   typename P::frag blo[SPLIT ? QN : 1][SPLIT ? NSTEP : 1];
+  float negone = -1.0f;
+  if constexpr (SPLIT) asm volatile("" : "+s"(negone));               // (no instruction: see the residual below)
 #pragma unroll
   for (int q = 0; q < QN; ++q)
 #pragma unroll
@@ -88,8 +93,19 @@ __device__ __forceinline__ void dense_o1(const char* smem, int frag_off, int bia
       bop[q][s] = P::pack(&in[q][KR * s]);
       if constexpr (SPLIT) {
         float res[KR];
+        if constexpr (NOF_SPLIT_FMA_MIX && sizeof(typename P::elem) == 2 && P::KR == 8 && __is_same(typename P::elem, _Float16)) {
+          // residual lo = round16(x - float(hi)) as ONE v_fma_mixlo_f16 / v_fma_mixhi_f16 per element (f16 source, fp32 addend, f16
+          // result into its half of the operand register): float(hi) * (-1) + x is exact -- x - round16(x) always fits fp32 -- so
+          // the single rounding to f16 gives the bits of the three-instruction form v_cvt_f32_f16, v_sub_f32, v_cvt_pk_f16_f32.  The
+          // -1 is opaque to the optimiser, which otherwise folds the fma back into the subtraction (round 6: 4 -> 2.5 VALU
+          // instructions per split element, 12 % of the fused forward's instructions).  tests/test_gpu_erratum.py: both forms are
+          // exact under MFMA load (forms 7, 8); the bitwise fused == two-launch and repeatability tests run through them.
 #pragma unroll
-        for (int t = 0; t < KR; ++t) res[t] = in[q][KR * s + t] - (float)bop[q][s][t];
+          for (int t = 0; t < KR; ++t) res[t] = __builtin_fmaf((float)bop[q][s][t], negone, in[q][KR * s + t]);
+        } else {
+#pragma unroll
+          for (int t = 0; t < KR; ++t) res[t] = in[q][KR * s + t] - (float)bop[q][s][t];
+        }
         blo[q][s] = P::pack(res);
       }
     }

@@ -25,8 +25,9 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, 'tools', 'repro', 'pk_swap_repro.hip')
 FORMS = {0: 'v_pk_mul_f32 D, D, B op_sel:[0,1]', 1: 'v_pk_mul_f32 D, D, B op_sel:[0,1] op_sel_hi:[1,0]', 2: 'v_pk_add_f32 D, D, B op_sel:[0,1]',
-         3: 'v_pk_fma_f32 D, D, B, C op_sel:[0,1,0]', 4: 'v_pk_mul_f32 D, D, B op_sel:[1,0]', 5: 'v_pk_mul_f32 D, D, B', 6: 'v_pk_mul_f32 D, A, B op_sel:[0,1]'}
-SAFE = (4, 5)
+         3: 'v_pk_fma_f32 D, D, B, C op_sel:[0,1,0]', 4: 'v_pk_mul_f32 D, D, B op_sel:[1,0]', 5: 'v_pk_mul_f32 D, D, B', 6: 'v_pk_mul_f32 D, A, B op_sel:[0,1]',
+         7: 'v_fma_mixlo_f16 D, H, S, X op_sel_hi:[1,0,0]', 8: 'v_fma_mixhi_f16 D, H, S, X op_sel_hi:[1,0,0]'}
+SAFE = (4, 5, 7, 8)        # (7, 8: round 6 -- the operand split's residual is one v_fma_mixlo / mixhi_f16 per element)
 
 
 def test_packed_fp32_source1_op_sel_under_mfma_load(nof, tmp_path):

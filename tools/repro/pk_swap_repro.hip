@@ -33,8 +33,16 @@ __global__ __launch_bounds__(768) void k_pk(int32_t* __restrict__ counts, float*
     case 2: want = {a.x + b.y, a.y + b.y}; break;                     // add  op_sel:[0,1]
     case 3: want = {fmaf(a.x, b.y, c.x), fmaf(a.y, b.y, c.y)}; break; // fma  op_sel:[0,1,0]
     case 4: want = {a.y * b.x, a.y * b.y}; break;                     // mul  op_sel:[1,0]  (source 0)
+    case 7: case 8: break;                                            // v_fma_mixlo_f16 / v_fma_mixhi_f16 (below)
     default: want = {a.x * b.x, a.y * b.y}; break;                    // mul, no op_sel
   }
+  // forms 7 / 8 (round 6): v_fma_mixlo_f16 / v_fma_mixhi_f16 with an f16 source 0 -- what the operand split of the MLP forward
+  // compiles to for its residual: lo = f16(float(hi) * (-1) + x), written to the low / high half of the destination
+  const _Float16 hs = (_Float16)(1.5f + 0.001f * (float)lane + 0.03125f * (float)(wave + 1));
+  const uint32_t hreg = (uint32_t)__builtin_bit_cast(uint16_t, hs);
+  float negone = -1.0f;
+  asm volatile("" : "+v"(negone));
+  if (FORM == 7 || FORM == 8) want = {(float)(_Float16)fmaf((float)hs, -1.0f, b.x), a.y};
   int bad = 0, bad_lo = 0, bad_hi = 0;
   uint32_t which = 0;                                                  // bit i: execution i after an MFMA chain was wrong at least once
   float first_lo = 0.0f;
@@ -52,6 +60,10 @@ __global__ __launch_bounds__(768) void k_pk(int32_t* __restrict__ counts, float*
       if (FORM == 4) PK("v_pk_mul_f32 %0, %0, %1 op_sel:[1,0]");
       if (FORM == 5) PK("v_pk_mul_f32 %0, %0, %1");
       if (FORM == 6) { v2f d; asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1]" : "=&v"(d) : "v"(t), "v"(b)); t = d; }
+      if (FORM == 7) { uint32_t d = 0u; asm volatile("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "+v"(d) : "v"(hreg), "v"(negone), "v"(b.x));
+                       t.x = (float)__builtin_bit_cast(_Float16, (uint16_t)(d & 0xffffu)); }
+      if (FORM == 8) { uint32_t d = 0u; asm volatile("v_fma_mixhi_f16 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "+v"(d) : "v"(hreg), "v"(negone), "v"(b.x));
+                       t.x = (float)__builtin_bit_cast(_Float16, (uint16_t)(d >> 16)); }
       const bool wl = t.x != want.x, wh = t.y != want.y;
       if (wl && bad_lo == 0) first_lo = t.x;
       bad += wl || wh; bad_lo += wl; bad_hi += wh;
@@ -68,6 +80,6 @@ __global__ __launch_bounds__(768) void k_pk(int32_t* __restrict__ counts, float*
 
 extern "C" int pk_run(int form, int blocks, int32_t* counts, float* sink, int iters, int mfma_iters, int pad, int32_t* by_index, void* stream) {
 #define GO(F) case F: hipLaunchKernelGGL(k_pk<F>, dim3(blocks), dim3(768), 0, (hipStream_t)stream, counts, sink, iters, mfma_iters, pad, by_index); break;
-  switch (form) { GO(0) GO(1) GO(2) GO(3) GO(4) GO(5) GO(6) default: return -1; }
+  switch (form) { GO(0) GO(1) GO(2) GO(3) GO(4) GO(5) GO(6) GO(7) GO(8) default: return -1; }
   return (int)hipGetLastError();
 }
