@@ -218,3 +218,54 @@ def test_bench_refuses_to_run_fewer_ranks_than_asked():
     p = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '0'],
                        capture_output=True, text=True, env=env2, timeout=300)
     assert p.returncode != 0 and 'WORLD_SIZE=1' in p.stderr
+
+
+def _rows_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from bundlesdf_amd import dist as D
+    D.init_from_env(torch.device('cpu'))
+    nrow = 4099
+    g = torch.Generator().manual_seed(7 + rank)
+    t = torch.zeros(nrow, 2)
+    hit = torch.randperm(nrow, generator=g)[:nrow // 8]
+    t[hit] = torch.randn(hit.numel(), 2, generator=g)
+    mine = t.reshape(-1).clone()
+    dense = mine.clone()
+    dist.all_reduce(dense)
+    sr = D.make_grad_sync(mode='rows')
+    k = sr.exchange_rows_(mine, 2)
+    sr.end_step()
+    masks = [torch.zeros(nrow, dtype=torch.bool) for _ in range(world)]
+    masks[rank] = (t != 0).any(1)
+    allm = torch.stack(masks).to(torch.uint8)
+    dist.all_reduce(allm)
+    assert k == int((allm.sum(0) > 0).sum())
+    # more than two ranks: the union's rows are summed by an all-reduce over another buffer, so the order of a row's terms may differ
+    # from the dense call's -- equal to rounding, identical on every rank, and exactly zero wherever no rank touched a row
+    assert torch.allclose(mine, dense, rtol=1e-6, atol=1e-7)
+    assert not mine.view(-1, 2)[allm.sum(0) == 0].any()
+    every = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(every, mine)
+    assert all(torch.equal(e, every[0]) for e in every)
+    if rank == 0:
+        out.put((k, sr.bytes_step))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_touched_row_exchange_three_ranks():
+    """GradSync mode 'rows' at a world size that is neither 2 nor a power of two: the union of three ranks' rows travels, every
+    rank ends with the same bits, untouched rows stay exactly zero, and the sum equals the dense all-reduce's to rounding."""
+    world = 3
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_rows_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    k, nbytes = q.get(timeout=240)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert 4099 // 8 < k < 3 * (4099 // 8) + 1 and nbytes == (4099 + 7) // 8 + 8 * k
