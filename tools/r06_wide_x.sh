@@ -1,5 +1,6 @@
 #!/bin/bash
-# round 6: cfg5 bench (no parity tests: the NOF_WIDE_X variants compute WRONG results by design, timing only) for the regular library and A/B builds
+# round 6: cfg5 bench only (no parity tests) for the regular library and A/B builds -- used for the wide backward's ablation, whose timing-only
+# knobs (NOF_WIDE_X: results wrong by design) lived in nof_mlp_wide.hip at commit cabe347 and went with the pipelined rewrite that followed
 #   gpurun -- 'bash tools/r06_wide_x.sh <tag> ab_x.so ...'
 cd "$GRAFT_REPO_ROOT" || exit 1
 T=${1:-r06_x}; shift
