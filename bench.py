@@ -295,6 +295,10 @@ def main():
     ap.add_argument('--unfused', action='store_true', help='training forward as nof_hash_encode_fwd + nof_mlp_fwd (fp32 embedding in HBM) instead of the fused nof_encode_mlp_fwd')
     ap.add_argument('--no-extra-configs', action='store_true', help='skip the BASELINE cfg4 / cfg5 sub-records (N = 1 default run only)')
     ap.add_argument('--extract', type=int, default=0, help='after the timed steps: time the dense SDF query + marching cubes of an N^3 grid (BASELINE cfg4: 512)')
+    ap.add_argument('--one-stream', type=int, default=None, choices=[0, 1],
+                    help='the backward tail as one chain with the scatter and dL/dx in one launch (field.one_stream_backward)')
+    ap.add_argument('--fused-tail', type=int, default=None, choices=[0, 1],
+                    help='the optimiser launch with the pose sums and the next step\'s operand image + pose table inside (field.fused_tail)')
     ap.add_argument('--scatter-wgs', type=int, default=0, help='persistent workgroups per CU of the table scatter (0 = library default)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--with-cpu-baseline', action='store_true', help='overrides --no-cpu-baseline (the cfg1-shapes sub-record)')
@@ -331,6 +335,10 @@ def main():
     R, S = args.rays, cfg['N_samples'] + cfg['N_samples_around_depth']
     B = R * S
 
+    if args.one_stream is not None:
+        fld.one_stream_backward = bool(args.one_stream)
+    if args.fused_tail is not None:
+        fld.fused_tail = bool(args.fused_tail)
     if args.unfused:
         fld.fused_forward = False
         fld.fused_forward_wide = False
@@ -506,8 +514,9 @@ def main():
     dense_ms = timed(args.steps) / args.steps * 1e3
     fld.backward_tiles = 'list'
     log(f'dense backward (every tile listed): {dense_ms:.3f} ms/step')
-    # cfg hip_graph = True replays the step as ONE captured HIP graph (NerfRunner.train_loop / GraphedStep): one chain instead of
-    # the eager step's two streams, i.e. a free host for a few per cent of step time.  Same K steps, captured, for the record:
+    # cfg hip_graph = True replays the step as ONE captured HIP graph (NerfRunner.train_loop / GraphedStep): one chain -- the table
+    # scatter and dL/dx as two roles of one launch, the pose rows as a passenger of the LDS levels' launch (round 6) -- instead of
+    # the eager step's two streams.  Same K steps, captured, for the record:
     graph_ms, graph_alt_ms = None, None
     if not dist.is_initialized() or world == 1:
         runner.cfg['hip_graph'] = True              # opt-in (the product default is the eager two-stream step)
@@ -521,7 +530,7 @@ def main():
             torch.cuda.synchronize()
             graph_ms = (time.perf_counter() - t1) / args.steps * 1e3
             log(f'captured-step mode: {graph_ms:.3f} ms/step')
-        # the same with the captured step as ONE chain (what rounds 3-4 captured): the fork / join inside the graph against none
+        # the same with the eager step's two branches kept inside the graph (round 5's captured step): fork / join against none
         fld.graph_fork = not fld.graph_fork
         runner._graph = None
         for _ in range(4):
@@ -561,6 +570,8 @@ def main():
         fld_r.scatter_wgs_per_cu = args.scatter_wgs
         fld_r.fused_forward = fld.fused_forward
         fld_r.fused_forward_wide = fld.fused_forward_wide
+        fld_r.one_stream_backward = fld.one_stream_backward
+        fld_r.fused_tail = fld.fused_tail
         barrier()
         t0 = time.perf_counter()
         for _ in range(args.round_steps):
@@ -704,7 +715,7 @@ def main():
             "ms_per_step_p50_timed": timed_intervals["p50"] if timed_intervals else None,
             "ms_step_max_timed": timed_intervals["max"] if timed_intervals else None,
             "host_enqueue_ms_p50": host_intervals["p50"] if host_intervals else None,
-            "train_iters_per_sec": it_s * 1.0, "captured_step_ms_per_step": graph_ms, "captured_step_one_chain_ms_per_step": graph_alt_ms,
+            "train_iters_per_sec": it_s * 1.0, "captured_step_ms_per_step": graph_ms, "captured_step_two_branches_ms_per_step": graph_alt_ms,
             # forward-only batches run before the warm-up steps (no parameter / optimiser / loader / RNG state touched)
             "preroll_forward_batches": args.preroll,
             # device-side duration of single steps (K more steps, one event after each): p10 / p50 / p90

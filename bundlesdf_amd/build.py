@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 OBJ = os.path.join(CSRC, 'build')
 LIB = os.path.join(HERE, 'libnof_hip.so')
-SOURCES = ['nof_capi.hip', 'nof_hash.hip', 'nof_trace.hip', 'nof_loss.hip', 'nof_pose.hip', 'nof_mlp.hip', 'nof_mlp_wide.hip', 'nof_mesh.hip', 'nof_texture.hip']
+SOURCES = ['nof_capi.hip', 'nof_hash.hip', 'nof_trace.hip', 'nof_loss.hip', 'nof_adam_tail.hip', 'nof_pose.hip', 'nof_mlp.hip', 'nof_mlp_wide.hip', 'nof_mesh.hip', 'nof_texture.hip']
 HEADERS = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith('.h')) + [os.path.join(HERE, '..', 'include', 'nof_hip.h')]
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=off', '-munsafe-fp-atomics',
          '-Wno-unused-result', '-Wno-pass-failed', '-fno-slp-vectorize']

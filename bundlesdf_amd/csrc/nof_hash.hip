@@ -19,6 +19,7 @@
 #include <type_traits>
 #include "nof_hash_dev.h"
 #include "nof_reduce_dev.h"
+#include "nof_pose_dev.h"
 #ifndef NOF_AGG_PRIO
 #define NOF_AGG_PRIO 1                                    // s_setprio by phase in the table scatter (A/B: profiles/r05_v_*): 1 = emission high, 2 = loads high
 #endif
@@ -227,11 +228,14 @@ __device__ __forceinline__ void wave_lds_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// (the body of k_hash_bwd_agg as a device function of (workgroup index, workgroup count): the stand-alone kernel passes blockIdx /
+//  gridDim, the merged launch k_hash_bwd_agg_dx its own numbering)
 template <bool EIK>
-__global__ __launch_bounds__(256) void k_hash_bwd_agg(NofHashGrid g, LevelList ll, const float* __restrict__ pts_w,
-                                                       const float2* __restrict__ dfeat, float* __restrict__ grad_table,
-                                                       int64_t B, const float2* __restrict__ geik, const float* __restrict__ dedn,
-                                                       const uint32_t* __restrict__ tile_list, int trim) {
+__device__ __forceinline__ void hash_bwd_agg_block(const NofHashGrid& g, const LevelList& ll, const float* __restrict__ pts_w,
+                                                   const float2* __restrict__ dfeat, float* __restrict__ grad_table,
+                                                   int64_t B, const float2* __restrict__ geik, const float* __restrict__ dedn,
+                                                   const uint32_t* __restrict__ tile_list, int trim, const uint32_t block_id,
+                                                   const uint32_t grid_n) {
   __shared__ __attribute__((aligned(16))) AggStage st;
   const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   float* val = st.val[w];
@@ -251,12 +255,12 @@ __global__ __launch_bounds__(256) void k_hash_bwd_agg(NofHashGrid g, LevelList l
   // the tiles once the field has settled, 50 % in the first steps -- 3 (A/B on one box, whole 501-step round 0.425-0.434 vs
   // 0.436-0.441 ms/step, settled 0.398-0.406 vs 0.410-0.414; every tile listed 0.662 vs 0.616: profiles/r04_s_scatter_wgs.txt).
   // The host launches the larger grid (default workgroup count only, `trim` != 0); the last quarter leaves at once when the list is short.
-  uint32_t n_blocks = gridDim.x;
+  uint32_t n_blocks = grid_n;
   if (trim != 0 && tile_list != nullptr && 4u * (uint32_t)__builtin_amdgcn_readfirstlane((int)tile_list[0]) < 3u * (uint32_t)__builtin_amdgcn_readfirstlane((int)tile_list[1]))
-    n_blocks = (gridDim.x * 3u) / 4u;
-  if (blockIdx.x >= n_blocks) return;
+    n_blocks = (grid_n * 3u) / 4u;
+  if (block_id >= n_blocks) return;
   const uint32_t n_lv = (uint32_t)ll.n, n_sb = n_items, n_waves = n_blocks * 4u;
-  const uint32_t t0 = blockIdx.x * 4u + (uint32_t)w, dq = n_waves / n_lv, dr = n_waves % n_lv;
+  const uint32_t t0 = block_id * 4u + (uint32_t)w, dq = n_waves / n_lv, dr = n_waves % n_lv;
   uint32_t sb = t0 / n_lv, slot_l = t0 % n_lv;
   for (; sb < n_sb; sb += dq, slot_l += dr, sb += slot_l >= n_lv ? 1u : 0u, slot_l -= slot_l >= n_lv ? n_lv : 0u) {
     const int level = ll.level[slot_l];
@@ -387,6 +391,14 @@ __global__ __launch_bounds__(256) void k_hash_bwd_agg(NofHashGrid g, LevelList l
   }
 }
 
+template <bool EIK>
+__global__ __launch_bounds__(256) void k_hash_bwd_agg(NofHashGrid g, LevelList ll, const float* __restrict__ pts_w,
+                                                       const float2* __restrict__ dfeat, float* __restrict__ grad_table,
+                                                       int64_t B, const float2* __restrict__ geik, const float* __restrict__ dedn,
+                                                       const uint32_t* __restrict__ tile_list, int trim) {
+  hash_bwd_agg_block<EIK>(g, ll, pts_w, dfeat, grad_table, B, geik, dedn, tile_list, trim, blockIdx.x, gridDim.x);
+}
+
 // The MLP backward's row reduction as a passenger of this launch (nof_hash_encode_bwd_parts_reduce): `partials` != NULL puts
 // ncb * RED_RSPLIT workgroups of reduce_partials_block in FRONT of the launch's own.  Both are 1024-thread workgroups; the reduction
 // needs the MLP backward only, which is long done here, and the step's tail loses a launch and the gap in front of it.
@@ -396,12 +408,18 @@ struct RedArgs {
   int32_t* flags;
   int n_rows, n_cols, ncb;
 };
+// ... and the per-ray pose / frame-feature gradient rows (nof_pose_grad_accum) as a second passenger (round 6: it needs dL/dx, which
+// the step's previous launch -- the merged scatter + dL/dx -- has finished; behind the reduction's workgroups, 16 rays per workgroup)
+struct PoseArgs {
+  NofPoseAccum a;                                                      // a.batch == NULL: no passenger
+  int nwg;
+};
 
 // levels whose slice fits LDS: accumulate privately, flush once
 __global__ __launch_bounds__(1024) void k_hash_bwd_lds(NofHashGrid g, LevelList ll, int chunks, const float* __restrict__ pts_w,
                                                         const float2* __restrict__ dfeat, float* __restrict__ grad_table,
                                                         int64_t B, const float2* __restrict__ geik, const float* __restrict__ dedn,
-                                                        const uint32_t* __restrict__ tile_list, RedArgs red) {
+                                                        const uint32_t* __restrict__ tile_list, RedArgs red, PoseArgs pose) {
   extern __shared__ __attribute__((aligned(16))) float acc[];
   int bid = (int)blockIdx.x;
   if (red.partials != nullptr) {                                       // (workgroup-uniform)
@@ -411,6 +429,16 @@ __global__ __launch_bounds__(1024) void k_hash_bwd_lds(NofHashGrid g, LevelList 
       return;
     }
     bid -= nred;
+  }
+  if (pose.a.batch != nullptr) {                                       // (workgroup-uniform)
+    if (bid < pose.nwg) {
+      const int64_t r = (int64_t)bid * 16 + (threadIdx.x >> 6);
+      if (r < pose.a.R)
+        pose_grad_accum_ray(pose.a.dpts, pose.a.dview, pose.a.batch, pose.a.z_vals, pose.a.c2w, pose.a.tf, pose.a.ff, pose.a.sh_degree,
+                            pose.a.R, pose.a.S, pose.a.g_ray, pose.a.frame_slots, r, (int)(threadIdx.x & 63));
+      return;
+    }
+    bid -= pose.nwg;
   }
   const int level = ll.level[bid % ll.n];
   const int chunk = bid / ll.n;
@@ -516,11 +544,12 @@ __device__ __forceinline__ void dx_level(const HashLevel& lv, const float2* __re
 // pair condition per level: one level's latency at a time).  A zero gradient or an out-of-range point contributes exact zeros
 // through its factors instead of through a branch.
 template <bool EIK>
-__global__ __launch_bounds__(256) void k_hash_dx(NofHashGrid g, LevelList pairs, LevelList singles, const float* __restrict__ pts_w,
-                                                  const float2* __restrict__ table, const float2* __restrict__ dfeat,
-                                                  float* __restrict__ dpts, int64_t B, const float2* __restrict__ geik,
-                                                  const float* __restrict__ dedn, const uint8_t* __restrict__ tile_flags) {
-  const int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x;
+__device__ __forceinline__ void hash_dx_block(const NofHashGrid& g, const LevelList& pairs, const LevelList& singles,
+                                              const float* __restrict__ pts_w, const float2* __restrict__ table,
+                                              const float2* __restrict__ dfeat, float* __restrict__ dpts, int64_t B,
+                                              const float2* __restrict__ geik, const float* __restrict__ dedn,
+                                              const uint8_t* __restrict__ tile_flags, const uint32_t block_id) {
+  const int64_t b = (int64_t)block_id * 256 + threadIdx.x;
   if (b >= B) return;
   // work list given: the samples of an unflagged tile have dL/dx = 0 (and their dfeat was not written: do not read it)
   if (tile_flags != nullptr && tile_flags[b >> 5] == 0) {
@@ -549,6 +578,35 @@ __global__ __launch_bounds__(256) void k_hash_dx(NofHashGrid g, LevelList pairs,
   for (int i = 0; i < singles.n; ++i) one(singles.level[i], std::false_type());
 #pragma unroll
   for (int gd = 0; gd < 3; ++gd) dpts[b * 3 + gd] = dx[gd] * 0.5f + dxe[gd];    // d x01 / d x = 1/2 (grid.py:160)
+}
+
+template <bool EIK>
+__global__ __launch_bounds__(256) void k_hash_dx(NofHashGrid g, LevelList pairs, LevelList singles, const float* __restrict__ pts_w,
+                                                  const float2* __restrict__ table, const float2* __restrict__ dfeat,
+                                                  float* __restrict__ dpts, int64_t B, const float2* __restrict__ geik,
+                                                  const float* __restrict__ dedn, const uint8_t* __restrict__ tile_flags) {
+  hash_dx_block<EIK>(g, pairs, singles, pts_w, table, dfeat, dpts, B, geik, dedn, tile_flags, blockIdx.x);
+}
+
+// The table scatter of the large levels and dL/dx as two ROLES of one launch (round 6; NOF_HASH_BWD_MERGE_INPUT): the training step
+// ran them beside each other on two streams, paying a fork and a join (12-15 us each on this runtime) for it.  Every `period`-th
+// workgroup of the launch is one of the scatter's persistent workgroups -- so that they are resident from the start --, the others
+// take 256 samples of dL/dx each.  Same device functions as the two stand-alone kernels: the same results.
+template <bool EIK>
+__global__ __launch_bounds__(256) void k_hash_bwd_agg_dx(NofHashGrid g, LevelList ll, LevelList pairs, LevelList singles,
+                                                          const float* __restrict__ pts_w, const float2* __restrict__ table,
+                                                          const float2* __restrict__ dfeat, float* __restrict__ grad_table,
+                                                          float* __restrict__ dpts, int64_t B, const float2* __restrict__ geik,
+                                                          const float* __restrict__ dedn, const uint32_t* __restrict__ tile_list,
+                                                          const uint8_t* __restrict__ tile_flags, int trim, uint32_t n_agg,
+                                                          uint32_t period) {
+  const uint32_t q = blockIdx.x / period, r = blockIdx.x - q * period;
+  if (r == 0u && q < n_agg) {                                          // (workgroup-uniform)
+    hash_bwd_agg_block<EIK>(g, ll, pts_w, dfeat, grad_table, B, geik, dedn, tile_list, trim, q, n_agg);
+    return;
+  }
+  const uint32_t before = q + 1u < n_agg ? q + 1u : n_agg;            // scatter workgroups among the launch's workgroups 0 .. blockIdx
+  hash_dx_block<EIK>(g, pairs, singles, pts_w, table, dfeat, dpts, B, geik, dedn, tile_flags, blockIdx.x - before);
 }
 
 __global__ __launch_bounds__(256) void k_hash_indices(NofHashGrid g, const float* __restrict__ pts_w,
@@ -645,14 +703,19 @@ extern "C" int nof_hash_encode_bwd_eik(const NofHashGrid* g, const float* pts_w,
 //   NOF_HASH_BWD_TABLE_SMALL  the others: accumulated in LDS, flushed once per workgroup (k_hash_bwd_lds)
 //   NOF_HASH_BWD_INPUT        dL/dpts over ALL levels (k_hash_dx; needs dpts)
 // tile_list (NofTileList or NULL): only the listed tiles are read and scattered; dpts of unlisted tiles is written as 0.
+static __global__ __launch_bounds__(64) void k_pose_accum_alone(NofPoseAccum a) {
+  pose_grad_accum_ray(a.dpts, a.dview, a.batch, a.z_vals, a.c2w, a.tf, a.ff, a.sh_degree, a.R, a.S, a.g_ray, a.frame_slots,
+                      (int64_t)blockIdx.x, (int)threadIdx.x);
+}
+
 static int hash_bwd_parts(const NofHashGrid* g, const float* pts_w, const float* table, const float* dfeat,
                           const float* geik_, const float* dedn, float* grad_table, float* dpts, int32_t level_lo,
                           int32_t level_hi, const void* tile_list, int32_t parts, int32_t wgs_per_cu, int64_t B,
-                          RedArgs red, void* stream) {
+                          RedArgs red, void* stream, const NofPoseAccum* pose_accum = nullptr) {
   if (int e = check_grid(g)) return e;
   NOF_ARG(pts_w && table && dfeat && grad_table && B >= 0 && level_lo >= 0 && level_lo <= level_hi && level_hi <= g->L);
   NOF_ARG((geik_ == nullptr) == (dedn == nullptr));
-  NOF_ARG(parts >= 0 && parts <= NOF_HASH_BWD_ALL && wgs_per_cu >= 0 && wgs_per_cu <= 16);
+  NOF_ARG(parts >= 0 && parts <= (NOF_HASH_BWD_ALL | NOF_HASH_BWD_MERGE_INPUT) && wgs_per_cu >= 0 && wgs_per_cu <= 16);
   NOF_ARG(tile_list == nullptr || geik_ == nullptr);                   // the eikonal term has a gradient at every sample
   const float2* geik = (const float2*)geik_;
   if (B == 0) return 0;
@@ -671,6 +734,37 @@ static int hash_bwd_parts(const NofHashGrid* g, const float* pts_w, const float*
     else big.level[big.n++] = l;
   }
   const uint32_t* tl = (const uint32_t*)tile_list;
+  LevelList pairs, singles;                                            // dL/dx: the same test as level_pairs() on the device
+  pairs.n = singles.n = 0;
+  for (int l = 0; l < g->L; ++l) {
+    const uint64_t r1 = (uint64_t)g->resolution[l] + 1;
+    if (!g->hashed[l] && r1 <= 1024 && r1 * r1 * r1 <= g->size[l]) pairs.level[pairs.n++] = l;
+    else singles.level[singles.n++] = l;
+  }
+  // NOF_HASH_BWD_MERGE_INPUT: the large levels' scatter and dL/dx as two roles of ONE launch (k_hash_bwd_agg_dx)
+  if ((parts & NOF_HASH_BWD_MERGE_INPUT) && (parts & NOF_HASH_BWD_TABLE_BIG) && (parts & NOF_HASH_BWD_INPUT) && dpts && big.n > 0) {
+    int64_t n_agg = (int64_t)(wgs_per_cu > 0 ? wgs_per_cu : 4) * nof_cu_count();
+    if (tl == nullptr) {
+      const int64_t need = nof_div_up(nof_div_up(B, 64) * big.n, 4);
+      if (n_agg > need) n_agg = need;
+    }
+    const int64_t n_dx = nof_div_up(B, 256), total = n_agg + n_dx;
+    // the scatter's persistent workgroups FIRST (consecutive workgroups go round the eight XCDs: resident everywhere from the start),
+    // dL/dx's behind them.  (Measured: every 4th workgroup a scatter workgroup put all of them on two XCDs -- the call 236 instead
+    // of 121 us; every 3rd: 140, the late ones start late.)
+    const int64_t period = 1;
+    const int trim = wgs_per_cu == 0 ? 1 : 0;
+    if (geik != nullptr)
+      hipLaunchKernelGGL(k_hash_bwd_agg_dx<true>, dim3((unsigned)total), dim3(256), 0, st, *g, big, pairs, singles, pts_w,
+                         (const float2*)table, (const float2*)dfeat, grad_table, dpts, B, geik, dedn, tl, nof_tile_flags(tile_list, B), trim,
+                         (uint32_t)n_agg, (uint32_t)period);
+    else
+      hipLaunchKernelGGL(k_hash_bwd_agg_dx<false>, dim3((unsigned)total), dim3(256), 0, st, *g, big, pairs, singles, pts_w,
+                         (const float2*)table, (const float2*)dfeat, grad_table, dpts, B, geik, dedn, tl, nof_tile_flags(tile_list, B), trim,
+                         (uint32_t)n_agg, (uint32_t)period);
+    NOF_LAUNCH_OK();
+    parts &= ~(NOF_HASH_BWD_TABLE_BIG | NOF_HASH_BWD_INPUT);
+  }
   if ((parts & NOF_HASH_BWD_TABLE_BIG) && big.n > 0) {
     // persistent waves.  With every sample contributing (6.9 M line requests at cfg2) the kernel is bound by the atomic rate of
     // the memory side: two workgroups per CU saturate it and more only take L2 bandwidth from the kernels beside it
@@ -692,13 +786,6 @@ static int hash_bwd_parts(const NofHashGrid* g, const float* pts_w, const float*
     NOF_LAUNCH_OK();
   }
   if ((parts & NOF_HASH_BWD_INPUT) && dpts) {
-    LevelList pairs, singles;                                          // the same test as level_pairs() on the device
-    pairs.n = singles.n = 0;
-    for (int l = 0; l < g->L; ++l) {
-      const uint64_t r1 = (uint64_t)g->resolution[l] + 1;
-      if (!g->hashed[l] && r1 <= 1024 && r1 * r1 * r1 <= g->size[l]) pairs.level[pairs.n++] = l;
-      else singles.level[singles.n++] = l;
-    }
     if (geik != nullptr)
       hipLaunchKernelGGL(k_hash_dx<true>, dim3((unsigned)nof_div_up(B, 256)), dim3(256), 0, st, *g, pairs, singles, pts_w,
                          (const float2*)table, (const float2*)dfeat, dpts, B, geik, dedn, nof_tile_flags(tile_list, B));
@@ -715,10 +802,21 @@ static int hash_bwd_parts(const NofHashGrid* g, const float* pts_w, const float*
     if (lds_need > 64 * 1024)
       NOF_HIP(hipFuncSetAttribute((const void*)k_hash_bwd_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_need));
     const unsigned nred = red.partials != nullptr ? (unsigned)(red.ncb * RED_RSPLIT) : 0u;
-    hipLaunchKernelGGL(k_hash_bwd_lds, dim3((unsigned)(chunks * small.n) + nred), dim3(1024), lds_need, st, *g, small, chunks, pts_w,
-                       (const float2*)dfeat, grad_table, B, geik, dedn, tl, red);
+    PoseArgs pa;
+    pa.a = NofPoseAccum{};
+    pa.nwg = 0;
+    if (pose_accum != nullptr && pose_accum->R > 0) { pa.a = *pose_accum; pa.nwg = (int)nof_div_up(pose_accum->R, 16); }
+    hipLaunchKernelGGL(k_hash_bwd_lds, dim3((unsigned)(chunks * small.n) + nred + (unsigned)pa.nwg), dim3(1024), lds_need, st, *g, small,
+                       chunks, pts_w, (const float2*)dfeat, grad_table, B, geik, dedn, tl, red, pa);
     NOF_LAUNCH_OK();
     red.partials = nullptr;                                            // done
+    pose_accum = nullptr;
+  }
+  if (pose_accum != nullptr && pose_accum->R > 0) {                    // no LDS-level launch to ride in: on its own (one wave per ray)
+    PoseArgs pa;
+    pa.a = *pose_accum;
+    hipLaunchKernelGGL(k_pose_accum_alone, dim3((unsigned)pa.a.R), dim3(64), 0, st, pa.a);
+    NOF_LAUNCH_OK();
   }
   if (red.partials != nullptr)                                         // no LDS-level launch to ride in: on its own
     return reduce_partials_launch(red.partials, red.n_rows, red.n_cols, red.out, red.flags, stream);
@@ -746,6 +844,29 @@ extern "C" int nof_hash_encode_bwd_parts_reduce(const NofHashGrid* g, const floa
   if (B == 0 && red.partials != nullptr) return reduce_partials_launch(partials, n_rows, n_cols, grad_mlp, flags, stream);
   return hash_bwd_parts(g, pts_w, table, dfeat, geik_, dedn, grad_table, dpts, level_lo, level_hi, tile_list, parts, wgs_per_cu, B, red,
                         stream);
+}
+
+/* The hash side of the training step's backward in TWO launches (round 6): nof_hash_encode_bwd_parts_reduce with
+ * NOF_HASH_BWD_MERGE_INPUT (the large levels' scatter + dL/dpts as roles of one launch), and -- `pose` != NULL -- the per-ray pose /
+ * frame-feature gradient rows of nof_pose_grad_accum (same arguments, as a struct) as a passenger of the LDS levels' launch beside
+ * the MLP backward's row reduction.  Same results as the separate calls. */
+extern "C" int nof_hash_encode_bwd_step(const NofHashGrid* g, const float* pts_w, const float* table, const float* dfeat,
+                                         const float* geik_, const float* dedn, float* grad_table, float* dpts, int32_t level_lo,
+                                         int32_t level_hi, const void* tile_list, int32_t parts, int32_t wgs_per_cu, int64_t B,
+                                         const float* partials, int32_t n_rows, int32_t n_cols, float* grad_mlp, int32_t* flags,
+                                         const NofPoseAccum* pose, void* stream) {
+  RedArgs red{partials, grad_mlp, flags, n_rows, n_cols, (int)nof_div_up(n_cols, 32)};
+  if (partials == nullptr || n_rows <= 0 || n_cols <= 0) red.partials = nullptr;
+  if (pose != nullptr) {
+    NOF_ARG(pose->batch && pose->z_vals && pose->c2w && pose->tf && pose->g_ray && pose->R >= 0 && pose->S >= 1 && pose->ff >= 0 &&
+            pose->ff <= NOF_VIEW_COLS && pose->sh_degree >= 1 && pose->sh_degree <= 3 && (pose->frame_slots == nullptr || pose->dview != nullptr));
+  }
+  if (B == 0) {
+    if (red.partials != nullptr) return reduce_partials_launch(partials, n_rows, n_cols, grad_mlp, flags, stream);
+    return 0;
+  }
+  return hash_bwd_parts(g, pts_w, table, dfeat, geik_, dedn, grad_table, dpts, level_lo, level_hi, tile_list, parts, wgs_per_cu, B, red,
+                        stream, pose);
 }
 
 extern "C" int nof_hash_corner_indices(const NofHashGrid* g, const float* pts_w, int32_t* idx, int64_t B, void* stream) {

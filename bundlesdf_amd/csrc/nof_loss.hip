@@ -8,6 +8,7 @@
 // raw[R,S,4] is read as one float4 per sample and dL/draw written the same way.
 #include "nof_common.h"
 #include "nof_reduce_dev.h"
+#include "nof_adam_dev.h"
 #pragma clang fp contract(off)
 
 __device__ __forceinline__ float wave_sum(float v) {
@@ -492,67 +493,12 @@ extern "C" int nof_tile_list_build(const float* draw, int64_t B, int32_t all, vo
 }
 
 // ------------------------------------------------------------------------------------------------
-// torch.optim.Adam, single tensor form: m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2;
-// p -= (lr/bc1) * m / (sqrt(v)/sqrt(bc2) + eps).  HBM streaming: 16 B read + 16 B written per parameter.
-struct AdamK { float step_basic, step_pose, b1, b2, eps, inv_sqrt_bc2; };
-
-__device__ __forceinline__ void adam_one(float& p, float& g, float& m, float& v, float ss, const AdamK& k) {
-  const float mi = k.b1 * m + (1.0f - k.b1) * g;
-  const float vi = k.b2 * v + (1.0f - k.b2) * g * g;
-  const float denom = sqrtf(vi) * k.inv_sqrt_bc2 + k.eps;
-  p = p - ss * (mi / denom);
-  m = mi;
-  v = vi;
-  g = 0.0f;                                                            // optimizer.zero_grad() for the next step
-}
-
-// Entries [0, n) of the four flat buffers.  When they share their offset from a 16-byte boundary (they do: same index range of
-// four allocations) the body moves 16 bytes per lane and array -- 4x the bytes in flight of the scalar form, which is what a
-// 59 M-parameter table (cfg5: nothing of it stays in the MALL) needs to approach the HBM rate; element arithmetic is unchanged.
-// `skip_flags` (may be NULL): bit 2 of skip_flags[0] = this step's weight gradient is not finite (raised by nof_reduce_partials /
-// nof_grad_check before this launch).  Then the step is SKIPPED the way torch's GradScaler.step skips it (nerf_runner.py:756-761):
-// parameters and moments stay as they are, the gradient is zeroed for the next step.
-__device__ __forceinline__ void adam_range(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
-                                           float* __restrict__ v, int64_t n, int64_t n_basic, const AdamK& k,
-                                           const int32_t* __restrict__ skip_flags) {
-  const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (int64_t)gridDim.x * blockDim.x;
-  if (skip_flags != nullptr && (skip_flags[0] & 4)) {        // workgroup-uniform
-    for (int64_t i = tid; i < n; i += stride) g[i] = 0.0f;
-    return;
-  }
-  const unsigned mis = (unsigned)((uintptr_t)p >> 2) & 3u;
-  const bool same = (((uintptr_t)g >> 2) & 3u) == mis && (((uintptr_t)m >> 2) & 3u) == mis && (((uintptr_t)v >> 2) & 3u) == mis;
-  int64_t head = same ? (int64_t)((4u - mis) & 3u) : n;
-  if (head > n) head = n;
-  const int64_t nvec = (n - head) >> 2, tail = head + (nvec << 2);
-  for (int64_t i = tid; i < head; i += stride) adam_one(p[i], g[i], m[i], v[i], i < n_basic ? k.step_basic : k.step_pose, k);
-  float4* p4 = (float4*)(p + head); float4* g4 = (float4*)(g + head); float4* m4 = (float4*)(m + head); float4* v4 = (float4*)(v + head);
-  for (int64_t q = tid; q < nvec; q += stride) {
-    float4 pp = p4[q], gg = g4[q], mm = m4[q], vv = v4[q];
-    // Stores that would write back the bits already there are left out (the loads are not: they decide).  A gradient that is
-    // all-zero bits needs no zeroing -- six of seven table rows at cfg2 in any one step -- and an entry whose gradient and moments
-    // are all-zero bits is a fixed point of the update (m = v = +0, p - step * (0 / eps) = p): hash rows no sample has reached yet,
-    // most of the table in the first steps of a run.  Bit patterns, not values: -0 takes the arithmetic path.
-    const bool g_zero = (__float_as_uint(gg.x) | __float_as_uint(gg.y) | __float_as_uint(gg.z) | __float_as_uint(gg.w)) == 0u;
-    const bool idle = g_zero && (__float_as_uint(mm.x) | __float_as_uint(mm.y) | __float_as_uint(mm.z) | __float_as_uint(mm.w) |
-                                 __float_as_uint(vv.x) | __float_as_uint(vv.y) | __float_as_uint(vv.z) | __float_as_uint(vv.w)) == 0u;
-    if (idle) continue;
-    const int64_t i = head + (q << 2);
-    adam_one(pp.x, gg.x, mm.x, vv.x, i < n_basic ? k.step_basic : k.step_pose, k);
-    adam_one(pp.y, gg.y, mm.y, vv.y, i + 1 < n_basic ? k.step_basic : k.step_pose, k);
-    adam_one(pp.z, gg.z, mm.z, vv.z, i + 2 < n_basic ? k.step_basic : k.step_pose, k);
-    adam_one(pp.w, gg.w, mm.w, vv.w, i + 3 < n_basic ? k.step_basic : k.step_pose, k);
-    p4[q] = pp; m4[q] = mm; v4[q] = vv;
-    if (!g_zero) g4[q] = gg;
-  }
-  for (int64_t i = tail + tid; i < n; i += stride) adam_one(p[i], g[i], m[i], v[i], i < n_basic ? k.step_basic : k.step_pose, k);
-}
-
+// (AdamK, adam_one, adam_range: nof_adam_dev.h)
 __global__ __launch_bounds__(256) void k_adam(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
                                                float* __restrict__ v, int64_t n, int64_t n_basic, float step_basic,
                                                float step_pose, float b1, float b2, float eps, float inv_sqrt_bc2,
                                                const int32_t* __restrict__ skip_flags) {
-  adam_range(p, g, m, v, n, n_basic, AdamK{step_basic, step_pose, b1, b2, eps, inv_sqrt_bc2}, skip_flags);
+  adam_range(p, g, m, v, n, n_basic, AdamK{step_basic, step_pose, b1, b2, eps, inv_sqrt_bc2}, skip_flags, blockIdx.x, gridDim.x);
 }
 
 // ---- the same with the per-step scalars in device memory (replayable captured step) ----------------------------------
@@ -575,7 +521,7 @@ __global__ __launch_bounds__(256) void k_adam_dyn(float* __restrict__ p, float* 
                                                    float* __restrict__ v, int64_t n, int64_t n_basic,
                                                    const NofStepState* __restrict__ st, float b1, float b2, float eps,
                                                    const int32_t* __restrict__ skip_flags) {
-  adam_range(p, g, m, v, n, n_basic, AdamK{st->step_basic, st->step_pose, b1, b2, eps, st->inv_sqrt_bc2}, skip_flags);
+  adam_range(p, g, m, v, n, n_basic, AdamK{st->step_basic, st->step_pose, b1, b2, eps, st->inv_sqrt_bc2}, skip_flags, blockIdx.x, gridDim.x);
 }
 
 extern "C" int nof_step_state_advance(NofStepState* d_state, float lrate, float lrate_pose, float decay_rate, int32_t n_iters,

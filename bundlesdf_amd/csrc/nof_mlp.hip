@@ -16,6 +16,7 @@
 //     ever goes to HBM.
 // Accumulator layout of v_mfma_f32_32x32x*: lane l = (hi = l>>5, j = l&31) holds column j, rows (r&3)+8(r>>2)+4hi.
 #include "nof_mlp_dev.h"
+#include "nof_pose_dev.h"
 // Packs the fp32 PyTorch-layout weights into the MFMA fragment image the kernels keep in LDS (once per optimiser step,
 // by one small launch; every workgroup of the fwd/bwd kernels then just streams the image into LDS with 16-byte copies
 // -- packing inside each workgroup cost ~60 us of dependent global loads per workgroup and dominated the forward).

@@ -120,7 +120,19 @@ class NeuralObjectField:
         # the wide networks' counterpart (round 6): encode + sigma net in one launch, colour net behind it; the backward reads the
         # operand-precision embedding `featq`.  False: nof_hash_encode_fwd + nof_mlp_wide_fwd with the fp32 embedding in HBM
         self.fused_forward_wide = self.wide
-        self.graph_fork = True            # a captured step (GraphedStep) keeps the backward's two branches (False: one chain)
+        # the large levels' scatter and dL/dx as two roles of ONE launch, the per-ray pose rows as a passenger of the LDS levels'
+        # launch on the same stream: no side stream, no fork, no join (round 6).  Measured at the driver's invocation, three
+        # alternating pairs on one box (profiles/r06_y_one_stream_driver.txt): eager 0.471-0.474 against 0.475-0.479 ms with the two
+        # streams, settled 0.409-0.413 against 0.409-0.418, captured 0.400-0.416 against 0.437-0.449; cfg5 2.88 / 2.87 captured
+        # against 2.90 / 3.05 (r06_x_one_stream.txt).  False: the two-stream tail of rounds 3-5; None: in a captured step only.
+        # (The bucketed data-parallel exchange keeps the two streams: it needs the fine levels' slice early.)
+        self.one_stream_backward = True
+        # single-GPU step with the reference's defaults (poses optimised, no frame features, no pose regulariser): the optimiser
+        # launch also sums the frames' pose gradients in front of its update and leaves the NEXT step's MFMA operand image and pose
+        # table behind it (nof_adam_step_tail, round 6) -- two launches and their gaps less per step; False: the three calls
+        self.fused_tail = True
+        self._tail_step = None       # optimiser step whose operand image AND pose table the last nof_adam_step_tail left
+        self.graph_fork = False           # a captured step (GraphedStep) is ONE chain (True: it keeps the backward's two branches)
         self.marcher = lib.MARCHER_WAVE   # NofSampleCfg.marcher: the ray marcher of nof_raymarch_sample (lib.MARCHER_WALK: the per-lane walk)
         self.scatter_wgs_per_cu = 0                  # persistent workgroups per CU of the table scatter (0 = the library's default)
         self._state = None           # NofStepState on the device (captured-step mode): see sync_step_state / GraphedStep
@@ -380,7 +392,7 @@ class NeuralObjectField:
             if self.eikonal:
                 self._call('nof_mlp_pack', C.byref(self.desc32), self.mlp, self.packed32)
             self._packed_step = self.global_step
-        else:
+        elif self._tail_step != self.global_step:      # (the last optimiser launch left this step's pose table as well: fused_tail)
             self.update_poses()
         cid = None
         if want_cells:
@@ -512,7 +524,25 @@ class NeuralObjectField:
                 with torch.cuda.stream(self._st):
                     b['dview'].zero_()
 
-        if dyn and not self.graph_fork:
+        one_stream = self.one_stream_backward if self.one_stream_backward is not None else (dyn and not self.graph_fork)
+        one_stream = one_stream and not bucketed and self.optimize_poses and not self.eikonal
+        # (the optimiser launch takes the per-frame sums and the next step's prologue along: see fused_tail)
+        tail = (self.fused_tail and one_stream and do_step and not dyn and grad_sync is None and self.world_size == 1
+                and self.ff == 0 and float(cfg.get('pose_reg_weight', 0)) == 0 and self._packed_step == self.global_step)
+        if one_stream:
+            # ONE chain of three launches: { large levels' scatter | dL/dx } as roles of one launch (NOF_HASH_BWD_MERGE_INPUT),
+            # { LDS level | MLP row reduction | per-ray pose rows } as roles of the next (nof_hash_encode_bwd_step), the per-frame sums
+            pa = lib.NofPoseAccum(b['dpts'].data_ptr(), b['dview'].data_ptr(), b['batch'].data_ptr(), b['z_vals'].data_ptr(),
+                                  self.c2w.data_ptr(), self.tf.data_ptr(), self.ff, self.sh_degree, R, S, b['g_ray'].data_ptr(),
+                                  self.pose_slots.data_ptr())
+            self._call('nof_hash_encode_bwd_step', C.byref(self.grid), b['pts_w'], self.table, b['dfeat'], None, None, gtab, dpts,
+                       0, self.L, tiles, ALL | lib.HASH_BWD_MERGE_INPUT, self.scatter_wgs_per_cu, B, b['partials'], self.nblk,
+                       self.n_mlp, self._seg(self.grads, 'mlp'), self.flags, C.byref(pa), tag='hash_bwd[table+table_lds]')
+            if not tail:
+                self._call('nof_pose_reduce_bwd', self.pose, None, None, None, R, self.ff, C.c_float(self.max_trans),
+                           C.c_float(self.max_rot), self._seg(self.grads, 'pose'),
+                           self._seg(self.grads, 'feat') if self.ff > 0 else None, None, self.F, 0, self.pose_slots)
+        elif dyn and not self.graph_fork:
             # captured step as ONE chain
             reduce_mlp()
             hash_bwd(ALL, 0, self.L)
@@ -628,6 +658,8 @@ class NeuralObjectField:
             if adam_done is not None:                                  # (data parallel: everything on either side of the early slice)
                 self.adam_step(dyn, 0, adam_done[0], advance=False)
                 self.adam_step(dyn, adam_done[1])
+            elif tail:
+                self.adam_step_tail()
             else:
                 self.adam_step(dyn)
         return b
@@ -651,6 +683,18 @@ class NeuralObjectField:
         if advance:
             self.global_step += 1
             self.adam_steps += 1
+
+    def adam_step_tail(self):
+        """nof_pose_reduce_bwd + Adam over everything + nof_mlp_pack_pose for the next step, as ONE launch (nof_adam_step_tail)"""
+        lr, lr_pose = self.learning_rates()
+        t = lib.NofAdamTail(C.addressof(self.desc), self.packed.data_ptr(), self.n_table, self.n_mlp, self.n_basic, self.F,
+                            self.max_trans, self.max_rot, self.c2w.data_ptr(), self.tf.data_ptr(), self.pose_slots.data_ptr())
+        self._call('nof_adam_step_tail', self.params, self.grads, self.exp_avg, self.exp_avg_sq, self.n_total, self.n_basic,
+                   C.c_float(lr), C.c_float(lr_pose), C.c_float(0.9), C.c_float(0.999), C.c_float(1e-15), self.adam_steps + 1,
+                   self.flags, C.byref(t), tag='nof_adam_step')
+        self.global_step += 1
+        self.adam_steps += 1
+        self._packed_step = self._tail_step = self.global_step
 
     def gather_optimizer_state(self):
         """after steps with the sharded optimiser (GradSync mode 'zero1') a rank's Adam moments are current on its own shard only:

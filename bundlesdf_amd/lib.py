@@ -18,7 +18,7 @@ NOF_MAX_LEVELS = 16
 NOF_MAX_LAYERS = 8
 RAY_COLS = 12
 VIEW_COLS = 16
-HASH_BWD_TABLE_BIG, HASH_BWD_TABLE_SMALL, HASH_BWD_INPUT, HASH_BWD_ALL = 1, 2, 4, 7
+HASH_BWD_TABLE_BIG, HASH_BWD_TABLE_SMALL, HASH_BWD_INPUT, HASH_BWD_ALL, HASH_BWD_MERGE_INPUT = 1, 2, 4, 7, 8
 MARCHER_WAVE, MARCHER_WALK = 0, 1
 
 
@@ -47,6 +47,21 @@ class NofSampleCfg(C.Structure):
                 ('near_sc', C.c_float), ('far_sc', C.c_float), ('trunc', C.c_float), ('neg_trunc_ratio', C.c_float),
                 ('seed', C.c_uint64), ('step', C.c_uint32), ('d_step', C.c_void_p), ('deterministic', C.c_int32),
                 ('marcher', C.c_int32)]
+
+
+class NofPoseAccum(C.Structure):
+    """nof_pose_grad_accum's arguments as a struct (include/nof_hip.h): nof_hash_encode_bwd_step carries that kernel as a passenger"""
+    _fields_ = [('dpts', C.c_void_p), ('dview', C.c_void_p), ('batch', C.c_void_p), ('z_vals', C.c_void_p), ('c2w', C.c_void_p),
+                ('tf', C.c_void_p), ('ff', C.c_int32), ('sh_degree', C.c_int32), ('R', C.c_int64), ('S', C.c_int32),
+                ('g_ray', C.c_void_p), ('frame_slots', C.c_void_p)]
+
+
+class NofAdamTail(C.Structure):
+    """nof_adam_step_tail's neighbours (include/nof_hip.h): the pose gradient sums in front of Adam, the operand image and the pose
+    table of the next step behind it"""
+    _fields_ = [('desc', C.c_void_p), ('packed', C.c_void_p), ('mlp_off', C.c_int64), ('n_mlp', C.c_int64), ('pose_off', C.c_int64),
+                ('F', C.c_int32), ('max_trans', C.c_float), ('max_rot', C.c_float), ('c2w', C.c_void_p), ('tf', C.c_void_p),
+                ('frame_slots', C.c_void_p)]
 
 
 NOF_MCL_TABLES = 47
@@ -101,6 +116,7 @@ _SIGNATURES = {
     'nof_pose_reg': ([_P, _P, _I32, _F, _F, _P, _P], C.c_int),
     'nof_small_regs': ([_P, _P, _I32, _F, _F, _P], C.c_int),
     'nof_adam_step': ([_P, _P, _P, _P, _I64, _I64, _F, _F, _F, _F, _F, _I32, _P, _P], C.c_int),
+    'nof_adam_step_tail': ([_P, _P, _P, _P, _I64, _I64, _F, _F, _F, _F, _F, _I32, _P, C.POINTER(NofAdamTail), _P], C.c_int),
     'nof_grad_check': ([_P, _I64, _P, _P], C.c_int),
     'nof_render_depth': ([_P, _P, _I64, _I32, _F, _P, _P], C.c_int),
     'nof_step_state_advance': ([_P, _F, _F, _F, _I32, _F, _F, _I32, _P], C.c_int),
@@ -114,6 +130,8 @@ _SIGNATURES = {
     'nof_hash_encode_bwd_parts': ([C.POINTER(NofHashGrid), _P, _P, _P, _P, _P, _P, _P, _I32, _I32, _P, _I32, _I32, _I64, _P], C.c_int),
     'nof_hash_encode_bwd_parts_reduce': ([C.POINTER(NofHashGrid), _P, _P, _P, _P, _P, _P, _P, _I32, _I32, _P, _I32, _I32, _I64,
                                           _P, _I32, _I32, _P, _P, _P], C.c_int),
+    'nof_hash_encode_bwd_step': ([C.POINTER(NofHashGrid), _P, _P, _P, _P, _P, _P, _P, _I32, _I32, _P, _I32, _I32, _I64,
+                                          _P, _I32, _I32, _P, _P, C.POINTER(NofPoseAccum), _P], C.c_int),
     'nof_mlp_bwd_workspace_bytes': ([C.POINTER(NofMlpDesc)], C.c_int64),
     'nof_sdf_grid_query': ([C.POINTER(NofHashGrid), C.POINTER(NofMlpDesc), _P, _P, _P, _I32, _P, _P, _P, _I32, _I32, _I32,
                             _F, _P, _P], C.c_int),
@@ -145,7 +163,7 @@ _SIGNATURES = {
     'nof_texture_bake_frame': ([_P, _P, _I32, _I32, _P, _P, _I64, _P, _P, _P, _F, _I32, _P, _P, _P, _P, _P], C.c_int),
 }
 OPTIONAL = set()
-ABI_VERSION = 121           # include/nof_hip.h: NOF_ABI_VERSION
+ABI_VERSION = 122           # include/nof_hip.h: NOF_ABI_VERSION
 
 _lib = None
 

@@ -40,7 +40,7 @@ const char* nof_last_error(void);
  *   120  round 6: nof_mlp_wide_bwd_parts gained `featq`; the wide networks' workspace holds the sigma head's hand-off only
  *   121  round 6: new entry points nof_encode_mlp_wide_fwd, nof_mcl_count_blocks, nof_mcl_emit_blocks (nothing existing changed);
  *        the wide entry points refuse precisions 3 / 4 instead of running them as 2 / 1 */
-#define NOF_ABI_VERSION 121
+#define NOF_ABI_VERSION 122
 int nof_version(void);
 
 /* ---- multires hash grid (replaces gridencoder.*) --------------------------------------------- */
@@ -81,6 +81,7 @@ int nof_hash_encode_bwd_eik(const NofHashGrid* h_grid, const float* pts_w, const
 #define NOF_HASH_BWD_TABLE_SMALL 2      /* levels accumulated in LDS and flushed once per workgroup */
 #define NOF_HASH_BWD_INPUT 4            /* dL/dpts over all levels (needs dpts) */
 #define NOF_HASH_BWD_ALL 7
+#define NOF_HASH_BWD_MERGE_INPUT 8      /* with TABLE_BIG | INPUT: the large levels' scatter and dL/dpts as two roles of ONE launch (round 6) */
 int nof_hash_encode_bwd_parts(const NofHashGrid* h_grid, const float* pts_w, const float* table, const float* dfeat,
                               const float* geik, const float* dedn, float* grad_table, float* dpts, int32_t level_lo,
                               int32_t level_hi, const void* tile_list, int32_t parts, int32_t wgs_per_cu, int64_t B, void* stream);
@@ -442,6 +443,18 @@ int nof_composite_loss_fwd_bwd(const NofLossCfg* h_cfg, const float* raw, const 
  * batch for the frame's rays. */
 #define NOF_POSE_SLOTS 16
 #define NOF_POSE_SLOT_W 28                  /* 12 + NOF_VIEW_COLS */
+/* nof_pose_grad_accum's arguments as a struct (nof_hash_encode_bwd_step carries that kernel as a passenger of another launch) */
+typedef struct {
+  const float* dpts; float* dview; const float* batch; const float* z_vals; const float* c2w; const float* tf;
+  int32_t ff, sh_degree; int64_t R; int32_t S; float* g_ray; float* frame_slots;
+} NofPoseAccum;
+/* The hash side of the training step's backward in two launches: nof_hash_encode_bwd_parts_reduce with
+ * NOF_HASH_BWD_MERGE_INPUT, and -- pose != NULL -- nof_pose_grad_accum(pose->...) as a passenger of the LDS levels' launch (it
+ * needs dL/dpts, which the merged launch in front of it has finished).  Same results as the separate calls. */
+int nof_hash_encode_bwd_step(const NofHashGrid* g, const float* pts_w, const float* table, const float* dfeat, const float* geik,
+                             const float* dedn, float* grad_table, float* dpts, int32_t level_lo, int32_t level_hi,
+                             const void* tile_list, int32_t parts, int32_t wgs_per_cu, int64_t B, const float* partials,
+                             int32_t n_rows, int32_t n_cols, float* grad_mlp, int32_t* flags, const NofPoseAccum* pose, void* stream);
 int nof_pose_grad_accum(const float* dpts, float* dview, const float* batch, const float* z_vals,
                         const float* c2w, const float* tf, int32_t ff, int32_t sh_degree, int64_t R, int32_t S,
                         float* g_ray, float* frame_slots, void* stream);
@@ -478,6 +491,24 @@ int nof_render_depth(const float* raw, const float* z_vals, int64_t R, int32_t S
 int nof_adam_step(float* params, float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, int64_t n_basic,
                   float lr, float lr_pose, float beta1, float beta2, float eps, int32_t step, const int32_t* skip_flags,
                   void* stream);
+/* The optimiser launch of a single-GPU training step with its two neighbours inside (round 6): nof_pose_reduce_bwd (slot mode, no
+ * frame features) in front -- grads[pose_off + 6 f ..] += SE(3) backward of frame f's summed slots --, nof_adam_step over the flat
+ * buffers [table | MLP | 6 F pose entries] (mlp_off + n_mlp == pose_off == n_basic, pose_off + 6 F == n), and nof_mlp_pack_pose
+ * behind: `packed` (packed once before by nof_mlp_pack for the same desc) and the pose table `tf` [F,12] hold the UPDATED weights and
+ * poses when the launch ends, so the next step starts at its ray marcher.  Bit-identical to the three calls. */
+typedef struct {
+  const NofMlpDesc* desc;                 /* host pointer, like every descriptor argument */
+  void* packed;                           /* the MFMA operand image of nof_mlp_pack (device) */
+  int64_t mlp_off, n_mlp, pose_off;       /* the MLP segment and the first pose entry in the flat buffers */
+  int32_t F;
+  float max_trans, max_rot;
+  const float* c2w;                       /* [F,16] */
+  float* tf;                              /* [F,12] */
+  float* frame_slots;                     /* nof_pose_grad_accum's partial sums, handed back zeroed */
+} NofAdamTail;
+int nof_adam_step_tail(float* params, float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, int64_t n_basic,
+                       float lr, float lr_pose, float beta1, float beta2, float eps, int32_t step, const int32_t* skip_flags,
+                       const NofAdamTail* tail, void* stream);
 /* flags[0] |= 4 when any of grad[0, n) is not finite (the check of nof_reduce_partials, for a gradient that was summed over the
  * data-parallel ranks afterwards: every rank must skip the same step). */
 int nof_grad_check(const float* grad, int64_t n, int32_t* flags, void* stream);

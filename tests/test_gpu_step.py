@@ -2,6 +2,8 @@
 train_loop restatement (oracle/nof_oracle.py:OracleField.train_step) on identical rays, identical injected uniforms
 and identical initial parameters: z samples, ray-hit indices, raw outputs, loss terms, every gradient group, and the
 parameters after several Adam steps."""
+import ctypes as C
+
 import numpy as np
 import pytest
 import torch
@@ -466,3 +468,57 @@ def test_dyn_step_with_grad_sync_hook(nof):
     fld.train_step(pool, torch.arange(R, device='cuda'), R, seed=1, grad_sync=Sync(), dyn=True)
     torch.cuda.synchronize()
     assert Sync.calls == 1
+
+
+@pytest.mark.parametrize("precision,ns,nc,hidden", [('fp16x3', 2, 3, 64), ('fp16x3', 3, 2, 64), ('bf16', 2, 3, 64), ('fp32', 3, 2, 64),
+                                                    ('fp16', 4, 4, 128)])
+def test_adam_step_tail_equals_the_three_calls(nof, precision, ns, nc, hidden):
+    """round 6: nof_adam_step_tail = nof_pose_reduce_bwd (slot mode) + nof_adam_step + nof_mlp_pack_pose in one launch -- every
+    output BIT for bit: parameters, both moments, the zeroed gradient, the zeroed slots, the MFMA operand image (forward, residual and
+    backward fragments, biases) and the pose table; once as a normal step, once with the overflow mark set (the update is skipped)."""
+    cfg, fld, orc, batch, rng = _pair(nof, precision, ns=ns, nc=nc, R=128, hidden=hidden)
+    R = batch.shape[0]
+    pool = U.dev(batch)
+    fld.fused_tail = False
+    for it in range(3):                                  # two real steps (non-zero moments), then a backward whose gradient stays
+        u1 = rng.random((R, cfg['N_samples'])).astype(np.float32)
+        u2 = rng.random((R, cfg['N_samples_around_depth'])).astype(np.float32)
+        fld.train_step(pool, None, R, U.dev(u1), U.dev(u2), do_step=(it < 2))
+    torch.cuda.synchronize()
+    assert fld.grads.abs().max().item() > 0 and fld.exp_avg.abs().max().item() > 0
+    gen = torch.Generator(device='cuda').manual_seed(3)
+    fld.pose_slots.copy_(torch.randn(fld.pose_slots.shape, device='cuda', generator=gen) * 1e-3)     # what nof_pose_grad_accum leaves
+    fld.pose_slots.view(-1)[::7] = 0
+    keep = [x.clone() for x in (fld.params, fld.grads, fld.exp_avg, fld.exp_avg_sq, fld.pose_slots, fld.packed, fld.tf)]
+    lr, lr_pose = fld.learning_rates()
+    for skip in (0, 4):
+        out = []
+        for tail in (False, True):
+            for dst, src in zip((fld.params, fld.grads, fld.exp_avg, fld.exp_avg_sq, fld.pose_slots, fld.packed, fld.tf), keep):
+                dst.copy_(src)
+            fld.flags.zero_()
+            fld.flags[0] = skip
+            if tail:
+                t = nof.NofAdamTail(C.addressof(fld.desc), fld.packed.data_ptr(), fld.n_table, fld.n_mlp, fld.n_basic, fld.F,
+                                    fld.max_trans, fld.max_rot, fld.c2w.data_ptr(), fld.tf.data_ptr(), fld.pose_slots.data_ptr())
+                nof.call('nof_adam_step_tail', fld.params, fld.grads, fld.exp_avg, fld.exp_avg_sq, fld.n_total, fld.n_basic,
+                         C.c_float(lr), C.c_float(lr_pose), C.c_float(0.9), C.c_float(0.999), C.c_float(1e-15), fld.adam_steps + 1,
+                         fld.flags, C.byref(t))
+            else:
+                nof.call('nof_pose_reduce_bwd', fld.pose, None, None, None, R, 0, C.c_float(fld.max_trans), C.c_float(fld.max_rot),
+                         fld._seg(fld.grads, 'pose'), None, None, fld.F, 0, fld.pose_slots)
+                nof.call('nof_adam_step', fld.params, fld.grads, fld.exp_avg, fld.exp_avg_sq, fld.n_total, fld.n_basic,
+                         C.c_float(lr), C.c_float(lr_pose), C.c_float(0.9), C.c_float(0.999), C.c_float(1e-15), fld.adam_steps + 1,
+                         fld.flags)
+                nof.call('nof_mlp_pack_pose', C.byref(fld.desc), fld.mlp, fld.packed, fld.pose, fld.c2w, C.c_float(fld.max_trans),
+                         C.c_float(fld.max_rot), fld.tf, fld.F)
+            torch.cuda.synchronize()
+            out.append([x.clone() for x in (fld.params, fld.grads, fld.exp_avg, fld.exp_avg_sq, fld.pose_slots, fld.packed, fld.tf)])
+        names = ('params', 'grads', 'exp_avg', 'exp_avg_sq', 'pose_slots', 'packed', 'tf')
+        for n, a, b in zip(names, *out):
+            assert torch.equal(a.view(torch.uint8).view(-1), b.view(torch.uint8).view(-1)), (skip, n)
+        moved = not torch.equal(out[0][0], keep[0])
+        assert moved == (skip == 0)
+        if skip == 0:
+            assert not torch.equal(out[1][5], keep[5]) and not torch.equal(out[1][6], keep[6])      # image and pose table really moved
+        assert out[1][1].abs().max().item() == 0 and out[1][4].abs().max().item() == 0

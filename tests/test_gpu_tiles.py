@@ -251,6 +251,16 @@ def test_hash_backward_over_the_list_equals_whole_batch(nof, T, finest, R, S):
         got = g_l[off[l]:off[l + 1]].double().sum(0)
         want = g_w[off[l]:off[l + 1]].double().sum(0)
         assert ((got - want).abs() / g_w[off[l]:off[l + 1]].double().abs().sum(0).clamp_min(1e-30)).max().item() < 1e-6, l
+    # the large levels' scatter and dL/dx as two roles of ONE launch (round 6, NOF_HASH_BWD_MERGE_INPUT), with and without a list:
+    # dL/dx bit-equal, the table gradient up to the atomics' order
+    for lst, df_in in ((tl, dfeat_garbage), (None, dfeat)):
+        g_m = torch.zeros(geo.n_entries, 2, device='cuda')
+        dp_m = torch.full((B, 3), 7.0, device='cuda')
+        nof.call('nof_hash_encode_bwd_parts', C.byref(g), pts, table, df_in, None, None, g_m, dp_m, 0, L, lst,
+                 nof.HASH_BWD_ALL | nof.HASH_BWD_MERGE_INPUT, 0, B)
+        torch.cuda.synchronize()
+        assert torch.equal(dp_m, dp_w)
+        assert (g_m - g_w).abs().max().item() <= 2e-5 * scale
     # the table levels with the MLP backward's row reduction riding in the LDS levels' launch (what the step calls): the same table
     # gradient, and the reduction's own result bit for bit (fixed summation order per column and row range; two atomics per column
     # onto zeros commute) -- incl. the overflow flag for a non-finite column
@@ -296,3 +306,39 @@ def test_step_over_the_list_equals_step_without(nof):
         # Adam moves such an entry by ~lr whatever its size): bound the fraction
         assert (np.abs(p - p0) > 0.05 * cfg['lrate']).mean() < 2e-3, mode
         assert np.linalg.norm(g - g0) <= 2e-3 * np.linalg.norm(g0), mode
+
+
+@pytest.mark.parametrize("ff,tail", [(0, False), (0, True), (2, True)])
+def test_one_stream_backward_equals_two_streams(nof, ff, tail):
+    """round 6: the backward tail as ONE chain -- { large levels' scatter | dL/dx } as roles of one launch, { LDS levels | MLP row
+    reduction | per-ray pose rows } as roles of the next (nof_hash_encode_bwd_step) -- against the two-stream tail: a first step's
+    gradients (pose and frame-feature rows included; dL/dx itself is bit-equal in test_hash_backward_over_the_list_equals_whole_batch),
+    then the parameters after three Adam steps.  tail: the one-chain side also with the optimiser launch that carries the per-frame
+    pose sums and the next step's operand image + pose table (nof_adam_step_tail; with frame features it must fall back by itself)."""
+    from tests.test_gpu_step import _pair
+    res = {}
+    for one in (False, True):
+        cfg, fld, orc, batch, rng = _pair(nof, 'fp16x3', ff=ff, ns=2, nc=3, R=256)
+        fld.one_stream_backward = one
+        fld.fused_tail = one and tail
+        R = batch.shape[0]
+        pool = U.dev(batch)
+        first = None
+        for it in range(4):
+            u1 = rng.random((R, cfg['N_samples'])).astype(np.float32)
+            u2 = rng.random((R, cfg['N_samples_around_depth'])).astype(np.float32)
+            fld.train_step(pool, None, R, U.dev(u1), U.dev(u2), do_step=(0 < it < 4))
+            if it == 0:
+                torch.cuda.synchronize()
+                first = {k: cpu(fld._seg(fld.grads, k)).copy() for k in ('table', 'mlp', 'pose') + (('feat',) if ff else ())}
+                fld.grads.zero_()
+        torch.cuda.synchronize()
+        assert fld._buffers(R, cfg['N_samples'] + cfg['N_samples_around_depth'])['dview'].abs().max().item() == 0   # re-zeroed for the next step
+        assert (fld._tail_step == fld.global_step) == (one and tail and ff == 0)
+        res[one] = (first, cpu(fld.params).copy(), fld.losses()['loss'])
+    (g0, p0, l0), (g1, p1, l1) = res[False], res[True]
+    assert abs(l1 - l0) <= 1e-6 * abs(l0)
+    for k in g0:
+        assert np.abs(g0[k]).max() > 0, k
+        assert np.linalg.norm(g1[k] - g0[k]) <= 1e-4 * np.linalg.norm(g0[k]), k
+    assert (np.abs(p1 - p0) > 0.05 * cfg['lrate']).mean() < 2e-3
