@@ -531,7 +531,8 @@ def main():
             graph_ms = (time.perf_counter() - t1) / args.steps * 1e3
             log(f'captured-step mode: {graph_ms:.3f} ms/step')
         # the same with the eager step's two branches kept inside the graph (round 5's captured step): fork / join against none
-        fld.graph_fork = not fld.graph_fork
+        keep_modes = (fld.graph_fork, fld.one_stream_backward)
+        fld.graph_fork, fld.one_stream_backward = True, False
         runner._graph = None
         for _ in range(4):
             step()
@@ -542,8 +543,8 @@ def main():
                 step()
             torch.cuda.synchronize()
             graph_alt_ms = (time.perf_counter() - t1) / args.steps * 1e3
-            log(f'captured-step mode, graph_fork={fld.graph_fork}: {graph_alt_ms:.3f} ms/step')
-        fld.graph_fork = not fld.graph_fork
+            log(f'captured-step mode, two branches inside the graph: {graph_alt_ms:.3f} ms/step')
+        fld.graph_fork, fld.one_stream_backward = keep_modes
         runner.cfg['hip_graph'] = False
         runner._graph = None
     extraction = time_extraction(runner, args.extract) if args.extract > 0 and world == 1 else None

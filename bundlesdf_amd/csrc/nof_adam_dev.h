@@ -61,3 +61,17 @@ __device__ __forceinline__ void adam_range(float* __restrict__ p, float* __restr
   for (int64_t i = tail + tid; i < n; i += stride) adam_one(p[i], g[i], m[i], v[i], i < n_basic ? k.step_basic : k.step_pose, k);
 }
 
+// NofStepState of the NEXT optimiser step (one thread): set_step < 0: step += 1, else step = set_step
+__device__ __forceinline__ void step_state_advance(NofStepState* st, float lrate, float lrate_pose, float decay_rate, int n_iters,
+                                                   float b1, float b2, int set_step) {
+  const uint32_t s = set_step < 0 ? st->step + 1u : (uint32_t)set_step;
+  st->step = s;
+  // the optimiser step with index s uses the rate set at the last g <= s - 1 with g % 10 == 0, g > 0 (nerf_runner.py:762-763)
+  const uint32_t g = s <= 10u ? 0u : ((s - 1u) / 10u) * 10u;
+  const double k = g == 0u ? 1.0 : pow((double)decay_rate, (double)g / (double)n_iters);
+  const double t = (double)s + 1.0;
+  const double bc1 = 1.0 - pow((double)b1, t), bc2 = 1.0 - pow((double)b2, t);
+  st->step_basic = (float)((double)lrate * k / bc1);
+  st->step_pose = (float)((double)lrate_pose * k / bc1);
+  st->inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
+}

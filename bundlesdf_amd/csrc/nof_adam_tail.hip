@@ -21,12 +21,27 @@
 //   * the rest: the table entries [0, mlp_off) as in nof_adam_step.
 // Same bits as nof_pose_reduce_bwd + nof_adam_step + nof_mlp_pack_pose (tests/test_gpu_step.py).
 // =====================================================================================================
+struct TailArgs {                                                     // (by value: the neighbours' share of the kernel arguments)
+  char* image;
+  int with_lo, mlp_blocks, F;
+  int64_t mlp_off, pose_off;
+  const float* c2w;
+  float max_trans, max_rot;
+  float* tf;
+  float* slots;
+};
+
 template <class P>
-__global__ __launch_bounds__(256) void k_adam_tail(NofMlpDesc d, float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
-                                                    float* __restrict__ v, AdamK k, const int32_t* __restrict__ skip_flags,
-                                                    char* __restrict__ image, int with_lo, int64_t mlp_off, int mlp_blocks,
-                                                    int64_t pose_off, int F, const float* __restrict__ c2w, float max_trans,
-                                                    float max_rot, float* __restrict__ tf, float* __restrict__ slots) {
+__device__ __forceinline__ void adam_tail_roles(const NofMlpDesc& d, float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
+                                                float* __restrict__ v, const AdamK& k, const int32_t* __restrict__ skip_flags,
+                                                const TailArgs& a) {
+  char* __restrict__ image = a.image;
+  const int with_lo = a.with_lo, mlp_blocks = a.mlp_blocks, F = a.F;
+  const int64_t mlp_off = a.mlp_off, pose_off = a.pose_off;
+  const float* __restrict__ c2w = a.c2w;
+  const float max_trans = a.max_trans, max_rot = a.max_rot;
+  float* __restrict__ tf = a.tf;
+  float* __restrict__ slots = a.slots;
   const bool skip = skip_flags != nullptr && (skip_flags[0] & 4);     // (uniform) this step's gradient is not finite: no update
   if ((int)blockIdx.x < F) {                                           // ---- one frame's pose entries (workgroup-uniform) ----
     __shared__ float sm[32];
@@ -139,10 +154,43 @@ __global__ __launch_bounds__(256) void k_adam_tail(NofMlpDesc d, float* __restri
   adam_range(p, g, m, v, mlp_off, mlp_off, k, skip_flags, (uint32_t)(bid - mlp_blocks), gridDim.x - (uint32_t)F - (uint32_t)mlp_blocks);
 }
 
-extern "C" int nof_adam_step_tail(float* params, float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, int64_t n_basic,
-                                   float lr, float lr_pose, float beta1, float beta2, float eps, int32_t step,
-                                   const int32_t* skip_flags, const NofAdamTail* t, void* stream) {
-  NOF_ARG(params && grads && exp_avg && exp_avg_sq && n >= 0 && n_basic >= 0 && n_basic <= n && step >= 1 && t);
+template <class P>
+__global__ __launch_bounds__(256) void k_adam_tail(NofMlpDesc d, float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
+                                                    float* __restrict__ v, AdamK k, const int32_t* __restrict__ skip_flags, TailArgs a) {
+  adam_tail_roles<P>(d, p, g, m, v, k, skip_flags, a);
+}
+
+// The same with the step's scalars in device memory (a captured, replayable step): every workgroup reads the NofStepState when it
+// starts; the LAST one to finish -- counters in `done`, left at zero -- advances the state to the next optimiser step, which was
+// the launch nof_step_state_advance behind nof_adam_step_dyn.
+template <class P>
+__global__ __launch_bounds__(256) void k_adam_tail_dyn(NofMlpDesc d, float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
+                                                        float* __restrict__ v, NofStepState* st, float b1, float b2, float eps,
+                                                        const int32_t* __restrict__ skip_flags, TailArgs a, float lrate,
+                                                        float lrate_pose, float decay_rate, int n_iters, uint32_t* __restrict__ done) {
+  const AdamK k{st->step_basic, st->step_pose, b1, b2, eps, st->inv_sqrt_bc2};
+  adam_tail_roles<P>(d, p, g, m, v, k, skip_flags, a);
+  // No fence: a workgroup's reads of *st have returned before anything that depends on them was stored, and that is all the
+  // advance has to wait for (an agent-scope release here writes the XCD's L2 back once per workgroup: 242 instead of 37 us).
+  // Two levels of counters, each on its own 64-byte line: 4000 atomics on ONE line would serialise at 12 ns each.
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const uint32_t G = gridDim.x, grp = blockIdx.x & 63u;
+    const uint32_t members = (G - grp + 63u) / 64u, groups = G < 64u ? G : 64u;
+    uint32_t* c = done + (1u + grp) * 16u;
+    if (atomicAdd(c, 1u) == members - 1u) {
+      *c = 0u;
+      if (atomicAdd(done, 1u) == groups - 1u) {                        // every other workgroup has read the state and left
+        *done = 0u;
+        step_state_advance(st, lrate, lrate_pose, decay_rate, n_iters, b1, b2, -1);
+      }
+    }
+  }
+}
+
+static int adam_tail_check(const float* params, const float* grads, const float* exp_avg, const float* exp_avg_sq, int64_t n,
+                           int64_t n_basic, const NofAdamTail* t, TailArgs* a, dim3* grid) {
+  NOF_ARG(params && grads && exp_avg && exp_avg_sq && n >= 0 && n_basic >= 0 && n_basic <= n && t);
   if (int e = check_desc(t->desc)) return e;
   const NofMlpDesc& d = *t->desc;
   // the flat layout this launch understands: [table | MLP | 6 F pose entries], the learning-rate boundary in front of the poses
@@ -150,17 +198,46 @@ extern "C" int nof_adam_step_tail(float* params, float* grads, float* exp_avg, f
   NOF_ARG(t->mlp_off + t->n_mlp == t->pose_off && t->pose_off == n_basic && t->pose_off + 6 * (int64_t)t->F == n);
   const int nl = d.n_sigma + d.n_color;
   NOF_ARG((int64_t)d.b_off[nl - 1] + d.out_dim[nl - 1] <= t->n_mlp);
+  const int mlp_blocks = (int)nof_div_up((int64_t)n_pairs(d, nl) * 1024, 256);
+  const int64_t tb = t->mlp_off > 0 ? (nof_div_up(t->mlp_off, 1024) < 4096 ? nof_div_up(t->mlp_off, 1024) : 4096) : 0;
+  *grid = dim3((unsigned)(t->F + mlp_blocks + tb));
+  *a = TailArgs{(char*)t->packed, is_split(d.precision) ? 1 : 0, mlp_blocks, (int)t->F, t->mlp_off, t->pose_off, t->c2w,
+                t->max_trans, t->max_rot, t->tf, t->frame_slots};
+  return 0;
+}
+
+extern "C" int nof_adam_step_tail(float* params, float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, int64_t n_basic,
+                                   float lr, float lr_pose, float beta1, float beta2, float eps, int32_t step,
+                                   const int32_t* skip_flags, const NofAdamTail* t, void* stream) {
+  TailArgs a;
+  dim3 grid;
+  NOF_ARG(step >= 1);
+  if (int e = adam_tail_check(params, grads, exp_avg, exp_avg_sq, n, n_basic, t, &a, &grid)) return e;
+  const NofMlpDesc& d = *t->desc;
   const double bc1 = 1.0 - pow((double)beta1, (double)step);
   const double bc2 = 1.0 - pow((double)beta2, (double)step);
   const AdamK k{(float)(lr / bc1), (float)(lr_pose / bc1), beta1, beta2, eps, (float)(1.0 / sqrt(bc2))};
-  const int lo = is_split(d.precision) ? 1 : 0;
-  const int mlp_blocks = (int)nof_div_up((int64_t)n_pairs(d, nl) * 1024, 256);
-  const int64_t tb = t->mlp_off > 0 ? (nof_div_up(t->mlp_off, 1024) < 4096 ? nof_div_up(t->mlp_off, 1024) : 4096) : 0;
-  const dim3 grid((unsigned)(t->F + mlp_blocks + tb));
-#define NOF_TAIL(P)                                                                                                          \
-  hipLaunchKernelGGL(k_adam_tail<P>, grid, dim3(256), 0, (hipStream_t)stream, d, params, grads, exp_avg, exp_avg_sq, k, skip_flags, \
-                     (char*)t->packed, lo, t->mlp_off, mlp_blocks, t->pose_off, (int)t->F, t->c2w, t->max_trans, t->max_rot, t->tf,  \
-                     t->frame_slots)
+#define NOF_TAIL(P) hipLaunchKernelGGL(k_adam_tail<P>, grid, dim3(256), 0, (hipStream_t)stream, d, params, grads, exp_avg, exp_avg_sq, k, skip_flags, a)
+  if (d.precision == 0) NOF_TAIL(PrecF32);
+  else if (is_bf16(d.precision)) NOF_TAIL(PrecBF16);
+  else NOF_TAIL(PrecF16);
+#undef NOF_TAIL
+  NOF_LAUNCH_OK();
+  return 0;
+}
+
+extern "C" int nof_adam_step_tail_dyn(float* params, float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, int64_t n_basic,
+                                       NofStepState* d_state, float lrate, float lrate_pose, float decay_rate, int32_t n_iters,
+                                       float beta1, float beta2, float eps, const int32_t* skip_flags, const NofAdamTail* t,
+                                       uint32_t* d_done, void* stream) {
+  TailArgs a;
+  dim3 grid;
+  NOF_ARG(d_state && d_done && n_iters > 0);
+  if (int e = adam_tail_check(params, grads, exp_avg, exp_avg_sq, n, n_basic, t, &a, &grid)) return e;
+  const NofMlpDesc& d = *t->desc;
+#define NOF_TAIL(P)                                                                                                              \
+  hipLaunchKernelGGL(k_adam_tail_dyn<P>, grid, dim3(256), 0, (hipStream_t)stream, d, params, grads, exp_avg, exp_avg_sq, d_state, \
+                     beta1, beta2, eps, skip_flags, a, lrate, lrate_pose, decay_rate, (int)n_iters, d_done)
   if (d.precision == 0) NOF_TAIL(PrecF32);
   else if (is_bf16(d.precision)) NOF_TAIL(PrecBF16);
   else NOF_TAIL(PrecF16);

@@ -505,16 +505,7 @@ __global__ __launch_bounds__(256) void k_adam(float* __restrict__ p, float* __re
 __global__ void k_step_advance(NofStepState* st, float lrate, float lrate_pose, float decay_rate, int n_iters, float b1, float b2,
                                int set_step) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  const uint32_t s = set_step < 0 ? st->step + 1u : (uint32_t)set_step;
-  st->step = s;
-  // the optimiser step with index s uses the rate set at the last g <= s - 1 with g % 10 == 0, g > 0 (nerf_runner.py:762-763)
-  const uint32_t g = s <= 10u ? 0u : ((s - 1u) / 10u) * 10u;
-  const double k = g == 0u ? 1.0 : pow((double)decay_rate, (double)g / (double)n_iters);
-  const double t = (double)s + 1.0;
-  const double bc1 = 1.0 - pow((double)b1, t), bc2 = 1.0 - pow((double)b2, t);
-  st->step_basic = (float)((double)lrate * k / bc1);
-  st->step_pose = (float)((double)lrate_pose * k / bc1);
-  st->inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
+  step_state_advance(st, lrate, lrate_pose, decay_rate, n_iters, b1, b2, set_step);
 }
 
 __global__ __launch_bounds__(256) void k_adam_dyn(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,

@@ -132,6 +132,8 @@ class NeuralObjectField:
         # table behind it (nof_adam_step_tail, round 6) -- two launches and their gaps less per step; False: the three calls
         self.fused_tail = True
         self._tail_step = None       # optimiser step whose operand image AND pose table the last nof_adam_step_tail left
+        self._tail_done = torch.zeros(1040, dtype=torch.int32, device=dev)     # nof_adam_step_tail_dyn's counter (zero between launches)
+        self._tail_plan = False      # inside a train_step: this step's optimiser launch will be nof_adam_step_tail
         self.graph_fork = False           # a captured step (GraphedStep) is ONE chain (True: it keeps the backward's two branches)
         self.marcher = lib.MARCHER_WAVE   # NofSampleCfg.marcher: the ray marcher of nof_raymarch_sample (lib.MARCHER_WALK: the per-lane walk)
         self.scatter_wgs_per_cu = 0                  # persistent workgroups per CU of the table scatter (0 = the library's default)
@@ -384,7 +386,7 @@ class NeuralObjectField:
         (Running the NEXT batch's prologue at the end of a step, on the side stream beside Adam -- it needs only the few KB of
         poses / features / MLPs, updated first -- was built and measured: 0.526 vs 0.515 ms/step.  The fork and the join cost what
         the overlap returns, and the ray marcher's dependent loads slow down under Adam's streaming.)"""
-        if dyn or self._packed_step != self.global_step:
+        if (dyn and not self._tail_plan) or self._packed_step != self.global_step:
             # pose table + MFMA fragment image in ONE launch (two 6-microsecond kernels before: the pose update is one short
             # dependent chain per frame and rides as one extra workgroup of the packing launch)
             self._call('nof_mlp_pack_pose', C.byref(self.desc), self.mlp, self.packed, self.pose if self.optimize_poses else None,
@@ -442,7 +444,13 @@ class NeuralObjectField:
         step sizes) are read from the device-resident NofStepState instead of being passed by value, and the state is advanced
         by the step's last launch -- the form GraphedStep captures."""
         cfg = self.cfg
-        b, S = self.forward_batch(pool, ids, R, u_occ, u_dep, seed, want_cells, dyn)
+        # (decided before the prologue: a captured step whose optimiser launch leaves the next operand image packs none itself)
+        one_stream = self.one_stream_backward if self.one_stream_backward is not None else (dyn and not self.graph_fork)
+        tail = self._tail_plan = bool(one_stream and do_step and self._tail_ok(grad_sync))
+        try:
+            b, S = self.forward_batch(pool, ids, R, u_occ, u_dep, seed, want_cells, dyn)
+        finally:
+            self._tail_plan = False
         B = R * S
         lc = self._loss_cfg()
         # the work list of the backward; the eikonal term has a gradient at every sample, so it takes none
@@ -524,11 +532,9 @@ class NeuralObjectField:
                 with torch.cuda.stream(self._st):
                     b['dview'].zero_()
 
-        one_stream = self.one_stream_backward if self.one_stream_backward is not None else (dyn and not self.graph_fork)
         one_stream = one_stream and not bucketed and self.optimize_poses and not self.eikonal
-        # (the optimiser launch takes the per-frame sums and the next step's prologue along: see fused_tail)
-        tail = (self.fused_tail and one_stream and do_step and not dyn and grad_sync is None and self.world_size == 1
-                and self.ff == 0 and float(cfg.get('pose_reg_weight', 0)) == 0 and self._packed_step == self.global_step)
+        assert one_stream or not tail
+        # (tail: the optimiser launch takes the per-frame sums and the next step's prologue along, see fused_tail)
         if one_stream:
             # ONE chain of three launches: { large levels' scatter | dL/dx } as roles of one launch (NOF_HASH_BWD_MERGE_INPUT),
             # { LDS level | MLP row reduction | per-ray pose rows } as roles of the next (nof_hash_encode_bwd_step), the per-frame sums
@@ -659,7 +665,7 @@ class NeuralObjectField:
                 self.adam_step(dyn, 0, adam_done[0], advance=False)
                 self.adam_step(dyn, adam_done[1])
             elif tail:
-                self.adam_step_tail()
+                self.adam_step_tail(dyn)
             else:
                 self.adam_step(dyn)
         return b
@@ -684,14 +690,29 @@ class NeuralObjectField:
             self.global_step += 1
             self.adam_steps += 1
 
-    def adam_step_tail(self):
-        """nof_pose_reduce_bwd + Adam over everything + nof_mlp_pack_pose for the next step, as ONE launch (nof_adam_step_tail)"""
-        lr, lr_pose = self.learning_rates()
+    def _tail_ok(self, grad_sync=None):
+        """may the optimiser launch carry the pose sums and the next step's prologue (fused_tail)?  Single GPU and the reference's
+        defaults.  (The operand image it updates was packed for the current parameters by the step's own prologue -- or by the
+        previous step's optimiser launch: its structural zeros are never rewritten.)"""
+        return (self.fused_tail and grad_sync is None and self.world_size == 1 and self.optimize_poses and not self.eikonal
+                and self.ff == 0 and float(self.cfg.get('pose_reg_weight', 0)) == 0)
+
+    def adam_step_tail(self, dyn=False):
+        """nof_pose_reduce_bwd + Adam over everything + nof_mlp_pack_pose for the next step (+ nof_step_state_advance in a captured
+        step), as ONE launch (nof_adam_step_tail / nof_adam_step_tail_dyn)"""
         t = lib.NofAdamTail(C.addressof(self.desc), self.packed.data_ptr(), self.n_table, self.n_mlp, self.n_basic, self.F,
                             self.max_trans, self.max_rot, self.c2w.data_ptr(), self.tf.data_ptr(), self.pose_slots.data_ptr())
-        self._call('nof_adam_step_tail', self.params, self.grads, self.exp_avg, self.exp_avg_sq, self.n_total, self.n_basic,
-                   C.c_float(lr), C.c_float(lr_pose), C.c_float(0.9), C.c_float(0.999), C.c_float(1e-15), self.adam_steps + 1,
-                   self.flags, C.byref(t), tag='nof_adam_step')
+        if dyn:
+            cfg = self.cfg
+            self._call('nof_adam_step_tail_dyn', self.params, self.grads, self.exp_avg, self.exp_avg_sq, self.n_total, self.n_basic,
+                       self._state, C.c_float(cfg['lrate']), C.c_float(cfg['lrate_pose']), C.c_float(cfg['decay_rate']),
+                       int(cfg['n_step']) + 1, C.c_float(0.9), C.c_float(0.999), C.c_float(1e-15), self.flags, C.byref(t),
+                       self._tail_done, tag='nof_adam_step')
+        else:
+            lr, lr_pose = self.learning_rates()
+            self._call('nof_adam_step_tail', self.params, self.grads, self.exp_avg, self.exp_avg_sq, self.n_total, self.n_basic,
+                       C.c_float(lr), C.c_float(lr_pose), C.c_float(0.9), C.c_float(0.999), C.c_float(1e-15), self.adam_steps + 1,
+                       self.flags, C.byref(t), tag='nof_adam_step')
         self.global_step += 1
         self.adam_steps += 1
         self._packed_step = self._tail_step = self.global_step
@@ -844,6 +865,11 @@ class GraphedStep:
         field._buffers(R, field.cfg['N_samples'] + field.cfg['N_samples_around_depth'])
         field._side_stream()
         field.sync_step_state()
+        # a captured step whose optimiser launch leaves the NEXT step's operand image and pose table (nof_adam_step_tail_dyn) holds
+        # no packing launch: the first replay starts from what is built here
+        field.pack_weights(force=True)
+        field.update_poses()
+        field._tail_step = field.global_step
         step0, adam0 = field.global_step, field.adam_steps
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
@@ -853,8 +879,9 @@ class GraphedStep:
             with torch.cuda.graph(self.graph, stream=s):
                 field.train_step(pool, self.ids, R, seed=seed, dyn=True)
         torch.cuda.current_stream().wait_stream(s)
+        self.has_tail = field._tail_step == field.global_step and field.global_step == step0 + 1   # (set by adam_step_tail)
         field.global_step, field.adam_steps = step0, adam0       # capturing executes nothing: only the host-side counters moved
-        field._packed_step = None
+        field._packed_step = field._tail_step = step0 if self.has_tail else None
         self.trunc = field.truncation()
         self.grad_scale = float(field.desc.grad_scale)           # baked into the captured launches
 
@@ -866,8 +893,13 @@ class GraphedStep:
                 and float(f.desc.grad_scale) == self.grad_scale)   # (a loss-scale back-off since the capture: capture again)
 
     def __call__(self, ids):
+        f = self.field
+        if self.has_tail and not (f._packed_step == f._tail_step == f.global_step):
+            f.pack_weights(force=True)         # (the parameters were replaced since the last replay: the graph itself packs nothing)
+            f.update_poses()
         self.ids.copy_(ids)
         self.graph.replay()
-        self.field.global_step += 1
-        self.field.adam_steps += 1
-        self.field._packed_step = None         # the fragment image inside the graph belongs to the parameters before this step
+        f.global_step += 1
+        f.adam_steps += 1
+        # without the tail: the fragment image inside the graph belongs to the parameters before this step
+        f._packed_step = f._tail_step = f.global_step if self.has_tail else None

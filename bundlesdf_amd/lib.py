@@ -117,6 +117,7 @@ _SIGNATURES = {
     'nof_small_regs': ([_P, _P, _I32, _F, _F, _P], C.c_int),
     'nof_adam_step': ([_P, _P, _P, _P, _I64, _I64, _F, _F, _F, _F, _F, _I32, _P, _P], C.c_int),
     'nof_adam_step_tail': ([_P, _P, _P, _P, _I64, _I64, _F, _F, _F, _F, _F, _I32, _P, C.POINTER(NofAdamTail), _P], C.c_int),
+    'nof_adam_step_tail_dyn': ([_P, _P, _P, _P, _I64, _I64, _P, _F, _F, _F, _I32, _F, _F, _F, _P, C.POINTER(NofAdamTail), _P, _P], C.c_int),
     'nof_grad_check': ([_P, _I64, _P, _P], C.c_int),
     'nof_render_depth': ([_P, _P, _I64, _I32, _F, _P, _P], C.c_int),
     'nof_step_state_advance': ([_P, _F, _F, _F, _I32, _F, _F, _I32, _P], C.c_int),

@@ -509,6 +509,13 @@ typedef struct {
 int nof_adam_step_tail(float* params, float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, int64_t n_basic,
                        float lr, float lr_pose, float beta1, float beta2, float eps, int32_t step, const int32_t* skip_flags,
                        const NofAdamTail* tail, void* stream);
+/* ... with the step's scalars read from the device state (a captured, replayable step: nof_adam_step_dyn's arguments), and
+ * nof_step_state_advance(set_step = -1) inside as well: the last workgroup to finish advances *d_state.  d_done:
+ * NOF_ADAM_TAIL_DONE_WORDS device uint32, zero before the launch and zero again after it. */
+#define NOF_ADAM_TAIL_DONE_WORDS 1040       /* 65 counters, one per 64-byte line */
+int nof_adam_step_tail_dyn(float* params, float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, int64_t n_basic,
+                           NofStepState* d_state, float lrate, float lrate_pose, float decay_rate, int32_t n_iters, float beta1,
+                           float beta2, float eps, const int32_t* skip_flags, const NofAdamTail* tail, uint32_t* d_done, void* stream);
 /* flags[0] |= 4 when any of grad[0, n) is not finite (the check of nof_reduce_partials, for a gradient that was summed over the
  * data-parallel ranks afterwards: every rank must skip the same step). */
 int nof_grad_check(const float* grad, int64_t n, int32_t* flags, void* stream);

@@ -358,6 +358,8 @@ def test_graphed_step_equals_eager_steps(nof, fork):
     twin.params.copy_(fld.params)
     twin.occ_bits, twin.level, twin.max_level, twin.max_hits = fld.occ_bits, fld.level, fld.max_level, fld.max_hits
     twin.graph_fork = fork
+    if fork:
+        twin.one_stream_backward = False                 # (round 6's default is one chain with merged launches, captured or not)
     pool = U.dev(batch)
     R = batch.shape[0]
     gen = torch.Generator(device='cuda').manual_seed(0)
@@ -367,6 +369,7 @@ def test_graphed_step_equals_eager_steps(nof, fork):
         fld.train_step(pool, id_list[i], R, seed=11)
         twin.train_step(pool, id_list[i], R, seed=11)
     g = GraphedStep(twin, pool, R, seed=11)
+    assert g.has_tail == (not fork)                      # the one-chain capture carries nof_adam_step_tail_dyn: no packing launch inside
     assert twin.global_step == 3
     z_seen = []
     for i in range(3, N):
