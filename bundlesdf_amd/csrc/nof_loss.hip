@@ -276,24 +276,43 @@ __global__ __launch_bounds__(256) void k_tile_flags(const float4* __restrict__ d
   if (lane == 32 && b < B) tile_flags[t0 + 1] = (uint32_t)(nz >> 32) != 0u ? 1 : 0;
 }
 
-// flags -> ascending list of the flagged tiles + their number.  ONE workgroup (the list of a 786 432-sample batch is 24 576
-// flags): thread t owns a contiguous chunk, counts, the counts are scanned through LDS, every WAVE writes its 64 chunks' tiles.
-// Deterministic (no atomics): the order of the list fixes the order in which the backward kernels sum their partial results.
+// flags -> ascending list of the flagged tiles + their number.  Thread t owns a contiguous chunk, counts, the counts are scanned
+// through LDS, every WAVE writes its 64 chunks' tiles.  Deterministic (no atomics): the order of the list fixes the order in which
+// the backward kernels sum their partial results.
+// Round 6: `nchunks` workgroups share the flags (one took 36 us for the 98 304 tiles of a cfg5 batch and 10 for cfg2's 24 576,
+// with the step waiting for it): workgroup `chunk` owns the words [chunk * W, (chunk + 1) * W), counts the listed tiles IN FRONT of
+// its range by itself (at most ~100 KB of flags out of L2, 16 bytes per load: no hand-over between workgroups, no ordering among
+// them) and places its own behind that count; the last one writes the head.  The same list as one workgroup's.
 __device__ void tile_scan(const uint8_t* __restrict__ flags, uint32_t ntiles, uint32_t* __restrict__ head,
-                          uint32_t* __restrict__ tiles, int all) {
-  __shared__ uint32_t wsum[16];
+                          uint32_t* __restrict__ tiles, int all, uint32_t chunk = 0u, uint32_t nchunks = 1u) {
+  __shared__ uint32_t wsum[16], psum[16];
   const uint32_t nt = blockDim.x, t = threadIdx.x;
   // four flags per 32-bit word (the flag array is 16-byte aligned and padded to 16 bytes); a thread owns `wper` consecutive words
   // and requests them eight at a time, so that their latencies overlap (a byte-by-byte loop waited ~0.5 us per flag: 15 us)
   const uint32_t* __restrict__ fw = reinterpret_cast<const uint32_t*>(flags);
-  const uint32_t nwords = (ntiles + 3) / 4;
-  const uint32_t wper = (nwords + nt - 1) / nt;
-  const uint32_t lo = t * wper < nwords ? t * wper : nwords, hi = lo + wper < nwords ? lo + wper : nwords;
+  const uint32_t nwords_all = (ntiles + 3) / 4;
+  const uint32_t W = ((nwords_all + nchunks - 1) / nchunks + 3u) & ~3u;            // words per workgroup (whole 16-byte groups)
+  const uint32_t w0 = chunk * W < nwords_all ? chunk * W : nwords_all;
+  const uint32_t nwords = w0 + W < nwords_all ? w0 + W : nwords_all;               // this workgroup's words: [w0, nwords)
+  const uint32_t wper = (nwords - w0 + nt - 1) / nt;
+  const uint32_t lo = w0 + t * wper < nwords ? w0 + t * wper : nwords, hi = lo + wper < nwords ? lo + wper : nwords;
   auto word = [&](uint32_t wi) -> uint32_t {                           // 0x01 in every byte whose tile is listed
     const uint32_t left = ntiles - 4u * wi;                            // flags that exist in this word (the last one may be partial)
     const uint32_t m = left >= 4u ? 0x01010101u : ((1u << (8u * left)) - 1u) & 0x01010101u;
     return (all ? 0x01010101u : fw[wi]) & m;
   };
+  // listed tiles in front of this workgroup's range (whole words, all of them complete: w0 < nwords_all is a multiple of 4 words)
+  uint32_t pre = 0;
+  if (all) {
+    pre = t == 0 ? (4u * w0 < ntiles ? 4u * w0 : ntiles) : 0u;
+  } else {
+    const uint4* __restrict__ f4 = reinterpret_cast<const uint4*>(flags);
+    for (uint32_t q = t; q < w0 / 4u; q += nt) {
+      const uint4 v = f4[q];
+      pre += __popc(v.x & 0x01010101u) + __popc(v.y & 0x01010101u) + __popc(v.z & 0x01010101u) + __popc(v.w & 0x01010101u);
+    }
+    for (uint32_t wi = (w0 & ~3u) + t; wi < w0; wi += nt) pre += __popc(word(wi));       // (an empty last range behind a partial group)
+  }
   uint32_t cnt = 0;
   for (uint32_t base = lo; base < hi; base += 8) {
     uint32_t w[8];
@@ -310,19 +329,24 @@ __device__ void tile_scan(const uint8_t* __restrict__ flags, uint32_t ntiles, ui
     const uint32_t v = __shfl_up(inc, o, 64);
     if (lane >= o) inc += v;
   }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) pre += __shfl_xor(pre, o, 64);
   if (lane == 63) wsum[t >> 6] = inc;
+  if (lane == 0) psum[t >> 6] = pre;
   __syncthreads();
   uint32_t before = 0, total = 0;
   for (uint32_t w = 0; w < (nt + 63) / 64; ++w) {
     if (w < (t >> 6)) before += wsum[w];
     total += wsum[w];
+    before += psum[w];
+    total += psum[w];
   }
   // emission, wave-cooperative (round 6): the wave's 64 threads own one contiguous range of flags; it walks that range 64 flags at a
   // time, one flag per lane, and a ballot's prefix count places the listed ones -- one coalesced store instruction per 64 tiles.
   // (Rounds 3-5: every thread wrote its own chunk's tiles one store after the other, ~55 per thread at cfg5: 51 us for 98 304 tiles.)
   {
     const uint32_t wv = t >> 6;
-    const uint32_t wlo = wv * 64u * wper < nwords ? wv * 64u * wper : nwords;                 // the wave's words [wlo, whi)
+    const uint32_t wlo = w0 + wv * 64u * wper < nwords ? w0 + wv * 64u * wper : nwords;       // the wave's words [wlo, whi)
     const uint32_t whi = wlo + 64u * wper < nwords ? wlo + 64u * wper : nwords;
     // tiles listed before this wave's range = `before`; (inc - cnt of lane 0 is 0)
     uint32_t at = before;
@@ -336,8 +360,10 @@ __device__ void tile_scan(const uint8_t* __restrict__ flags, uint32_t ntiles, ui
       at += (uint32_t)__popcll(m);
     }
   }
-  if (t == 0) { head[0] = total; head[1] = ntiles; head[2] = 0; head[3] = 0; }
-  if (t == 0 && (total & 1u)) tiles[total] = ntiles;                   // an odd list ends in a tile that does not exist (pairs of tiles per wave)
+  if (chunk + 1u == nchunks) {                                         // (the last workgroup's `total` is the list's)
+    if (t == 0) { head[0] = total; head[1] = ntiles; head[2] = 0; head[3] = 0; }
+    if (t == 0 && (total & 1u)) tiles[total] = ntiles;                 // an odd list ends in a tile that does not exist (pairs of tiles per wave)
+  }
 }
 
 __global__ __launch_bounds__(1024) void k_tile_scan(uint8_t* __restrict__ flags, uint32_t ntiles, uint32_t* __restrict__ head,
@@ -353,12 +379,13 @@ extern "C" int64_t nof_tile_list_bytes(int64_t B) {
   return (int64_t)(nof_tile_list_words(nt) * 4 + (((size_t)nt + 15) & ~(size_t)15));
 }
 
-// workgroup 0: the per-ray loss rows -> loss_out; workgroup 1 (when a work list is asked for): the tile scan
+// workgroup 0: the per-ray loss rows -> loss_out; the others (when a work list is asked for): the tile scan, a share of the flags each
 __global__ __launch_bounds__(1024) void k_loss_reduce(const float* __restrict__ rows, int64_t R, float* __restrict__ loss_out,
                                                        const uint8_t* __restrict__ tile_flags, uint32_t ntiles,
-                                                       uint32_t* __restrict__ head, uint32_t* __restrict__ tiles, int overwrite) {
-  if (blockIdx.x == 1 || loss_out == nullptr) {
-    tile_scan(tile_flags, ntiles, head, tiles, 0);
+                                                       uint32_t* __restrict__ head, uint32_t* __restrict__ tiles, int overwrite,
+                                                       uint32_t nchunks) {
+  if (blockIdx.x >= 1 || loss_out == nullptr) {
+    tile_scan(tile_flags, ntiles, head, tiles, 0, blockIdx.x - (loss_out != nullptr ? 1u : 0u), nchunks);
     return;
   }
   __shared__ float sm[16][8];
@@ -428,8 +455,10 @@ static int composite_loss(const NofLossCfg* cfg, const float* raw, const float* 
     NOF_LAUNCH_OK();
   }
   if (loss_out || flags) {
-    hipLaunchKernelGGL(k_loss_reduce, dim3(loss_out && flags ? 2 : 1), dim3(1024), 0, (hipStream_t)stream, loss_rows, R, loss_out,
-                       flags, nt, head, tiles, overwrite);
+    // (the scan: one workgroup per ~6000 tiles -- 4 at cfg2, 16 at cfg5)
+    const uint32_t nchunks = flags ? (nt / 6144u < 1u ? 1u : (nt / 6144u > 32u ? 32u : nt / 6144u)) : 0u;
+    hipLaunchKernelGGL(k_loss_reduce, dim3((loss_out ? 1u : 0u) + nchunks), dim3(1024), 0, (hipStream_t)stream, loss_rows, R, loss_out,
+                       flags, nt, head, tiles, overwrite, nchunks);
     NOF_LAUNCH_OK();
   }
   return 0;

@@ -187,8 +187,9 @@ class NeuralObjectField:
 
     def kernel_times_ms(self, stat='mean', skip=0):
         """launch duration per timed call (ms; `stat`: 'mean' or 'median' over the recorded launches, the first `skip` of each
-        left out: a kernel's first launch includes loading its code object); the events are recorded on the stream the launch
-        goes to."""
+        left out: a kernel's first launch includes loading its code object -- a call that was made no more than `skip` times is
+        not a per-step launch and is left out altogether, e.g. the packing launch of a run's first step when every later step's
+        operand image comes from the optimiser launch before it); the events are recorded on the stream the launch goes to."""
         if not self.profile:
             return {}
         torch.cuda.synchronize()
@@ -196,7 +197,7 @@ class NeuralObjectField:
         out = {}
         for k, v in self.profile.items():
             t = [a.elapsed_time(b) for a, b in v]
-            t = t[skip:] if len(t) > skip else t
+            t = t[skip:] if skip else t
             if t:
                 out[k] = float(f(t))
         return out

@@ -103,6 +103,48 @@ def test_loss_kernel_emits_the_list_of_its_own_draw(nof, S):
     assert torch.equal(draw, draw2) and torch.equal(loss, loss2)
 
 
+@pytest.mark.parametrize("R,S", [(2100, 192), (4099, 192), (16384, 192), (20001, 40), (9000, 96)])
+def test_loss_kernel_list_over_several_workgroups(nof, R, S):
+    """round 6: the scan of the flags is shared by one workgroup per ~6000 tiles (2 / 4 / 16 / 4 / 4 here; each counts the listed
+    tiles in front of its range by itself): the list is the ascending list of the tiles with a non-zero row of the dL/draw the
+    call wrote, the head holds their number, an odd list ends in the sentinel -- sizes with a partial last word and a partial last
+    16-byte group, fused flags (S % 32 == 0) and the separate flag pass (S = 40)."""
+    cfg, occ, c2w, batch0 = _scene(nof, R=300)
+    from bundlesdf_amd import lib
+    batch = np.ascontiguousarray(np.tile(batch0, ((R + batch0.shape[0] - 1) // batch0.shape[0], 1))[:R])
+    B = R * S
+    rng = np.random.default_rng(R)
+    raw = rng.normal(size=(B, 4)).astype(np.float32)
+    z = np.sort(rng.uniform(2.0, 3.6, size=(R, S)).astype(np.float32), axis=1)
+    valid = (rng.random(B) > 0.1).astype(np.uint8)
+    sc = cfg['sc_factor']
+    lc = lib.NofLossCfg(cfg['trunc'] * sc, cfg['neg_trunc_ratio'], cfg['sdf_lambda'], cfg['near'] * sc, cfg['far'] * sc,
+                        cfg['rgb_weight'], cfg['fs_weight'], cfg['trunc_weight'], cfg['empty_weight'], cfg['fs_sdf'], 0.0,
+                        cfg['first_frame_weight'], 1.0)
+    rgb, draw, rows = torch.empty(R, 3, device='cuda'), torch.empty(B, 4, device='cuda'), torch.empty(R, 8, device='cuda')
+    loss = torch.zeros(8, device='cuda')
+    tl = torch.full((int(nof.load().nof_tile_list_bytes(B)),), 0xCD, dtype=torch.uint8, device='cuda')
+    nof.call('nof_composite_loss_fwd_bwd', C.byref(lc), U.dev(raw), U.dev(z), U.dev(valid), U.dev(batch), R, S, rgb, None, draw,
+             rows, loss, tl)
+    torch.cuda.synchronize()
+    nt = (B + 31) // 32
+    assert nt // 6144 >= 2
+    pad = np.zeros((nt * 32, 4), np.float32)
+    pad[:B] = cpu(draw)
+    want = (pad.reshape(nt, 128) != 0).any(1)
+    assert 0.05 < want.mean() < 0.95
+    n, ntl, tiles, flags = _parse(nof, tl, B)
+    assert ntl == nt and n == int(want.sum())
+    assert np.array_equal(tiles[:n], np.nonzero(want)[0]) and np.array_equal(flags.astype(bool), want)
+    if n & 1:
+        assert tiles[n] == nt
+    # the loss terms: the row sum of the same call without a list
+    loss2 = torch.zeros(8, device='cuda')
+    nof.call('nof_composite_loss', C.byref(lc), U.dev(raw), U.dev(z), U.dev(valid), U.dev(batch), R, S, rgb, None, draw, rows, loss2)
+    torch.cuda.synchronize()
+    assert torch.equal(loss, loss2)
+
+
 @pytest.mark.parametrize("ns,nc,precision", [(3, 2, 3), (2, 3, 2), (2, 3, 0), (3, 3, 1)])
 @pytest.mark.parametrize("R,S", [(40, 192), (21, 48)])
 def test_mlp_backward_over_the_list_equals_whole_batch(nof, ns, nc, precision, R, S):
