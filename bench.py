@@ -299,6 +299,8 @@ def main():
                     help='the backward tail as one chain with the scatter and dL/dx in one launch (field.one_stream_backward)')
     ap.add_argument('--fused-tail', type=int, default=None, choices=[0, 1],
                     help='the optimiser launch with the pose sums and the next step\'s operand image + pose table inside (field.fused_tail)')
+    ap.add_argument('--mlp-bwd-one-launch', type=int, default=None, choices=[0, 1],
+                    help='the 16-bit MLP backward\'s two halves as one launch (field.mlp_bwd_one_launch)')
     ap.add_argument('--scatter-wgs', type=int, default=0, help='persistent workgroups per CU of the table scatter (0 = library default)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--with-cpu-baseline', action='store_true', help='overrides --no-cpu-baseline (the cfg1-shapes sub-record)')
@@ -339,6 +341,8 @@ def main():
         fld.one_stream_backward = bool(args.one_stream)
     if args.fused_tail is not None:
         fld.fused_tail = bool(args.fused_tail)
+    if args.mlp_bwd_one_launch is not None:
+        fld.mlp_bwd_one_launch = bool(args.mlp_bwd_one_launch)
     if args.unfused:
         fld.fused_forward = False
         fld.fused_forward_wide = False
@@ -573,6 +577,7 @@ def main():
         fld_r.fused_forward_wide = fld.fused_forward_wide
         fld_r.one_stream_backward = fld.one_stream_backward
         fld_r.fused_tail = fld.fused_tail
+        fld_r.mlp_bwd_one_launch = fld.mlp_bwd_one_launch
         barrier()
         t0 = time.perf_counter()
         for _ in range(args.round_steps):

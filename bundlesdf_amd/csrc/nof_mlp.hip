@@ -821,14 +821,14 @@ __global__ __launch_bounds__(256) void k_mlp_bwd(NofMlpDesc d, const char* __res
 template <int NC> struct ColorWaves { static constexpr int value = NC >= 3 ? 8 : NOF_BWD_WAVES_C2; };
 template <int NS> struct SigmaWaves { static constexpr int value = NOF_BWD_WAVES_S; };
 
+// (the body of k_mlp_bwd_color as a device function: the stand-alone kernel and the merged launch k_mlp_bwd_both call it)
 template <class P, int NS, int NC>
-__global__ __launch_bounds__(64 * ColorWaves<NC>::value, 2) void k_mlp_bwd_color(NofMlpDesc d, const char* __restrict__ image,
-                                                           const typename P::elem* __restrict__ sig,
-                                                           const float* __restrict__ view, int S,
-                                                           const float4* __restrict__ draw, typename P::elem* __restrict__ dsig,
-                                                           float* __restrict__ dview, float* __restrict__ partials, int64_t B,
-                                                           const void* __restrict__ tile_list) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
+__device__ __forceinline__ void mlp_bwd_color_body(const NofMlpDesc& d, const char* __restrict__ image,
+                                                   const typename P::elem* __restrict__ sig,
+                                                   const float* __restrict__ view, int S,
+                                                   const float4* __restrict__ draw, typename P::elem* dsig,
+                                                   float* __restrict__ dview, float* __restrict__ partials, int64_t B,
+                                                   const void* __restrict__ tile_list, char* smem) {
   typedef Shp<NS, NC> SH;
   constexpr int NL = NS + NC;
   constexpr int KR = P::KR, NSTEP = 16 / KR;
@@ -1032,13 +1032,24 @@ __global__ __launch_bounds__(64 * ColorWaves<NC>::value, 2) void k_mlp_bwd_color
 }
 
 template <class P, int NS, int NC>
-__global__ __launch_bounds__(64 * SigmaWaves<NS>::value, 2) void k_mlp_bwd_sigma(NofMlpDesc d, const char* __restrict__ image,
-                                                           const float2* __restrict__ feat, int L,
-                                                           const typename P::elem* __restrict__ dsig, float2* __restrict__ dfeat,
-                                                           float* __restrict__ partials, int64_t B,
-                                                           const void* __restrict__ tile_list,
-                                                           const typename P::elem* __restrict__ featq) {
+__global__ __launch_bounds__(64 * ColorWaves<NC>::value, 2) void k_mlp_bwd_color(NofMlpDesc d, const char* __restrict__ image,
+                                                           const typename P::elem* __restrict__ sig,
+                                                           const float* __restrict__ view, int S,
+                                                           const float4* __restrict__ draw, typename P::elem* __restrict__ dsig,
+                                                           float* __restrict__ dview, float* __restrict__ partials, int64_t B,
+                                                           const void* __restrict__ tile_list) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  mlp_bwd_color_body<P, NS, NC>(d, image, sig, view, S, draw, dsig, dview, partials, B, tile_list, smem);
+}
+
+// (the body of k_mlp_bwd_sigma as a device function, like the colour half)
+template <class P, int NS, int NC>
+__device__ __forceinline__ void mlp_bwd_sigma_body(const NofMlpDesc& d, const char* __restrict__ image,
+                                                   const float2* __restrict__ feat, int L,
+                                                   const typename P::elem* dsig, float2* __restrict__ dfeat,
+                                                   float* __restrict__ partials, int64_t B,
+                                                   const void* __restrict__ tile_list,
+                                                   const typename P::elem* __restrict__ featq, char* smem) {
   typedef Shp<NS, NC> SH;
   constexpr int NL = NS + NC;
   constexpr int KR = P::KR, NSTEP = 16 / KR;
@@ -1187,6 +1198,38 @@ __global__ __launch_bounds__(64 * SigmaWaves<NS>::value, 2) void k_mlp_bwd_sigma
 #undef SFW
 #undef SBW
 #undef SBIAS
+}
+
+template <class P, int NS, int NC>
+__global__ __launch_bounds__(64 * SigmaWaves<NS>::value, 2) void k_mlp_bwd_sigma(NofMlpDesc d, const char* __restrict__ image,
+                                                           const float2* __restrict__ feat, int L,
+                                                           const typename P::elem* __restrict__ dsig, float2* __restrict__ dfeat,
+                                                           float* __restrict__ partials, int64_t B,
+                                                           const void* __restrict__ tile_list,
+                                                           const typename P::elem* __restrict__ featq) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  mlp_bwd_sigma_body<P, NS, NC>(d, image, feat, L, dsig, dfeat, partials, B, tile_list, featq, smem);
+}
+
+// Both halves in ONE launch (round 6; shapes whose halves use the same number of waves per workgroup): a workgroup walks its share
+// of the work list through the colour net, then -- new fragments in the same LDS -- the SAME tiles through the sigma net.  Every wave
+// reads back the dsig rows it wrote itself, so no workgroup waits for another; the second half's fragments load while other
+// workgroups still finish their first half, and the step loses a launch, a ramp and a drain.  Same code as the two kernels: same bits.
+template <class P, int NS, int NC>
+__global__ __launch_bounds__(64 * SigmaWaves<NS>::value, 2) void k_mlp_bwd_both(NofMlpDesc d, const char* __restrict__ image,
+                                                           const typename P::elem* __restrict__ sig, const float* __restrict__ view,
+                                                           int S, const float4* __restrict__ draw, typename P::elem* dsig,
+                                                           float* __restrict__ dview, float* __restrict__ partials, int64_t B,
+                                                           const void* __restrict__ tile_list, const float2* __restrict__ feat, int L,
+                                                           float2* __restrict__ dfeat, const typename P::elem* __restrict__ featq) {
+  static_assert(ColorWaves<NC>::value == SigmaWaves<NS>::value, "the halves must deal the work list to the same waves");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  mlp_bwd_color_body<P, NS, NC>(d, image, sig, view, S, draw, dsig, dview, partials, B, tile_list, smem);
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");               // (this workgroup's dsig rows, before it reads them back)
+  __syncthreads();                                                      // (and nobody still reads the colour fragments)
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  asm volatile("" ::: "memory");
+  mlp_bwd_sigma_body<P, NS, NC>(d, image, feat, L, dsig, dfeat, partials, B, tile_list, featq, smem);
 }
 
 // =====================================================================================================
@@ -1576,7 +1619,7 @@ extern "C" int nof_mlp_bwd(const NofMlpDesc* d, const void* packed, const float*
 // dfeat (and the dsigma workspace) of unlisted tiles is NOT written -- the consumers of the same step take the same list.
 static int mlp_bwd_tiles(const NofMlpDesc* d, const void* packed, const float* feat, const void* featq, int32_t L, const float* view,
                          int32_t S, const float* draw, const void* sigma_out, void* dsigma_ws, float* dfeat, float* dview,
-                         float* partials, const void* tile_list, int64_t B, void* stream);
+                         float* partials, const void* tile_list, int64_t B, void* stream, bool one_launch = true);
 extern "C" int nof_mlp_bwd_tiles(const NofMlpDesc* d, const void* packed, const float* feat, int32_t L, const float* view,
                                   int32_t S, const float* draw, const void* sigma_out, void* dsigma_ws, float* dfeat, float* dview,
                                   float* partials, const void* tile_list, int64_t B, void* stream) {
@@ -1591,9 +1634,18 @@ extern "C" int nof_mlp_bwd_featq(const NofMlpDesc* d, const void* packed, const 
   NOF_ARG(featq && d && d->precision != 0 && sigma_out && dsigma_ws);
   return mlp_bwd_tiles(d, packed, nullptr, featq, L, view, S, draw, sigma_out, dsigma_ws, dfeat, dview, partials, tile_list, B, stream);
 }
+// The same as two launches, colour half then sigma half, whatever the shape (nof_mlp_bwd_featq merges them where it can: the A/B
+// and the bit-equality test of the merged launch).
+extern "C" int nof_mlp_bwd_featq_two_launches(const NofMlpDesc* d, const void* packed, const void* featq, int32_t L, const float* view,
+                                               int32_t S, const float* draw, const void* sigma_out, void* dsigma_ws, float* dfeat,
+                                               float* dview, float* partials, const void* tile_list, int64_t B, void* stream) {
+  NOF_ARG(featq && d && d->precision != 0 && sigma_out && dsigma_ws);
+  return mlp_bwd_tiles(d, packed, nullptr, featq, L, view, S, draw, sigma_out, dsigma_ws, dfeat, dview, partials, tile_list, B, stream,
+                       false);
+}
 static int mlp_bwd_tiles(const NofMlpDesc* d, const void* packed, const float* feat, const void* featq, int32_t L, const float* view,
                          int32_t S, const float* draw, const void* sigma_out, void* dsigma_ws, float* dfeat, float* dview,
-                         float* partials, const void* tile_list, int64_t B, void* stream) {
+                         float* partials, const void* tile_list, int64_t B, void* stream, bool one_launch) {
   if (int e = check_narrow(d)) return e;
   NOF_ARG(packed && (feat || featq) && view && draw && dfeat && dview && partials && B >= 0 && S >= 32 && L * 2 == d->in_feat);
   NOF_ARG((int64_t)L * B * 8 < (1ll << 32));                   // level-major arrays are addressed with 32-bit lane offsets
@@ -1610,6 +1662,19 @@ static int mlp_bwd_tiles(const NofMlpDesc* d, const void* packed, const float* f
                          ws * (2 * ns - 1) * 2 * 64 * 16 + ws * (2 * ns) * 64 * 4;
     const unsigned blocks_c = rows * 4 / (unsigned)wc, blocks_s = rows * 4 / (unsigned)ws;
 #define LAUNCH_SPLIT(P, NS_, NC_, dummy)                                                                  \
+  if constexpr (ColorWaves<NC_>::value == SigmaWaves<NS_>::value) {                                       \
+    if (one_launch) {                                                                                     \
+      auto kb = k_mlp_bwd_both<P, NS_, NC_>;                                                              \
+      const size_t shm_b = shm_c > shm_s ? shm_c : shm_s;                                                 \
+      if (int e = set_smem(kb, shm_b)) return e;                                                          \
+      hipLaunchKernelGGL(kb, dim3(blocks_c), dim3(64 * (unsigned)wc), shm_b, (hipStream_t)stream, *d, (const char*)packed, \
+                         (const typename P::elem*)sigma_out, view, (int)S, (const float4*)draw,           \
+                         (typename P::elem*)dsigma_ws, dview, partials, B, tile_list, (const float2*)feat, (int)L, \
+                         (float2*)dfeat, (const typename P::elem*)featq);                                 \
+      NOF_LAUNCH_OK();                                                                                    \
+      return 0;                                                                                           \
+    }                                                                                                     \
+  }                                                                                                       \
   {                                                                                                       \
     auto kc = k_mlp_bwd_color<P, NS_, NC_>;                                                               \
     auto ks = k_mlp_bwd_sigma<P, NS_, NC_>;                                                               \

@@ -131,6 +131,7 @@ class NeuralObjectField:
         # launch also sums the frames' pose gradients in front of its update and leaves the NEXT step's MFMA operand image and pose
         # table behind it (nof_adam_step_tail, round 6) -- two launches and their gaps less per step; False: the three calls
         self.fused_tail = True
+        self.mlp_bwd_one_launch = True   # the 64-wide 16-bit backward's colour and sigma halves as one launch (two colour layers)
         self._tail_step = None       # optimiser step whose operand image AND pose table the last nof_adam_step_tail left
         self._tail_done = torch.zeros(1040, dtype=torch.int32, device=dev)     # nof_adam_step_tail_dyn's counter (zero between launches)
         self._tail_plan = False      # inside a train_step: this step's optimiser launch will be nof_adam_step_tail
@@ -469,7 +470,8 @@ class NeuralObjectField:
                        b['featq'] if fused else None, self.L, b['view'], S, b['draw'],
                        b['wide_ws'], b['dfeat'], b['dview'], b['partials'], tiles, 3, B, tag='nof_mlp_wide_bwd')
         elif self.fused_forward:
-            self._call('nof_mlp_bwd_featq', C.byref(self.desc), self.packed, b['featq'], self.L, b['view'], S, b['draw'], b['sig'],
+            # (both networks' halves in ONE launch where their workgroup shapes agree, round 6; mlp_bwd_one_launch = False: two)
+            self._call('nof_mlp_bwd_featq' if self.mlp_bwd_one_launch else 'nof_mlp_bwd_featq_two_launches', C.byref(self.desc), self.packed, b['featq'], self.L, b['view'], S, b['draw'], b['sig'],
                        b['dsig'], b['dfeat'], b['dview'], b['partials'], tiles, B, tag='nof_mlp_bwd_tiles')
         else:
             self._call('nof_mlp_bwd_tiles', C.byref(self.desc), self.packed, b['feat'], self.L, b['view'], S, b['draw'], b['sig'],

@@ -106,6 +106,7 @@ _SIGNATURES = {
     'nof_mlp_fwd': ([C.POINTER(NofMlpDesc), _P, _P, _I32, _P, _I32, _P, _P, _I64, _P], C.c_int),
     'nof_encode_mlp_fwd': ([C.POINTER(NofHashGrid), C.POINTER(NofMlpDesc), _P, _P, _P, _P, _I32, _P, _P, _P, _I64, _P], C.c_int),
     'nof_mlp_bwd_featq': ([C.POINTER(NofMlpDesc), _P, _P, _I32, _P, _I32, _P, _P, _P, _P, _P, _P, _P, _I64, _P], C.c_int),
+    'nof_mlp_bwd_featq_two_launches': ([C.POINTER(NofMlpDesc), _P, _P, _I32, _P, _I32, _P, _P, _P, _P, _P, _P, _P, _I64, _P], C.c_int),
     'nof_mlp_bwd_blocks': ([], C.c_int),
     'nof_mlp_bwd': ([C.POINTER(NofMlpDesc), _P, _P, _I32, _P, _I32, _P, _P, _P, _P, _P, _P, _I64, _P], C.c_int),
     'nof_reduce_partials': ([_P, _I32, _I32, _P, _P, _P], C.c_int),

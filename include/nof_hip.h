@@ -262,6 +262,12 @@ int nof_encode_mlp_fwd(const NofHashGrid* h_grid, const NofMlpDesc* h_desc, cons
 int nof_mlp_bwd_featq(const NofMlpDesc* h_desc, const void* packed, const void* featq, int32_t L,
                       const float* view, int32_t S, const float* draw, const void* sigma_out, void* dsigma_ws,
                       float* dfeat, float* dview, float* partials, const void* tile_list, int64_t B, void* stream);
+/* The 16-bit backward runs per network, colour then sigma.  Where both halves use the same workgroup shape (two colour layers) they are
+ * ONE launch since round 6 -- a workgroup walks its tiles through the colour net, then the same tiles through the sigma net --;
+ * this entry point keeps them as two launches whatever the shape (same bits: the A/B and the parity test of the merged launch). */
+int nof_mlp_bwd_featq_two_launches(const NofMlpDesc* h_desc, const void* packed, const void* featq, int32_t L,
+                                   const float* view, int32_t S, const float* draw, const void* sigma_out, void* dsigma_ws,
+                                   float* dfeat, float* dview, float* partials, const void* tile_list, int64_t B, void* stream);
 /* out[j] += sum_i partials[i,j].  flags (int32, may be NULL): flags[0] |= 4 when a column sum is not finite -- an overflow inside the
  * 16-bit backward, where the reference's GradScaler skips the step and backs off (nerf_runner.py:756-761): nof_adam_step[_dyn]
  * given the same flags skips the update, the next batch's nof_sample_points turns the mark into the sticky bit 3 (value 8), the

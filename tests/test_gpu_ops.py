@@ -862,6 +862,24 @@ def test_fused_encode_mlp_forward_equals_the_two_launches(nof, ns, nc, ff, L, T,
         torch.cuda.synchronize()
         outs.append((dfeat, partials, dsig))
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[0][2], outs[1][2])
+    # round 6: nof_mlp_bwd_featq runs both networks' halves as ONE launch where their workgroup shapes agree (two colour layers);
+    # nof_mlp_bwd_featq_two_launches keeps them apart: the same bits, over the whole batch and over a work list
+    tl = torch.zeros(int(nof.load().nof_tile_list_bytes(B)), dtype=torch.uint8, device='cuda')
+    nof.call('nof_tile_list_build', draw, B, 0, tl)
+    for lst in (None, tl):
+        res = []
+        for entry in ('nof_mlp_bwd_featq', 'nof_mlp_bwd_featq_two_launches'):
+            dsig = torch.zeros(B, 16, dtype=torch.int16, device='cuda')
+            dfeat = torch.full((L, B, 2), 3.0, device='cuda')
+            dview = torch.zeros(R, 16, device='cuda')
+            partials = torch.full((nblk, desc.n_params), 5.0, device='cuda')
+            nof.call(entry, C.byref(desc), packed, featq, L, d_view, S, draw, sig_a, dsig, dfeat, dview, partials, lst, B)
+            torch.cuda.synchronize()
+            res.append((dfeat, partials, dsig, dview))
+        assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1]) and torch.equal(res[0][2], res[1][2])
+        assert (res[0][3] - res[1][3]).abs().max().item() <= 1e-5 * res[1][3].abs().max().item()      # (atomics: order only)
+        if lst is None:
+            assert torch.equal(res[0][0], outs[1][0])
 
 
 @pytest.mark.parametrize("ns,nc,hidden,ff,L,T,finest", [(4, 4, 128, 0, 16, 19, 512), (2, 3, 128, 2, 16, 14, 256), (4, 4, 64, 0, 16, 20, 512),
