@@ -301,6 +301,8 @@ def main():
                     help='the optimiser launch with the pose sums and the next step\'s operand image + pose table inside (field.fused_tail)')
     ap.add_argument('--mlp-bwd-one-launch', type=int, default=None, choices=[0, 1],
                     help='the 16-bit MLP backward\'s two halves as one launch (field.mlp_bwd_one_launch)')
+    ap.add_argument('--march-ahead', type=int, default=None, choices=[0, 1],
+                    help='the next batch\'s ray marcher inside the optimiser launch (field.march_ahead; measured slower, off by default)')
     ap.add_argument('--scatter-wgs', type=int, default=0, help='persistent workgroups per CU of the table scatter (0 = library default)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--with-cpu-baseline', action='store_true', help='overrides --no-cpu-baseline (the cfg1-shapes sub-record)')
@@ -341,6 +343,8 @@ def main():
         fld.one_stream_backward = bool(args.one_stream)
     if args.fused_tail is not None:
         fld.fused_tail = bool(args.fused_tail)
+    if args.march_ahead is not None:
+        fld.march_ahead = bool(args.march_ahead)
     if args.mlp_bwd_one_launch is not None:
         fld.mlp_bwd_one_launch = bool(args.mlp_bwd_one_launch)
     if args.unfused:

@@ -599,7 +599,12 @@ __global__ __launch_bounds__(256) void k_hash_bwd_agg_dx(NofHashGrid g, LevelLis
                                                           float* __restrict__ dpts, int64_t B, const float2* __restrict__ geik,
                                                           const float* __restrict__ dedn, const uint32_t* __restrict__ tile_list,
                                                           const uint8_t* __restrict__ tile_flags, int trim, uint32_t n_agg,
-                                                          uint32_t period) {
+                                                          uint32_t period, int32_t* __restrict__ batch_flags) {
+  // (NOF_HASH_BWD_NEW_BATCH: the overflow mark of the PREVIOUS step -- bit 2, read by that step's optimiser launch, long done --
+  //  becomes the sticky bit 3 here instead of in the batch's ray marcher; this step's own mark is raised by the launch after this one)
+  if (batch_flags != nullptr && blockIdx.x == gridDim.x - 1u && threadIdx.x == 0) {
+    if (atomicAnd(&batch_flags[0], ~4) & 4) atomicOr(&batch_flags[0], 8);
+  }
   const uint32_t q = blockIdx.x / period, r = blockIdx.x - q * period;
   if (r == 0u && q < n_agg) {                                          // (workgroup-uniform)
     hash_bwd_agg_block<EIK>(g, ll, pts_w, dfeat, grad_table, B, geik, dedn, tile_list, trim, q, n_agg);
@@ -715,7 +720,10 @@ static int hash_bwd_parts(const NofHashGrid* g, const float* pts_w, const float*
   if (int e = check_grid(g)) return e;
   NOF_ARG(pts_w && table && dfeat && grad_table && B >= 0 && level_lo >= 0 && level_lo <= level_hi && level_hi <= g->L);
   NOF_ARG((geik_ == nullptr) == (dedn == nullptr));
-  NOF_ARG(parts >= 0 && parts <= (NOF_HASH_BWD_ALL | NOF_HASH_BWD_MERGE_INPUT) && wgs_per_cu >= 0 && wgs_per_cu <= 16);
+  NOF_ARG(parts >= 0 && parts <= (NOF_HASH_BWD_ALL | NOF_HASH_BWD_MERGE_INPUT | NOF_HASH_BWD_NEW_BATCH) && wgs_per_cu >= 0 && wgs_per_cu <= 16);
+  int32_t* batch_flags = (parts & NOF_HASH_BWD_NEW_BATCH) ? red.flags : nullptr;
+  NOF_ARG(!(parts & NOF_HASH_BWD_NEW_BATCH) || (batch_flags != nullptr && (parts & NOF_HASH_BWD_MERGE_INPUT)));
+  parts &= ~NOF_HASH_BWD_NEW_BATCH;
   NOF_ARG(tile_list == nullptr || geik_ == nullptr);                   // the eikonal term has a gradient at every sample
   const float2* geik = (const float2*)geik_;
   if (B == 0) return 0;
@@ -757,14 +765,16 @@ static int hash_bwd_parts(const NofHashGrid* g, const float* pts_w, const float*
     if (geik != nullptr)
       hipLaunchKernelGGL(k_hash_bwd_agg_dx<true>, dim3((unsigned)total), dim3(256), 0, st, *g, big, pairs, singles, pts_w,
                          (const float2*)table, (const float2*)dfeat, grad_table, dpts, B, geik, dedn, tl, nof_tile_flags(tile_list, B), trim,
-                         (uint32_t)n_agg, (uint32_t)period);
+                         (uint32_t)n_agg, (uint32_t)period, batch_flags);
     else
       hipLaunchKernelGGL(k_hash_bwd_agg_dx<false>, dim3((unsigned)total), dim3(256), 0, st, *g, big, pairs, singles, pts_w,
                          (const float2*)table, (const float2*)dfeat, grad_table, dpts, B, geik, dedn, tl, nof_tile_flags(tile_list, B), trim,
-                         (uint32_t)n_agg, (uint32_t)period);
+                         (uint32_t)n_agg, (uint32_t)period, batch_flags);
     NOF_LAUNCH_OK();
+    batch_flags = nullptr;
     parts &= ~(NOF_HASH_BWD_TABLE_BIG | NOF_HASH_BWD_INPUT);
   }
+  NOF_ARG(batch_flags == nullptr);                                      // (NEW_BATCH rides in the merged launch only)
   if ((parts & NOF_HASH_BWD_TABLE_BIG) && big.n > 0) {
     // persistent waves.  With every sample contributing (6.9 M line requests at cfg2) the kernel is bound by the atomic rate of
     // the memory side: two workgroups per CU saturate it and more only take L2 bandwidth from the kernels beside it

@@ -11,6 +11,7 @@
 // evaluates every interval from the integer cell index (never incrementally), so that a cell's [t_in,t_out]
 // is bit-identical to the brute-force slab test of the oracle.
 #include "nof_common.h"
+#include "nof_adam_tail_dev.h"
 #pragma clang fp contract(off)
 
 #define ZERO_DIR 1e-20f
@@ -601,24 +602,27 @@ __device__ __forceinline__ int trace_wave(int n, const float o[3], const float d
 
 // SAMPLE: followed, in the same wave, by the sampler (k_sample_points' arithmetic through sample_place, the intervals taken from the
 // LDS table instead of being read back): nof_raymarch_sample as ONE launch.
-template <bool SAMPLE>
-__global__ __launch_bounds__(256) void k_raymarch_wave(const float* __restrict__ pool, const int64_t* __restrict__ ids,
-                                                           const float* __restrict__ tf, const float* __restrict__ frame_feat, int ff,
-                                                           int sh_degree, const uint32_t* __restrict__ bits, int n, int64_t R,
-                                                           int max_hits, float* __restrict__ batch, float* __restrict__ rays_o_w,
-                                                           float* __restrict__ viewdirs_w, float* __restrict__ view,
-                                                           float* __restrict__ t_in_out, int32_t* __restrict__ cell_ids,
-                                                           int32_t* __restrict__ n_hits, int32_t* __restrict__ flags, int cells_off,
-                                                           NofSampleCfg cfg, const float* __restrict__ u_occ,
-                                                           const float* __restrict__ u_dep, float* __restrict__ z_vals,
-                                                           float* __restrict__ pts_w, uint8_t* __restrict__ valid) {
-  extern __shared__ uint32_t occ_lds[];
-  if (SAMPLE && blockIdx.x == 0 && threadIdx.x == 0 && flags != nullptr) {   // a new batch starts here: see k_sample_points
+// (the kernel's body as a device function of the workgroup's number: the stand-alone kernel passes blockIdx.x; the optimiser launch of
+//  the step BEFORE carries the same workgroups as one of its roles, nof_adam_step_tail_march.  NEWBATCH: this launch is also where a
+//  batch starts for the overflow mark of the device flags -- not so inside the optimiser launch, whose other workgroups still read it.)
+template <bool SAMPLE, bool NEWBATCH>
+__device__ __forceinline__ void raymarch_wave_block(const float* __restrict__ pool, const int64_t* __restrict__ ids,
+                                                    const float* __restrict__ tf, const float* __restrict__ frame_feat, int ff,
+                                                    int sh_degree, const uint32_t* __restrict__ bits, int n, int64_t R,
+                                                    int max_hits, float* __restrict__ batch, float* __restrict__ rays_o_w,
+                                                    float* __restrict__ viewdirs_w, float* __restrict__ view,
+                                                    float* __restrict__ t_in_out, int32_t* __restrict__ cell_ids,
+                                                    int32_t* __restrict__ n_hits, int32_t* __restrict__ flags, int cells_off,
+                                                    const NofSampleCfg cfg, const float* __restrict__ u_occ,
+                                                    const float* __restrict__ u_dep, float* __restrict__ z_vals,
+                                                    float* __restrict__ pts_w, uint8_t* __restrict__ valid, const uint32_t block_id,
+                                                    uint32_t* occ_lds) {
+  if (SAMPLE && NEWBATCH && block_id == 0 && threadIdx.x == 0 && flags != nullptr) {   // a new batch starts here: see k_sample_points
     if (atomicAnd(&flags[0], ~4) & 4) atomicOr(&flags[0], 8);
   }
   stage_occ(bits, n, occ_lds);                                           // (levels <= 6 only: the bitfield is in LDS)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int64_t r = (int64_t)blockIdx.x * 4 + wave;
+  const int64_t r = (int64_t)block_id * 4 + wave;
   if (r >= R) return;                                                    // (wave-uniform)
   WaveCells* wc = reinterpret_cast<WaveCells*>(reinterpret_cast<char*>(occ_lds) + cells_off) + wave;
   // every lane holds the ray (uniform loads); lanes 0..11 / 0..15 / 0..2 write its rows
@@ -636,21 +640,21 @@ __global__ __launch_bounds__(256) void k_raymarch_wave(const float* __restrict__
     o[i] = T[i * 4 + 3];
     d[i] = (T[i * 4 + 0] * v[0] + T[i * 4 + 1] * v[1]) + T[i * 4 + 2] * v[2];
   }
-  float vw[NOF_VIEW_COLS];
-#pragma unroll
-  for (int k = 0; k < NOF_VIEW_COLS; ++k) vw[k] = 0.0f;
   float sh[16];
   sh_eval(sh_degree, d[0], d[1], d[2], sh);
   const int nsh = sh_degree * sh_degree;
-  for (int k = 0; k < ff; ++k) vw[k] = frame_feat[(int64_t)f * ff + k];
-  for (int k = 0; k < nsh && ff + k < NOF_VIEW_COLS; ++k) vw[ff + k] = sh[k];
   if (lane == 0) {
 #pragma unroll
     for (int k = 0; k < NOF_RAY_COLS; ++k) batch[r * NOF_RAY_COLS + k] = row[k];
 #pragma unroll
     for (int i = 0; i < 3; ++i) { rays_o_w[r * 3 + i] = o[i]; viewdirs_w[r * 3 + i] = d[i]; }
+    // the view row [frame features | SH | 0]: placed by ADDRESS (a register array indexed by ff went to scratch)
+    float* vrow = view + r * NOF_VIEW_COLS;
+    for (int k = 0; k < ff; ++k) vrow[k] = frame_feat[(int64_t)f * ff + k];
 #pragma unroll
-    for (int k = 0; k < NOF_VIEW_COLS; ++k) view[r * NOF_VIEW_COLS + k] = vw[k];
+    for (int k = 0; k < 16; ++k)
+      if (k < nsh && ff + k < NOF_VIEW_COLS) vrow[ff + k] = sh[k];
+    for (int k = ff + nsh; k < NOF_VIEW_COLS; ++k) vrow[k] = 0.0f;
   }
   float* tio = t_in_out + r * max_hits * 2;
   int32_t* cid = cell_ids ? cell_ids + r * max_hits : nullptr;
@@ -691,6 +695,113 @@ __global__ __launch_bounds__(256) void k_raymarch_wave(const float* __restrict__
       sample_place(cfg, r, sidx, S, nh, tot, wc->zin, wc->zout, valid_depth, depth, dx, dy, dz, f, tf, u_occ, u_dep, z_vals, pts_w,
                    valid, flags);
   }
+}
+
+template <bool SAMPLE>
+__global__ __launch_bounds__(256) void k_raymarch_wave(const float* __restrict__ pool, const int64_t* __restrict__ ids,
+                                                           const float* __restrict__ tf, const float* __restrict__ frame_feat, int ff,
+                                                           int sh_degree, const uint32_t* __restrict__ bits, int n, int64_t R,
+                                                           int max_hits, float* __restrict__ batch, float* __restrict__ rays_o_w,
+                                                           float* __restrict__ viewdirs_w, float* __restrict__ view,
+                                                           float* __restrict__ t_in_out, int32_t* __restrict__ cell_ids,
+                                                           int32_t* __restrict__ n_hits, int32_t* __restrict__ flags, int cells_off,
+                                                           NofSampleCfg cfg, const float* __restrict__ u_occ,
+                                                           const float* __restrict__ u_dep, float* __restrict__ z_vals,
+                                                           float* __restrict__ pts_w, uint8_t* __restrict__ valid) {
+  extern __shared__ uint32_t occ_lds[];
+  raymarch_wave_block<SAMPLE, true>(pool, ids, tf, frame_feat, ff, sh_degree, bits, n, R, max_hits, batch, rays_o_w, viewdirs_w, view,
+                                    t_in_out, cell_ids, n_hits, flags, cells_off, cfg, u_occ, u_dep, z_vals, pts_w, valid, blockIdx.x,
+                                    occ_lds);
+}
+
+// =====================================================================================================
+// nof_adam_step_tail_march (round 6): the optimiser launch of step N (nof_adam_step_tail: pose sums, Adam, the next operand image and
+// pose table) with the RAY MARCHER OF STEP N + 1 as one more role.  The marcher is a latency chain per ray (20 us for 4096 rays on a
+// chip that Adam keeps busy with streaming for 37): side by side in one launch they take what the longer one takes.  The only thing
+// the marcher needs from the optimiser is the pose table, a row per frame -- written by the launch's first F workgroups, which are
+// resident before any other.  Each of them publishes its row with a release increment of a device counter (`epoch`, which only ever
+// grows: the host passes the value it reaches when all F rows of THIS launch are out); a marcher workgroup's first thread waits for
+// it -- bounded, a time-out raises flag bit 2 instead of hanging --, and an acquire fence makes the rows visible.
+// MEASURED AND NOT THE DEFAULT (field.march_ahead = False): the merged launch takes 86-88 us where Adam's takes 37 and the marcher's
+// 20 -- with or without the fences and the wait (profiles/r06_ak_march_x.txt) --: under Adam's streaming the marcher's dependent
+// loads take four times as long, the same finding as round 3's side-stream prologue.  Kept as an option with its tests.
+// =====================================================================================================
+static size_t occ_lds_bytes(int level);
+struct MarchArgs {
+  const float* pool; const int64_t* ids; const uint32_t* bits; int n, sh_degree, max_hits, cells_off; int64_t R;
+  float* batch; float* rays_o_w; float* viewdirs_w; float* view; float* t_in_out; int32_t* n_hits; int32_t* flags;
+  NofSampleCfg cfg; float* z_vals; float* pts_w; uint8_t* valid;
+};
+
+template <class P>
+__global__ __launch_bounds__(256) void k_adam_tail_march(NofMlpDesc d, float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
+                                                          float* __restrict__ v, AdamK k, const int32_t* __restrict__ skip_flags,
+                                                          TailArgs a, MarchArgs q, uint32_t n_march, uint32_t* __restrict__ epoch,
+                                                          uint32_t target) {
+  extern __shared__ uint32_t occ_lds[];
+  const uint32_t F = (uint32_t)a.F, nb = gridDim.x - n_march;
+  if (blockIdx.x < F) {                                                // (workgroup-uniform)
+    adam_tail_roles<P>(d, p, g, m, v, k, skip_flags, a, blockIdx.x, nb);
+    if (threadIdx.x == 0)                                              // (the thread that wrote the frame's row)
+      __hip_atomic_fetch_add(epoch, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    return;
+  }
+  if (blockIdx.x < F + n_march) {
+    if (threadIdx.x == 0) {
+      int spins = 0;
+      while ((int32_t)(__hip_atomic_load(epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
+        __builtin_amdgcn_s_sleep(8);
+        if (++spins > (1 << 20)) {                                     // (~a second: never in a healthy launch)
+          if (q.flags) atomicOr(&q.flags[0], 2);
+          break;
+        }
+      }
+    }
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    raymarch_wave_block<true, false>(q.pool, q.ids, a.tf, nullptr, 0, q.sh_degree, q.bits, q.n, q.R, q.max_hits, q.batch, q.rays_o_w,
+                                     q.viewdirs_w, q.view, q.t_in_out, nullptr, q.n_hits, q.flags, q.cells_off, q.cfg, nullptr, nullptr,
+                                     q.z_vals, q.pts_w, q.valid, blockIdx.x - F, occ_lds);
+    return;
+  }
+  adam_tail_roles<P>(d, p, g, m, v, k, skip_flags, a, blockIdx.x - n_march, nb);
+}
+
+extern "C" int nof_adam_step_tail_march(float* params, float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, int64_t n_basic,
+                                         float lr, float lr_pose, float beta1, float beta2, float eps, int32_t step,
+                                         const int32_t* skip_flags, const NofAdamTail* t, const NofMarchNext* nx, uint32_t* d_epoch,
+                                         uint32_t epoch_target, void* stream) {
+  TailArgs a;
+  dim3 grid;
+  NOF_ARG(step >= 1 && nx && d_epoch);
+  if (int e = adam_tail_check(params, grads, exp_avg, exp_avg_sq, n, n_basic, t, &a, &grid)) return e;
+  const NofSampleCfg* cfg = nx->cfg;
+  // the next batch's ray marcher as nof_raymarch_sample would launch it in its one-launch form (and only that form)
+  NOF_ARG(cfg && cfg->marcher == NOF_MARCHER_WAVE && cfg->d_step == nullptr && nx->level >= 0 && nx->level <= 6 &&
+          nx->max_hits >= 1 && nx->max_hits <= NOF_TW_SLOTS && nx->R >= 1 && nx->sh_degree >= 1 && nx->sh_degree <= 4 &&
+          nx->sh_degree * nx->sh_degree <= NOF_VIEW_COLS);
+  NOF_ARG(nx->pool && nx->occ_bits && nx->batch && nx->rays_o_w && nx->viewdirs_w && nx->view && nx->t_in_out && nx->n_hits &&
+          nx->z_vals && nx->pts_w && nx->valid);
+  NOF_ARG(cfg->n_samples >= 2 && cfg->n_around >= 0 && cfg->n_around != 1 && cfg->n_samples + cfg->n_around <= 1024);
+  const NofMlpDesc& d = *t->desc;
+  const double bc1 = 1.0 - pow((double)beta1, (double)step);
+  const double bc2 = 1.0 - pow((double)beta2, (double)step);
+  const AdamK k{(float)(lr / bc1), (float)(lr_pose / bc1), beta1, beta2, eps, (float)(1.0 / sqrt(bc2))};
+  const size_t cells_off = (occ_lds_bytes(nx->level) + 15) & ~(size_t)15;
+  const unsigned n_march = (unsigned)nof_div_up(nx->R, 4);
+  MarchArgs q{nx->pool, nx->ids, nx->occ_bits, 1 << nx->level, nx->sh_degree, nx->max_hits, (int)cells_off, nx->R,
+              nx->batch, nx->rays_o_w, nx->viewdirs_w, nx->view, nx->t_in_out, nx->n_hits, nx->flags, *cfg, nx->z_vals, nx->pts_w,
+              nx->valid};
+  grid.x += n_march;
+#define NOF_TAIL(P)                                                                                                          \
+  hipLaunchKernelGGL(k_adam_tail_march<P>, grid, dim3(256), cells_off + 4 * sizeof(WaveCells), (hipStream_t)stream, d, params,   \
+                     grads, exp_avg, exp_avg_sq, k, skip_flags, a, q, n_march, d_epoch, epoch_target)
+  if (d.precision == 0) NOF_TAIL(PrecF32);
+  else if (is_bf16(d.precision)) NOF_TAIL(PrecBF16);
+  else NOF_TAIL(PrecF16);
+#undef NOF_TAIL
+  NOF_LAUNCH_OK();
+  return 0;
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -132,6 +132,16 @@ class NeuralObjectField:
         # table behind it (nof_adam_step_tail, round 6) -- two launches and their gaps less per step; False: the three calls
         self.fused_tail = True
         self.mlp_bwd_one_launch = True   # the 64-wide 16-bit backward's colour and sigma halves as one launch (two colour layers)
+        # train_step(next_ids=...): the optimiser launch of a step also carries the NEXT batch's ray marcher (nof_adam_step_tail_march,
+        # round 6) -- a latency chain per ray beside Adam's streaming; the next step then starts at its forward.  Needs fused_tail.
+        # OFF: measured 0.475-0.482 against 0.455-0.459 ms at the driver's invocation -- the merged launch takes 86-88 us where
+        # Adam's takes 37 and the marcher's 20, fences and wait or not (profiles/r06_ai_tail_driver.txt, r06_ak_march_x.txt): the
+        # marcher's dependent loads crawl under Adam's streaming (round 3 found the same with the prologue on a side stream).
+        self.march_ahead = False
+        self._marched = None         # (step, ids tensor, R, pool pointer, seed) of the batch the last optimiser launch marched
+        self._new_batch_pending = False
+        self._tf_epoch = 0           # running target of the device counter the marcher's workgroups wait on (F more per launch)
+        self._tf_epoch_dev = torch.zeros(1, dtype=torch.int32, device=dev)
         self._tail_step = None       # optimiser step whose operand image AND pose table the last nof_adam_step_tail left
         self._tail_done = torch.zeros(1040, dtype=torch.int32, device=dev)     # nof_adam_step_tail_dyn's counter (zero between launches)
         self._tail_plan = False      # inside a train_step: this step's optimiser launch will be nof_adam_step_tail
@@ -252,6 +262,7 @@ class NeuralObjectField:
     def set_occupancy(self, coords_max_level, max_level, level):
         """coords [P,3] int occupied cells at max_level (dilated) -> bitfield of the ray-tracing level."""
         n = 1 << level
+        self._marched = None
         self.level, self.max_level = int(level), int(max_level)
         self.occ_bits = torch.zeros((n ** 3 + 31) // 32, dtype=torch.int32, device=self.device)
         coords = torch.as_tensor(np.ascontiguousarray(coords_max_level, dtype=np.int32)).to(self.device)
@@ -388,6 +399,7 @@ class NeuralObjectField:
         (Running the NEXT batch's prologue at the end of a step, on the side stream beside Adam -- it needs only the few KB of
         poses / features / MLPs, updated first -- was built and measured: 0.526 vs 0.515 ms/step.  The fork and the join cost what
         the overlap returns, and the ray marcher's dependent loads slow down under Adam's streaming.)"""
+        fresh = self._packed_step == self.global_step == self._tail_step   # (nothing replaced the parameters since the last optimiser launch)
         if (dyn and not self._tail_plan) or self._packed_step != self.global_step:
             # pose table + MFMA fragment image in ONE launch (two 6-microsecond kernels before: the pose update is one short
             # dependent chain per frame and rides as one extra workgroup of the packing launch)
@@ -401,6 +413,14 @@ class NeuralObjectField:
         cid = None
         if want_cells:
             cid = b.setdefault('cell_ids', torch.empty(R, self.max_hits, dtype=torch.int32, device=self.device))
+        mk, self._marched = self._marched, None
+        if (mk is not None and self._tail_plan and not dyn and not deterministic and not want_cells and u_occ is None and u_dep is None
+                and mk[0] == self.global_step and ids is not None and mk[1].data_ptr() == ids.data_ptr() and mk[2] == R == ids.shape[0]
+                and mk[3] == pool.data_ptr() and mk[4] == seed and fresh):
+            # the previous step's optimiser launch marched this batch (nof_adam_step_tail_march); what the marcher does for the
+            # device flags when a batch starts rides in this step's merged scatter launch instead (HASH_BWD_NEW_BATCH)
+            self._new_batch_pending = True
+            return
         sc = self._sample_cfg(seed, self.global_step, dyn, deterministic)
         self._call('nof_raymarch_sample', C.byref(sc), pool, ids, self.tf, self.feat if self.ff > 0 else None, self.ff,
                    self.sh_degree, self.occ_bits, self.level, R, self.max_hits, u_occ, u_dep, b['batch'], b['rays_o_w'],
@@ -436,11 +456,14 @@ class NeuralObjectField:
         return b, S
 
     def train_step(self, pool, ids, R, u_occ=None, u_dep=None, seed=0, do_step=True, want_cells=False,
-                   grad_sync=None, dyn=False):
+                   grad_sync=None, dyn=False, next_ids=None):
+        """next_ids (optional): the ids of the batch the NEXT train_step call will be given (same pool, R and seed): where it can,
+        this step's optimiser launch marches that batch's rays beside Adam and the next call starts at its forward (march_ahead).
+        The step's buffer dict is then overwritten with the next batch's rays / samples by the time this call's launches end."""
         with self._on(torch.cuda.current_stream()):
-            return self._train_step(pool, ids, R, u_occ, u_dep, seed, do_step, want_cells, grad_sync, dyn)
+            return self._train_step(pool, ids, R, u_occ, u_dep, seed, do_step, want_cells, grad_sync, dyn, next_ids)
 
-    def _train_step(self, pool, ids, R, u_occ, u_dep, seed, do_step, want_cells, grad_sync, dyn):
+    def _train_step(self, pool, ids, R, u_occ, u_dep, seed, do_step, want_cells, grad_sync, dyn, next_ids=None):
         """One train_loop iteration (nerf_runner.py:679-763).  `grad_sync(flat_grads)` is the data-parallel hook
         (RCCL all-reduce); gradients are already scaled by 1/world_size.  dyn=True: the per-step scalars (Philox step, Adam
         step sizes) are read from the device-resident NofStepState instead of being passed by value, and the state is advanced
@@ -449,10 +472,13 @@ class NeuralObjectField:
         # (decided before the prologue: a captured step whose optimiser launch leaves the next operand image packs none itself)
         one_stream = self.one_stream_backward if self.one_stream_backward is not None else (dyn and not self.graph_fork)
         tail = self._tail_plan = bool(one_stream and do_step and self._tail_ok(grad_sync))
+        self._new_batch_pending = False
         try:
             b, S = self.forward_batch(pool, ids, R, u_occ, u_dep, seed, want_cells, dyn)
         finally:
             self._tail_plan = False
+        new_batch = self._new_batch_pending        # (this batch was marched by the previous optimiser launch: see _prologue)
+        self._new_batch_pending = False
         B = R * S
         lc = self._loss_cfg()
         # the work list of the backward; the eikonal term has a gradient at every sample, so it takes none
@@ -545,7 +571,8 @@ class NeuralObjectField:
                                   self.c2w.data_ptr(), self.tf.data_ptr(), self.ff, self.sh_degree, R, S, b['g_ray'].data_ptr(),
                                   self.pose_slots.data_ptr())
             self._call('nof_hash_encode_bwd_step', C.byref(self.grid), b['pts_w'], self.table, b['dfeat'], None, None, gtab, dpts,
-                       0, self.L, tiles, ALL | lib.HASH_BWD_MERGE_INPUT, self.scatter_wgs_per_cu, B, b['partials'], self.nblk,
+                       0, self.L, tiles, ALL | lib.HASH_BWD_MERGE_INPUT | (lib.HASH_BWD_NEW_BATCH if new_batch else 0),
+                       self.scatter_wgs_per_cu, B, b['partials'], self.nblk,
                        self.n_mlp, self._seg(self.grads, 'mlp'), self.flags, C.byref(pa), tag='hash_bwd[table+table_lds]')
             if not tail:
                 self._call('nof_pose_reduce_bwd', self.pose, None, None, None, R, self.ff, C.c_float(self.max_trans),
@@ -668,7 +695,11 @@ class NeuralObjectField:
                 self.adam_step(dyn, 0, adam_done[0], advance=False)
                 self.adam_step(dyn, adam_done[1])
             elif tail:
-                self.adam_step_tail(dyn)
+                ahead = None
+                if (next_ids is not None and self.march_ahead and not dyn and self.marcher == lib.MARCHER_WAVE and self.level <= 5
+                        and self.max_hits <= 196 and next_ids.shape[0] == R and not cfg.get('trunc_decay_type', '')):
+                    ahead = (pool, next_ids, R, seed, b)
+                self.adam_step_tail(dyn, ahead)
             else:
                 self.adam_step(dyn)
         return b
@@ -700,9 +731,10 @@ class NeuralObjectField:
         return (self.fused_tail and grad_sync is None and self.world_size == 1 and self.optimize_poses and not self.eikonal
                 and self.ff == 0 and float(self.cfg.get('pose_reg_weight', 0)) == 0)
 
-    def adam_step_tail(self, dyn=False):
+    def adam_step_tail(self, dyn=False, ahead=None):
         """nof_pose_reduce_bwd + Adam over everything + nof_mlp_pack_pose for the next step (+ nof_step_state_advance in a captured
-        step), as ONE launch (nof_adam_step_tail / nof_adam_step_tail_dyn)"""
+        step), as ONE launch (nof_adam_step_tail / nof_adam_step_tail_dyn); ahead = (pool, ids, R, seed, buffers): + the ray marcher
+        of the next batch (nof_adam_step_tail_march)"""
         t = lib.NofAdamTail(C.addressof(self.desc), self.packed.data_ptr(), self.n_table, self.n_mlp, self.n_basic, self.F,
                             self.max_trans, self.max_rot, self.c2w.data_ptr(), self.tf.data_ptr(), self.pose_slots.data_ptr())
         if dyn:
@@ -711,6 +743,19 @@ class NeuralObjectField:
                        self._state, C.c_float(cfg['lrate']), C.c_float(cfg['lrate_pose']), C.c_float(cfg['decay_rate']),
                        int(cfg['n_step']) + 1, C.c_float(0.9), C.c_float(0.999), C.c_float(1e-15), self.flags, C.byref(t),
                        self._tail_done, tag='nof_adam_step')
+        elif ahead is not None:
+            pool, ids, R, seed, b = ahead
+            lr, lr_pose = self.learning_rates()
+            sc = self._sample_cfg(seed, self.global_step + 1)                  # (the next step's Philox counter)
+            nx = lib.NofMarchNext(C.addressof(sc), pool.data_ptr(), ids.data_ptr(), self.occ_bits.data_ptr(), self.sh_degree,
+                                  self.level, self.max_hits, 0, R, b['batch'].data_ptr(), b['rays_o_w'].data_ptr(),
+                                  b['viewdirs_w'].data_ptr(), b['view'].data_ptr(), b['t_in_out'].data_ptr(), b['n_hits'].data_ptr(),
+                                  b['z_vals'].data_ptr(), b['pts_w'].data_ptr(), b['valid'].data_ptr(), self.flags.data_ptr())
+            self._tf_epoch = (self._tf_epoch + self.F) & 0xffffffff
+            self._call('nof_adam_step_tail_march', self.params, self.grads, self.exp_avg, self.exp_avg_sq, self.n_total, self.n_basic,
+                       C.c_float(lr), C.c_float(lr_pose), C.c_float(0.9), C.c_float(0.999), C.c_float(1e-15), self.adam_steps + 1,
+                       self.flags, C.byref(t), C.byref(nx), self._tf_epoch_dev, self._tf_epoch, tag='nof_adam_step')
+            self._marched = (self.global_step + 1, ids, R, pool.data_ptr(), seed)
         else:
             lr, lr_pose = self.learning_rates()
             self._call('nof_adam_step_tail', self.params, self.grads, self.exp_avg, self.exp_avg_sq, self.n_total, self.n_basic,

@@ -18,7 +18,7 @@ NOF_MAX_LEVELS = 16
 NOF_MAX_LAYERS = 8
 RAY_COLS = 12
 VIEW_COLS = 16
-HASH_BWD_TABLE_BIG, HASH_BWD_TABLE_SMALL, HASH_BWD_INPUT, HASH_BWD_ALL, HASH_BWD_MERGE_INPUT = 1, 2, 4, 7, 8
+HASH_BWD_TABLE_BIG, HASH_BWD_TABLE_SMALL, HASH_BWD_INPUT, HASH_BWD_ALL, HASH_BWD_MERGE_INPUT, HASH_BWD_NEW_BATCH = 1, 2, 4, 7, 8, 16
 MARCHER_WAVE, MARCHER_WALK = 0, 1
 
 
@@ -62,6 +62,14 @@ class NofAdamTail(C.Structure):
     _fields_ = [('desc', C.c_void_p), ('packed', C.c_void_p), ('mlp_off', C.c_int64), ('n_mlp', C.c_int64), ('pose_off', C.c_int64),
                 ('F', C.c_int32), ('max_trans', C.c_float), ('max_rot', C.c_float), ('c2w', C.c_void_p), ('tf', C.c_void_p),
                 ('frame_slots', C.c_void_p)]
+
+
+class NofMarchNext(C.Structure):
+    """nof_adam_step_tail_march: the NEXT batch's nof_raymarch_sample, carried by this step's optimiser launch (include/nof_hip.h)"""
+    _fields_ = [('cfg', C.c_void_p), ('pool', C.c_void_p), ('ids', C.c_void_p), ('occ_bits', C.c_void_p), ('sh_degree', C.c_int32),
+                ('level', C.c_int32), ('max_hits', C.c_int32), ('reserved', C.c_int32), ('R', C.c_int64), ('batch', C.c_void_p),
+                ('rays_o_w', C.c_void_p), ('viewdirs_w', C.c_void_p), ('view', C.c_void_p), ('t_in_out', C.c_void_p),
+                ('n_hits', C.c_void_p), ('z_vals', C.c_void_p), ('pts_w', C.c_void_p), ('valid', C.c_void_p), ('flags', C.c_void_p)]
 
 
 NOF_MCL_TABLES = 47
@@ -118,6 +126,8 @@ _SIGNATURES = {
     'nof_small_regs': ([_P, _P, _I32, _F, _F, _P], C.c_int),
     'nof_adam_step': ([_P, _P, _P, _P, _I64, _I64, _F, _F, _F, _F, _F, _I32, _P, _P], C.c_int),
     'nof_adam_step_tail': ([_P, _P, _P, _P, _I64, _I64, _F, _F, _F, _F, _F, _I32, _P, C.POINTER(NofAdamTail), _P], C.c_int),
+    'nof_adam_step_tail_march': ([_P, _P, _P, _P, _I64, _I64, _F, _F, _F, _F, _F, _I32, _P, C.POINTER(NofAdamTail),
+                                  C.POINTER(NofMarchNext), _P, C.c_uint32, _P], C.c_int),
     'nof_adam_step_tail_dyn': ([_P, _P, _P, _P, _I64, _I64, _P, _F, _F, _F, _I32, _F, _F, _F, _P, C.POINTER(NofAdamTail), _P, _P], C.c_int),
     'nof_grad_check': ([_P, _I64, _P, _P], C.c_int),
     'nof_render_depth': ([_P, _P, _I64, _I32, _F, _P, _P], C.c_int),

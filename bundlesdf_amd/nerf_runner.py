@@ -227,8 +227,21 @@ class NerfRunner:
     def train_loop(self, ids=None):
         """One optimisation step on the next batch of the loader (the reference passes the gathered rows; here the
         rows are gathered on the device from the resident pool)."""
-        if ids is None:
+        next_ids = None
+        if ids is None and not self.field.march_ahead:
             ids = self.data_loader.next_ids()
+        elif ids is None:
+            # the loader runs one batch ahead: this step's optimiser launch marches the NEXT batch's rays (field.march_ahead, off by default)
+            dl = self.data_loader
+            ahead = getattr(self, '_ids_ahead', None)
+            if ahead is not None and ahead[2] is dl:
+                ids, host_ids = ahead[0], ahead[1]
+            else:
+                ids = dl.next_ids()
+                host_ids = dl.batch_ray_ids
+            next_ids = dl.next_ids()
+            self._ids_ahead = (next_ids, dl.batch_ray_ids, dl)
+            dl.batch_ray_ids = host_ids                    # (what the loader reports: the batch being trained)
         seed = self.cfg.get('seed', 0) + 7919 * self.rank
         f = self.field
         # captured-step mode (cfg hip_graph, default OFF since the eager step overlaps its two backward chains on two streams and is
@@ -251,7 +264,7 @@ class NerfRunner:
             if getattr(self, '_graph_field', None) is not f:
                 self._graph_field, self._eager_steps = f, 0
             self._eager_steps += 1
-            f.train_step(self.rays, ids, ids.shape[0], seed=seed, grad_sync=self.grad_sync)
+            f.train_step(self.rays, ids, ids.shape[0], seed=seed, grad_sync=self.grad_sync, next_ids=next_ids)
         if self.global_step % self.cfg['i_print'] == 0 and self.global_step > 0:
             if self.field.poll_flags() & 4:
                 logging.warning('non-finite weight gradient in the fp16 backward: that step was skipped, loss scale halved')

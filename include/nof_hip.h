@@ -82,6 +82,9 @@ int nof_hash_encode_bwd_eik(const NofHashGrid* h_grid, const float* pts_w, const
 #define NOF_HASH_BWD_INPUT 4            /* dL/dpts over all levels (needs dpts) */
 #define NOF_HASH_BWD_ALL 7
 #define NOF_HASH_BWD_MERGE_INPUT 8      /* with TABLE_BIG | INPUT: the large levels' scatter and dL/dpts as two roles of ONE launch (round 6) */
+#define NOF_HASH_BWD_NEW_BATCH 16       /* nof_hash_encode_bwd_step with MERGE_INPUT: the merged launch also moves the overflow mark of `flags`
+                                         * (bit 2 -> the sticky bit 3), which the batch's ray marcher does unless it ran inside the
+                                         * previous optimiser launch (nof_adam_step_tail_march) */
 int nof_hash_encode_bwd_parts(const NofHashGrid* h_grid, const float* pts_w, const float* table, const float* dfeat,
                               const float* geik, const float* dedn, float* grad_table, float* dpts, int32_t level_lo,
                               int32_t level_hi, const void* tile_list, int32_t parts, int32_t wgs_per_cu, int64_t B, void* stream);
@@ -515,6 +518,26 @@ typedef struct {
 int nof_adam_step_tail(float* params, float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, int64_t n_basic,
                        float lr, float lr_pose, float beta1, float beta2, float eps, int32_t step, const int32_t* skip_flags,
                        const NofAdamTail* tail, void* stream);
+/* ... and with the NEXT batch's ray marcher as one more role of the launch (nof_raymarch_sample in its one-launch form: the wave
+ * marcher, level <= 6, injected uniforms NULL, no frame features, no cell ids): a latency chain per ray beside Adam's streaming, for
+ * the time of the longer one.  The marcher's workgroups wait inside the launch for the pose-table rows the launch's first F
+ * workgroups write: d_epoch is one device uint32 that only grows -- by F per call --, epoch_target the value it has when this
+ * call's rows are out (the caller keeps the running sum, starting from the counter's initial 0).  The overflow mark of the device
+ * flags (bit 2 -> bit 3 when a new batch starts) is NOT moved by this marcher -- the launch's other workgroups still read bit 2;
+ * the following step passes NOF_HASH_BWD_NEW_BATCH to nof_hash_encode_bwd_step instead.  Same results as nof_adam_step_tail
+ * followed by nof_raymarch_sample. */
+typedef struct {
+  const NofSampleCfg* cfg;                /* host pointer: seed / step of the NEXT batch (d_step NULL) */
+  const float* pool; const int64_t* ids; const uint32_t* occ_bits;
+  int32_t sh_degree, level, max_hits, reserved;
+  int64_t R;
+  float* batch; float* rays_o_w; float* viewdirs_w; float* view; float* t_in_out; int32_t* n_hits;
+  float* z_vals; float* pts_w; uint8_t* valid; int32_t* flags;
+} NofMarchNext;
+int nof_adam_step_tail_march(float* params, float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, int64_t n_basic,
+                             float lr, float lr_pose, float beta1, float beta2, float eps, int32_t step, const int32_t* skip_flags,
+                             const NofAdamTail* tail, const NofMarchNext* next, uint32_t* d_epoch, uint32_t epoch_target,
+                             void* stream);
 /* ... with the step's scalars read from the device state (a captured, replayable step: nof_adam_step_dyn's arguments), and
  * nof_step_state_advance(set_step = -1) inside as well: the last workgroup to finish advances *d_state.  d_done:
  * NOF_ADAM_TAIL_DONE_WORDS device uint32, zero before the launch and zero again after it. */

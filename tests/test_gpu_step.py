@@ -525,3 +525,88 @@ def test_adam_step_tail_equals_the_three_calls(nof, precision, ns, nc, hidden):
         if skip == 0:
             assert not torch.equal(out[1][5], keep[5]) and not torch.equal(out[1][6], keep[6])      # image and pose table really moved
         assert out[1][1].abs().max().item() == 0 and out[1][4].abs().max().item() == 0
+
+
+def test_optimiser_launch_marches_the_next_batch(nof):
+    """round 6: train_step(next_ids=...) -- the optimiser launch of a step carries the NEXT batch's ray marcher
+    (nof_adam_step_tail_march).  What it leaves in the step's buffers equals, bit for bit, nof_raymarch_sample run afterwards on the
+    same ids with the pose table the launch itself updated and the next step's Philox counter; the next train_step then launches no
+    marcher of its own, and training over several steps goes where it goes without the look-ahead (up to the atomics' order)."""
+    from bundlesdf_amd import lib
+    cfg, fld, orc, batch, rng = _pair(nof, 'fp16x3', R=256)
+    _, twin, _, _, _ = _pair(nof, 'fp16x3', R=256)
+    pool = U.dev(batch)
+    R = batch.shape[0]
+    gen = torch.Generator(device='cuda').manual_seed(5)
+    ids = [torch.randperm(R, device='cuda', generator=gen) for _ in range(6)]
+    S = cfg['N_samples'] + cfg['N_samples_around_depth']
+    fld.march_ahead = True                               # (an option: measured slower than the marcher's own launch, see field.py)
+    fld.train_step(pool, ids[0], R, seed=9, next_ids=ids[1])
+    torch.cuda.synchronize()
+    assert fld._marched is not None and fld._marched[0] == fld.global_step == 1
+    b = fld._buffers(R, S)
+    names = ('batch', 'rays_o_w', 'viewdirs_w', 'view', 't_in_out', 'n_hits', 'z_vals', 'pts_w', 'valid')
+    got = {k: b[k].clone() for k in names}
+    want = {k: torch.full_like(b[k], 3) for k in names}
+    sc = fld._sample_cfg(9, fld.global_step)
+    nof.call('nof_raymarch_sample', C.byref(sc), pool, ids[1], fld.tf, None, 0, fld.sh_degree, fld.occ_bits, fld.level, R, fld.max_hits,
+             None, None, want['batch'], want['rays_o_w'], want['viewdirs_w'], want['view'], want['t_in_out'], None, want['n_hits'],
+             want['z_vals'], want['pts_w'], want['valid'], fld.flags)
+    torch.cuda.synchronize()
+    for k in names:
+        assert torch.equal(got[k].view(torch.uint8), want[k].view(torch.uint8)), k
+    assert int(fld.flags[0].item()) == 0
+    # the next step takes the marched batch: no marcher launch of its own
+    fld.profile = {}
+    fld.train_step(pool, ids[1], R, seed=9, next_ids=ids[2])
+    torch.cuda.synchronize()
+    assert 'nof_raymarch_sample' not in fld.profile and 'nof_adam_step' in fld.profile
+    fld.profile = None
+    # a batch other than the announced one: the marcher runs as usual
+    fld.profile = {}
+    fld.train_step(pool, ids[4], R, seed=9, next_ids=ids[3])
+    torch.cuda.synchronize()
+    assert 'nof_raymarch_sample' in fld.profile
+    fld.profile = None
+    # whole steps with and without the look-ahead, from the same initial state
+    _, ahead, _, _, _ = _pair(nof, 'fp16x3', R=256)
+    ahead.march_ahead = True
+    assert torch.equal(ahead.params, twin.params)
+    seq = [ids[k % 6] for k in range(8)]
+    for k in range(7):
+        ahead.train_step(pool, seq[k], R, seed=9, next_ids=seq[k + 1])
+        twin.train_step(pool, seq[k], R, seed=9)
+    torch.cuda.synchronize()
+    assert ahead._marched is not None and twin._marched is None
+    d = (ahead.params - twin.params).abs()
+    assert d.max().item() < 2.0 * 7 * cfg['lrate'] and (d > 1e-3).float().mean().item() < 2e-2
+    assert abs(ahead.losses()['loss'] - twin.losses()['loss']) < 5e-2 * abs(twin.losses()['loss'])
+
+
+def test_overflow_mark_with_the_marcher_inside_the_optimiser_launch(nof):
+    """the overflow protocol of test_fp16_overflow_skips_the_step_on_the_device when every step's marcher ran inside the previous
+    optimiser launch: the skipped step's mark (bit 2) must survive that launch -- whose Adam workgroups read it -- and become the
+    sticky bit 3 in the NEXT step (NOF_HASH_BWD_NEW_BATCH in its merged scatter launch)."""
+    cfg, fld, orc, batch, rng = _pair(nof, 'fp16x3', R=256)
+    fld.march_ahead = True
+    pool = U.dev(batch)
+    R = batch.shape[0]
+    gen = torch.Generator(device='cuda').manual_seed(0)
+    ids = [torch.randperm(R, device='cuda', generator=gen) for _ in range(6)]
+    for k in range(2):
+        fld.train_step(pool, ids[k], R, seed=3, next_ids=ids[k + 1])
+    torch.cuda.synchronize()
+    assert cpu(fld.flags)[0] == 0 and fld._marched is not None
+    p0, m0, v0 = fld.params.clone(), fld.exp_avg.clone(), fld.exp_avg_sq.clone()
+    fld._scale_backoff = -30                                           # loss scale x 2^30: binary16 overflows
+    fld.train_step(pool, ids[2], R, seed=3, next_ids=ids[3])
+    torch.cuda.synchronize()
+    assert cpu(fld.flags)[0] & 12 == 4, 'the overflow was not noticed (or its mark already moved)'
+    assert torch.equal(fld.params, p0) and torch.equal(fld.exp_avg, m0) and torch.equal(fld.exp_avg_sq, v0), 'the step was applied'
+    assert (fld.grads == 0).all()
+    fld._scale_backoff = 0
+    fld.train_step(pool, ids[3], R, seed=3, next_ids=ids[4])
+    torch.cuda.synchronize()
+    assert cpu(fld.flags)[0] & 12 == 8, 'the mark of the skipped step should be sticky now'
+    assert not torch.equal(fld.params, p0) and torch.isfinite(fld.params).all()
+    assert fld.poll_flags() & 4 and fld._scale_backoff == 1
