@@ -661,6 +661,9 @@ def main():
                         roof = {"kernel": dominant, "bound": "atomic", "achieved": at["achieved"], "peak": at["peak"], "unit": at["unit"],
                                 "frac": at["frac"], "traffic": traffic, "avg_ms": dom_ms, "line_requests": at["line_requests"],
                                 "floor_ms": at["floor_ms"], "sample": at["sample"], "traffic_source": src if traffic else None,
+                                "call": ("the call's two launches: { large levels' scatter | dL/dx } and { LDS levels | MLP row reduction | "
+                                         "per-ray pose rows } (round 6: one chain); avg_ms is the whole call, the requests are the scatter's"
+                                         if fld.one_stream_backward else "scatter launch + LDS-level launch (dL/dx beside them on a second stream)"),
                                 "peak_source": "tools/atomic_probe.py on MI355X: 20.8 G fp32-atomic line requests/s, whatever the scope, "
                                                "cache flags or data type (profiles/r02_d_atomic_probe.txt)",
                                 "hbm": {"achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,

@@ -16,8 +16,9 @@ def per_kernel(dbdir, counter):
 fetch, write = per_kernel('pmc_fetch', 'FETCH_SIZE'), per_kernel('pmc_write', 'WRITE_SIZE')
 # kernels of each C-ABI entry point, by name prefix (the template arguments follow the bench's precision / network shape)
 # (keys = the tags NeuralObjectField._call times its launches under: what bench.py names as the dominant entry)
+# (since round 6 the scatter launch k_hash_bwd_agg_dx also computes dL/dx, and k_hash_bwd_lds carries the row reduction and the pose rows)
 groups = {'hash_bwd[table+table_lds]': ['k_hash_bwd_agg', 'k_hash_bwd_lds'], 'hash_bwd[input]': ['k_hash_dx'],
-          'nof_hash_encode_fwd': ['k_hash_fwd'], 'nof_mlp_bwd_tiles': ['k_mlp_bwd_color<', 'k_mlp_bwd_sigma<'],
+          'nof_hash_encode_fwd': ['k_hash_fwd'], 'nof_mlp_bwd_tiles': ['k_mlp_bwd_color<', 'k_mlp_bwd_sigma<', 'k_mlp_bwd_both<'],
           'nof_mlp_fwd': ['k_mlp_fwd<'], 'nof_encode_mlp_fwd': ['k_enc_mlp_fwd<'], 'nof_adam_step': ['k_adam']}
 
 
