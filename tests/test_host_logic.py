@@ -475,3 +475,60 @@ def test_row_bitmap_round_trip():
         want = torch.nonzero((rows != 0).any(1)).reshape(-1)
         assert torch.equal(idx, want)
         assert set(want.tolist()) <= set(hit.tolist())
+
+
+def test_operand_image_backward_position_is_the_inverse_of_the_packing_map():
+    """nof_adam_step_tail (csrc/nof_adam_tail_dev.h) updates a weight where the FORWARD operand image holds it and stores the new value
+    at its place in the BACKWARD image as well, through the closed-form inverse of k_mlp_pack's second mapping (csrc/nof_mlp.hip):
+    for the fw element (pair (p, q), register r, lane (hi, i)) that is the bw element at pair (q, p), register r' and lane (hi', i')
+    with nloc(hi', r') = i and i' = nloc(hi, r).  Restated here in Python for every network shape the library accepts: both images
+    hold every weight exactly once, and the closed form lands on the bw element that holds the same weight."""
+    import itertools
+
+    def nloc(hi, r):
+        return (r & 3) + 8 * (r >> 2) + 4 * hi
+
+    def check(n_sigma, n_color, hidden, in_feat, n_view, geo):
+        nl = n_sigma + n_color
+        in_dim, out_dim = [], []
+        for l in range(nl):
+            in_dim.append(in_feat if l == 0 else (n_view + geo if l == n_sigma else hidden))
+            out_dim.append(1 + geo if l == n_sigma - 1 else (3 if l == nl - 1 else hidden))
+        qn = lambda l: 1 if l == 0 else (2 if l == n_sigma else hidden // 32)
+        pn = lambda l: (out_dim[l] + 31) // 32
+
+        def inmap(l, q, hi, r):                                   # csrc/nof_mlp_dev.h:inmap
+            if l == 0:
+                c = 16 * hi + r
+                return c if c < in_feat else -1
+            if l == n_sigma:
+                if q == 0:
+                    o = nloc(hi, r)
+                    return n_view + o - 1 if 1 <= o <= geo else -1
+                u = 8 * hi + r
+                return u if (r < 8 and u < n_view) else -1
+            c = 32 * q + nloc(hi, r)
+            return c if c < in_dim[l] else -1
+        for l in range(nl):
+            fw, bw = {}, {}
+            for pair, r, lane in itertools.product(range(pn(l) * qn(l)), range(16), range(64)):
+                hi, i = lane >> 5, lane & 31
+                p, q = pair // qn(l), pair % qn(l)
+                row, col = 32 * p + i, inmap(l, q, hi, r)
+                if row < out_dim[l] and col >= 0:
+                    fw[(p * qn(l) + q, r, lane)] = (row, col)
+                q2, p2 = pair // pn(l), pair % pn(l)
+                row2, col2 = 32 * p2 + nloc(hi, r), inmap(l, q2, (i >> 2) & 1, (i & 3) + 4 * (i >> 3))
+                if row2 < out_dim[l] and col2 >= 0:
+                    bw[(q2 * pn(l) + p2, r, lane)] = (row2, col2)
+            every = sorted(itertools.product(range(out_dim[l]), range(in_dim[l])))
+            assert sorted(fw.values()) == every and sorted(bw.values()) == every, (n_sigma, n_color, hidden, l)
+            where = {v: k for k, v in bw.items()}
+            for (pr, r, lane), rc in fw.items():
+                hi, i = lane >> 5, lane & 31
+                p, q = pr // qn(l), pr % qn(l)
+                assert where[rc] == (q * pn(l) + p, (i & 3) + 4 * (i >> 3), 32 * ((i >> 2) & 1) + nloc(hi, r)), (l, pr, r, lane)
+
+    for shape in ((2, 3, 64, 32, 9, 15), (3, 2, 64, 32, 9, 15), (2, 2, 64, 32, 11, 15), (3, 3, 64, 24, 9, 15), (4, 4, 128, 32, 9, 15),
+                  (2, 3, 128, 32, 11, 15)):
+        check(*shape)
