@@ -303,6 +303,10 @@ def main():
                     help='the 16-bit MLP backward\'s two halves as one launch (field.mlp_bwd_one_launch)')
     ap.add_argument('--march-ahead', type=int, default=None, choices=[0, 1],
                     help='the next batch\'s ray marcher inside the optimiser launch (field.march_ahead; measured slower, off by default)')
+    ap.add_argument('--event-stride', type=int, default=4,
+                    help='timed region: HIP events around the dominant launch in every Nth step only (a timing event recorded on the '
+                         'stream costs the queue a ~6 us bubble: profiles/r06_am_gap_probe.txt)')
+    ap.add_argument('--marker-stride', type=int, default=4, help='timed region: one step-boundary event every Nth step')
     ap.add_argument('--scatter-wgs', type=int, default=0, help='persistent workgroups per CU of the table scatter (0 = library default)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--with-cpu-baseline', action='store_true', help='overrides --no-cpu-baseline (the cfg1-shapes sub-record)')
@@ -416,9 +420,17 @@ def main():
     dominant = max(ktimes, key=ktimes.get) if ktimes else 'hash_bwd[table+table_lds]'
     fld.profile = {dominant: []} if dominant else None          # timed region: only the dominant kernel keeps its events
     fld.profile_only = dominant
-    # the hash lookup (north_star: ">= 40 % HBM roofline for hash lookup") is timed as well: two more events per step
-    if dominant != fwd_name:
-        fld.profile_also = fwd_name
+    # A timing event recorded on the stream is not free under the profiler: the queue idles ~5.8 us around each (tools/gap_probe.py,
+    # profiles/r06_am_gap_probe.txt: dependent kernels run back to back without one, 5.8 us apart with one between them).  Rounds 3-5
+    # recorded five per step inside the timed region (two around the dominant launch, two around the forward, one step marker):
+    # 29 us of every step in a rocprofv3 trace -- exactly the "gaps" of the profiled timelines of those rounds.  WITHOUT the profiler
+    # the cost is small (profiles/r06_an_events.txt: 3 events per step against 0.75: 0.445-0.450 against 0.437-0.451 ms), but it is
+    # not work of the step: the dominant launch keeps its events on every `event_stride`-th step of the region, the hash lookup
+    # (north_star: ">= 40 % HBM roofline for hash lookup") is timed in the spread pass right behind the region, the step markers
+    # come every `marker_stride` steps.
+    ev_stride = max(int(args.event_stride), 1) if args.steps >= 4 * max(int(args.event_stride), 1) else 1    # (>= 4 samples)
+    mk_stride = max(int(args.marker_stride), 1) if args.steps >= 4 * max(int(args.marker_stride), 1) else 1
+    fld.profile_stride = ev_stride
     if sync is not None:
         sync.timing, sync.timed_steps = [], 0
 
@@ -436,14 +448,17 @@ def main():
         gc.collect()
         gc.disable()
         marks = []
-        evs = [torch.cuda.Event(enable_timing=True) for _ in range(n + 1)]      # (created outside the timed region)
+        ms_ = mk_stride if n == args.steps else 1
+        at = [i for i in range(n + 1) if i % ms_ == 0 or i == n]       # step boundaries that get a marker (0 and n always)
+        evs = {i: torch.cuda.Event(enable_timing=True) for i in at}    # (created outside the timed region)
         try:                                                           # (an exception in step() must not leave the collector off)
             barrier()
             t0 = time.perf_counter()
             evs[0].record()
             for i in range(n):
                 step()
-                evs[i + 1].record()                                    # (a marker on the step's stream: ~1 us of host time, no device work)
+                if i + 1 in evs:
+                    evs[i + 1].record()                                # (a marker on the step's stream: ~1 us of host time, a ~6 us bubble in the queue)
                 marks.append(time.perf_counter())                      # (50 ns: when the host finished enqueueing the step)
             barrier()
             dt = time.perf_counter() - t0
@@ -452,8 +467,9 @@ def main():
         # DEVICE-side duration of every step of the timed region (event to event on the step's stream): their median and maximum
         # make a one-off stall inside the region visible in the record itself (round 5: one driver-style run in eleven read a MEAN of
         # 0.73 instead of 0.47 ms)
-        dv = np.array([evs[i].elapsed_time(evs[i + 1]) for i in range(n)]) if n else np.zeros(0)
-        timed.device_intervals = {"p50": float(np.median(dv)), "max": float(dv.max()), "n": int(len(dv))} if len(dv) else None
+        dv = np.array([evs[a].elapsed_time(evs[b]) / (b - a) for a, b in zip(at[:-1], at[1:])]) if n else np.zeros(0)
+        timed.device_intervals = ({"p50": float(np.median(dv)), "max": float(dv.max()), "n": int(len(dv)), "steps_per_interval": ms_}
+                                  if len(dv) else None)
         # ... and the HOST's enqueue intervals (the host runs ahead of the device: these say how long a step takes to ENQUEUE)
         iv = np.diff(np.array([t0] + marks)) * 1e3
         timed.host_intervals = {"p50": float(np.median(iv)), "max": float(iv.max()), "n": int(len(iv))} if len(iv) else None
@@ -486,14 +502,18 @@ def main():
     zero_last = zero_fraction()
     kt = fld.kernel_times_ms()
     dom_ms = kt.get(dominant) if dominant else None
-    hash_fwd_ms = kt.get(fwd_name)
+    hash_fwd_ms = kt.get(fwd_name)                # (the forward IS the dominant launch; otherwise timed in the spread pass below)
     exposed_comm_ms = None
     if sync is not None and sync.timing:
         torch.cuda.synchronize()
         exposed_comm_ms = float(np.sum([a.elapsed_time(b) for a, b in sync.timing])) / max(sync.timed_steps, 1)
         sync.timing = None
-    fld.profile, fld.profile_only, fld.profile_also = None, None, None
+    fld.profile, fld.profile_only, fld.profile_also, fld.profile_stride = None, None, None, 1
+    timed_events_per_step = (2.0 / ev_stride if dominant else 0.0) + 1.0 / mk_stride
     # ---- spread of the step time: K more steps with one event after each (device-side durations, no host sync in between) ----
+    # (the same steps also time the forward -- the hash lookup's own roofline entry -- with two events per step)
+    if dominant != fwd_name:
+        fld.profile, fld.profile_only = {fwd_name: []}, fwd_name
     evs = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     barrier()
     evs[0].record()
@@ -502,6 +522,9 @@ def main():
         evs[i + 1].record()
     barrier()
     per_step = np.array([evs[i].elapsed_time(evs[i + 1]) for i in range(args.steps)])
+    if dominant != fwd_name:
+        hash_fwd_ms = fld.kernel_times_ms().get(fwd_name)
+        fld.profile, fld.profile_only = None, None
     # (the events are recorded when the step's last launch retires; a step that found the queue empty shows its host time instead)
     spread = {"p10": float(np.percentile(per_step, 10)), "p50": float(np.percentile(per_step, 50)),
               "p90": float(np.percentile(per_step, 90)), "n": int(args.steps)} if args.steps >= 5 else None
@@ -727,6 +750,10 @@ def main():
             # stall inside the region, not the steady step.  host_enqueue_ms_p50: how long the host takes to enqueue a step
             "ms_per_step_p50_timed": timed_intervals["p50"] if timed_intervals else None,
             "ms_step_max_timed": timed_intervals["max"] if timed_intervals else None,
+            "timing_events": {"per_event_queue_bubble_us_under_rocprofv3": 5.8, "source": "tools/gap_probe.py, profiles/r06_am_gap_probe.txt "
+                              "(without the profiler: profiles/r06_an_events.txt)",
+                              "dominant_launch_event_stride": ev_stride, "step_marker_stride": mk_stride,
+                              "events_per_timed_step": timed_events_per_step},
             "host_enqueue_ms_p50": host_intervals["p50"] if host_intervals else None,
             "train_iters_per_sec": it_s * 1.0, "captured_step_ms_per_step": graph_ms, "captured_step_two_branches_ms_per_step": graph_alt_ms,
             # forward-only batches run before the warm-up steps (no parameter / optimiser / loader / RNG state touched)

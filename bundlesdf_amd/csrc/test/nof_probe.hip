@@ -133,3 +133,39 @@ extern "C" int nof_atomic_probe(int32_t variant, const uint32_t* idx, float* tab
   NOF_LAUNCH_OK();
   return 0;
 }
+
+// ---- test hook: what the queue leaves between two dependent launches (tools/gap_probe.py, round 6) -------------------------------
+// kernel A streams `n` float4 into `dst` -- mode 0: plain stores, 1: __builtin_nontemporal_store, 2: stores with sc0 sc1 (write-through
+// past the XCD's L2), 3: no stores (loads only) --, kernel B is one workgroup that touches one word.  Under rocprofv3 --kernel-trace the
+// distance from A's end to B's start shows whether the end-of-kernel write-back of A's dirty L2 lines is what the gaps of the
+// training step's timeline are made of.
+__global__ __launch_bounds__(256) void k_gap_store(float4* __restrict__ dst, const float4* __restrict__ src, int64_t n, int mode) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const float4 v = src[i];
+    if (mode == 0) dst[i] = v;
+    else if (mode == 1) {
+      __builtin_nontemporal_store(v.x, &dst[i].x); __builtin_nontemporal_store(v.y, &dst[i].y);
+      __builtin_nontemporal_store(v.z, &dst[i].z); __builtin_nontemporal_store(v.w, &dst[i].w);
+    } else if (mode == 2) {
+      typedef float f4v __attribute__((ext_vector_type(4)));
+      const f4v vv = {v.x, v.y, v.z, v.w};
+      asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(&dst[i]), "v"(vv) : "memory");
+    } else {
+      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+  }
+  if (mode == 3 && acc.x == 12345.678f) dst[0] = acc;
+}
+__global__ void k_gap_touch(float* __restrict__ p) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) p[0] += 1.0f;
+}
+extern "C" int nof_gap_probe(float* dst, const float* src, int64_t n_float4, int32_t mode, int32_t blocks, float* word, void* stream) {
+  NOF_ARG(dst && src && word && n_float4 > 0 && mode >= 0 && mode <= 3 && blocks > 0);
+  hipLaunchKernelGGL(k_gap_store, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (float4*)dst, (const float4*)src, n_float4, (int)mode);
+  NOF_LAUNCH_OK();
+  hipLaunchKernelGGL(k_gap_touch, dim3(1), dim3(64), 0, (hipStream_t)stream, word);
+  NOF_LAUNCH_OK();
+  return 0;
+}

@@ -111,6 +111,7 @@ class NeuralObjectField:
         self.profile = None          # dict name -> [(start_event, end_event)] when per-kernel timing is on (bench.py)
         self.profile_only = None
         self.profile_also = None     # a second entry point that keeps its events beside profile_only
+        self.profile_stride = 1      # events only in steps whose index is a multiple of this (an event record costs the queue ~6 us)
         # backward over the work list of non-zero tiles ('list'), over every tile through the same code path ('all': what the
         # dense-backward figure of bench.py measures), or without a list ('off': every tile, zero tiles skipped in place)
         self.backward_tiles = 'list'
@@ -158,7 +159,8 @@ class NeuralObjectField:
         bracketed by events recorded on that same stream under `tag` (default: the entry point's name)"""
         prof = self.profile
         key = tag or name
-        if prof is None or (self.profile_only is not None and key != self.profile_only and key != self.profile_also):
+        if (prof is None or (self.profile_only is not None and key != self.profile_only and key != self.profile_also)
+                or (self.profile_stride > 1 and self.global_step % self.profile_stride != 0)):
             return lib.call(name, *args, stream=self._sh)
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         st = self._st if self._st is not None else torch.cuda.current_stream()
