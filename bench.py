@@ -307,6 +307,7 @@ def main():
                     help='timed region: HIP events around the dominant launch in every Nth step only (a timing event recorded on the '
                          'stream costs the queue a ~6 us bubble: profiles/r06_am_gap_probe.txt)')
     ap.add_argument('--marker-stride', type=int, default=4, help='timed region: one step-boundary event every Nth step')
+    ap.add_argument('--host-trace', action='store_true', help='diagnosis: host time of every C-ABI call of the first three timed steps (log)')
     ap.add_argument('--scatter-wgs', type=int, default=0, help='persistent workgroups per CU of the table scatter (0 = library default)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--with-cpu-baseline', action='store_true', help='overrides --no-cpu-baseline (the cfg1-shapes sub-record)')
@@ -409,13 +410,19 @@ def main():
     fld.profile = {}
     sync = runner.grad_sync if hasattr(runner.grad_sync, 'finish') else None
     dp_mode = getattr(runner.grad_sync, 'mode', None) if runner.grad_sync is not None else None
-    for _ in range(args.warmup):
+    # The LAST two warm-up steps run right in front of the timed region's barrier, after this analysis (and after the interpreter's
+    # garbage collection): the first timed step of rounds 3-5 took 0.63-0.65 ms where the others take 0.44 -- the HOST needed 0.29-0.43
+    # ms to enqueue it instead of 0.08 (a full heap walk and an idle wait had just emptied the CPU's caches), and the device waited for
+    # its launches (--host-trace; profiles/r06_ap_first_step.txt).  W warm-up steps in all, as before.
+    n_prof = args.warmup - 2 if args.warmup >= 4 else args.warmup
+    for _ in range(n_prof):
         step()
     torch.cuda.synchronize()
-    log('warm-up done')
-    # median over the warm-up steps, the first two left out: a kernel's first launch loads its code object (with the mean, a
-    # 5-microsecond kernel that happened to go first looked like the longest launch of a 5-step warm-up)
-    ktimes = fld.kernel_times_ms(stat='median', skip=2)
+    log('warm-up (profiled part) done')
+    # median over the profiled warm-up steps, the first two left out (the first one if there are only three): a kernel's first launch
+    # loads its code object (with the mean, a 5-microsecond kernel that happened to go first looked like the longest launch of a
+    # 5-step warm-up)
+    ktimes = fld.kernel_times_ms(stat='median', skip=2 if n_prof > 3 else max(n_prof - 2, 0))
     # (no warm-up step to look at: the launch that is the longest in every committed trace of this workload)
     dominant = max(ktimes, key=ktimes.get) if ktimes else 'hash_bwd[table+table_lds]'
     fld.profile = {dominant: []} if dominant else None          # timed region: only the dominant kernel keeps its events
@@ -439,7 +446,9 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def timed(n):
+    def timed(n, pre=2):
+        # `pre` UNTIMED steps between the garbage collection and the barrier (see the warm-up above: the host enqueues its first
+        # step after a heap walk three to five times slower than the others); the main region's are its last warm-up steps.
         # (no cyclic garbage collection inside the timed region: a generation-2 pass of the interpreter is milliseconds of host
         # time, i.e. ten steps' worth.  One driver-style run in eleven read 0.73 instead of 0.47-0.48 ms/step -- a one-off host stall
         # of unknown origin, profiles/r05_final4_*, r05_x_headline_repeat.txt -- and this is the one such pause the script can rule
@@ -452,10 +461,30 @@ def main():
         at = [i for i in range(n + 1) if i % ms_ == 0 or i == n]       # step boundaries that get a marker (0 and n always)
         evs = {i: torch.cuda.Event(enable_timing=True) for i in at}    # (created outside the timed region)
         try:                                                           # (an exception in step() must not leave the collector off)
+            for _ in range(pre):
+                step()
             barrier()
             t0 = time.perf_counter()
             evs[0].record()
             for i in range(n):
+                if args.host_trace and n == args.steps and i < 3:
+                    from bundlesdf_amd import lib as _lib
+                    real, rec = _lib.call, []
+
+                    def traced(name, *a, **k):
+                        ta = time.perf_counter()
+                        real(name, *a, **k)
+                        rec.append((name, (ta - t0) * 1e6, (time.perf_counter() - ta) * 1e6))
+                    _lib.call = traced
+                    ts = time.perf_counter()
+                    step()
+                    _lib.call = real
+                    log(f'host trace, timed step {i}: step() {1e6 * (time.perf_counter() - ts):.0f} us; calls (name, start us after t0, host us): '
+                        + ', '.join(f'{nm} {a_:.0f} {d_:.0f}' for nm, a_, d_ in rec))
+                    if i + 1 in evs:
+                        evs[i + 1].record()
+                    marks.append(time.perf_counter())
+                    continue
                 step()
                 if i + 1 in evs:
                     evs[i + 1].record()                                # (a marker on the step's stream: ~1 us of host time, a ~6 us bubble in the queue)
@@ -468,8 +497,8 @@ def main():
         # make a one-off stall inside the region visible in the record itself (round 5: one driver-style run in eleven read a MEAN of
         # 0.73 instead of 0.47 ms)
         dv = np.array([evs[a].elapsed_time(evs[b]) / (b - a) for a, b in zip(at[:-1], at[1:])]) if n else np.zeros(0)
-        timed.device_intervals = ({"p50": float(np.median(dv)), "max": float(dv.max()), "n": int(len(dv)), "steps_per_interval": ms_}
-                                  if len(dv) else None)
+        timed.device_intervals = ({"p50": float(np.median(dv)), "max": float(dv.max()), "n": int(len(dv)), "steps_per_interval": ms_,
+                                   "all": [round(float(x), 4) for x in dv]} if len(dv) else None)
         # ... and the HOST's enqueue intervals (the host runs ahead of the device: these say how long a step takes to ENQUEUE)
         iv = np.diff(np.array([t0] + marks)) * 1e3
         timed.host_intervals = {"p50": float(np.median(iv)), "max": float(iv.max()), "n": int(len(iv))} if len(iv) else None
@@ -485,7 +514,7 @@ def main():
     # the same K steps once the fraction has settled, with every tile listed, and the mean over a whole reference round
     # (501 steps from a fresh field, config.yml:2) are reported beside it under their own names.
     zero_first = zero_fraction() if args.warmup > 0 else None
-    dt = timed(args.steps)
+    dt = timed(args.steps, pre=args.warmup - n_prof)
     timed_intervals, host_intervals = timed.device_intervals, timed.host_intervals
     log(f'timed region done: {dt / args.steps * 1e3:.3f} ms/step; device step intervals {timed_intervals}; host enqueue intervals {host_intervals}')
     # The parameters after exactly W + K steps: what the tests compare between the forms of the data-parallel step.  Taken HERE and
@@ -541,7 +570,7 @@ def main():
     # The same K steps with EVERY tile in the backward's work list (nothing skipped, same kernels): what the step costs when no
     # loss gradient is zero -- the sparsity-independent figure.
     fld.backward_tiles = 'all'
-    timed(2)
+    timed(2, pre=0)
     dense_ms = timed(args.steps) / args.steps * 1e3
     fld.backward_tiles = 'list'
     log(f'dense backward (every tile listed): {dense_ms:.3f} ms/step')
