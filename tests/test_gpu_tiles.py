@@ -350,8 +350,8 @@ def test_step_over_the_list_equals_step_without(nof):
         assert np.linalg.norm(g - g0) <= 2e-3 * np.linalg.norm(g0), mode
 
 
-@pytest.mark.parametrize("ff,tail", [(0, False), (0, True), (2, True)])
-def test_one_stream_backward_equals_two_streams(nof, ff, tail):
+@pytest.mark.parametrize("ff,tail,R", [(0, False, 256), (0, True, 256), (2, True, 256), (0, True, 203)])
+def test_one_stream_backward_equals_two_streams(nof, ff, tail, R):
     """round 6: the backward tail as ONE chain -- { large levels' scatter | dL/dx } as roles of one launch, { LDS levels | MLP row
     reduction | per-ray pose rows } as roles of the next (nof_hash_encode_bwd_step) -- against the two-stream tail: a first step's
     gradients (pose and frame-feature rows included; dL/dx itself is bit-equal in test_hash_backward_over_the_list_equals_whole_batch),
@@ -360,7 +360,7 @@ def test_one_stream_backward_equals_two_streams(nof, ff, tail):
     from tests.test_gpu_step import _pair
     res = {}
     for one in (False, True):
-        cfg, fld, orc, batch, rng = _pair(nof, 'fp16x3', ff=ff, ns=2, nc=3, R=256)
+        cfg, fld, orc, batch, rng = _pair(nof, 'fp16x3', ff=ff, ns=2, nc=3, R=R)      # (203 rays: ragged last workgroups of every role)
         fld.one_stream_backward = one
         fld.fused_tail = one and tail
         R = batch.shape[0]
